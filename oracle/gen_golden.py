@@ -1,0 +1,237 @@
+"""Generate the golden vectors under tests/golden/ by IMPORTING AND RUNNING the reference.
+
+Runs only in the authoring container (needs /root/reference, read-only).  Nothing of the reference
+travels: this script imports it in place, feeds it seeded inputs and stores inputs -> outputs as small
+.npz fixtures.  Shims: stub modules for `imageio`/`cv2` (only used for PNG I/O) and a
+no-op `Tensor.cuda` (the reference hard-codes .cuda() calls; there is no GPU here).
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, HERE)
+import nerf_oracle as O  # noqa: E402  (only for the synthetic-weight recipe and the camera constants)
+
+REF = "/root/reference/optimization"
+
+
+def import_reference():
+    for m in ("imageio", "cv2"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    import utils.run_nerf_noscale as RN
+    import utils.run_nerf_helpers as RH
+    import utils.load_LINEMOD_noscale as LL
+    return RN, RH, LL
+
+
+def build_nets(RN, RH, seed):
+    """Reference NeRF modules (RH:70) loaded with the oracle's synthetic weights."""
+    sd_c = O.synth_weights(seed)
+    sd_f = O.synth_weights(seed + 1000, fine_of=sd_c)
+    nets = []
+    for sd in (sd_c, sd_f):
+        net = RH.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(net)
+    embed_fn, _ = RH.get_embedder(10, 0)
+    embeddirs_fn, _ = RH.get_embedder(4, 0)
+    query = lambda inputs, viewdirs, fn: RN.run_network(inputs, viewdirs, fn, embed_fn=embed_fn,
+                                                        embeddirs_fn=embeddirs_fn, netchunk=65536)
+    kwargs = dict(network_query_fn=query, perturb=False, N_importance=128, network_fine=nets[1],
+                  N_samples=64, network_fn=nets[0], use_viewdirs=True, white_bkgd=False,
+                  raw_noise_std=0.0, ndc=False, lindisp=False,
+                  near=O.YCBV_NEAR, far=O.YCBV_FAR)
+    return nets, kwargs, embed_fn, embeddirs_fn
+
+
+class Capture:
+    """Records what the reference's sample_pdf saw and produced (bins, weights, cdf, inds, samples)."""
+
+    def __init__(self, RN, RH):
+        self.RN, self.RH = RN, RH
+        self.log = []
+
+    def __enter__(self):
+        self.orig_pdf = self.RN.sample_pdf
+        self.orig_ss = torch.searchsorted
+        cap = self
+
+        def ss(cdf, u, right=False, **kw):
+            out = cap.orig_ss(cdf, u, right=right, **kw)
+            cap.cur.update(cdf=cdf.detach().numpy().copy(), inds=out.numpy().copy(),
+                           u=u.detach().numpy().copy())
+            return out
+
+        def pdf(bins, weights, N_samples, det=False, pytest=False):
+            cap.cur = dict(bins=bins.detach().numpy().copy(), weights=weights.detach().numpy().copy())
+            torch.searchsorted = ss
+            try:
+                s = cap.orig_pdf(bins, weights, N_samples, det=det, pytest=pytest)
+            finally:
+                torch.searchsorted = cap.orig_ss
+            cap.cur["samples"] = s.detach().numpy().copy()
+            cap.log.append(cap.cur)
+            return s
+
+        self.RN.sample_pdf = pdf
+        return self
+
+    def __exit__(self, *a):
+        self.RN.sample_pdf = self.orig_pdf
+        torch.searchsorted = self.orig_ss
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    RN, RH, LL = import_reference()
+    torch.manual_seed(0)
+    rng = np.random.RandomState(1234)
+    SEED = 7
+    nets, kwargs, embed_fn, embeddirs_fn = build_nets(RN, RH, SEED)
+
+    # ---- G9 poses (LL:89-94) ----------------------------------------------------------------
+    angles = np.array([[90.0, 30.0 - 180.0], [85.5, 200.0 - 180.0], [94.2, 311.0 - 180.0], [88.0, -170.0]])
+    poses = np.stack([LL.pose_spherical_nograd(t, p, 1.01).numpy() for t, p in angles])
+    save("g9_pose", angles=angles, radius=np.float64(1.01), c2w=poses)
+    c2w = torch.from_numpy(poses[0])
+
+    # ---- G1 get_rays (RH:156-165) -----------------------------------------------------------
+    K8 = O.scaled_K(50.0)
+    o8, d8 = RH.get_rays(8, 8, K8, c2w[:3, :4])
+    o400, d400 = RH.get_rays(400, 400, O.YCBV_K, c2w[:3, :4])
+    pix = np.array([[0, 0], [0, 399], [399, 0], [399, 399], [200, 195], [17, 301], [250, 3]])
+    save("g1_get_rays", c2w=poses[0], K8=np.array(K8), o8=o8.numpy(), d8=d8.numpy(),
+         K400=np.array(O.YCBV_K), pix=pix, o400=o400.numpy()[pix[:, 0], pix[:, 1]],
+         d400=d400.numpy()[pix[:, 0], pix[:, 1]])
+
+    # ---- G2 embedding (RH:18-66) ------------------------------------------------------------
+    pts = rng.uniform(-2, 2, size=(512, 3)).astype(np.float32)
+    dirs = rng.standard_normal((128, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    save("g2_embed", pts=pts, e_pts=embed_fn(torch.from_numpy(pts)).numpy(),
+         dirs=dirs, e_dirs=embeddirs_fn(torch.from_numpy(dirs)).numpy())
+
+    # ---- G3 MLP (RH:99-122) -----------------------------------------------------------------
+    x = np.concatenate([embed_fn(torch.from_numpy(pts[:256])).numpy(),
+                        embeddirs_fn(torch.from_numpy(dirs[np.arange(256) % 128])).numpy()], -1)
+    hid = {}
+    hooks = [nets[0].pts_linears[i].register_forward_hook(
+        lambda m, a, out, i=i: hid.__setitem__("h%d" % i, torch.relu(out).detach().numpy().copy()))
+        for i in (0, 4, 7)]
+    with torch.no_grad():
+        y_c = nets[0](torch.from_numpy(x)).numpy()
+        for h in hooks:
+            h.remove()
+        y_f = nets[1](torch.from_numpy(x)).numpy()
+    save("g3_mlp", seed=np.int64(SEED), x=x, y_coarse=y_c, y_fine=y_f, **hid)
+
+    # ---- G4 raw2outputs (RN:343-387) --------------------------------------------------------
+    def analytic_raw(n, s):
+        zc = np.linspace(0, 1, s)[None, :]
+        mu = rng.uniform(0.2, 0.8, size=(n, 1))
+        sg = rng.uniform(0.02, 0.2, size=(n, 1))
+        amp = rng.uniform(5, 400, size=(n, 1))
+        sigma = amp * np.exp(-0.5 * ((zc - mu) / sg) ** 2) - 2.0
+        raw = np.concatenate([rng.standard_normal((n, s, 3)) * 2, sigma[..., None]], -1).astype(np.float32)
+        raw[0, :, 3] = -1.0          # empty ray: acc = 0 -> disp = NaN (RN:381)
+        raw[1, :, 3] = 1e4           # saturated ray
+        raw[2, :, 3] = 0.0
+        raw[2, -1, 3] = 1e-9         # only the 1e10 last interval contributes
+        return raw
+    g4 = {}
+    for s in (64, 192):
+        n = 48
+        raw = analytic_raw(n, s)
+        z = np.sort(rng.uniform(O.YCBV_NEAR, O.YCBV_FAR, size=(n, s)).astype(np.float32), -1)
+        rd = rng.standard_normal((n, 3)).astype(np.float32)
+        with torch.no_grad():
+            outs = RN.raw2outputs(torch.from_numpy(raw), torch.from_numpy(z), torch.from_numpy(rd), 0, False)
+        for nm, v in zip(("rgb", "disp", "acc", "weights", "depth"), outs):
+            g4["%s_%d" % (nm, s)] = v.numpy()
+        g4.update({"raw_%d" % s: raw, "z_%d" % s: z, "rays_d_%d" % s: rd})
+    save("g4_raw2outputs", **g4)
+
+    # ---- G5 sample_pdf (RH:199-243) ---------------------------------------------------------
+    n = 96
+    z = O.coarse_z(np.full(n, O.YCBV_NEAR, np.float32), np.full(n, O.YCBV_FAR, np.float32))
+    bins = (0.5 * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    w = rng.uniform(0, 1, size=(n, 62)).astype(np.float32) ** 4
+    w[0] = 0.0                                   # all-zero weights
+    w[1] = 0.25                                  # uniform
+    w[2] = 0.0; w[2, 30] = 0.9                   # single spike
+    w[3] = 0.0; w[3, 5] = 0.4; w[3, 50] = 0.5    # two spikes
+    w[4] = 0.0; w[4, 0] = 1.0                    # mass in the first bin
+    w[5] = 0.0; w[5, 61] = 1.0                   # mass in the last bin
+    w[6:40] *= 1e-4                              # tiny weights: the +1e-5 dominates
+    with Capture(RN, RH) as cap:
+        with torch.no_grad():
+            RN.sample_pdf(torch.from_numpy(bins), torch.from_numpy(w), 128, det=True)
+    c = cap.log[0]
+    save("g5_sample_pdf", bins=bins, weights=w, cdf=c["cdf"], inds=c["inds"], samples=c["samples"], u=c["u"][0])
+
+    # ---- G6 render_rays end to end (RN:390-501) ---------------------------------------------
+    o32, d32 = RH.get_rays(400, 400, O.YCBV_K, c2w[:3, :4])
+    sel = rng.choice(160000, size=192, replace=False)
+    ro = o32.reshape(-1, 3)[sel]
+    rd = d32.reshape(-1, 3)[sel]
+    with Capture(RN, RH) as cap:
+        with torch.no_grad():
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=64, rays=torch.stack([ro, rd], 0),
+                                           retraw=True, **kwargs)
+    cat = lambda k: np.concatenate([c[k] for c in cap.log], 0)
+    save("g6_render_rays", seed=np.int64(SEED), rays_o=ro.numpy(), rays_d=rd.numpy(),
+         near=np.float64(O.YCBV_NEAR), far=np.float64(O.YCBV_FAR),
+         rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(), raw=ex["raw"].numpy(),
+         rgb0=ex["rgb0"].numpy(), disp0=ex["disp0"].numpy(), acc0=ex["acc0"].numpy(), z_std=ex["z_std"].numpy(),
+         pdf_bins=cat("bins"), pdf_weights=cat("weights"), cdf=cat("cdf"), inds=cat("inds"),
+         z_samples=cat("samples"))
+
+    # ---- G7 full-image render (RN:58-123) ---------------------------------------------------
+    K64 = O.scaled_K(6.25)
+    kw0 = dict(kwargs, N_importance=0)
+    with torch.no_grad():
+        rgb, disp, acc, _ = RN.render(64, 64, K64, chunk=512, c2w=c2w[:3, :4], **kw0)
+    g7 = dict(seed=np.int64(SEED), c2w=poses[0], K64=np.array(K64), rgb_c1=rgb.numpy(), disp_c1=disp.numpy(),
+              acc_c1=acc.numpy())
+    K32 = O.scaled_K(12.5)
+    with torch.no_grad():
+        rgb, disp, acc, ex = RN.render(32, 32, K32, chunk=512, c2w=torch.from_numpy(poses[2])[:3, :4], **kwargs)
+    g7.update(c2w_b=poses[2], K32=np.array(K32), rgb_c2=rgb.numpy(), disp_c2=disp.numpy(), acc_c2=acc.numpy(),
+              rgb0_c2=ex["rgb0"].numpy(), disp0_c2=ex["disp0"].numpy(), acc0_c2=ex["acc0"].numpy(),
+              z_std_c2=ex["z_std"].numpy())
+    save("g7_render", **g7)
+
+    # ---- G8 backward: d(rgb)/d(rays) VJP (RN:168-178) -----------------------------------------
+    nb = 96
+    sel = rng.choice(160000, size=nb, replace=False)
+    rays = torch.stack([o32.reshape(-1, 3)[sel], d32.reshape(-1, 3)[sel]], 0).clone().requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((nb, 3)).astype(np.float32))
+    rgb_p, _, _, _ = RN.render(400, 400, O.YCBV_K, chunk=nb, rays=rays, retraw=True, **kwargs)
+    (g,) = torch.autograd.grad(rgb_p, rays, grad_outputs=cot)
+    save("g8_backward", seed=np.int64(SEED), rays=rays.detach().numpy(), cot=cot.numpy(),
+         rgb=rgb_p.detach().numpy(), grad_rays=g.numpy())
+
+    # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
+    save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,380 @@
+"""CPU oracle for the NeRF volumetric-render hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain numpy fp32, the algorithm of the reference's render path
+(gyhandy/Neural-Sim-NeRF, files cited per function below; RN = optimization/utils/run_nerf_noscale.py,
+RH = optimization/utils/run_nerf_helpers.py).  It exists so that tests can check the HIP path against
+something that does not live in the product.  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it.  The product (`neural-sim-nerf_amd/`) never does.
+
+Pinning: every function here is checked against golden vectors produced by importing and running the
+reference itself (see oracle/gen_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).
+
+Numerics conventions (measured against torch 2.10 CPU, the reference's only runnable backend here):
+  * everything is IEEE fp32, one rounding per op, NO fused multiply-add (torch evaluates op by op);
+  * torch.cumprod / torch.cumsum on CPU fp32 accumulate sequentially in fp64 and round every prefix to
+    fp32 (RN:376, RH:203) -> `_cumprod_f64`, `_cumsum_f64`;
+  * torch.sum over a contiguous inner dim uses an 8-lane vectorised cascade (ATen SumKernel.cpp) whose
+    association order is reproduced exactly by `_torch_sum_lastdim` -- needed because the pdf
+    normaliser (RH:202) feeds the searchsorted indices that must be bit-exact;
+  * torch.linspace(0,1,n) fp32 on CPU is NOT np.linspace (vectorised base + k*step with FMAs); the
+    tables are constants of the path and are taken from host torch, as the reference does (RN:439);
+  * sin/cos/exp/sigmoid come from numpy's fp32 libm here and from Sleef in torch: they agree to ~1 ulp,
+    not bitwise -> the parity tests use a tolerance on everything downstream of them.
+"""
+import numpy as np
+
+f32 = np.float32
+f64 = np.float64
+
+# ----------------------------------------------------------------------------------------------
+# configuration of the path (reference: configs/nerf_param_ycbv_general.txt, NM:1232-1272 defaults)
+# ----------------------------------------------------------------------------------------------
+N_SAMPLES = 64          # CF:12
+N_IMPORTANCE = 128      # CF:13
+MULTIRES = 10           # NM:1268  -> 63 input channels
+MULTIRES_VIEWS = 4      # NM:1270  -> 27 view channels
+NET_DEPTH = 8           # NM:1232
+NET_WIDTH = 256         # NM:1234
+SKIP_AT = 4             # RN:269 skips=[4]
+IN_CH = 3 + 3 * 2 * MULTIRES            # 63
+IN_CH_VIEWS = 3 + 3 * 2 * MULTIRES_VIEWS  # 27
+
+# camera of the YCB-V object-2 data (logs/nerfdata/nerf_traindata_info.json:2-5,35-51; LL:197-198)
+YCBV_K = [[1333.3333740234375, 0.0, 195.4293212890625],
+          [0.0, 1334.2196044921875, 200.63180541992188],
+          [0.0, 0.0, 1.0]]
+YCBV_NEAR = 0.8103964843749999 - 0.5
+YCBV_FAR = 1.4297681884765627 + 0.5
+YCBV_HW = 400
+
+
+def scaled_K(scale):
+    """Intrinsics for an (400/scale)x(400/scale) image, the way LL:185-192 rescales them."""
+    K = [list(r) for r in YCBV_K]
+    K[0] = [v / scale for v in K[0]]
+    K[1] = [v / scale for v in K[1]]
+    return K
+
+
+# ----------------------------------------------------------------------------------------------
+# torch-CPU arithmetic emulation helpers
+# ----------------------------------------------------------------------------------------------
+def torch_linspace01(n):
+    """torch.linspace(0., 1., n) fp32 as computed on the CPU (RN:439, RH:208: the reference builds both
+    tables on the host and then moves them).  ATen's vectorised kernel is not bit-equal to
+    np.linspace (its lanes are base + k*step with fused multiply-adds), so the table is taken from the
+    host's own torch -- the same call the reference makes -- and only falls back to a closed form (equal
+    to ~93 % of the entries, 1 ulp off elsewhere) when torch is not importable."""
+    try:
+        import torch
+        return torch.linspace(0., 1., steps=n).numpy().astype(f32)
+    except ImportError:  # pragma: no cover
+        step = f32(f32(1.0) / f32(n - 1))
+        i = np.arange(n)
+        lo = (i.astype(f32) * step).astype(f32)
+        hi = (f32(1.0) - ((n - 1 - i).astype(f32) * step).astype(f32)).astype(f32)
+        return np.where(i < n // 2, lo, hi).astype(f32)
+
+
+def _add(a, b):
+    return (a + b).astype(f32)
+
+
+def _torch_sum_lastdim(x):
+    """torch.sum(x, -1) for contiguous fp32 [N, n] -- ATen's vectorised inner cascade sum, 8 lanes,
+    4-way ILP.  Exact association order (valid for n < 8*4*16 = 512)."""
+    x = np.ascontiguousarray(x, dtype=f32)
+    n_rows, n = x.shape
+    W, ILP = 8, 4
+    nvec = n // W
+    size_ilp = nvec // ILP
+    assert size_ilp < 16, "cascade levels beyond the first are not emulated"
+    vec = lambda v: x[:, v * W:(v + 1) * W]
+    zero = np.zeros((n_rows, W), f32)
+    ps = [zero.copy() for _ in range(ILP)]
+    for i in range(size_ilp):
+        for k in range(ILP):
+            ps[k] = _add(ps[k], vec(i * ILP + k))
+    for v in range(size_ilp * ILP, nvec):
+        ps[0] = _add(ps[0], vec(v))
+    for k in range(1, ILP):
+        ps[0] = _add(ps[0], ps[k])
+    total = np.zeros(n_rows, f32)
+    for k in range(nvec * W, n):
+        total = _add(total, x[:, k])
+    for k in range(W):
+        total = _add(total, ps[0][:, k])
+    return total
+
+
+def _cumsum_f64(x):
+    acc = np.zeros(x.shape[:-1], f64)
+    out = np.empty_like(x, dtype=f32)
+    for k in range(x.shape[-1]):
+        acc = acc + x[..., k].astype(f64)
+        out[..., k] = acc.astype(f32)
+    return out
+
+
+def _cumprod_f64(x):
+    acc = np.ones(x.shape[:-1], f64)
+    out = np.empty_like(x, dtype=f32)
+    for k in range(x.shape[-1]):
+        acc = acc * x[..., k].astype(f64)
+        out[..., k] = acc.astype(f32)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic weights (no pretrained YCB-V checkpoints are available: reference .gitignore:7)
+# ----------------------------------------------------------------------------------------------
+LAYER_SHAPES = (
+    [("pts_linears.0", NET_WIDTH, IN_CH)]
+    + [("pts_linears.%d" % i, NET_WIDTH, NET_WIDTH + (IN_CH if i == SKIP_AT + 1 else 0))
+       for i in range(1, NET_DEPTH)]
+    + [("feature_linear", NET_WIDTH, NET_WIDTH),
+       ("alpha_linear", 1, NET_WIDTH),
+       ("views_linears.0", NET_WIDTH // 2, NET_WIDTH + IN_CH_VIEWS),
+       ("rgb_linear", 3, NET_WIDTH // 2)]
+)
+N_PARAMS = sum(o * i + o for _, o, i in LAYER_SHAPES)   # 595844 (RH:70-122)
+MACS_PER_POINT = sum(o * i for _, o, i in LAYER_SHAPES)  # 593408
+
+
+def synth_weights(seed, fine_of=None):
+    """Deterministic non-degenerate weights with the state_dict names/shapes of RH:70-122.
+
+    nn.Linear-style U(-1/sqrt(in), 1/sqrt(in)) init, then: trunk weights x1.6, alpha weight x50,
+    alpha bias -0.5 (so rays carry a mix of empty and opaque space: acc in (0.4,1), non-trivial z_std).
+    `fine_of`: derive a *different but consistent* fine net from a coarse one (x(1+0.05 N(0,1)))."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+    if fine_of is not None:
+        for k, v in fine_of.items():
+            sd[k] = (v * (1.0 + 0.05 * rng.standard_normal(v.shape))).astype(f32)
+        return sd
+    for name, o, i in LAYER_SHAPES:
+        bound = 1.0 / np.sqrt(i)
+        w = rng.uniform(-bound, bound, size=(o, i))
+        b = rng.uniform(-bound, bound, size=(o,))
+        if name.startswith("pts_linears"):
+            w = w * 1.6
+        if name == "alpha_linear":
+            w = w * 50.0
+            b = b * 0.0 - 0.5
+        sd[name + ".weight"] = w.astype(f32)
+        sd[name + ".bias"] = b.astype(f32)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------------
+# the path
+# ----------------------------------------------------------------------------------------------
+def get_rays(H, W, K, c2w):
+    """RH:156-165.  K is the nested python-float list the reference reads from JSON (LL:177); the
+    scalars enter fp32 tensor ops, i.e. are rounded to fp32 first.  Returns rays_o, rays_d [H,W,3]."""
+    c2w = np.asarray(c2w, dtype=f32)
+    col = np.arange(W, dtype=f32)[None, :].repeat(H, 0)   # "i" after .t(): x / column index
+    row = np.arange(H, dtype=f32)[:, None].repeat(W, 1)   # "j": y / row index
+    dx = ((col - f32(K[0][2])) / f32(K[0][0])).astype(f32)
+    dy = (-((row - f32(K[1][2])) / f32(K[1][1]))).astype(f32)
+    dz = -np.ones_like(dx)
+    dirs = np.stack([dx, dy, dz], -1)
+    prod = (dirs[..., None, :] * c2w[:3, :3]).astype(f32)              # [H,W,3(a),3(k)]
+    rays_d = _add(_add(prod[..., 0], prod[..., 1]), prod[..., 2])       # sum over k, in order
+    rays_o = np.broadcast_to(c2w[:3, 3], rays_d.shape).astype(f32)
+    return rays_o, rays_d
+
+
+def normalize_dirs(rays_d):
+    """RN:97: viewdirs = d / ||d||  (torch.norm: sqrt of the sequential fp32 sum of squares)."""
+    d = rays_d.astype(f32)
+    sq = (d * d).astype(f32)
+    n = np.sqrt(_add(_add(sq[..., 0], sq[..., 1]), sq[..., 2])).astype(f32)
+    return (d / n[..., None]).astype(f32)
+
+
+def dir_norm(rays_d):
+    d = rays_d.astype(f32)
+    sq = (d * d).astype(f32)
+    return np.sqrt(_add(_add(sq[..., 0], sq[..., 1]), sq[..., 2])).astype(f32)
+
+
+def embed(x, n_freqs):
+    """RH:18-48: [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)], 3 channels each."""
+    x = x.astype(f32)
+    out = [x]
+    for l in range(n_freqs):
+        xs = (x * f32(2.0 ** l)).astype(f32)
+        out.append(np.sin(xs).astype(f32))
+        out.append(np.cos(xs).astype(f32))
+    return np.concatenate(out, -1)
+
+
+def mlp(sd, x_embedded, keep=None):
+    """RH:99-122 (use_viewdirs=True).  x_embedded [P, 90] -> [P, 4] = (rgb logits, sigma)."""
+    lin = lambda name, h: (h @ sd[name + ".weight"].T + sd[name + ".bias"]).astype(f32)
+    pts, views = x_embedded[:, :IN_CH], x_embedded[:, IN_CH:]
+    h = pts
+    for i in range(NET_DEPTH):
+        h = np.maximum(lin("pts_linears.%d" % i, h), f32(0))
+        if keep is not None:
+            keep["h%d" % i] = h
+        if i == SKIP_AT:
+            h = np.concatenate([pts, h], -1)
+    alpha = lin("alpha_linear", h)
+    feature = lin("feature_linear", h)
+    hv = np.maximum(lin("views_linears.0", np.concatenate([feature, views], -1)), f32(0))
+    rgb = lin("rgb_linear", hv)
+    return np.concatenate([rgb, alpha], -1)
+
+
+def run_network(sd, pts, viewdirs):
+    """RN:26-40: pts [N,S,3], viewdirs [N,3] -> raw [N,S,4]."""
+    N, S, _ = pts.shape
+    e = embed(pts.reshape(-1, 3), MULTIRES)
+    ed = embed(np.broadcast_to(viewdirs[:, None, :], pts.shape).reshape(-1, 3), MULTIRES_VIEWS)
+    return mlp(sd, np.concatenate([e, ed], -1)).reshape(N, S, 4)
+
+
+def raw2outputs(raw, z_vals, rays_d):
+    """RN:343-387 with raw_noise_std=0, white_bkgd=False.
+    Returns rgb_map [N,3], disp_map [N], acc_map [N], weights [N,S], depth_map [N]."""
+    raw = raw.astype(f32)
+    z = z_vals.astype(f32)
+    N, S = z.shape
+    dists = np.concatenate([(z[:, 1:] - z[:, :-1]).astype(f32), np.full((N, 1), 1e10, f32)], -1)
+    dists = (dists * dir_norm(rays_d)[:, None]).astype(f32)
+    with np.errstate(over="ignore"):
+        rgb = (f32(1) / (f32(1) + np.exp(-raw[..., :3]).astype(f32))).astype(f32)
+        sig = np.maximum(raw[..., 3], f32(0))
+        alpha = (f32(1) - np.exp((-sig * dists).astype(f32)).astype(f32)).astype(f32)
+    one_minus = _add((f32(1) - alpha).astype(f32), f32(1e-10))
+    T = _cumprod_f64(np.concatenate([np.ones((N, 1), f32), one_minus], -1))[:, :-1]
+    weights = (alpha * T).astype(f32)
+    rgb_map = np.sum((weights[..., None] * rgb).astype(f32), -2, dtype=f32)
+    depth_map = np.sum((weights * z).astype(f32), -1, dtype=f32)
+    acc_map = np.sum(weights, -1, dtype=f32)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        q = (depth_map / acc_map).astype(f32)
+        disp_map = (f32(1) / np.where(np.isnan(q), q, np.maximum(f32(1e-10), q))).astype(f32)
+    return rgb_map, disp_map, acc_map, weights, depth_map
+
+
+def sample_pdf(bins, weights, n_samples=N_IMPORTANCE, u=None):
+    """RH:199-243, deterministic branch (det=True because perturb==0, RN:474).
+    bins [N,63] (z mid-points), weights [N,62] (coarse weights[1:-1]).
+    Returns samples [N,n], inds int64 [N,n] (searchsorted right=True), cdf [N,63]."""
+    w = _add(weights.astype(f32), f32(1e-5))
+    pdf = (w / _torch_sum_lastdim(w)[:, None]).astype(f32)
+    cdf = np.concatenate([np.zeros((w.shape[0], 1), f32), _cumsum_f64(pdf)], -1)
+    if u is None:
+        u = torch_linspace01(n_samples)
+    nb = cdf.shape[-1]
+    inds = (cdf[:, None, :] <= u[None, :, None]).sum(-1).astype(np.int64)   # first idx with cdf > u
+    below = np.maximum(inds - 1, 0)
+    above = np.minimum(inds, nb - 1)
+    take = lambda a, i: np.take_along_axis(a, i, -1)
+    c0, c1 = take(cdf, below), take(cdf, above)
+    b0, b1 = take(bins.astype(f32), below), take(bins.astype(f32), above)
+    denom = (c1 - c0).astype(f32)
+    denom = np.where(denom < f32(1e-5), f32(1), denom)
+    t = ((u[None, :] - c0).astype(f32) / denom).astype(f32)
+    samples = _add(b0, (t * (b1 - b0).astype(f32)).astype(f32))
+    return samples, inds, cdf
+
+
+def coarse_z(near, far, n=N_SAMPLES):
+    """RN:439-441: z = near*(1-t) + far*t, per ray (near/far [N])."""
+    t = torch_linspace01(n)
+    near = np.asarray(near, f32).reshape(-1, 1)
+    far = np.asarray(far, f32).reshape(-1, 1)
+    return _add((near * (f32(1) - t).astype(f32)).astype(f32), (far * t).astype(f32))
+
+
+def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
+                n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, extras=False):
+    """RN:390-501 with perturb=0, lindisp=False, raw_noise_std=0, white_bkgd=False.
+    rays_o/rays_d/viewdirs [N,3], near/far scalars or [N]."""
+    rays_o, rays_d, viewdirs = (a.astype(f32) for a in (rays_o, rays_d, viewdirs))
+    N = rays_o.shape[0]
+    near = np.broadcast_to(np.asarray(near, f32), (N,))
+    far = np.broadcast_to(np.asarray(far, f32), (N,))
+    z = coarse_z(near, far, n_samples)
+    pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32))
+    raw = run_network(sd_coarse, pts, viewdirs)
+    rgb_map, disp_map, acc_map, weights, _ = raw2outputs(raw, z, rays_d)
+    ret = {}
+    if n_importance > 0:
+        ret.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
+        z_mid = (f32(0.5) * _add(z[:, 1:], z[:, :-1])).astype(f32)
+        z_samples, inds, cdf = sample_pdf(z_mid, weights[:, 1:-1], n_importance)
+        z_fine = np.sort(np.concatenate([z, z_samples], -1), -1)
+        pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z_fine[:, :, None]).astype(f32))
+        raw = run_network(sd_fine if sd_fine is not None else sd_coarse, pts, viewdirs)
+        rgb_map, disp_map, acc_map, weights_f, _ = raw2outputs(raw, z_fine, rays_d)
+        ret["z_std"] = np.std(z_samples.astype(f64), -1).astype(f32)   # RN:495 (unbiased=False)
+        if extras:
+            ret.update(z_samples=z_samples, inds=inds, cdf=cdf, z_fine=z_fine, weights0=weights,
+                       weights=weights_f, raw=raw)
+    ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)
+    return ret
+
+
+def render(sd_coarse, sd_fine, H, W, K, c2w=None, rays=None, near=0.0, far=1.0,
+           n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, chunk=4096, extras=False):
+    """RN:58-123 with use_viewdirs=True, ndc=False.  Returns dict of [H,W,...] (c2w form) or [N,...]."""
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    sh = rays_d.shape[:-1]
+    rays_o = rays_o.reshape(-1, 3).astype(f32)
+    rays_d = rays_d.reshape(-1, 3).astype(f32)
+    viewdirs = normalize_dirs(rays_d)
+    outs = []
+    for i in range(0, rays_o.shape[0], chunk):
+        s = slice(i, i + chunk)
+        outs.append(render_rays(sd_coarse, sd_fine, rays_o[s], rays_d[s], viewdirs[s], near, far,
+                                n_samples, n_importance, extras))
+    ret = {k: np.concatenate([o[k] for o in outs], 0) for k in outs[0]}
+    return {k: v.reshape(sh + v.shape[1:]) for k, v in ret.items()}
+
+
+def to8b(x):
+    """RH:14 (truncating conversion)."""
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def psnr(a, b):
+    """RH:12-13 convention."""
+    mse = np.mean((a.astype(f64) - b.astype(f64)) ** 2)
+    return float("inf") if mse == 0 else float(-10.0 * np.log10(mse))
+
+
+# ----------------------------------------------------------------------------------------------
+# poses (LL:89-94 pose_spherical_nograd; LL:250-301 sampling is replaced by a seeded draw)
+# ----------------------------------------------------------------------------------------------
+def pose_spherical(theta_deg, phi_deg, radius):
+    """LL:89-94 pose_spherical_nograd, fp32 4x4 camera-to-world."""
+    th = theta_deg / 180.0 * np.pi
+    ph = phi_deg / 180.0 * np.pi
+    trans = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, radius], [0, 0, 0, 1]], f32)
+    rphi = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0],
+                     [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1]], f32)
+    rth = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0],
+                    [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1]], f32)
+    flip = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1]], f32)
+    return (flip @ (rth @ (rphi @ trans))).astype(f32)
+
+
+def sweep_poses(n_views, seed=0):
+    """Synthetic stand-in for the Gumbel-softmax pose sweep (LL:250-301, NM:1164-1165): theta~U(85,95),
+    phi drawn around the dominant 45-degree bin, radius 1.01 (LL:292-293)."""
+    rng = np.random.RandomState(seed)
+    poses = []
+    for _ in range(n_views):
+        theta = rng.uniform(85, 95)
+        phi = rng.uniform(0, 360)
+        poses.append(pose_spherical(theta, phi - 180.0, 1.01))
+    return np.stack(poses, 0)

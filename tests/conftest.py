@@ -1,0 +1,50 @@
+"""pytest configuration: `gpu` marker + shared fixtures (golden vectors, oracle import)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import nerf_oracle
+    return nerf_oracle
+
+
+@pytest.fixture(scope="session")
+def synth_nets(oracle):
+    """(coarse, fine) synthetic state dicts for the seed the golden files were generated with."""
+    seed = int(load_golden("g3_mlp")["seed"])
+    sd_c = oracle.synth_weights(seed)
+    return sd_c, oracle.synth_weights(seed + 1000, fine_of=sd_c)
+
+
+def assert_close(a, b, atol=0.0, rtol=0.0, what=""):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    both_nan = np.isnan(a) & np.isnan(b)
+    with np.errstate(invalid="ignore"):
+        err = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        ok = both_nan | (err <= atol + rtol * np.abs(b.astype(np.float64)))
+    assert ok.all(), "%s: %d/%d out of tolerance, max abs err %.3e" % (
+        what, (~ok).sum(), ok.size, np.nanmax(np.where(both_nan, 0, err)))

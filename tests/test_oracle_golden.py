@@ -1,0 +1,121 @@
+"""Pin the oracle (oracle/nerf_oracle.py) to the reference: every function against the golden vectors
+that oracle/gen_golden.py produced by running the reference itself (RN/RH file:line in the oracle).
+
+Tolerances: bit-exact wherever the arithmetic is IEEE add/mul/div/sqrt/compare (ray generation, poses,
+cdf, searchsorted indices, inverse-CDF samples); ~1 ulp-level tolerances downstream of sin/cos/exp,
+which numpy's libm and torch's Sleef round differently."""
+import numpy as np
+
+from conftest import assert_close
+
+
+def test_tables_exact(golden, oracle):
+    g = golden("g0_tables")
+    assert np.array_equal(oracle.torch_linspace01(64), g["t64"])
+    assert np.array_equal(oracle.torch_linspace01(128), g["t128"])
+
+
+def test_pose_exact(golden, oracle):
+    g = golden("g9_pose")
+    for (t, p), c in zip(g["angles"], g["c2w"]):
+        assert np.array_equal(oracle.pose_spherical(t, p, float(g["radius"])), c)
+
+
+def test_get_rays_exact(golden, oracle):
+    g = golden("g1_get_rays")
+    o, d = oracle.get_rays(8, 8, g["K8"].tolist(), g["c2w"][:3, :4])
+    assert np.array_equal(o, g["o8"]) and np.array_equal(d, g["d8"])
+    o, d = oracle.get_rays(400, 400, g["K400"].tolist(), g["c2w"][:3, :4])
+    p = g["pix"]
+    assert np.array_equal(o[p[:, 0], p[:, 1]], g["o400"])
+    assert np.array_equal(d[p[:, 0], p[:, 1]], g["d400"])
+
+
+def test_embed(golden, oracle):
+    g = golden("g2_embed")
+    e = oracle.embed(g["pts"], 10)
+    assert e.shape == (512, 63)
+    assert np.array_equal(e[:, :3], g["pts"])
+    assert_close(e, g["e_pts"], atol=2e-7, what="embed pts")       # |sin|,|cos| <= 1: 1-2 ulp
+    assert_close(oracle.embed(g["dirs"], 4), g["e_dirs"], atol=2e-7, what="embed dirs")
+
+
+def test_mlp(golden, oracle, synth_nets):
+    g = golden("g3_mlp")
+    sd_c, sd_f = synth_nets
+    keep = {}
+    y = oracle.mlp(sd_c, g["x"], keep)
+    for k in ("h0", "h4", "h7"):
+        assert_close(keep[k], g[k], atol=1e-5, rtol=1e-5, what=k)
+    assert_close(y, g["y_coarse"], atol=2e-5, rtol=1e-5, what="coarse net")
+    assert_close(oracle.mlp(sd_f, g["x"]), g["y_fine"], atol=2e-5, rtol=1e-5, what="fine net")
+    # the two nets must be distinguishable, or a coarse/fine mix-up would go unnoticed
+    assert np.abs(g["y_coarse"] - g["y_fine"]).max() > 1e-2
+
+
+def test_raw2outputs(golden, oracle):
+    g = golden("g4_raw2outputs")
+    for s in (64, 192):
+        outs = oracle.raw2outputs(g["raw_%d" % s], g["z_%d" % s], g["rays_d_%d" % s])
+        for nm, v in zip(("rgb", "disp", "acc", "weights", "depth"), outs):
+            assert_close(v, g["%s_%d" % (nm, s)], atol=1e-6, rtol=1e-6, what="%s_%d" % (nm, s))
+        assert np.isnan(outs[1][0]) and np.isnan(g["disp_%d" % s][0])     # acc==0 -> 0/0 -> NaN (RN:381)
+        assert outs[2][0] == 0.0
+
+
+def test_sample_pdf_bit_exact(golden, oracle):
+    g = golden("g5_sample_pdf")
+    samples, inds, cdf = oracle.sample_pdf(g["bins"], g["weights"], 128, u=g["u"])
+    assert np.array_equal(cdf, g["cdf"])
+    assert np.array_equal(inds, g["inds"])
+    assert inds.dtype == np.int64
+    assert np.array_equal(samples, g["samples"])
+
+
+def test_sample_pdf_on_render_rays_inputs(golden, oracle):
+    g = golden("g6_render_rays")
+    samples, inds, cdf = oracle.sample_pdf(g["pdf_bins"], g["pdf_weights"], 128)
+    assert np.array_equal(cdf, g["cdf"])
+    assert np.array_equal(inds, g["inds"])
+    assert np.array_equal(samples, g["z_samples"])
+
+
+def test_render_rays_end_to_end(golden, oracle, synth_nets):
+    """End to end the path is ill-conditioned by construction: a 1e-7 change of a coarse weight moves
+    an importance sample by up to ~1e-3 where the pdf is almost flat (denominator ~1e-5, RH:238-240).
+    Coarse outputs are therefore held to 1e-5, fine outputs to 2e-3 per ray and 1e-4 on average."""
+    g = golden("g6_render_rays")
+    sd_c, sd_f = synth_nets
+    vd = oracle.normalize_dirs(g["rays_d"])
+    r = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, float(g["near"]), float(g["far"]),
+                           extras=True)
+    assert_close(r["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
+    assert_close(r["acc0"], g["acc0"], atol=1e-5, what="acc0")
+    assert_close(r["disp0"], g["disp0"], rtol=1e-4, what="disp0")
+    assert (r["inds"] == g["inds"]).mean() > 0.99
+    assert_close(r["z_samples"], g["z_samples"], atol=3e-3, what="z_samples")
+    for k, kk in (("rgb_map", "rgb"), ("acc_map", "acc")):
+        assert_close(r[k], g[kk], atol=5e-3, what=k)
+        assert np.abs(r[k] - g[kk]).mean() < 1e-4
+    assert oracle.psnr(r["rgb_map"], g["rgb"]) > 60.0
+
+
+def test_render_image(golden, oracle, synth_nets):
+    g = golden("g7_render")
+    sd_c, sd_f = synth_nets
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    r = oracle.render(sd_c, None, 64, 64, g["K64"].tolist(), c2w=g["c2w"][:3, :4], near=near, far=far,
+                      n_importance=0)
+    assert r["rgb_map"].shape == (64, 64, 3) and r["disp_map"].shape == (64, 64)
+    assert_close(r["rgb_map"], g["rgb_c1"], atol=1e-5, what="config-1 rgb")
+    assert_close(r["acc_map"], g["acc_c1"], atol=1e-5, what="config-1 acc")
+    assert_close(r["disp_map"], g["disp_c1"], rtol=1e-4, what="config-1 disp")
+    r = oracle.render(sd_c, sd_f, 32, 32, g["K32"].tolist(), c2w=g["c2w_b"][:3, :4], near=near, far=far)
+    assert_close(r["rgb0"], g["rgb0_c2"], atol=1e-5, what="rgb0")
+    assert oracle.psnr(r["rgb_map"], g["rgb_c2"]) > 55.0
+    assert np.abs(r["rgb_map"] - g["rgb_c2"]).mean() < 2e-4
+
+
+def test_to8b_truncates(oracle):
+    x = np.array([-0.2, 0.0, 0.5, 0.999, 1.0, 1.7], np.float32)
+    assert oracle.to8b(x).tolist() == [0, 0, 127, 254, 255, 255]
