@@ -1,0 +1,135 @@
+/*
+ * nsr.h -- C ABI of libnsr.so, the MI355X-native NeRF volumetric renderer.
+ *
+ * This is the drop-in boundary below the reference's Python render API.  The reference
+ * (gyhandy/Neural-Sim-NeRF) has no native layer: its hot path is a chain of PyTorch ops in
+ *   RN = optimization/utils/run_nerf_noscale.py, RH = optimization/utils/run_nerf_helpers.py.
+ * Each entry point below replaces the reference functions cited next to it.  The binding a maintainer
+ * adds on the reference side is a ctypes stub; `neural-sim-nerf_amd/_lib.py` is that stub.
+ *
+ * Conventions
+ *   - plain C types only; every `const float*` / `float*` / `int64_t*` named d_* is a DEVICE pointer
+ *     owned by the caller (e.g. a PyTorch-ROCm tensor's data_ptr); the library never frees them;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered,
+ *     no hidden synchronisation except in nsr_create/nsr_destroy/nsr_upload_* (setup, not hot path);
+ *   - return value: 0 = OK, non-zero = error, message via nsr_last_error() (thread-local);
+ *   - one handle per (model, stream); a handle is not thread-safe, distinct handles are;
+ *   - the arithmetic is fp32 end to end (MFMA v_mfma_f32_32x32x2_f32 for the MLP GEMMs), fp64 only
+ *     inside the two sequential scans where torch-CPU accumulates in fp64 (RN:376 cumprod, RH:203 cumsum).
+ */
+#ifndef NSR_H_
+#define NSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSR_ABI_VERSION 1
+
+/* Fixed architecture of the path (configs/nerf_param_ycbv_general.txt:12-13; NM:1232-1272). */
+#define NSR_N_SAMPLES     64   /* N_samples    (coarse, RN:439)          */
+#define NSR_N_IMPORTANCE  128  /* N_importance (fine,   RN:474)          */
+#define NSR_NET_WIDTH     256  /* netwidth                               */
+#define NSR_NET_DEPTH     8    /* netdepth, skip after layer 4 (RN:269)  */
+#define NSR_MULTIRES      10   /* -> 63 position channels (RH:51-66)     */
+#define NSR_MULTIRES_VIEWS 4   /* -> 27 direction channels               */
+
+/* Size in floats of one packed network as produced by the host packer (pack.py / nsr_pack_layout). */
+#define NSR_SLAB_FLOATS   4096                 /* one 16 KiB LDS ring slab                          */
+#define NSR_STREAM_SLABS  145                  /* slabs per network pass                            */
+#define NSR_AUX_FLOATS    3328                 /* biases + alpha/rgb heads, 13 KiB                  */
+#define NSR_PACKED_FLOATS (NSR_STREAM_SLABS * NSR_SLAB_FLOATS + NSR_AUX_FLOATS)
+
+typedef struct nsr_handle_s* nsr_handle;
+
+typedef struct NsrConfig {
+  int32_t abi_version;     /* must be NSR_ABI_VERSION                                              */
+  int32_t device;          /* HIP device ordinal                                                   */
+  int32_t n_samples;       /* must be 64                                                           */
+  int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1)               */
+  int32_t max_workgroups;  /* 0 = one persistent workgroup per CU                                  */
+  int32_t reserved[3];
+} NsrConfig;
+
+/* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
+typedef struct NsrDebugOut {
+  float*   d_weights0;   /* [N,64]   coarse weights             (RN:467)   */
+  float*   d_z_samples;  /* [N,128]  importance samples         (RH:241)   */
+  int64_t* d_inds;       /* [N,128]  searchsorted indices       (RH:227)   */
+  float*   d_z_fine;     /* [N,192]  sorted merged z            (RN:477)   */
+  float*   d_raw0;       /* [N,64,4] coarse network output      (RN:466)   */
+  float*   d_raw;        /* [N,192,4] fine network output       (RN:483)   */
+} NsrDebugOut;
+
+typedef struct NsrRenderOut {
+  float* d_rgb;    /* [N,3]  rgb_map  (fine, or coarse when n_importance==0) */
+  float* d_disp;   /* [N]    disp_map */
+  float* d_acc;    /* [N]    acc_map  */
+  float* d_rgb0;   /* [N,3]  coarse rgb_map  (NULL allowed)                  */
+  float* d_disp0;  /* [N]                                                     */
+  float* d_acc0;   /* [N]                                                     */
+  float* d_z_std;  /* [N]    std of the importance samples (RN:495)           */
+} NsrRenderOut;
+
+const char* nsr_last_error(void);
+int nsr_abi_version(void);
+
+/* create_nerf (RN:258-340): allocates device-side weight storage + tables for one model. */
+int nsr_create(const NsrConfig* cfg, nsr_handle* out);
+int nsr_destroy(nsr_handle h);
+
+/* Weight upload: `packed` is a HOST buffer of NSR_PACKED_FLOATS floats in the kernel layout
+ * (pack.py).  net_id 0 = network_fn (coarse), 1 = network_fine.  Replaces the .to(device) of RN:269-278. */
+int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_floats);
+
+/* The two linspace tables the reference builds on the host and moves to the device
+ * (RN:439 t_vals[64], RH:208 u[128]); host buffers. */
+int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine);
+
+/* render(rays=...) -> batchify_rays -> render_rays (RN:58-123, RN:43-55, RN:390-501), use_viewdirs=True,
+ * ndc=False, perturb=0, raw_noise_std=0, white_bkgd=False, lindisp=False.
+ * d_rays_o, d_rays_d: [N,3].  viewdirs = rays_d/|rays_d| are computed in-kernel (RN:97). */
+int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
+                    float near_, float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream);
+
+/* render(c2w=...) for a batch of views (RN:84-86 get_rays + the above; render_path's loop RN:229-235 is
+ * folded into one launch).  d_c2w: [n_views,3,4] row-major; K9: HOST 3x3 intrinsics (row-major, as the
+ * python floats of LL:177); ray r of view v is pixel (row = r / W, col = r % W); outputs are
+ * [n_views*H*W, ...].  Rays are generated in-kernel: no HBM traffic for ray origins/directions. */
+int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9,
+                     float near_, float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream);
+
+/* Stage entry points (same device code as the fused kernel; used by the parity tests and usable alone). */
+
+/* get_rays (RH:156-165): d_rays_o, d_rays_d [H*W,3] for one c2w [3,4]. */
+int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K9,
+                 float* d_rays_o, float* d_rays_d, void* stream);
+
+/* run_network (RN:26-40) = Embedder (RH:18-48) + NeRF MLP (RH:99-122): d_pts [P,3], d_viewdirs [P,3]
+ * (already unit length) -> d_raw [P,4]. */
+int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts,
+                    float* d_raw, void* stream);
+
+/* raw2outputs (RN:343-387), n_samples in {64,192}: d_raw [N,S,4], d_z [N,S], d_rays_d [N,3]. */
+int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays,
+                    int n_samples, float* d_rgb, float* d_disp, float* d_acc, float* d_weights, float* d_depth,
+                    void* stream);
+
+/* sample_pdf (RH:199-243), det=True: d_bins [N,63], d_weights [N,62] -> d_samples [N,128], d_inds [N,128]. */
+int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, int64_t n_rays,
+                   float* d_samples, int64_t* d_inds, void* stream);
+
+/* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
+int nsr_selftest(nsr_handle h, void* stream);
+
+/* Timing helper for bench.py: HIP-event time in ms of the last nsr_render_* launch on this handle
+ * (events recorded on the launch stream; this call synchronises on the stop event). */
+int nsr_last_kernel_ms(nsr_handle h, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_H_ */

@@ -1,0 +1,79 @@
+"""ctypes binding of csrc/libnsr.so (C ABI: include/nsr.h).  This is the binding a maintainer of the reference
+would add next to utils/run_nerf_noscale.py.  No fallback: if the library is missing or
+was not built for the device at hand, every entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnsr.so")
+
+ABI_VERSION = 1
+PACKED_FLOATS = 145 * 4096 + 3328
+
+
+class NsrConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_samples", C.c_int32),
+                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class NsrDebugOut(C.Structure):
+    _fields_ = [("d_weights0", C.c_void_p), ("d_z_samples", C.c_void_p), ("d_inds", C.c_void_p),
+                ("d_z_fine", C.c_void_p), ("d_raw0", C.c_void_p), ("d_raw", C.c_void_p)]
+
+
+class NsrRenderOut(C.Structure):
+    _fields_ = [("d_rgb", C.c_void_p), ("d_disp", C.c_void_p), ("d_acc", C.c_void_p), ("d_rgb0", C.c_void_p),
+                ("d_disp0", C.c_void_p), ("d_acc0", C.c_void_p), ("d_z_std", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/nsr.h declares
+SIGNATURES = {
+    "nsr_last_error": (C.c_char_p, []),
+    "nsr_abi_version": (C.c_int, []),
+    "nsr_create": (C.c_int, [C.POINTER(NsrConfig), C.POINTER(C.c_void_p)]),
+    "nsr_destroy": (C.c_int, [C.c_void_p]),
+    "nsr_upload_weights": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "nsr_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "nsr_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                  C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut), C.c_void_p]),
+    "nsr_render_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                   C.c_float, C.c_float, C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut),
+                                   C.c_void_p]),
+    "nsr_get_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p,
+                               C.c_void_p, C.c_void_p]),
+    "nsr_run_network": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nsr_raw2outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsr_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsr_selftest": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nsr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class NsrError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol.  Raises NsrError if it is missing (no fallback path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NsrError("libnsr.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; "
+                       "g.build()' or make -C neural-sim-nerf_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so is stale
+        fn.restype, fn.argtypes = res, args
+    if lib.nsr_abi_version() != ABI_VERSION:
+        raise NsrError("libnsr.so ABI version %d, binding expects %d" % (lib.nsr_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NsrError(load().nsr_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,283 @@
+// nsr_api.hip -- C ABI (include/nsr.h) over the kernels in nsr_kernels.hip.  Host side only: argument
+// checking, weight/table residency, launches, HIP-event timing.  No torch types, no hidden synchronisation on
+// the hot path.
+#include "nsr_kernels.hip"
+
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/nsr.h"
+
+static_assert(NSR_SLAB_FLOATS == nsr::kSlabFloats, "header/kernels out of sync");
+static_assert(NSR_STREAM_SLABS == nsr::kStreamSlabs, "header/kernels out of sync");
+static_assert(NSR_AUX_FLOATS == nsr::kAuxFloats, "header/kernels out of sync");
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+
+#define NSR_HIP(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
+constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
+
+}  // namespace
+
+struct nsr_handle_s {
+  NsrConfig cfg;
+  int n_cu = 0;
+  float* d_packed[2] = {nullptr, nullptr};
+  bool have_net[2] = {false, false};
+  float* d_tables = nullptr;  // [64] + [128]
+  bool have_tables = false;
+  float* d_scratch = nullptr;  // selftest
+  nsr::RenderArgs* d_args = nullptr;  // kernel argument block (device), one per handle
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+};
+
+extern "C" {
+
+const char* nsr_last_error(void) { return g_err.c_str(); }
+int nsr_abi_version(void) { return NSR_ABI_VERSION; }
+
+int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
+  if (!cfg || !out) return fail("nsr_create: null argument");
+  if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
+  if (cfg->n_samples != NSR_N_SAMPLES)
+    return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
+  if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0)
+    return fail("nsr_create: unsupported N_importance (128, or 0 for coarse-only)");
+  int ndev = 0;
+  NSR_HIP(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail("nsr_create: no such HIP device");
+  NSR_HIP(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  NSR_HIP(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(std::string("nsr_create: this library is built for gfx950 (MI355X), device is ") + prop.gcnArchName);
+  nsr_handle h = new nsr_handle_s();
+  h->cfg = *cfg;
+  h->n_cu = prop.multiProcessorCount;
+  for (int i = 0; i < 2; ++i) NSR_HIP(hipMalloc(&h->d_packed[i], sizeof(float) * NSR_PACKED_FLOATS));
+  NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
+  NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
+  NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
+  NSR_HIP(hipEventCreate(&h->ev0));
+  NSR_HIP(hipEventCreate(&h->ev1));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_run_network, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNetLds));
+  *out = h;
+  return 0;
+}
+
+int nsr_destroy(nsr_handle h) {
+  if (!h) return 0;
+  hipSetDevice(h->cfg.device);
+  hipDeviceSynchronize();
+  for (int i = 0; i < 2; ++i) hipFree(h->d_packed[i]);
+  hipFree(h->d_tables);
+  hipFree(h->d_scratch);
+  hipFree(h->d_args);
+  hipEventDestroy(h->ev0);
+  hipEventDestroy(h->ev1);
+  delete h;
+  return 0;
+}
+
+int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_floats) {
+  if (!h || !packed) return fail("nsr_upload_weights: null argument");
+  if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights: net_id must be 0 (coarse) or 1 (fine)");
+  if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights: wrong packed size");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_HIP(hipMemcpy(h->d_packed[net_id], packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  h->have_net[net_id] = true;
+  return 0;
+}
+
+int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine) {
+  if (!h || !t_coarse || !u_fine) return fail("nsr_upload_tables: null argument");
+  if (n_coarse != 64 || n_fine != 128) return fail("nsr_upload_tables: tables must have 64 and 128 entries");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_HIP(hipMemcpy(h->d_tables, t_coarse, sizeof(float) * 64, hipMemcpyHostToDevice));
+  NSR_HIP(hipMemcpy(h->d_tables + 64, u_fine, sizeof(float) * 128, hipMemcpyHostToDevice));
+  h->have_tables = true;
+  return 0;
+}
+
+static int check_ready(nsr_handle h, bool need_fine) {
+  if (!h) return fail("null handle");
+  if (!h->have_tables) return fail("tables not uploaded (nsr_upload_tables)");
+  if (!h->have_net[0]) return fail("coarse network not uploaded (nsr_upload_weights net_id 0)");
+  if (need_fine && !h->have_net[1]) return fail("fine network not uploaded (nsr_upload_weights net_id 1)");
+  return 0;
+}
+
+static int grid_for(nsr_handle h, long long n_items) {
+  long long g = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : h->n_cu;
+  if (g > n_items) g = n_items;
+  return (int)(g < 1 ? 1 : g);
+}
+
+static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* out, const NsrDebugOut* dbg,
+                         void* stream) {
+  const bool fine = h->cfg.n_importance > 0;
+  if (int e = check_ready(h, fine)) return e;
+  if (!out || !out->d_rgb || !out->d_disp || !out->d_acc) return fail("render: rgb/disp/acc outputs are required");
+  if (a.n_rays <= 0) return 0;
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  a.stream[0] = h->d_packed[0];
+  a.stream[1] = h->d_packed[fine ? 1 : 0];
+  a.aux[0] = h->d_packed[0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.aux[1] = h->d_packed[fine ? 1 : 0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.tcoarse = h->d_tables;
+  a.ufine = h->d_tables + 64;
+  a.fine = fine ? 1 : 0;
+  a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc;
+  a.rgb0 = out->d_rgb0; a.disp0 = out->d_disp0; a.acc0 = out->d_acc0; a.z_std = out->d_z_std;
+  a.dbg_w0 = dbg ? dbg->d_weights0 : nullptr;
+  a.dbg_zs = dbg ? dbg->d_z_samples : nullptr;
+  a.dbg_zf = dbg ? dbg->d_z_fine : nullptr;
+  a.dbg_raw0 = dbg ? dbg->d_raw0 : nullptr;
+  a.dbg_raw = dbg ? dbg->d_raw : nullptr;
+  a.dbg_inds = dbg ? (long long*)dbg->d_inds : nullptr;
+  const long long n_items = (a.n_rays + 1) / 2;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);
+  NSR_HIP(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(nsr::k_render, dim3(grid_for(h, n_items)), dim3(256), kRenderLds, s,
+                     (const nsr::RenderArgs*)h->d_args);
+  NSR_HIP(hipGetLastError());
+  NSR_HIP(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  return 0;
+}
+
+int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                    float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
+  if (!d_rays_o || !d_rays_d) return fail("nsr_render_rays: null rays");
+  if (n_rays < 0) return fail("nsr_render_rays: negative ray count");
+  nsr::RenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.n_rays = n_rays; a.near_ = near_; a.far_ = far_; a.camera = 0;
+  return launch_render(h, a, out, dbg, stream);
+}
+
+int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9, float near_,
+                     float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
+  if (!d_c2w || !K9) return fail("nsr_render_views: null argument");
+  if (n_views < 0 || H <= 0 || W <= 0) return fail("nsr_render_views: bad image geometry");
+  nsr::RenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.c2w = d_c2w; a.H = H; a.W = W; a.n_rays = (long long)n_views * H * W; a.near_ = near_; a.far_ = far_;
+  a.camera = 1;
+  a.fx = (float)K9[0]; a.cx = (float)K9[2]; a.fy = (float)K9[4]; a.cy = (float)K9[5];   // RH:160 (fp32 tensor op)
+  return launch_render(h, a, out, dbg, stream);
+}
+
+int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K9, float* d_rays_o,
+                 float* d_rays_d, void* stream) {
+  if (!h || !d_c2w || !K9 || !d_rays_o || !d_rays_d) return fail("nsr_get_rays: null argument");
+  if (H <= 0 || W <= 0) return fail("nsr_get_rays: bad image geometry");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const int n = H * W;
+  hipLaunchKernelGGL(nsr::k_get_rays, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_c2w, (float)K9[0],
+                     (float)K9[4], (float)K9[2], (float)K9[5], H, W, d_rays_o, d_rays_d);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts,
+                    float* d_raw, void* stream) {
+  if (!h || !d_pts || !d_viewdirs || !d_raw) return fail("nsr_run_network: null argument");
+  if (net_id < 0 || net_id > 1 || !h->have_net[net_id]) return fail("nsr_run_network: network not uploaded");
+  if (n_pts <= 0) return n_pts == 0 ? 0 : fail("nsr_run_network: negative point count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  nsr::NetArgs a;
+  a.stream = h->d_packed[net_id];
+  a.aux = h->d_packed[net_id] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.pts = d_pts; a.dirs = d_viewdirs; a.raw = d_raw; a.n_pts = n_pts;
+  const long long tiles = (n_pts + 127) / 128;
+  hipLaunchKernelGGL(nsr::k_run_network, dim3(grid_for(h, tiles)), dim3(256), kNetLds, (hipStream_t)stream, a);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays,
+                    int n_samples, float* d_rgb, float* d_disp, float* d_acc, float* d_weights, float* d_depth,
+                    void* stream) {
+  if (!h || !d_raw || !d_z || !d_rays_d || !d_rgb || !d_disp || !d_acc || !d_weights || !d_depth)
+    return fail("nsr_raw2outputs: null argument");
+  if (n_samples != 64 && n_samples != 192) return fail("nsr_raw2outputs: n_samples must be 64 or 192");
+  if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_raw2outputs: negative ray count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  nsr::R2OArgs a{d_raw, d_z, d_rays_d, n_rays, d_rgb, d_disp, d_acc, d_weights, d_depth};
+  const long long items = (n_rays + 1) / 2;
+  const int grid = (int)(items < 4096 ? items : 4096);
+  if (n_samples == 64)
+    hipLaunchKernelGGL(nsr::k_raw2outputs<64>, dim3(grid), dim3(256), sizeof(nsr::ItemState), (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(nsr::k_raw2outputs<192>, dim3(grid), dim3(256), sizeof(nsr::ItemState), (hipStream_t)stream, a);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, int64_t n_rays, float* d_samples,
+                   int64_t* d_inds, void* stream) {
+  if (!h || !d_bins || !d_weights || !d_samples) return fail("nsr_sample_pdf: null argument");
+  if (!h->have_tables) return fail("nsr_sample_pdf: tables not uploaded");
+  if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_sample_pdf: negative ray count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  nsr::PdfArgs a{d_bins, d_weights, h->d_tables + 64, n_rays, d_samples, (long long*)d_inds};
+  const long long items = (n_rays + 1) / 2;
+  const int grid = (int)(items < 4096 ? items : 4096);
+  hipLaunchKernelGGL(nsr::k_sample_pdf, dim3(grid), dim3(256), sizeof(nsr::ItemState), (hipStream_t)stream, a);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_selftest(nsr_handle h, void* stream) {
+  if (!h) return fail("nsr_selftest: null handle");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nsr::k_selftest, dim3(1), dim3(64), 0, s, h->d_scratch);
+  NSR_HIP(hipGetLastError());
+  std::vector<float> host(64 * 16);
+  NSR_HIP(hipMemcpyAsync(host.data(), h->d_scratch, sizeof(float) * host.size(), hipMemcpyDeviceToHost, s));
+  NSR_HIP(hipStreamSynchronize(s));
+  // expected D[i][j] = sum_k A[i][k] B[k][j], lane l holds col j = l&31, rows (r&3)+8*(r>>2)+4*(l>>5)
+  for (int l = 0; l < 64; ++l)
+    for (int r = 0; r < 16; ++r) {
+      const int j = l & 31, i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      double want = 0;
+      for (int k = 0; k < 2; ++k) want += (1.0 + i + 100.0 * k) * (3.0 + 7.0 * j - 1000.0 * k);
+      if ((double)host[l * 16 + r] != want) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "nsr_selftest: MFMA 32x32x2 layout mismatch at lane %d reg %d: got %g want %g", l, r,
+                 (double)host[l * 16 + r], want);
+        return fail(buf);
+      }
+    }
+  return 0;
+}
+
+int nsr_last_kernel_ms(nsr_handle h, float* ms) {
+  if (!h || !ms) return fail("nsr_last_kernel_ms: null argument");
+  if (!h->timed) return fail("nsr_last_kernel_ms: no render launched yet");
+  NSR_HIP(hipEventSynchronize(h->ev1));
+  NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// nsr_device.h -- constants shared by the kernels, the host API and (via nsr_pack_layout) the Python packer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nsr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMultires = 10;        // NM:1268
+constexpr int kMultiresViews = 4;    // NM:1270
+constexpr int kRingSlots = 6;        // 16 KiB slabs resident in LDS
+constexpr int kSlabBytes = 16384;
+constexpr int kStepBytes = 8192;
+constexpr int kSlabFloats = 4096;
+// slabs per network pass: L0 4 | L1-4 64 | L5 skip 4 + 16 | L6-7 32 | feature 16 | views 9
+constexpr int kStreamSlabs = 145;
+
+// aux block (floats): biases in C-fragment order, alpha/rgb heads
+constexpr int kAuxBias = 0;          // 9 x 256 (pts_linears.0-7, feature_linear)
+constexpr int kAuxBiasV = 2304;      // 128      (views_linears.0)
+constexpr int kAuxWAlpha = 2432;     // 256      (alpha_linear.weight, B-operand order)
+constexpr int kAuxWRgb = 2688;       // 3 x 128  (rgb_linear.weight, C-fragment order of the views layer)
+constexpr int kAuxBAlpha = 3072;     // 1
+constexpr int kAuxBRgb = 3073;       // 3
+constexpr int kAuxFloats = 3328;     // padded to 13 KiB
+
+// LDS map of the fused kernel (bytes)
+constexpr int kLdsRing = 0;
+constexpr int kLdsAux = kRingSlots * kSlabBytes;              //  98304
+constexpr int kLdsState = kLdsAux + 2 * kAuxFloats * 4;       // 124928
+
+// global -> LDS DMA, 16 B per lane: LDS destination = wave-uniform base + lane*16 (M0), source per lane.
+#define NSR_GLDS16(gptr, lptr)                                                                        \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
+                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ f32x16 max16(f32x16 x, float lo) {
+  f32x16 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = fmaxf(x[i], lo);
+  return r;
+}
+__device__ __forceinline__ f32x16 relu16(f32x16 x) { return max16(x, 0.0f); }
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask);
+  hi = __shfl_xor(hi, mask);
+  return __hiloint2double(hi, lo);
+}
+
+}  // namespace nsr

@@ -1,0 +1,789 @@
+// nsr_kernels.hip -- MI355X (gfx950 / CDNA4) kernels of the NeRF volumetric render path.
+//
+// What this file replaces (reference gyhandy/Neural-Sim-NeRF, all pure-PyTorch op chains):
+//   RN = optimization/utils/run_nerf_noscale.py, RH = optimization/utils/run_nerf_helpers.py
+//   render_rays RN:390-501, batchify_rays RN:43-55, run_network RN:26-40, raw2outputs RN:343-387,
+//   Embedder RH:18-48, NeRF MLP RH:99-122, get_rays RH:156-165, sample_pdf RH:199-243.
+//
+// Design:
+//   * one persistent 256-thread workgroup per CU (4 waves, ONE wave per SIMD, up to 512 VGPR+AGPR each);
+//   * a work item = 2 rays = 1 coarse network pass (2x64 points) + 3 fine passes (2x192 points);
+//   * a network pass evaluates 128 points (32 per wave).  Activations never leave registers: every layer is
+//       H_out^T[256 x 32pts] = W[256 x K] * H_in^T[K x 32pts]
+//     on v_mfma_f32_32x32x2_f32 with the WEIGHTS as the A operand and the activations as the B operand, so
+//     the C/D fragment of layer L (lane = point, register = feature) is, register for register, the B
+//     operand of layer L+1.  The host packer permutes each weight matrix's K order to match (kappa below);
+//   * the weights (2.3 MiB fp32 per network, L2-resident) are streamed through a 6 x 16 KiB LDS ring by
+//     global_load_lds_dwordx4 (LDS-DMA), NS-1 slabs ahead, one s_barrier per 64 MFMAs; the packed global
+//     image IS the LDS image (lane-linear), read back with conflict-free ds_read_b128;
+//   * per-ray state (z values, raw network outputs, weights, cdf) lives in LDS; the transmittance scan and the
+//     cdf scan accumulate sequentially in fp64 exactly like torch-CPU cumprod/cumsum do;
+//   * arithmetic that feeds comparisons (cdf, searchsorted, inverse-CDF samples, sort) is IEEE fp32 op by op:
+//     this file is compiled with -ffp-contract=off and uses fmaf only where the reference has a GEMM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nsr_device.h"
+
+namespace nsr {
+
+// ------------------------------------------------------------------------------------------------------
+// ring (LDS weight stream)
+// ------------------------------------------------------------------------------------------------------
+struct Ring {
+  char* smem;            // LDS base (generic pointer)
+  const char* net[2];    // packed streams (global), coarse / fine
+  const char* psrc;      // producer: current net base + this lane's offset (wave*4096 + lane*16)
+  int lane_off;          // wave*4096 + lane*16
+  int wave_lds;          // wave*4096
+  int pslab;             // producer: next slab index within the pass stream
+  int pslot;             // producer: next ring slot
+  int pphase;            // producer: pass index within the item (0 = coarse net)
+  int ppi;               // passes per item (1 or 4)
+  int cslot;             // consumer: slot of the slab being consumed
+};
+
+__device__ __forceinline__ void ring_issue(Ring& rg) {
+  const char* g = rg.psrc + (size_t)rg.pslab * kSlabBytes;
+  char* l = rg.smem + rg.pslot * kSlabBytes + rg.wave_lds;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) NSR_GLDS16(g + c * 1024, l + c * 1024);
+  rg.pslot = (rg.pslot + 1 == kRingSlots) ? 0 : rg.pslot + 1;
+  if (++rg.pslab == kStreamSlabs) {
+    rg.pslab = 0;
+    rg.pphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
+    rg.psrc = rg.net[rg.pphase == 0 ? 0 : 1] + rg.lane_off;
+  }
+}
+
+// Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
+__device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[8], int lane) {
+#pragma unroll 1
+  for (int s = 0; s < kRingSlots; ++s) ring_issue(rg);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRingSlots - 1)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) A0[c] = *(const f32x4*)(p + c * 1024);
+}
+
+// Even step: the second half of the current slab is already certified; fetch it.
+__device__ __forceinline__ void ring_load_second(const Ring& rg, f32x4 (&A)[8], int lane) {
+  const char* p = rg.smem + rg.cslot * kSlabBytes + kStepBytes + lane * 16;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) A[c] = *(const f32x4*)(p + c * 1024);
+}
+
+// Odd step: all of this wave's reads of the current slab are complete after lgkmcnt(0); my share of the next
+// slab has landed after the counted vmcnt; the barrier makes both true for the whole workgroup, so the slot
+// of the current slab can be refilled (slab n+NS) and the next slab's first half can be read.
+__device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[8], int lane) {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (kRingSlots - 2)) : "memory");
+  __builtin_amdgcn_s_barrier();
+  ring_issue(rg);  // refills the slot that was just drained (pslot == cslot here)
+  rg.cslot = (rg.cslot + 1 == kRingSlots) ? 0 : rg.cslot + 1;
+  const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) A[c] = *(const f32x4*)(p + c * 1024);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// MFMA steps.  A step = 8 KiB of weights = 8 float4 fragments per lane = 32 MFMAs.
+// ------------------------------------------------------------------------------------------------------
+#define NSR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// 8 output blocks x 4 k-steps; b0..b3 are this lane's B operands (activation values) for the 4 k-steps.
+__device__ __forceinline__ void mfma_step8(const f32x4 (&A)[8], float b0, float b1, float b2, float b3,
+                                           f32x16 (&acc)[8]) {
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][0], b0, acc[mo]);
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][1], b1, acc[mo]);
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][2], b2, acc[mo]);
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][3], b3, acc[mo]);
+}
+
+// views layer: 4 output blocks x 8 k-steps (fragment c: k-quad c>>2, block c&3)
+__device__ __forceinline__ void mfma_step4(const f32x4 (&A)[8], const float (&b)[8], f32x16 (&acc)[4]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int mo = 0; mo < 4; ++mo) acc[mo] = NSR_MFMA(A[q * 4 + mo][kk], b[q * 4 + kk], acc[mo]);
+}
+
+// K segment fed from 32 "encoding" registers (layer 0, and the skip columns of layer 5): 8 steps = 4 slabs.
+__device__ __forceinline__ void seg_enc(Ring& rg, f32x4 (&A0)[8], f32x4 (&A1)[8], const float (&e)[32],
+                                        f32x16 (&acc)[8], int lane) {
+#pragma unroll
+  for (int tq = 0; tq < 8; tq += 2) {
+    ring_load_second(rg, A1, lane);
+    mfma_step8(A0, e[4 * tq + 0], e[4 * tq + 1], e[4 * tq + 2], e[4 * tq + 3], acc);
+    ring_advance(rg, A0, lane);
+    mfma_step8(A1, e[4 * tq + 4], e[4 * tq + 5], e[4 * tq + 6], e[4 * tq + 7], acc);
+  }
+}
+
+// K = 256 segment fed from the previous layer's output registers: 32 steps = 16 slabs, 1024 MFMAs.
+__device__ __forceinline__ void seg_main(Ring& rg, f32x4 (&A0)[8], f32x4 (&A1)[8], const f32x16 (&in)[8],
+                                         f32x16 (&acc)[8], int lane) {
+#pragma unroll
+  for (int tq = 0; tq < 32; tq += 2) {
+    ring_load_second(rg, A1, lane);
+    mfma_step8(A0, in[tq >> 2][(tq & 3) * 4 + 0], in[tq >> 2][(tq & 3) * 4 + 1], in[tq >> 2][(tq & 3) * 4 + 2],
+               in[tq >> 2][(tq & 3) * 4 + 3], acc);
+    ring_advance(rg, A0, lane);
+    mfma_step8(A1, in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 0], in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 1],
+               in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 2], in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 3], acc);
+  }
+}
+
+// views layer: K = 256 (feature, registers) + 32 (direction encoding), 128 outputs: 18 steps = 9 slabs.
+__device__ __forceinline__ void seg_views(Ring& rg, f32x4 (&A0)[8], f32x4 (&A1)[8], const f32x16 (&in)[8],
+                                          const float (&ed)[16], f32x16 (&acc)[4], int lane) {
+#pragma unroll
+  for (int s = 0; s < 18; s += 2) {
+    float b[8];
+    ring_load_second(rg, A1, lane);
+    if (s < 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i] = in[(8 * s + i) >> 4][(8 * s + i) & 15];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i] = ed[8 * (s - 16) + i];
+    }
+    mfma_step4(A0, b, acc);
+    ring_advance(rg, A0, lane);
+    if (s + 1 < 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i] = in[(8 * (s + 1) + i) >> 4][(8 * (s + 1) + i) & 15];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) b[i] = ed[8 * (s + 1 - 16) + i];
+    }
+    mfma_step4(A1, b, acc);
+  }
+}
+
+// accumulator init = bias in C-fragment order (aux layout: [(mo*4+rq)*2+h] float4)
+template <int NMO>
+__device__ __forceinline__ void load_bias(const float* bias, int h, f32x16 (&acc)[NMO]) {
+#pragma unroll
+  for (int mo = 0; mo < NMO; ++mo)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      f32x4 v = *(const f32x4*)(bias + ((mo * 4 + rq) * 2 + h) * 4);
+      acc[mo][rq * 4 + 0] = v[0];
+      acc[mo][rq * 4 + 1] = v[1];
+      acc[mo][rq * 4 + 2] = v[2];
+      acc[mo][rq * 4 + 3] = v[3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// One network pass for this lane's point.  Lane (j = lane&31, h = lane>>5): both halves work on point j and
+// hold complementary halves of every feature vector.  Returns raw = (r,g,b logits, sigma) in all lanes.
+//   Embedder RH:18-48 (in-register), NeRF.forward RH:99-122.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[8], f32x4 (&A1)[8], int lane,
+                                         float px, float py, float pz, float vx, float vy, float vz,
+                                         float (&raw)[4]) {
+  const int h = lane >> 5;
+  float e[32];   // position encoding, k-step t: h=0 -> sin(2^L p_ax), h=1 -> cos(2^L p_ax), t = 3L+ax
+  float ed[16];  // direction encoding, same scheme with L < 4
+  {
+    const float p[3] = {px, py, pz};
+#pragma unroll
+    for (int L = 0; L < kMultires; ++L)
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        float s, c;
+        sincosf(p[ax] * (float)(1 << L), &s, &c);
+        e[3 * L + ax] = h ? c : s;
+      }
+    e[30] = h ? pz : px;
+    e[31] = h ? 0.0f : py;
+    const float v[3] = {vx, vy, vz};
+#pragma unroll
+    for (int L = 0; L < kMultiresViews; ++L)
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        float s, c;
+        sincosf(v[ax] * (float)(1 << L), &s, &c);
+        ed[3 * L + ax] = h ? c : s;
+      }
+    ed[12] = h ? vz : vx;
+    ed[13] = h ? 0.0f : vy;
+    ed[14] = 0.0f;
+    ed[15] = 0.0f;
+  }
+
+  f32x16 acc[8];
+  f32x16 in[8];
+  // layer 0
+  load_bias<8>(aux + kAuxBias, h, acc);
+  seg_enc(rg, A0, A1, e, acc, lane);
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
+
+  float alpha_part = 0.0f;
+  // layers 1..7 (ReLU) and 8 = feature_linear (no activation)
+#pragma unroll 1
+  for (int L = 1; L <= 8; ++L) {
+    load_bias<8>(aux + kAuxBias + L * 256, h, acc);
+    if (L == 5) seg_enc(rg, A0, A1, e, acc, lane);  // skip: cat([input_pts, h]) -> input columns first (RH:105)
+    if (L == 8) {
+      // alpha_linear on h7 (RH:109): VALU dot product over this lane's 128 features, halves summed below
+      const float* wa = aux + kAuxWAlpha;
+#pragma unroll
+      for (int tq = 0; tq < 32; ++tq) {
+        f32x4 w = *(const f32x4*)(wa + (tq * 2 + h) * 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          alpha_part = __builtin_fmaf(w[kk], in[(4 * tq + kk) >> 4][(4 * tq + kk) & 15], alpha_part);
+      }
+    }
+    seg_main(rg, A0, A1, in, acc, lane);
+    const float lo = (L == 8) ? -__builtin_inff() : 0.0f;
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) in[mo] = max16(acc[mo], lo);
+  }
+
+  // views_linears.0 (RH:111-115): cat([feature, input_views]) -> 128, ReLU
+  f32x16 av[4];
+  load_bias<4>(aux + kAuxBiasV, h, av);
+  seg_views(rg, A0, A1, in, ed, av, lane);
+
+  // rgb_linear (RH:117) on relu(av): VALU
+  float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* wr = aux + kAuxWRgb + c * 128;
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        f32x4 w = *(const f32x4*)(wr + ((mo * 4 + rq) * 2 + h) * 4);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri)
+          part[c] = __builtin_fmaf(w[ri], fmaxf(av[mo][rq * 4 + ri], 0.0f), part[c]);
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float other = __shfl_xor(part[c], 32);
+    float lo_half = h ? other : part[c];
+    float hi_half = h ? part[c] : other;
+    raw[c] = (lo_half + hi_half) + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// per-item state in LDS (2 rays)
+// ------------------------------------------------------------------------------------------------------
+struct ItemState {
+  float tcoarse[64];        // torch.linspace(0,1,64)   RN:439
+  float ufine[128];         // torch.linspace(0,1,128)  RH:208
+  float ray[2][16];         // o[0..2] d[3..5] viewdir[6..8] near far |d|
+  float zc[2][64];          // coarse z               RN:441
+  float rawc[2][64][4];     // coarse raw             RN:466
+  float w0[2][64];          // coarse weights         RN:467
+  float cdf[2][64];         // 63 used                RH:203-204
+  float zs[2][128];         // importance samples     RH:241
+  float zf[2][192];         // sorted merged z        RN:477
+  float rawf[2][192][4];    // fine raw               RN:483
+  float alpha[2][192];      // compositing scratch
+  float wf[2][192];         // fine weights           RN:485
+  float res[2][8];          // rgb(3) disp acc depth
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// raw2outputs RN:343-387 for both rays of the item.  z: [2][S], raw: [2][S][4] (rgb overwritten by sigmoid),
+// wout: [2][S] weights.  Results in st.res.
+template <int S>
+__device__ __forceinline__ void composite(ItemState& st, const float* z, float* raw, float* wout, int tid) {
+  for (int idx = tid; idx < 2 * S; idx += 256) {
+    const int r = idx / S, i = idx - r * S;
+    const float* zr = z + r * S;
+    float dist = (i < S - 1) ? (zr[i + 1] - zr[i]) : 1e10f;   // RN:358-359
+    dist = dist * st.ray[r][11];                               // RN:361
+    float* q = raw + (r * S + i) * 4;
+    const float sigma = fmaxf(q[3], 0.0f);
+    st.alpha[r][i] = 1.0f - expf(-sigma * dist);               // RN:356
+    q[0] = sigmoidf_(q[0]);                                    // RN:363
+    q[1] = sigmoidf_(q[1]);
+    q[2] = sigmoidf_(q[2]);
+  }
+  __syncthreads();
+  if ((tid & 63) == 0 && tid < 128) {
+    const int r = tid >> 6;
+    const float* zr = z + r * S;
+    const float* q = raw + r * S * 4;
+    double T = 1.0;  // torch-CPU cumprod: sequential, fp64 accumulator, every prefix rounded to fp32 (RN:376)
+    float cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, acc = 0.f;
+#pragma unroll 4
+    for (int i = 0; i < S; ++i) {
+      const float a = st.alpha[r][i];
+      const float w = a * (float)T;
+      wout[r * S + i] = w;
+      cr = cr + w * q[i * 4 + 0];
+      cg = cg + w * q[i * 4 + 1];
+      cb = cb + w * q[i * 4 + 2];
+      depth = depth + w * zr[i];
+      acc = acc + w;
+      T = T * (double)((1.0f - a) + 1e-10f);
+    }
+    const float qd = depth / acc;
+    float disp;
+    if (qd != qd) disp = qd;                                   // 0/0 -> NaN propagates through torch.max (RN:381)
+    else disp = 1.0f / fmaxf(1e-10f, qd);
+    st.res[r][0] = cr; st.res[r][1] = cg; st.res[r][2] = cb;
+    st.res[r][3] = disp; st.res[r][4] = acc; st.res[r][5] = depth;
+  }
+  __syncthreads();
+}
+
+// sample_pdf RH:199-243 (det=True) for both rays: weights w[r][0..61] (= coarse weights[1:-1]), bins = mid-points.
+// Writes st.cdf, st.zs; optional inds.  `bins` is a callable: bins(r, k), k in 0..62.
+template <typename BinsFn>
+__device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*[2][stride]*/, int wstride,
+                                                BinsFn bins, int64_t* inds_out /*[2][128] or null*/,
+                                                int64_t inds_stride, int tid, int valid_rays) {
+  if ((tid & 63) == 0 && tid < 128) {
+    const int r = tid >> 6;
+    const float* wr = w + r * wstride;
+    float x[62];
+#pragma unroll
+    for (int i = 0; i < 62; ++i) x[i] = wr[i] + 1e-5f;          // RH:201
+    // torch.sum over 62 contiguous floats: ATen's 8-lane x 4-ILP cascade (RH:202), exact association order
+    float lanes[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float p0 = ((x[j] + x[32 + j]) + x[40 + j]) + x[48 + j];
+      lanes[j] = ((p0 + x[8 + j]) + x[16 + j]) + x[24 + j];
+    }
+    float total = 0.0f;
+#pragma unroll
+    for (int i = 56; i < 62; ++i) total = total + x[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) total = total + lanes[j];
+    // cdf = [0, cumsum(pdf)]: sequential fp64 accumulator, each prefix rounded to fp32 (RH:203-204)
+    double run = 0.0;
+    st.cdf[r][0] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 62; ++i) {
+      run = run + (double)(x[i] / total);
+      st.cdf[r][i + 1] = (float)run;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 7, k = tid & 127;
+    const float u = st.ufine[k];
+    const float* cdf = st.cdf[r];
+    // searchsorted(cdf, u, right=True): number of entries <= u among 63 (RH:227)
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int ind = lo;
+    const int below = max(ind - 1, 0);
+    const int above = min(ind, 62);
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = bins(r, below), b1 = bins(r, above);
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;                            // RH:238-239
+    const float t = (u - c0) / denom;
+    st.zs[r][k] = b0 + t * (b1 - b0);                           // RH:241
+    if (inds_out && r < valid_rays) inds_out[r * inds_stride + k] = (int64_t)ind;
+  }
+  __syncthreads();
+}
+
+// std(z_samples, unbiased=False) RN:495, fp64 two-pass; result valid in lane 0 of waves 0 / 1 (ray = wave).
+__device__ __forceinline__ float zstd_wave(const ItemState& st, int r, int lane) {
+  double s = (double)st.zs[r][lane] + (double)st.zs[r][lane + 64];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) s += shfl_xor_f64(s, m);
+  const double mean = s * (1.0 / 128.0);
+  const double d0 = (double)st.zs[r][lane] - mean, d1 = (double)st.zs[r][lane + 64] - mean;
+  double v = d0 * d0 + d1 * d1;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+  return (float)sqrt(v * (1.0 / 128.0));
+}
+
+// z_vals = sort(cat([z_coarse, z_samples])) RN:477 by rank counting (no sortedness assumption).
+__device__ __forceinline__ void merge_sort_item(ItemState& st, int tid) {
+  for (int e = tid; e < 384; e += 256) {
+    const int r = e / 192, k = e - r * 192;
+    const float x = (k < 64) ? st.zc[r][k] : st.zs[r][k - 64];
+    int rank = 0;
+    for (int j = 0; j < 64; ++j) {
+      const float y = st.zc[r][j];
+      rank += (y < x) || (y == x && j < k);
+    }
+    for (int j = 0; j < 128; ++j) {
+      const float y = st.zs[r][j];
+      rank += (y < x) || (y == x && (j + 64) < k);
+    }
+    st.zf[r][rank] = x;
+  }
+  __syncthreads();
+}
+
+// get_rays RH:156-165 for pixel (row, col); cam = {c2w[12], fx, fy, cx, cy}
+__device__ __forceinline__ void gen_ray(const float* __restrict__ c2w, float fx, float fy, float cx, float cy,
+                                        int row, int col, float (&o)[3], float (&d)[3]) {
+  const float dx = ((float)col - cx) / fx;
+  const float dy = -(((float)row - cy) / fy);
+  const float dz = -1.0f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    d[a] = ((dx * c2w[a * 4 + 0]) + (dy * c2w[a * 4 + 1])) + (dz * c2w[a * 4 + 2]);
+    o[a] = c2w[a * 4 + 3];
+  }
+}
+
+struct RenderArgs {
+  const float* stream[2];   // packed weight streams (coarse, fine)
+  const float* aux[2];      // aux blocks
+  const float* tcoarse;     // [64]
+  const float* ufine;       // [128]
+  const float* rays_o;      // [N,3]   (RAYS mode)
+  const float* rays_d;      // [N,3]
+  const float* c2w;         // [V,3,4] (CAMERA mode)
+  float fx, fy, cx, cy;
+  int H, W;
+  long long n_rays;
+  float near_, far_;
+  int fine;                 // 0: coarse only
+  int camera;               // 1: generate rays in-kernel
+  float *rgb, *disp, *acc, *rgb0, *disp0, *acc0, *z_std;
+  float *dbg_w0, *dbg_zs, *dbg_zf, *dbg_raw0, *dbg_raw;
+  long long* dbg_inds;
+};
+
+__device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
+  float* dst = (float*)(smem + kLdsAux);
+  for (int i = tid; i < kAuxFloats; i += 256) {
+    dst[i] = a.aux[0][i];
+    dst[kAuxFloats + i] = a.aux[1][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The fused persistent render kernel.
+// ------------------------------------------------------------------------------------------------------
+// Argument block transport: the launcher writes the block to device memory with a 1-thread kernel
+// (stream-ordered, no host staging buffer to keep alive), and the render kernel reads its fields with scalar
+// loads at the point of use -- by-value kernel arguments were all preloaded into SGPRs and cost 70 more SGPR
+// spills inside the MFMA passes.
+__global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; }
+
+__global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RenderArgs& a = *ap;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  ItemState& st = *(ItemState*)(smem + kLdsState);
+
+  const long long n_rays = a.n_rays;
+  const long long n_items = (n_rays + 1) >> 1;
+  if ((long long)blockIdx.x >= n_items) return;
+  const int fine = a.fine;
+
+  Ring rg;
+  rg.smem = smem;
+  rg.net[0] = (const char*)a.stream[0];
+  rg.net[1] = (const char*)a.stream[1];
+  rg.lane_off = wave * 4096 + lane * 16;
+  rg.wave_lds = wave * 4096;
+  rg.psrc = rg.net[0] + rg.lane_off;
+  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0;
+  rg.ppi = fine ? 4 : 1;
+
+  f32x4 A0[8], A1[8];
+  ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
+
+  load_aux(smem, a, tid);
+  if (tid < 64) st.tcoarse[tid] = a.tcoarse[tid];
+  if (tid < 128) st.ufine[tid] = a.ufine[tid];
+  __syncthreads();
+  const float* aux_c = (const float*)(smem + kLdsAux);
+
+  long long item = blockIdx.x;
+  int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current item
+#pragma unroll 1
+  while (item < n_items) {
+    const long long ray0 = item * 2;
+    const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
+    if (pass == 0) {
+      // ---- stage the two rays --------------------------------------------------------------------
+      const float near_ = a.near_, far_ = a.far_;
+      if (tid < 2) {
+        const long long rr = ray0 + (tid < valid ? tid : 0);
+        float o[3], d[3];
+        if (a.camera) {
+          const long long hw = (long long)a.H * a.W;
+          const long long v = rr / hw;
+          const int pix = (int)(rr - v * hw);
+          gen_ray(a.c2w + v * 12, a.fx, a.fy, a.cx, a.cy, pix / a.W, pix % a.W, o, d);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
+        }
+        const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));   // torch.norm RN:97, RN:361
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c]; st.ray[tid][6 + c] = d[c] / nrm; }
+        st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
+      }
+      if (tid < 128) {
+        const int r = tid >> 6, i = tid & 63;
+        const float t = st.tcoarse[i];
+        st.zc[r][i] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
+      }
+      __syncthreads();
+    }
+
+    // ---- one network pass: 128 points -------------------------------------------------------------
+    //   coarse: wave w -> ray w>>1, samples 32*(w&1) + j              (RN:463-466)
+    //   fine p: point q = 128(p-1) + 32w + j -> ray q/192, sample q%192 (RN:478-483)
+    {
+      int r, i;
+      const float* zsrc;
+      float* dst;
+      if (pass == 0) {
+        r = wave >> 1; i = 32 * (wave & 1) + j;
+        zsrc = &st.zc[r][i]; dst = st.rawc[r][i];
+      } else {
+        const int q0 = 128 * (pass - 1) + 32 * wave;
+        r = q0 / 192; i = q0 - r * 192 + j;
+        zsrc = &st.zf[r][i]; dst = st.rawf[r][i];
+      }
+      const float z = *zsrc;
+      const float* ry = st.ray[r];
+      float raw[4];
+      mlp_pass(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+               ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
+      if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    }
+
+    if (pass == 0) {
+      __syncthreads();
+      if (a.dbg_raw0) {
+        for (int idx = tid; idx < valid * 256; idx += 256) a.dbg_raw0[ray0 * 256 + idx] = (&st.rawc[0][0][0])[idx];
+        __syncthreads();
+      }
+      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], tid);
+      if (tid < valid * 8) {
+        const int r = tid >> 3, c = tid & 7;
+        const long long rr = ray0 + r;
+        const float v = st.res[r][c];
+        float* rgb_dst = fine ? a.rgb0 : a.rgb;
+        float* disp_dst = fine ? a.disp0 : a.disp;
+        float* acc_dst = fine ? a.acc0 : a.acc;
+        if (c < 3) { if (rgb_dst) rgb_dst[rr * 3 + c] = v; }
+        else if (c == 3) { if (disp_dst) disp_dst[rr] = v; }
+        else if (c == 4) { if (acc_dst) acc_dst[rr] = v; }
+      }
+      if (a.dbg_w0)
+        for (int idx = tid; idx < valid * 64; idx += 256) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
+      if (!fine) { __syncthreads(); item += gridDim.x; continue; }
+
+      // ---- hierarchical resampling ----------------------------------------------------------------
+      int64_t* inds = (int64_t*)a.dbg_inds;
+      sample_pdf_item(st, &st.w0[0][1], 64,
+                      [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
+                      inds ? inds + ray0 * 128 : nullptr, 128, tid, valid);
+      if (wave < 2) {
+        const float sd = zstd_wave(st, wave, lane);
+        if (lane == 0 && wave < valid && a.z_std) a.z_std[ray0 + wave] = sd;
+      }
+      if (a.dbg_zs)
+        for (int idx = tid; idx < valid * 128; idx += 256) a.dbg_zs[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
+      merge_sort_item(st, tid);
+      if (a.dbg_zf)
+        for (int idx = tid; idx < valid * 192; idx += 256) a.dbg_zf[ray0 * 192 + idx] = (&st.zf[0][0])[idx];
+      pass = 1;
+    } else if (pass < 3) {
+      ++pass;
+    } else {
+      __syncthreads();
+      if (a.dbg_raw) {
+        for (int idx = tid; idx < valid * 768; idx += 256) a.dbg_raw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
+        __syncthreads();
+      }
+      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], tid);
+      if (tid < valid * 8) {
+        const int r = tid >> 3, c = tid & 7;
+        const long long rr = ray0 + r;
+        const float v = st.res[r][c];
+        if (c < 3) { if (a.rgb) a.rgb[rr * 3 + c] = v; }
+        else if (c == 3) { if (a.disp) a.disp[rr] = v; }
+        else if (c == 4) { if (a.acc) a.acc[rr] = v; }
+      }
+      __syncthreads();
+      pass = 0;
+      item += gridDim.x;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+// ------------------------------------------------------------------------------------------------------
+// run_network (RN:26-40) as a stage kernel: 128 points per workgroup pass.
+// ------------------------------------------------------------------------------------------------------
+struct NetArgs {
+  const float* stream;
+  const float* aux;
+  const float* pts;     // [P,3]
+  const float* dirs;    // [P,3]
+  float* raw;           // [P,4]
+  long long n_pts;
+};
+
+__global__ void __launch_bounds__(256, 1) k_run_network(NetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long n_tiles = (a.n_pts + 127) >> 7;
+  if ((long long)blockIdx.x >= n_tiles) return;
+
+  Ring rg;
+  rg.smem = smem;
+  rg.net[0] = rg.net[1] = (const char*)a.stream;
+  rg.lane_off = wave * 4096 + lane * 16;
+  rg.wave_lds = wave * 4096;
+  rg.psrc = rg.net[0] + rg.lane_off;
+  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.ppi = 1;
+  f32x4 A0[8], A1[8];
+  ring_start(rg, A0, lane);
+  float* auxl = (float*)(smem + kLdsAux);
+  for (int i = tid; i < kAuxFloats; i += 256) auxl[i] = a.aux[i];
+  __syncthreads();
+
+  for (long long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    long long p = tile * 128 + wave * 32 + (lane & 31);
+    const bool ok = p < a.n_pts;
+    if (!ok) p = a.n_pts - 1;
+    float raw[4];
+    mlp_pass(rg, auxl, A0, A1, lane, a.pts[p * 3 + 0], a.pts[p * 3 + 1], a.pts[p * 3 + 2], a.dirs[p * 3 + 0],
+             a.dirs[p * 3 + 1], a.dirs[p * 3 + 2], raw);
+    if (ok && lane < 32) *(f32x4*)(a.raw + p * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------
+// small stage kernels (same device functions as the fused kernel)
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_get_rays(const float* __restrict__ c2w, float fx, float fy, float cx, float cy, int H, int W,
+                           float* rays_o, float* rays_d) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= H * W) return;
+  float o[3], d[3];
+  gen_ray(c2w, fx, fy, cx, cy, pix / W, pix % W, o, d);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { rays_o[pix * 3 + c] = o[c]; rays_d[pix * 3 + c] = d[c]; }
+}
+
+struct R2OArgs {
+  const float *raw, *z, *rays_d;
+  long long n_rays;
+  float *rgb, *disp, *acc, *weights, *depth;
+};
+
+template <int S>
+__global__ void __launch_bounds__(256) k_raw2outputs(R2OArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ItemState& st = *(ItemState*)smem;
+  float* zbuf = &st.zf[0][0];       // [2][S] (S <= 192)
+  float* rawbuf = &st.rawf[0][0][0];
+  float* wbuf = &st.wf[0][0];
+  const int tid = threadIdx.x;
+  const long long n_items = (a.n_rays + 1) >> 1;
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const long long ray0 = item * 2;
+    const int valid = (ray0 + 1 < a.n_rays) ? 2 : 1;
+    for (int idx = tid; idx < 2 * S; idx += 256) {
+      const int r = idx / S, i = idx - r * S;
+      const long long rr = ray0 + (r < valid ? r : 0);
+      zbuf[r * S + i] = a.z[rr * S + i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) rawbuf[(r * S + i) * 4 + c] = a.raw[(rr * S + i) * 4 + c];
+    }
+    if (tid < 2) {
+      const long long rr = ray0 + (tid < valid ? tid : 0);
+      const float dx = a.rays_d[rr * 3], dy = a.rays_d[rr * 3 + 1], dz = a.rays_d[rr * 3 + 2];
+      st.ray[tid][11] = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
+    }
+    __syncthreads();
+    composite<S>(st, zbuf, rawbuf, wbuf, tid);
+    for (int idx = tid; idx < valid * S; idx += 256) a.weights[ray0 * S + idx] = wbuf[idx];
+    if (tid < valid * 8) {
+      const int r = tid >> 3, c = tid & 7;
+      const float v = st.res[r][c];
+      if (c < 3) a.rgb[(ray0 + r) * 3 + c] = v;
+      else if (c == 3) a.disp[ray0 + r] = v;
+      else if (c == 4) a.acc[ray0 + r] = v;
+      else if (c == 5) a.depth[ray0 + r] = v;
+    }
+    __syncthreads();
+  }
+}
+
+struct PdfArgs {
+  const float *bins, *weights, *ufine;
+  long long n_rays;
+  float* samples;
+  long long* inds;
+};
+
+__global__ void __launch_bounds__(256) k_sample_pdf(PdfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  ItemState& st = *(ItemState*)smem;
+  const int tid = threadIdx.x;
+  float* binbuf = &st.zc[0][0];     // [2][64] (63 used)
+  float* wbuf = &st.w0[0][0];       // [2][64] (62 used)
+  if (tid < 128) st.ufine[tid] = a.ufine[tid];
+  const long long n_items = (a.n_rays + 1) >> 1;
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const long long ray0 = item * 2;
+    const int valid = (ray0 + 1 < a.n_rays) ? 2 : 1;
+    if (tid < 128) {
+      const int r = tid >> 6, i = tid & 63;
+      const long long rr = ray0 + (r < valid ? r : 0);
+      binbuf[r * 64 + i] = (i < 63) ? a.bins[rr * 63 + i] : 0.0f;
+      wbuf[r * 64 + i] = (i < 62) ? a.weights[rr * 62 + i] : 0.0f;
+    }
+    __syncthreads();
+    sample_pdf_item(st, wbuf, 64, [&](int r, int k) { return binbuf[r * 64 + k]; },
+                    a.inds ? (int64_t*)a.inds + ray0 * 128 : nullptr, 128, tid, valid);
+    for (int idx = tid; idx < valid * 128; idx += 256) a.samples[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
+    __syncthreads();
+  }
+}
+
+// MFMA fragment layout self-test: D = A(32x2) * B(2x32) with asymmetric operands, plus a chained second product
+// that uses D's registers as B operands the way the network layers do.
+__global__ void k_selftest(float* out /*[64][16] + [64][16]*/) {
+  const int lane = threadIdx.x;
+  const int i = lane & 31, k = lane >> 5;
+  // A[i][k] = 1 + i + 100k ; B[k][j] = 3 + 7j - 1000k (j = lane&31)
+  const float a = 1.0f + (float)i + 100.0f * (float)k;
+  const float b = 3.0f + 7.0f * (float)i - 1000.0f * (float)k;
+  f32x16 acc = {0};
+  acc = NSR_MFMA(a, b, acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
+}
+
+}  // namespace nsr

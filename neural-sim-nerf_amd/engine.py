@@ -1,0 +1,174 @@
+"""NsrModel: one native renderer handle (libnsr.so) = one (coarse, fine) NeRF pair on one GPU and stream.
+
+PyTorch is plumbing here: it owns the device buffers (torch tensors -> raw device pointers) and the stream;
+all arithmetic happens inside the hand-written gfx950 kernels.  Mirrors what the reference keeps in its
+`render_kwargs` dict (network_fn, network_fine, N_samples, N_importance; RN:318-334)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .pack import pack_network, PACKED_FLOATS
+
+N_SAMPLES = 64
+N_IMPORTANCE = 128
+
+
+def _host_tables():
+    """The reference builds both linspace tables on the HOST and moves them (RN:439, RH:208); torch's CPU
+    linspace is not bit-equal to numpy's, so the same call is made here."""
+    return (torch.linspace(0., 1., steps=N_SAMPLES).numpy().astype(np.float32),
+            torch.linspace(0., 1., steps=N_IMPORTANCE).numpy().astype(np.float32))
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dev(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class NsrModel:
+    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0):
+        """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu)."""
+        if not torch.cuda.is_available():
+            raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
+                                   (device.index if isinstance(device, torch.device) else int(device)))
+        if n_importance not in (0, N_IMPORTANCE):
+            raise NotImplementedError("N_importance must be 128 (or 0 for coarse-only); got %r" % (n_importance,))
+        if n_importance > 0 and sd_fine is None:
+            sd_fine = sd_coarse          # RN:482: run_fn = network_fn if network_fine is None
+        self.n_importance = n_importance
+        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups)
+        h = C.c_void_p()
+        _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.upload(sd_coarse, sd_fine)
+        t, u = _host_tables()
+        _lib.check(self.lib.nsr_upload_tables(self.h, _fptr(t), 64, _fptr(u), 128))
+
+    def upload(self, sd_coarse, sd_fine=None):
+        to_np = lambda sd: {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                            for k, v in sd.items()}
+        p = pack_network(to_np(sd_coarse))
+        _lib.check(self.lib.nsr_upload_weights(self.h, 0, _fptr(p), PACKED_FLOATS))
+        if sd_fine is not None:
+            p = pack_network(to_np(sd_fine))
+            _lib.check(self.lib.nsr_upload_weights(self.h, 1, _fptr(p), PACKED_FLOATS))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nsr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _f32(self, x, shape=None):
+        t = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        if shape is not None:
+            t = t.reshape(shape)
+        return t
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _outs(self, n, debug):
+        fine = self.n_importance > 0
+        o = dict(rgb_map=self._new(n, 3), disp_map=self._new(n), acc_map=self._new(n))
+        if fine:
+            o.update(rgb0=self._new(n, 3), disp0=self._new(n), acc0=self._new(n), z_std=self._new(n))
+        ro = _lib.NsrRenderOut(_dev(o["rgb_map"]), _dev(o["disp_map"]), _dev(o["acc_map"]), _dev(o.get("rgb0")),
+                               _dev(o.get("disp0")), _dev(o.get("acc0")), _dev(o.get("z_std")))
+        dbg = None
+        if debug:
+            d = dict(weights0=self._new(n, 64), raw0=self._new(n, 64, 4))
+            if fine:
+                d.update(z_samples=self._new(n, 128), inds=self._new(n, 128, dtype=torch.int64),
+                         z_fine=self._new(n, 192), raw=self._new(n, 192, 4))
+            o.update(d)
+            dbg = _lib.NsrDebugOut(_dev(d["weights0"]), _dev(d.get("z_samples")), _dev(d.get("inds")),
+                                   _dev(d.get("z_fine")), _dev(d["raw0"]), _dev(d.get("raw")))
+        return o, ro, dbg
+
+    # ---- the path -----------------------------------------------------------------------------------
+    def render_rays(self, rays_o, rays_d, near, far, debug=False):
+        """render(rays=...) (RN:58-123): rays_o, rays_d [N,3] -> dict of [N,...] tensors on the device."""
+        rays_o = self._f32(rays_o, (-1, 3))
+        rays_d = self._f32(rays_d, (-1, 3))
+        n = rays_o.shape[0]
+        o, ro, dbg = self._outs(n, debug)
+        _lib.check(self.lib.nsr_render_rays(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
+                                            C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
+        return o
+
+    def render_views(self, c2w, H, W, K, near, far, debug=False):
+        """render(c2w=...) for V views in one launch: c2w [V,3,4] (or [3,4]) -> dict of [V*H*W,...] tensors."""
+        c2w = self._f32(c2w)
+        if c2w.dim() == 2:
+            c2w = c2w[None]
+        c2w = c2w[:, :3, :4].contiguous()
+        v = c2w.shape[0]
+        n = v * int(H) * int(W)
+        K9 = (C.c_double * 9)(*[float(K[i][j]) for i in range(3) for j in range(3)])
+        o, ro, dbg = self._outs(n, debug)
+        _lib.check(self.lib.nsr_render_views(self.h, _dev(c2w), v, int(H), int(W), K9, float(near), float(far),
+                                             C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
+        return o
+
+    def get_rays(self, H, W, K, c2w):
+        c2w = self._f32(c2w)[:3, :4].contiguous()
+        K9 = (C.c_double * 9)(*[float(K[i][j]) for i in range(3) for j in range(3)])
+        o, d = self._new(H, W, 3), self._new(H, W, 3)
+        _lib.check(self.lib.nsr_get_rays(self.h, _dev(c2w), int(H), int(W), K9, _dev(o), _dev(d),
+                                         _stream_ptr(self.device)))
+        return o, d
+
+    def run_network(self, pts, viewdirs, net_id=0):
+        pts = self._f32(pts, (-1, 3))
+        viewdirs = self._f32(viewdirs, (-1, 3))
+        raw = self._new(pts.shape[0], 4)
+        _lib.check(self.lib.nsr_run_network(self.h, int(net_id), _dev(pts), _dev(viewdirs), pts.shape[0],
+                                            _dev(raw), _stream_ptr(self.device)))
+        return raw
+
+    def raw2outputs(self, raw, z_vals, rays_d):
+        raw = self._f32(raw)
+        n, s = raw.shape[0], raw.shape[1]
+        z_vals = self._f32(z_vals, (n, s))
+        rays_d = self._f32(rays_d, (n, 3))
+        rgb, disp, acc, w, depth = self._new(n, 3), self._new(n), self._new(n), self._new(n, s), self._new(n)
+        _lib.check(self.lib.nsr_raw2outputs(self.h, _dev(raw), _dev(z_vals), _dev(rays_d), n, s, _dev(rgb),
+                                            _dev(disp), _dev(acc), _dev(w), _dev(depth), _stream_ptr(self.device)))
+        return rgb, disp, acc, w, depth
+
+    def sample_pdf(self, bins, weights):
+        bins = self._f32(bins)
+        n = bins.shape[0]
+        if bins.shape[1] != 63 or tuple(weights.shape) != (n, 62):
+            raise NotImplementedError("sample_pdf is specialised to 63 bins / 62 weights / 128 samples")
+        weights = self._f32(weights)
+        samples, inds = self._new(n, 128), self._new(n, 128, dtype=torch.int64)
+        _lib.check(self.lib.nsr_sample_pdf(self.h, _dev(bins), _dev(weights), n, _dev(samples), _dev(inds),
+                                           _stream_ptr(self.device)))
+        return samples, inds
+
+    def selftest(self):
+        _lib.check(self.lib.nsr_selftest(self.h, _stream_ptr(self.device)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        _lib.check(self.lib.nsr_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,133 @@
+"""Weight packer: NeRF state_dict (RH:70-122 names) -> the layout the gfx950 kernel streams through LDS.
+
+The kernel (csrc/nsr_kernels.hip) computes every layer as  H_out^T = W * H_in^T  on v_mfma_f32_32x32x2_f32
+with the weights as the A operand.  One MFMA consumes, per lane l, A[i = l&31][k = l>>5]; the C/D fragment
+holds, in lane l register r, output row (r&3) + 8*(r>>2) + 4*(l>>5) of column l&31.  Because layer L's C/D
+registers are used *as they are* as layer L+1's B operands, k-step t of a 256-wide layer reads, in lane half
+h, input feature
+
+    kappa(t, h) = 32*(t>>4) + (t&3) + 8*((t&15)>>2) + 4*h            t = 0..127, h = 0..1
+
+so the packer stores W[:, kappa(t, h)] where a plain GEMM would store W[:, 2t+h].  The position / direction
+encodings (RH:18-48) are produced in-register in the order eps / eps_d below (sin in half 0, cos in half 1).
+
+Stream layout (floats): 290 steps of 2048 floats (two steps = one 16 KiB LDS slab).  A step is 8 chunks of
+[64 lanes][4] floats, read back by one ds_read_b128 per lane and chunk:
+    8-block layers : step = k-quad tq, chunk = output block mo, float kk -> W[32*mo + (l&31)][col(4*tq+kk, l>>5)]
+    views layer    : step s, chunk c -> k-quad 2*s + (c>>2), output block c&3
+followed by the aux block (biases in C-fragment order, alpha/rgb heads), see nsr_device.h.
+"""
+import numpy as np
+
+N_STEPS = 290
+STEP_FLOATS = 2048
+SLAB_FLOATS = 4096
+STREAM_SLABS = 145
+AUX_FLOATS = 3328
+PACKED_FLOATS = STREAM_SLABS * SLAB_FLOATS + AUX_FLOATS
+
+AUX_BIAS, AUX_BIAS_V, AUX_W_ALPHA, AUX_W_RGB, AUX_B_ALPHA, AUX_B_RGB = 0, 2304, 2432, 2688, 3072, 3073
+
+
+def kappa(t, h):
+    t = np.asarray(t)
+    return 32 * (t >> 4) + (t & 3) + 8 * ((t & 15) >> 2) + 4 * h
+
+
+def eps(t, h, n_freq):
+    """Reference embedding column produced in encoding register t of lane half h (-1 = zero padding).
+    Reference order (RH:39-48): [x y z | sin(2^0 .)(3) cos(2^0 .)(3) | sin(2^1 .) ...]."""
+    n_trig = 3 * n_freq
+    if t < n_trig:
+        return 3 + 6 * (t // 3) + 3 * h + (t % 3)
+    if t == n_trig:
+        return 0 if h == 0 else 2
+    if t == n_trig + 1:
+        return 1 if h == 0 else -1
+    return -1
+
+
+def _cfrag_index(n_feat):
+    """feature f -> position in the C-fragment-ordered vectors of the aux block."""
+    f = np.arange(n_feat)
+    mo, i = f >> 5, f & 31
+    h, ri, rq = (i >> 2) & 1, i & 3, i >> 3
+    return ((mo * 4 + rq) * 2 + h) * 4 + ri
+
+
+def _pack_steps8(W, cols):
+    """W [256, K]; cols [n_ksteps, 2] (reference column or -1) -> [n_ksteps/4, 8, 64, 4] floats."""
+    n_k = cols.shape[0]
+    assert W.shape[0] == 256 and n_k % 4 == 0
+    Wp = np.concatenate([W, np.zeros((W.shape[0], 1), W.dtype)], 1)       # column -1 -> zeros
+    lane = np.arange(64)
+    i, h = lane & 31, lane >> 5
+    out = np.empty((n_k // 4, 8, 64, 4), np.float32)
+    for tq in range(n_k // 4):
+        for kk in range(4):
+            c = cols[4 * tq + kk][h]                                        # [64]
+            for mo in range(8):
+                out[tq, mo, :, kk] = Wp[32 * mo + i, c]
+    return out
+
+
+def _pack_steps_views(W, cols):
+    """W [128, K]; cols [144, 2] -> [18 steps, 8 chunks, 64, 4]."""
+    assert W.shape[0] == 128 and cols.shape[0] == 144
+    Wp = np.concatenate([W, np.zeros((W.shape[0], 1), W.dtype)], 1)
+    lane = np.arange(64)
+    i, h = lane & 31, lane >> 5
+    out = np.empty((18, 8, 64, 4), np.float32)
+    for s in range(18):
+        for c in range(8):
+            tq, mo = 2 * s + (c >> 2), c & 3
+            for kk in range(4):
+                out[s, c, :, kk] = Wp[32 * mo + i, cols[4 * tq + kk][h]]
+    return out
+
+
+def pack_network(sd):
+    """sd: mapping name -> array-like with the reference's state_dict keys (RH:82-97).  Returns float32
+    [PACKED_FLOATS].  Raises on any shape that is not the 8x256 / skip-4 / use_viewdirs architecture."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    shapes = {"pts_linears.0.weight": (256, 63), "pts_linears.5.weight": (256, 319),
+              "feature_linear.weight": (256, 256), "alpha_linear.weight": (1, 256),
+              "views_linears.0.weight": (128, 283), "rgb_linear.weight": (3, 128)}
+    for i in (1, 2, 3, 4, 6, 7):
+        shapes["pts_linears.%d.weight" % i] = (256, 256)
+    for k, shp in shapes.items():
+        if k not in sd or tuple(np.shape(sd[k])) != shp:
+            raise ValueError("pack_network: %s must have shape %s (8x256 NeRF with skip at 4 and view "
+                             "directions, RH:70-122); got %s" % (k, shp, np.shape(sd[k]) if k in sd else None))
+    t = np.arange(128)
+    cols_main = np.stack([kappa(t, 0), kappa(t, 1)], 1)                                     # [128,2]
+    cols_enc = np.array([[eps(tt, 0, 10), eps(tt, 1, 10)] for tt in range(32)])
+    cols_dir = np.array([[eps(tt, 0, 4), eps(tt, 1, 4)] for tt in range(16)])
+    steps = [_pack_steps8(g("pts_linears.0.weight"), cols_enc)]
+    for i in range(1, 8):
+        W = g("pts_linears.%d.weight" % i)
+        if i == 5:                                   # cat([input_pts, h]) (RH:105): input columns first
+            steps.append(_pack_steps8(W[:, :63], cols_enc))
+            W = W[:, 63:]
+        steps.append(_pack_steps8(W, cols_main))
+    steps.append(_pack_steps8(g("feature_linear.weight"), cols_main))
+    cols_views = np.concatenate([cols_main, np.where(cols_dir >= 0, cols_dir + 256, -1)], 0)  # cat([feature, views])
+    steps.append(_pack_steps_views(g("views_linears.0.weight"), cols_views))
+    stream = np.concatenate([s.reshape(-1) for s in steps])
+    assert stream.size == N_STEPS * STEP_FLOATS == STREAM_SLABS * SLAB_FLOATS
+
+    aux = np.zeros(AUX_FLOATS, np.float32)
+    ci256, ci128 = _cfrag_index(256), _cfrag_index(128)
+    for L in range(8):
+        aux[AUX_BIAS + L * 256 + ci256] = g("pts_linears.%d.bias" % L)
+    aux[AUX_BIAS + 8 * 256 + ci256] = g("feature_linear.bias")
+    aux[AUX_BIAS_V + ci128] = g("views_linears.0.bias")
+    wa = g("alpha_linear.weight")[0]
+    tq, hh, kk = np.meshgrid(np.arange(32), np.arange(2), np.arange(4), indexing="ij")
+    aux[AUX_W_ALPHA + ((tq * 2 + hh) * 4 + kk).ravel()] = wa[kappa(4 * tq + kk, hh).ravel()]
+    wr = g("rgb_linear.weight")
+    for c in range(3):
+        aux[AUX_W_RGB + c * 128 + ci128] = wr[c]
+    aux[AUX_B_ALPHA] = g("alpha_linear.bias")[0]
+    aux[AUX_B_RGB:AUX_B_RGB + 3] = g("rgb_linear.bias")
+    return np.concatenate([stream, aux]).astype(np.float32)
