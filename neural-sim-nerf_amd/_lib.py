@@ -64,6 +64,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NsrError("libnsr.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; "
                        "g.build()' or make -C neural-sim-nerf_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7, the
+    # same SONAME libnsr.so was linked against).  Loading it FIRST makes the dynamic loader bind libnsr.so to
+    # that very instance, so device pointers and hipStream_t handles mean the same thing on both sides.  The
+    # other order would put two runtimes in the process and the second one finds no device.
+    import torch
+    torch_hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(torch_hip):
+        C.CDLL(torch_hip, mode=C.RTLD_GLOBAL)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so is stale
