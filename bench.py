@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""bench.py -- Mray-samples/s of the NeRF volumetric render path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic input = ONE 400x400 view rendered with 64 coarse
++ 128 importance samples per ray through the 8x256 NeRF MLP pair (BASELINE.json configs[1]), fp32 end to end,
+rays generated in-kernel from the camera, outputs (rgb/disp/acc/rgb0/disp0/acc0/z_std) written to HBM.
+With N GPUs every rank renders its own views (view sharding, no data-path collective); the rendered images
+are all-gathered over RCCL once, at the outer-loop boundary, inside the timed region (BASELINE configs[2]).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     -- dominant kernel nsr::k_render: algorithmic FLOP per launch / HIP-event kernel time, against
+                  the fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
+  cpu_baseline -- the oracle (CPU numpy restatement of the reference path, "port") timed on this host's cores
+                  on a bounded sample (a 64x64 view of the same scene: same per-ray work), rank 0, N=1 only;
+  parity       -- PSNR / max-abs of the GPU render vs the oracle on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from neural_sim_nerf_amd import synthetic as S          # noqa: E402
+from neural_sim_nerf_amd.engine import NsrModel         # noqa: E402
+
+H = W = 400
+SAMPLES_PER_RAY = 64 + 128                 # the metric's unit
+EVALS_PER_RAY = 64 + 192                   # network evaluations per ray (RN:477-483)
+FLOP_PER_RAY = EVALS_PER_RAY * S.FLOP_PER_POINT          # 303 824 896
+PEAK_F32_MFMA_TFLOPS = 157.3               # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+
+
+def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
+    """Oracle on a bounded sample (64x64 view, 64+128) -- the checker, timed; never the thing shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as O
+    K64 = S.scaled_K(6.25)
+    n_threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    ref = O.render(sd_c, sd_f, 64, 64, K64, c2w=c2w[:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=4096)
+    dt = time.perf_counter() - t0
+    got = model.render_views(c2w, 64, 64, K64, S.YCBV_NEAR, S.YCBV_FAR)
+    rgb = got["rgb_map"].cpu().numpy().reshape(64, 64, 3)
+    rgb0 = got["rgb0"].cpu().numpy().reshape(64, 64, 3)
+    # PSNR delta against a pseudo ground truth T = oracle + N(0, 0.01^2)
+    T = ref["rgb_map"] + np.random.RandomState(0).normal(0, 0.01, ref["rgb_map"].shape).astype(np.float32)
+    cpu = {"value": round(64 * 64 * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
+           "kind": "port", "sample": "one 64x64 view (4096 rays x (64+128) samples, same scene and networks), "
+           "oracle/nerf_oracle.py numpy+OpenBLAS, %.1f s" % dt}
+    par = {"psnr_vs_oracle_db": round(O.psnr(rgb, ref["rgb_map"]), 2),
+           "psnr_delta_db": round(abs(O.psnr(rgb, T) - O.psnr(ref["rgb_map"], T)), 4),
+           "max_abs_rgb_coarse": float(np.abs(rgb0 - ref["rgb0"]).max()),
+           "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
+           "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()), "sample": "64x64 view"}
+    return cpu, par
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    sd_c = S.synth_weights(0)
+    sd_f = S.synth_weights(1000, fine_of=sd_c)
+    model = NsrModel(sd_c, sd_f, device=local)
+    n_total = args.warmup + args.steps
+    poses = S.sweep_poses(n_total * world, seed=0)[rank::world]      # view i -> rank i mod world
+    poses_d = torch.as_tensor(poses[:, :3, :4], device=model.device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+    barrier()
+    kernel_ms = []
+    images = []
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_total):
+        out = model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+        kernel_ms.append(model.last_kernel_ms())      # HIP events on the launch stream (syncs on the stop event)
+        images.append(out["rgb_map"])
+    if dist is not None:                                # outer-loop boundary: gather the rendered images
+        mine = torch.stack(images, 0)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=model.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        rays = args.steps * H * W * world
+        value = rays * SAMPLES_PER_RAY / dt / 1e6
+        k_ms = float(np.mean(kernel_ms))
+        achieved = H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP",
+            "value": round(value, 3), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
+                                   "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), fp32, fused "
+                                   "persistent kernel, rays generated in-kernel",
+                       "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
+                       "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
+            "rays_per_s": round(rays / dt, 1),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "kernel": "nsr::k_render", "kernel_ms": round(k_ms, 3),
+                         "flop_per_launch": H * W * FLOP_PER_RAY},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, par = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
+            line["cpu_baseline"] = cpu
+            line["parity"] = par
+        print(json.dumps(line))
+    model.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
