@@ -85,6 +85,10 @@ int nsr_destroy(nsr_handle h);
  * (pack.py).  net_id 0 = network_fn (coarse), 1 = network_fine.  Replaces the .to(device) of RN:269-278. */
 int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_floats);
 
+/* Transposed stream of the FINE network for the input-gradient kernel (pack.py: pack_network_backward);
+ * host buffer of NSR_STREAM_SLABS*NSR_SLAB_FLOATS floats.  Needed only by nsr_render_rays_vjp. */
+int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats);
+
 /* The two linspace tables the reference builds on the host and moves to the device
  * (RN:439 t_vals[64], RH:208 u[128]); host buffers. */
 int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine);
@@ -101,6 +105,20 @@ int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, 
  * [n_views*H*W, ...].  Rays are generated in-kernel: no HBM traffic for ray origins/directions. */
 int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9,
                      float near_, float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream);
+
+/* Forward + input-side VJP in one launch: what render_path_grad obtains per 512-ray patch with
+ * torch.autograd.grad(rgb_p, batch_rays, grad_outputs=patch_grad_E) (RN:168-178).  Network weights are
+ * constants and z_samples is detached (RN:475), so the gradient reaches the rays only through the fine pass.
+ * d_grad_rgb [N,3] cotangent of rgb_map -> d_grad_o, d_grad_d [N,3].  `out` (optional, may be NULL; only
+ * d_rgb/d_disp/d_acc are written) receives the forward render of the same launch. */
+int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                        float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
+                        const NsrRenderOut* out, void* stream);
+
+/* Chain rule through get_rays (RH:160-164, linear in c2w): per patch of `patch` consecutive pixels (row-major,
+ * the order of RN:150-157), d_out[p] = dL/d c2w[3][4] given dL/d rays.  n_patches = ceil(H*W / patch). */
+int nsr_pose_grad(nsr_handle h, const float* d_grad_o, const float* d_grad_d, int H, int W, const double* K9,
+                  int patch, float* d_out, void* stream);
 
 /* Stage entry points (same device code as the fused kernel; used by the parity tests and usable alone). */
 

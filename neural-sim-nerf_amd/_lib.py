@@ -33,12 +33,17 @@ SIGNATURES = {
     "nsr_create": (C.c_int, [C.POINTER(NsrConfig), C.POINTER(C.c_void_p)]),
     "nsr_destroy": (C.c_int, [C.c_void_p]),
     "nsr_upload_weights": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "nsr_upload_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
     "nsr_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                   C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut), C.c_void_p]),
     "nsr_render_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                    C.c_float, C.c_float, C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut),
                                    C.c_void_p]),
+    "nsr_render_rays_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NsrRenderOut), C.c_void_p]),
+    "nsr_pose_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                C.c_int, C.c_void_p, C.c_void_p]),
     "nsr_get_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p,
                                C.c_void_p, C.c_void_p]),
     "nsr_run_network": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -37,12 +37,16 @@ constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
 struct nsr_handle_s {
   NsrConfig cfg;
   int n_cu = 0;
-  float* d_packed[2] = {nullptr, nullptr};
-  bool have_net[2] = {false, false};
+  float* d_nets = nullptr;
+  float* d_packed[3] = {nullptr, nullptr, nullptr};   // views into d_nets: coarse, fine, fine transposed
+  bool have_net[3] = {false, false, false};
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
   nsr::RenderArgs* d_args = nullptr;  // kernel argument block (device), one per handle
+  nsr::VjpArgs* d_vjp_args = nullptr;
+  uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [grid][3][9][256]
+  int mask_grid = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
 };
@@ -70,10 +74,14 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   nsr_handle h = new nsr_handle_s();
   h->cfg = *cfg;
   h->n_cu = prop.multiProcessorCount;
-  for (int i = 0; i < 2; ++i) NSR_HIP(hipMalloc(&h->d_packed[i], sizeof(float) * NSR_PACKED_FLOATS));
+  // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
+  NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
+  for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
+  NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   NSR_HIP(hipEventCreate(&h->ev0));
   NSR_HIP(hipEventCreate(&h->ev1));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
@@ -86,10 +94,12 @@ int nsr_destroy(nsr_handle h) {
   if (!h) return 0;
   hipSetDevice(h->cfg.device);
   hipDeviceSynchronize();
-  for (int i = 0; i < 2; ++i) hipFree(h->d_packed[i]);
+  hipFree(h->d_nets);
   hipFree(h->d_tables);
   hipFree(h->d_scratch);
   hipFree(h->d_args);
+  hipFree(h->d_vjp_args);
+  hipFree(h->d_mask_scratch);
   hipEventDestroy(h->ev0);
   hipEventDestroy(h->ev1);
   delete h;
@@ -103,6 +113,15 @@ int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_f
   NSR_HIP(hipSetDevice(h->cfg.device));
   NSR_HIP(hipMemcpy(h->d_packed[net_id], packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   h->have_net[net_id] = true;
+  return 0;
+}
+
+int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats) {
+  if (!h || !stream) return fail("nsr_upload_weights_bwd: null argument");
+  if (n_floats != (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd: wrong stream size");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_HIP(hipMemcpy(h->d_packed[2], stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  h->have_net[2] = true;
   return 0;
 }
 
@@ -137,8 +156,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   if (!out || !out->d_rgb || !out->d_disp || !out->d_acc) return fail("render: rgb/disp/acc outputs are required");
   if (a.n_rays <= 0) return 0;
   NSR_HIP(hipSetDevice(h->cfg.device));
-  a.stream[0] = h->d_packed[0];
-  a.stream[1] = h->d_packed[fine ? 1 : 0];
+  a.nets = h->d_nets;
+  a.net_stride = (long long)sizeof(float) * NSR_PACKED_FLOATS;
   a.aux[0] = h->d_packed[0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
   a.aux[1] = h->d_packed[fine ? 1 : 0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
   a.tcoarse = h->d_tables;
@@ -184,6 +203,58 @@ int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W
   a.camera = 1;
   a.fx = (float)K9[0]; a.cx = (float)K9[2]; a.fy = (float)K9[4]; a.cy = (float)K9[5];   // RH:160 (fp32 tensor op)
   return launch_render(h, a, out, dbg, stream);
+}
+
+int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                        float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
+                        const NsrRenderOut* out, void* stream) {
+  if (!h) return fail("nsr_render_rays_vjp: null handle");
+  if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
+  if (int e = check_ready(h, true)) return e;
+  if (!h->have_net[2]) return fail("nsr_render_rays_vjp: backward stream not uploaded (nsr_upload_weights_bwd)");
+  if (!d_rays_o || !d_rays_d || !d_grad_rgb || !d_grad_o || !d_grad_d) return fail("nsr_render_rays_vjp: null argument");
+  if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_render_rays_vjp: negative ray count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const long long n_items = (n_rays + 1) / 2;
+  const int grid = grid_for(h, n_items);
+  if (grid > h->mask_grid) {
+    if (h->d_mask_scratch) NSR_HIP(hipFree(h->d_mask_scratch));
+    NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)grid * 3 * 9 * 256));
+    h->mask_grid = grid;
+  }
+  nsr::VjpArgs v;
+  memset(&v, 0, sizeof(v));
+  nsr::RenderArgs& a = v.r;
+  a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.n_rays = n_rays; a.near_ = near_; a.far_ = far_; a.camera = 0;
+  a.nets = h->d_nets;
+  a.net_stride = (long long)sizeof(float) * NSR_PACKED_FLOATS;
+  a.aux[0] = h->d_packed[0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.aux[1] = h->d_packed[1] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.tcoarse = h->d_tables;
+  a.ufine = h->d_tables + 64;
+  a.fine = 1;
+  if (out) { a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc; }
+  v.grad_rgb = d_grad_rgb; v.grad_o = d_grad_o; v.grad_d = d_grad_d; v.mask_scratch = h->d_mask_scratch;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);
+  NSR_HIP(hipEventRecord(h->ev0, s));
+  hipLaunchKernelGGL(nsr::k_render_vjp, dim3(grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  NSR_HIP(hipGetLastError());
+  NSR_HIP(hipEventRecord(h->ev1, s));
+  h->timed = true;
+  return 0;
+}
+
+int nsr_pose_grad(nsr_handle h, const float* d_grad_o, const float* d_grad_d, int H, int W, const double* K9,
+                  int patch, float* d_out, void* stream) {
+  if (!h || !d_grad_o || !d_grad_d || !K9 || !d_out) return fail("nsr_pose_grad: null argument");
+  if (H <= 0 || W <= 0 || patch <= 0) return fail("nsr_pose_grad: bad geometry");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const int n = H * W, n_patches = (n + patch - 1) / patch;
+  hipLaunchKernelGGL(nsr::k_pose_grad, dim3(n_patches), dim3(256), 0, (hipStream_t)stream, d_grad_o, d_grad_d,
+                     (float)K9[0], (float)K9[4], (float)K9[2], (float)K9[5], W, n, patch, d_out);
+  NSR_HIP(hipGetLastError());
+  return 0;
 }
 
 int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K9, float* d_rays_o,

@@ -12,7 +12,7 @@ constexpr int kMultires = 10;        // NM:1268
 constexpr int kMultiresViews = 4;    // NM:1270
 constexpr int kRingSlots = 6;        // 16 KiB slabs resident in LDS
 constexpr int kSlabBytes = 16384;
-constexpr int kStepBytes = 8192;
+constexpr int kStepBytes = 4096;   // a step = 4 chunks of 1 KiB = 16 MFMAs
 constexpr int kSlabFloats = 4096;
 // slabs per network pass: L0 4 | L1-4 64 | L5 skip 4 + 16 | L6-7 32 | feature 16 | views 9
 constexpr int kStreamSlabs = 145;

@@ -31,14 +31,15 @@ namespace nsr {
 // ------------------------------------------------------------------------------------------------------
 struct Ring {
   char* smem;            // LDS base (generic pointer)
-  const char* net[2];    // packed streams (global), coarse / fine
+  const char* base;      // packed networks (global), consecutive at `stride` bytes: coarse | fine | fine^T (backward)
+  long long stride;
   const char* psrc;      // producer: current net base + this lane's offset (wave*4096 + lane*16)
   int lane_off;          // wave*4096 + lane*16
   int wave_lds;          // wave*4096
   int pslab;             // producer: next slab index within the pass stream
   int pslot;             // producer: next ring slot
   int pphase;            // producer: pass index within the item (0 = coarse net)
-  int ppi;               // passes per item (1 or 4)
+  int ppi;               // passes per item: 1 (coarse only), 4 (coarse + 3 fine) or 7 (+ 3 backward)
   int cslot;             // consumer: slot of the slab being consumed
 };
 
@@ -51,121 +52,96 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   if (++rg.pslab == kStreamSlabs) {
     rg.pslab = 0;
     rg.pphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
-    rg.psrc = rg.net[rg.pphase == 0 ? 0 : 1] + rg.lane_off;
+    const int net = rg.pphase == 0 ? 0 : (rg.pphase <= 3 ? 1 : 2);   // arithmetic, not a pointer table: keeps Ring in SGPRs
+    rg.psrc = rg.base + net * rg.stride + rg.lane_off;
   }
 }
 
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
-__device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[8], int lane) {
+// A step = 4 chunks of 1 KiB = 4 float4 fragments per lane = 16 MFMAs; a slab = 4 steps.
+__device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[4], int lane) {
 #pragma unroll 1
   for (int s = 0; s < kRingSlots; ++s) ring_issue(rg);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRingSlots - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) A0[c] = *(const f32x4*)(p + c * 1024);
+  for (int c = 0; c < 4; ++c) A0[c] = *(const f32x4*)(p + c * 1024);
 }
 
-// Even step: the second half of the current slab is already certified; fetch it.
-__device__ __forceinline__ void ring_load_second(const Ring& rg, f32x4 (&A)[8], int lane) {
-  const char* p = rg.smem + rg.cslot * kSlabBytes + kStepBytes + lane * 16;
+// Steps 0..2 of a slab: the slab is already certified; fetch quarter u+1 for the next step.
+template <int U>
+__device__ __forceinline__ void ring_load_quarter(const Ring& rg, f32x4 (&A)[4], int lane) {
+  const char* p = rg.smem + rg.cslot * kSlabBytes + U * kStepBytes + lane * 16;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) A[c] = *(const f32x4*)(p + c * 1024);
+  for (int c = 0; c < 4; ++c) A[c] = *(const f32x4*)(p + c * 1024);
 }
 
-// Odd step: all of this wave's reads of the current slab are complete after lgkmcnt(0); my share of the next
-// slab has landed after the counted vmcnt; the barrier makes both true for the whole workgroup, so the slot
-// of the current slab can be refilled (slab n+NS) and the next slab's first half can be read.
-__device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[8], int lane) {
+// Last step of a slab: all of this wave's reads of the current slab are complete after lgkmcnt(0); my share of
+// the next slab has landed after the counted vmcnt; the barrier makes both true for the whole workgroup, so the
+// slot of the current slab can be refilled (slab n+NS) and the next slab's first quarter can be read.
+__device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[4], int lane) {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (kRingSlots - 2)) : "memory");
   __builtin_amdgcn_s_barrier();
   ring_issue(rg);  // refills the slot that was just drained (pslot == cslot here)
   rg.cslot = (rg.cslot + 1 == kRingSlots) ? 0 : rg.cslot + 1;
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
 #pragma unroll
-  for (int c = 0; c < 8; ++c) A[c] = *(const f32x4*)(p + c * 1024);
+  for (int c = 0; c < 4; ++c) A[c] = *(const f32x4*)(p + c * 1024);
 }
 
 // ------------------------------------------------------------------------------------------------------
-// MFMA steps.  A step = 8 KiB of weights = 8 float4 fragments per lane = 32 MFMAs.
+// MFMA segments.  A segment is a GEMM  acc[mo] += W_block(mo) * B  with NMO output blocks of 32 rows and NTQ
+// k-quads (4 k-steps of 2 each); its weights are NMO*NTQ chunks in the stream, chunk n <-> (k-quad n / NMO,
+// output block n % NMO).  `bop(t)` returns this lane's B operand (activation / gradient value) of k-step t;
+// every index is a compile-time constant after unrolling.
 // ------------------------------------------------------------------------------------------------------
 #define NSR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// 8 output blocks x 4 k-steps; b0..b3 are this lane's B operands (activation values) for the 4 k-steps.
-__device__ __forceinline__ void mfma_step8(const f32x4 (&A)[8], float b0, float b1, float b2, float b3,
-                                           f32x16 (&acc)[8]) {
+template <int NMO, int NACC, typename BOp>
+__device__ __forceinline__ void consume(const f32x4 (&A)[4], int step, BOp bop, f32x16 (&acc)[NACC]) {
 #pragma unroll
-  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][0], b0, acc[mo]);
+  for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][1], b1, acc[mo]);
-#pragma unroll
-  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][2], b2, acc[mo]);
-#pragma unroll
-  for (int mo = 0; mo < 8; ++mo) acc[mo] = NSR_MFMA(A[mo][3], b3, acc[mo]);
-}
-
-// views layer: 4 output blocks x 8 k-steps (fragment c: k-quad c>>2, block c&3)
-__device__ __forceinline__ void mfma_step4(const f32x4 (&A)[8], const float (&b)[8], f32x16 (&acc)[4]) {
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-      for (int mo = 0; mo < 4; ++mo) acc[mo] = NSR_MFMA(A[q * 4 + mo][kk], b[q * 4 + kk], acc[mo]);
-}
-
-// K segment fed from 32 "encoding" registers (layer 0, and the skip columns of layer 5): 8 steps = 4 slabs.
-__device__ __forceinline__ void seg_enc(Ring& rg, f32x4 (&A0)[8], f32x4 (&A1)[8], const float (&e)[32],
-                                        f32x16 (&acc)[8], int lane) {
-#pragma unroll
-  for (int tq = 0; tq < 8; tq += 2) {
-    ring_load_second(rg, A1, lane);
-    mfma_step8(A0, e[4 * tq + 0], e[4 * tq + 1], e[4 * tq + 2], e[4 * tq + 3], acc);
-    ring_advance(rg, A0, lane);
-    mfma_step8(A1, e[4 * tq + 4], e[4 * tq + 5], e[4 * tq + 6], e[4 * tq + 7], acc);
-  }
-}
-
-// K = 256 segment fed from the previous layer's output registers: 32 steps = 16 slabs, 1024 MFMAs.
-__device__ __forceinline__ void seg_main(Ring& rg, f32x4 (&A0)[8], f32x4 (&A1)[8], const f32x16 (&in)[8],
-                                         f32x16 (&acc)[8], int lane) {
-#pragma unroll
-  for (int tq = 0; tq < 32; tq += 2) {
-    ring_load_second(rg, A1, lane);
-    mfma_step8(A0, in[tq >> 2][(tq & 3) * 4 + 0], in[tq >> 2][(tq & 3) * 4 + 1], in[tq >> 2][(tq & 3) * 4 + 2],
-               in[tq >> 2][(tq & 3) * 4 + 3], acc);
-    ring_advance(rg, A0, lane);
-    mfma_step8(A1, in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 0], in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 1],
-               in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 2], in[(tq + 1) >> 2][((tq + 1) & 3) * 4 + 3], acc);
-  }
-}
-
-// views layer: K = 256 (feature, registers) + 32 (direction encoding), 128 outputs: 18 steps = 9 slabs.
-__device__ __forceinline__ void seg_views(Ring& rg, f32x4 (&A0)[8], f32x4 (&A1)[8], const f32x16 (&in)[8],
-                                          const float (&ed)[16], f32x16 (&acc)[4], int lane) {
-#pragma unroll
-  for (int s = 0; s < 18; s += 2) {
-    float b[8];
-    ring_load_second(rg, A1, lane);
-    if (s < 16) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) b[i] = in[(8 * s + i) >> 4][(8 * s + i) & 15];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) b[i] = ed[8 * (s - 16) + i];
+    for (int c = 0; c < 4; ++c) {
+      const int n = 4 * step + c, tq = n / NMO, mo = n % NMO;
+      acc[mo] = NSR_MFMA(A[c][kk], bop(4 * tq + kk), acc[mo]);
     }
-    mfma_step4(A0, b, acc);
+}
+
+template <int NMO, int NTQ, int NACC, typename BOp>
+__device__ __forceinline__ void seg(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], BOp bop, f32x16 (&acc)[NACC],
+                                    int lane) {
+  static_assert((NMO * NTQ) % 16 == 0, "a segment is a whole number of slabs");
+#pragma unroll
+  for (int s = 0; s < NMO * NTQ / 4; s += 4) {
+    ring_load_quarter<1>(rg, A1, lane);
+    consume<NMO>(A0, s, bop, acc);
+    ring_load_quarter<2>(rg, A0, lane);
+    consume<NMO>(A1, s + 1, bop, acc);
+    ring_load_quarter<3>(rg, A1, lane);
+    consume<NMO>(A0, s + 2, bop, acc);
     ring_advance(rg, A0, lane);
-    if (s + 1 < 16) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) b[i] = in[(8 * (s + 1) + i) >> 4][(8 * (s + 1) + i) & 15];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) b[i] = ed[8 * (s + 1 - 16) + i];
-    }
-    mfma_step4(A1, b, acc);
+    consume<NMO>(A1, s + 3, bop, acc);
   }
 }
+
+// B-operand sources (references to register-resident arrays; all indices constant after unrolling)
+template <int NG>
+struct BRegs16 {   // previous layer's C fragment: k-step t <-> register (t>>4, t&15)
+  const f32x16 (&v)[NG];
+  __device__ __forceinline__ float operator()(int t) const { return v[t >> 4][t & 15]; }
+};
+template <int N>
+struct BArr {      // plain per-lane array (encodings)
+  const float (&v)[N];
+  __device__ __forceinline__ float operator()(int t) const { return v[t]; }
+};
+struct BViews {    // cat([feature, input_views]) (RH:111): 128 k-steps of registers, then 16 of direction encoding
+  const f32x16 (&v)[8];
+  const float (&ed)[16];
+  __device__ __forceinline__ float operator()(int t) const { return t < 128 ? v[(t & 127) >> 4][t & 15] : ed[t & 15]; }
+};
 
 // accumulator init = bias in C-fragment order (aux layout: [(mo*4+rq)*2+h] float4)
 template <int NMO>
@@ -187,9 +163,21 @@ __device__ __forceinline__ void load_bias(const float* bias, int h, f32x16 (&acc
 // hold complementary halves of every feature vector.  Returns raw = (r,g,b logits, sigma) in all lanes.
 //   Embedder RH:18-48 (in-register), NeRF.forward RH:99-122.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[8], f32x4 (&A1)[8], int lane,
+// relu pattern of one layer output (lane-private C fragment) as a bit mask: bit (mo&1)*16 + r of word mo>>1
+template <int NMO>
+__device__ __forceinline__ uint4 relu_mask(const f32x16 (&acc)[NMO]) {
+  unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int mo = 0; mo < NMO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[mo >> 1] |= (acc[mo][r] > 0.0f ? 1u : 0u) << ((mo & 1) * 16 + r);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool CAPTURE>
+__device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                          float px, float py, float pz, float vx, float vy, float vz,
-                                         float (&raw)[4]) {
+                                         float (&raw)[4], uint4* mask_dst = nullptr) {
   const int h = lane >> 5;
   float e[32];   // position encoding, k-step t: h=0 -> sin(2^L p_ax), h=1 -> cos(2^L p_ax), t = 3L+ax
   float ed[16];  // direction encoding, same scheme with L < 4
@@ -224,7 +212,8 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   f32x16 in[8];
   // layer 0
   load_bias<8>(aux + kAuxBias, h, acc);
-  seg_enc(rg, A0, A1, e, acc, lane);
+  seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
+  if (CAPTURE) mask_dst[0] = relu_mask<8>(acc);
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
 
@@ -233,7 +222,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 #pragma unroll 1
   for (int L = 1; L <= 8; ++L) {
     load_bias<8>(aux + kAuxBias + L * 256, h, acc);
-    if (L == 5) seg_enc(rg, A0, A1, e, acc, lane);  // skip: cat([input_pts, h]) -> input columns first (RH:105)
+    if (L == 5) seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);  // skip: cat([input_pts, h]) -> input columns first (RH:105)
     if (L == 8) {
       // alpha_linear on h7 (RH:109): VALU dot product over this lane's 128 features, halves summed below
       const float* wa = aux + kAuxWAlpha;
@@ -245,7 +234,8 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
           alpha_part = __builtin_fmaf(w[kk], in[(4 * tq + kk) >> 4][(4 * tq + kk) & 15], alpha_part);
       }
     }
-    seg_main(rg, A0, A1, in, acc, lane);
+    seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
+    if (CAPTURE && L < 8) mask_dst[L * 256] = relu_mask<8>(acc);
     const float lo = (L == 8) ? -__builtin_inff() : 0.0f;
 #pragma unroll
     for (int mo = 0; mo < 8; ++mo) in[mo] = max16(acc[mo], lo);
@@ -254,7 +244,8 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   // views_linears.0 (RH:111-115): cat([feature, input_views]) -> 128, ReLU
   f32x16 av[4];
   load_bias<4>(aux + kAuxBiasV, h, av);
-  seg_views(rg, A0, A1, in, ed, av, lane);
+  seg<4, 36>(rg, A0, A1, BViews{in, ed}, av, lane);
+  if (CAPTURE) mask_dst[8 * 256] = relu_mask<4>(av);
 
   // rgb_linear (RH:117) on relu(av): VALU
   float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};
@@ -296,6 +287,9 @@ struct ItemState {
   float rawf[2][192][4];    // fine raw               RN:483
   float alpha[2][192];      // compositing scratch
   float wf[2][192];         // fine weights           RN:485
+  float tf[2][192];         // fine transmittance (backward only)
+  float psum[2][6][12];     // backward: per (pass, wave) partial sums of d/dpts, z*d/dpts, d/dviewdir
+  float gnorm[2];           // backward: dL/d|rays_d| from dists*|d| (RN:361)
   float res[2][8];          // rgb(3) disp acc depth
 };
 
@@ -304,7 +298,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // raw2outputs RN:343-387 for both rays of the item.  z: [2][S], raw: [2][S][4] (rgb overwritten by sigmoid),
 // wout: [2][S] weights.  Results in st.res.
 template <int S>
-__device__ __forceinline__ void composite(ItemState& st, const float* z, float* raw, float* wout, int tid) {
+__device__ __forceinline__ void composite(ItemState& st, const float* z, float* raw, float* wout, int tid,
+                                          float* tout = nullptr) {
   for (int idx = tid; idx < 2 * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
     const float* zr = z + r * S;
@@ -329,6 +324,7 @@ __device__ __forceinline__ void composite(ItemState& st, const float* z, float* 
       const float a = st.alpha[r][i];
       const float w = a * (float)T;
       wout[r * S + i] = w;
+      if (tout) tout[r * S + i] = (float)T;
       cr = cr + w * q[i * 4 + 0];
       cg = cg + w * q[i * 4 + 1];
       cb = cb + w * q[i * 4 + 2];
@@ -450,8 +446,9 @@ __device__ __forceinline__ void gen_ray(const float* __restrict__ c2w, float fx,
 }
 
 struct RenderArgs {
-  const float* stream[2];   // packed weight streams (coarse, fine)
-  const float* aux[2];      // aux blocks
+  const float* nets;        // packed networks: coarse | fine | fine^T, `net_stride` BYTES apart
+  long long net_stride;
+  const float* aux[2];      // aux blocks (coarse, fine)
   const float* tcoarse;     // [64]
   const float* ufine;       // [128]
   const float* rays_o;      // [N,3]   (RAYS mode)
@@ -501,15 +498,15 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
 
   Ring rg;
   rg.smem = smem;
-  rg.net[0] = (const char*)a.stream[0];
-  rg.net[1] = (const char*)a.stream[1];
+  rg.base = (const char*)a.nets;
+  rg.stride = a.net_stride;
   rg.lane_off = wave * 4096 + lane * 16;
   rg.wave_lds = wave * 4096;
-  rg.psrc = rg.net[0] + rg.lane_off;
+  rg.psrc = rg.base + rg.lane_off;
   rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0;
   rg.ppi = fine ? 4 : 1;
 
-  f32x4 A0[8], A1[8];
+  f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
 
   load_aux(smem, a, tid);
@@ -570,7 +567,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+      mlp_pass<false>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
@@ -638,6 +635,367 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Backward (input-side VJP) of one network pass.  Same register-chained scheme with W^T as the A operand:
+//   G_in^T[K_in x 32pts] = W^T[K_in x K_out] * (G_out^T (.) relu')        (weights are constants: no dW)
+// The gradient fragment of layer l (C layout) is masked with the relu pattern captured in the forward pass
+// and is, register for register, the B operand of layer l-1's transposed GEMM.
+// Stream order: views^T 9 | feature^T 16 | L7^T 16 | L6^T 16 | L5^T 20 (8 blocks h4 + 2 blocks encoding) |
+//               L4^T..L1^T 64 | L0^T 4 (2 blocks encoding)  = 145 slabs.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 apply_mask(f32x16 x, unsigned word, int shift) {
+  f32x16 r;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r[i] = ((word >> (shift + i)) & 1u) ? x[i] : 0.0f;
+  return r;
+}
+
+// d(encoding)/d(x): this lane half holds G for sin features (h=0) or cos features (h=1) of x[ax]; identity
+// terms sit in registers 3L and 3L+1.  Returns the half's contribution; the caller adds the two halves.
+template <int NFREQ>
+__device__ __forceinline__ void embed_bwd(const float (&x)[3], const float* G /* NFREQ*3+2 values */, int h,
+                                          float (&out)[3]) {
+  out[0] = h ? 0.0f : G[3 * NFREQ];
+  out[1] = h ? 0.0f : G[3 * NFREQ + 1];
+  out[2] = h ? G[3 * NFREQ] : 0.0f;
+#pragma unroll
+  for (int L = 0; L < NFREQ; ++L)
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const float f = (float)(1 << L);
+      float sn, cs;
+      sincosf(x[ax] * f, &sn, &cs);
+      const float g = G[3 * L + ax];
+      out[ax] = __builtin_fmaf(f * g, h ? -sn : cs, out[ax]);     // d sin = f cos, d cos = -f sin
+    }
+}
+
+__device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
+                                             const uint4* mask_src, float g0, float g1, float g2, float gs,
+                                             float px, float py, float pz, float vx, float vy, float vz,
+                                             float (&dp)[3], float (&dv)[3]) {
+  const int h = lane >> 5;
+  // rgb_linear^T (VALU) masked by the views layer's relu pattern
+  f32x16 gv[4];
+  {
+    const uint4 mk = mask_src[8 * 256];
+    const unsigned mw[2] = {mk.x, mk.y};
+#pragma unroll
+    for (int mo = 0; mo < 4; ++mo)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const f32x4 w0 = *(const f32x4*)(aux + kAuxWRgb + 0 * 128 + ((mo * 4 + rq) * 2 + h) * 4);
+        const f32x4 w1 = *(const f32x4*)(aux + kAuxWRgb + 1 * 128 + ((mo * 4 + rq) * 2 + h) * 4);
+        const f32x4 w2 = *(const f32x4*)(aux + kAuxWRgb + 2 * 128 + ((mo * 4 + rq) * 2 + h) * 4);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) {
+          const float v = __builtin_fmaf(w2[ri], g2, __builtin_fmaf(w1[ri], g1, w0[ri] * g0));
+          const int r = rq * 4 + ri;
+          gv[mo][r] = ((mw[mo >> 1] >> ((mo & 1) * 16 + r)) & 1u) ? v : 0.0f;
+        }
+      }
+  }
+  // views^T: 256 feature rows (blocks 0-7) + 32 direction-encoding rows (block 8), K = 128
+  f32x16 accv[9];
+#pragma unroll
+  for (int mo = 0; mo < 9; ++mo) accv[mo] = f32x16{0};
+  seg<9, 16>(rg, A0, A1, BRegs16<4>{gv}, accv, lane);
+  {
+    float Gd[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) Gd[t] = accv[8][t];
+    const float v[3] = {vx, vy, vz};
+    float part[3];
+    embed_bwd<kMultiresViews>(v, Gd, h, part);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) dv[ax] = part[ax] + __shfl_xor(part[ax], 32);
+  }
+
+  f32x16 gin[8];
+  f32x16 acc[10];   // 0-7: gradient w.r.t. the 256 hidden features; 8-9: gradient w.r.t. the 64 encoding registers
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) gin[mo] = accv[mo];          // feature_linear has no activation
+  acc[8] = f32x16{0};
+  acc[9] = f32x16{0};
+  // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (10 blocks), 4..7 L4^T..L1^T
+#pragma unroll 1
+  for (int idx = 0; idx < 8; ++idx) {
+    const uint4 mk = mask_src[(7 - idx) * 256];              // relu pattern of the layer this GEMM feeds back to
+    if (idx == 0) {
+      const float* wa = aux + kAuxWAlpha;                    // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
+#pragma unroll
+      for (int tq = 0; tq < 32; ++tq) {
+        const f32x4 w = *(const f32x4*)(wa + (tq * 2 + h) * 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc[(4 * tq + kk) >> 4][(4 * tq + kk) & 15] = w[kk] * gs;
+      }
+    } else {
+#pragma unroll
+      for (int mo = 0; mo < 8; ++mo) acc[mo] = f32x16{0};
+    }
+    if (idx == 3) seg<10, 32>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+    else seg<8, 32>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+    const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) gin[mo] = apply_mask(acc[mo], mw[mo >> 1], (mo & 1) * 16);
+  }
+  // L0^T: the remaining 64 encoding rows
+  seg<2, 32>(rg, A0, A1, BRegs16<8>{gin}, *(f32x16(*)[2]) & acc[8], lane);
+  {
+    float Ge[32];
+#pragma unroll
+    for (int t = 0; t < 32; ++t) Ge[t] = acc[8 + (t >> 4)][t & 15];
+    const float p[3] = {px, py, pz};
+    float part[3];
+    embed_bwd<kMultires>(p, Ge, h, part);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) dp[ax] = part[ax] + __shfl_xor(part[ax], 32);
+  }
+}
+
+// Backward of raw2outputs (RN:343-387) for both rays: dL/d raw (written over st.rawf) and dL/d|rays_d|.
+// st.rawf holds sigmoid(rgb) and the raw sigma, st.alpha / st.wf / st.tf the forward alpha, weights, T.
+__device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /* [2][3] in LDS */, int tid) {
+  constexpr int S = 192;
+  if ((tid & 63) == 0 && tid < 128) {
+    const int r = tid >> 6;
+    const float g0 = grgb[r * 3 + 0], g1 = grgb[r * 3 + 1], g2 = grgb[r * 3 + 2];
+    const float nrm = st.ray[r][11];
+    float suffix = 0.0f, dn = 0.0f;
+    for (int i = S - 1; i >= 0; --i) {
+      float* q = st.rawf[r][i];
+      const float a = st.alpha[r][i], T = st.tf[r][i], w = st.wf[r][i];
+      const float c0 = q[0], c1 = q[1], c2 = q[2], sigma = q[3];
+      const float A = (g0 * c0 + g1 * c1) + g2 * c2;                     // dL/dw_i
+      const float om = (1.0f - a) + 1e-10f;
+      const float d_alpha = A * T - suffix / om;                          // T_k (k>i) carries the factor om_i
+      suffix = suffix + A * w;
+      const float dz = (i < S - 1) ? (st.zf[r][i + 1] - st.zf[r][i]) : 1e10f;
+      const float e = 1.0f - a;                                           // exp(-relu(sigma) * delta)
+      const float d_sigma = (sigma > 0.0f) ? d_alpha * (dz * nrm) * e : 0.0f;
+      dn = dn + (d_alpha * fmaxf(sigma, 0.0f) * e) * dz;                  // d delta / d|d| = dz
+      q[0] = w * g0 * c0 * (1.0f - c0);
+      q[1] = w * g1 * c1 * (1.0f - c1);
+      q[2] = w * g2 * c2 * (1.0f - c2);
+      q[3] = d_sigma;
+    }
+    st.gnorm[r] = dn;
+  }
+  __syncthreads();
+}
+
+struct VjpArgs {
+  RenderArgs r;             // forward arguments (fine must be 1)
+  const float* grad_rgb;    // [N,3] cotangent
+  float* grad_o;            // [N,3]
+  float* grad_d;            // [N,3]
+  uint4* mask_scratch;      // [gridDim][3 passes][9 layers][256 threads]
+};
+
+__global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; }
+
+// ------------------------------------------------------------------------------------------------------
+// Fused forward + input-gradient kernel (render_path_grad, RN:168-178).  Per item (2 rays):
+//   pass 0      coarse forward, compositing, resampling            (as k_render)
+//   pass 1-3    fine forward, relu patterns captured to an L2-resident scratch (110 KB per workgroup)
+//   --          compositing forward + backward -> dL/d raw per sample
+//   pass 4-6    fine backward through the transposed network -> dL/d pts, dL/d viewdir per sample
+//   --          per-ray reduction: dL/d rays_o, dL/d rays_d
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VjpArgs& va = *vp;
+  const RenderArgs& a = va.r;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31;
+  ItemState& st = *(ItemState*)(smem + kLdsState);
+
+  const long long n_rays = a.n_rays;
+  const long long n_items = (n_rays + 1) >> 1;
+  if ((long long)blockIdx.x >= n_items) return;
+
+  Ring rg;
+  rg.smem = smem;
+  rg.base = (const char*)a.nets;
+  rg.stride = a.net_stride;
+  rg.lane_off = wave * 4096 + lane * 16;
+  rg.wave_lds = wave * 4096;
+  rg.psrc = rg.base + rg.lane_off;
+  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0;
+  rg.ppi = 7;
+
+  f32x4 A0[4], A1[4];
+  ring_start(rg, A0, lane);
+  load_aux(smem, a, tid);
+  if (tid < 64) st.tcoarse[tid] = a.tcoarse[tid];
+  if (tid < 128) st.ufine[tid] = a.ufine[tid];
+  __syncthreads();
+  const float* aux_c = (const float*)(smem + kLdsAux);
+  const float* aux_f = aux_c + kAuxFloats;
+  uint4* my_masks = va.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256) + tid;
+  float* grgb = &st.res[0][0];   // [2][3] cotangent staged here during the backward half (res is free then)
+
+  long long item = blockIdx.x;
+  int pass = 0;
+#pragma unroll 1
+  while (item < n_items) {
+    const long long ray0 = item * 2;
+    const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
+    if (pass == 0) {
+      const float near_ = a.near_, far_ = a.far_;
+      if (tid < 2) {
+        const long long rr = ray0 + (tid < valid ? tid : 0);
+        float o[3], d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
+        const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c]; st.ray[tid][6 + c] = d[c] / nrm; }
+        st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
+      }
+      if (tid < 128) {
+        const int r = tid >> 6, i = tid & 63;
+        const float t = st.tcoarse[i];
+        st.zc[r][i] = (near_ * (1.0f - t)) + (far_ * t);
+      }
+      __syncthreads();
+    }
+
+    if (pass <= 3) {
+      // ---- forward passes (coarse, then 3 fine with relu capture) ----
+      int r, i;
+      const float* zsrc;
+      float* dst;
+      if (pass == 0) {
+        r = wave >> 1; i = 32 * (wave & 1) + j;
+        zsrc = &st.zc[r][i]; dst = st.rawc[r][i];
+      } else {
+        const int q0 = 128 * (pass - 1) + 32 * wave;
+        r = q0 / 192; i = q0 - r * 192 + j;
+        zsrc = &st.zf[r][i]; dst = st.rawf[r][i];
+      }
+      const float z = *zsrc;
+      const float* ry = st.ray[r];
+      float raw[4];
+      mlp_pass<true>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+                     ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256));
+      if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    } else {
+      // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
+      const int q0 = 128 * (pass - 4) + 32 * wave;
+      const int r = q0 / 192, slot = (q0 - r * 192) >> 5, i = q0 - r * 192 + j;
+      const float z = st.zf[r][i];
+      const float* ry = st.ray[r];
+      const f32x4 g = *(const f32x4*)st.rawf[r][i];
+      float dp[3], dv[3];
+      mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), g[0], g[1], g[2], g[3],
+                   ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
+      // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
+      float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
+#pragma unroll
+      for (int m = 16; m >= 1; m >>= 1)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) red[c] += __shfl_xor(red[c], m);
+      if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) st.psum[r][slot][c] = red[c];
+    }
+
+    if (pass == 0) {
+      __syncthreads();
+      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], tid);
+      int64_t* none = nullptr;
+      sample_pdf_item(st, &st.w0[0][1], 64,
+                      [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid);
+      merge_sort_item(st, tid);
+      pass = 1;
+    } else if (pass < 3) {
+      ++pass;
+    } else if (pass == 3) {
+      __syncthreads();
+      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], tid, &st.tf[0][0]);
+      if (tid < valid * 8) {
+        const int r = tid >> 3, c = tid & 7;
+        const long long rr = ray0 + r;
+        const float v = st.res[r][c];
+        if (c < 3) { if (a.rgb) a.rgb[rr * 3 + c] = v; }
+        else if (c == 3) { if (a.disp) a.disp[rr] = v; }
+        else if (c == 4) { if (a.acc) a.acc[rr] = v; }
+      }
+      __syncthreads();
+      if (tid < 6) {
+        const int r = tid / 3;
+        grgb[tid] = va.grad_rgb[(ray0 + (r < valid ? r : 0)) * 3 + (tid - r * 3)];
+      }
+      __syncthreads();
+      composite_bwd(st, grgb, tid);
+      pass = 4;
+    } else if (pass < 6) {
+      ++pass;
+    } else {
+      __syncthreads();
+      if (tid < valid) {
+        const int r = tid;
+        float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
+        for (int s = 0; s < 6; ++s)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            so[c] += st.psum[r][s][c];
+            sd[c] += st.psum[r][s][3 + c];
+            sv[c] += st.psum[r][s][6 + c];
+          }
+        const float* ry = st.ray[r];
+        const float nrm = ry[11];
+        const float vdot = (sv[0] * ry[6] + sv[1] * ry[7]) + sv[2] * ry[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = ry[6 + c];
+          va.grad_o[(ray0 + r) * 3 + c] = so[c];
+          va.grad_d[(ray0 + r) * 3 + c] = sd[c] + (sv[c] - v * vdot) / nrm + st.gnorm[r] * v;   // RN:97, RN:361
+        }
+      }
+      __syncthreads();
+      pass = 0;
+      item += gridDim.x;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):
+//   g[a][k] = sum_pix grad_d[pix][a] * dirs[pix][k]  (k < 3),  g[a][3] = sum_pix grad_o[pix][a]
+__global__ void __launch_bounds__(256) k_pose_grad(const float* __restrict__ go, const float* __restrict__ gd,
+                                                   float fx, float fy, float cx, float cy, int W, int n_pix,
+                                                   int patch, float* out /* [n_patches][12] */) {
+  __shared__ double red[256][12];
+  const int p0 = blockIdx.x * patch;
+  double acc[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) acc[c] = 0.0;
+  for (int pix = p0 + threadIdx.x; pix < min(p0 + patch, n_pix); pix += 256) {
+    const int row = pix / W, col = pix - row * W;
+    const float dirs[3] = {((float)col - cx) / fx, -(((float)row - cy) / fy), -1.0f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) acc[a * 4 + k] += (double)gd[pix * 3 + a] * (double)dirs[k];
+      acc[a * 4 + 3] += (double)go[pix * 3 + a];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 12; ++c) red[threadIdx.x][c] = acc[c];
+  __syncthreads();
+  for (int s = 128; s >= 1; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int c = 0; c < 12; ++c) red[threadIdx.x][c] += red[threadIdx.x + s][c];
+    __syncthreads();
+  }
+  if (threadIdx.x < 12) out[blockIdx.x * 12 + threadIdx.x] = (float)red[0][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------
 // run_network (RN:26-40) as a stage kernel: 128 points per workgroup pass.
 // ------------------------------------------------------------------------------------------------------
 struct NetArgs {
@@ -659,12 +1017,13 @@ __global__ void __launch_bounds__(256, 1) k_run_network(NetArgs a) {
 
   Ring rg;
   rg.smem = smem;
-  rg.net[0] = rg.net[1] = (const char*)a.stream;
+  rg.base = (const char*)a.stream;
+  rg.stride = 0;
   rg.lane_off = wave * 4096 + lane * 16;
   rg.wave_lds = wave * 4096;
-  rg.psrc = rg.net[0] + rg.lane_off;
+  rg.psrc = rg.base + rg.lane_off;
   rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.ppi = 1;
-  f32x4 A0[8], A1[8];
+  f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);
   float* auxl = (float*)(smem + kLdsAux);
   for (int i = tid; i < kAuxFloats; i += 256) auxl[i] = a.aux[i];
@@ -675,7 +1034,7 @@ __global__ void __launch_bounds__(256, 1) k_run_network(NetArgs a) {
     const bool ok = p < a.n_pts;
     if (!ok) p = a.n_pts - 1;
     float raw[4];
-    mlp_pass(rg, auxl, A0, A1, lane, a.pts[p * 3 + 0], a.pts[p * 3 + 1], a.pts[p * 3 + 2], a.dirs[p * 3 + 0],
+    mlp_pass<false>(rg, auxl, A0, A1, lane, a.pts[p * 3 + 0], a.pts[p * 3 + 1], a.pts[p * 3 + 2], a.dirs[p * 3 + 0],
              a.dirs[p * 3 + 1], a.dirs[p * 3 + 2], raw);
     if (ok && lane < 32) *(f32x4*)(a.raw + p * 4) = f32x4{raw[0], raw[1], raw[2], raw[3]};
   }

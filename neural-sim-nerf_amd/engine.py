@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .pack import pack_network, PACKED_FLOATS
+from .pack import pack_network, pack_network_backward, PACKED_FLOATS
 
 N_SAMPLES = 64
 N_IMPORTANCE = 128
@@ -60,8 +60,11 @@ class NsrModel:
                             for k, v in sd.items()}
         p = pack_network(to_np(sd_coarse))
         _lib.check(self.lib.nsr_upload_weights(self.h, 0, _fptr(p), PACKED_FLOATS))
+        self._sd_fine_np = None
+        self._bwd_ready = False
         if sd_fine is not None:
-            p = pack_network(to_np(sd_fine))
+            self._sd_fine_np = to_np(sd_fine)
+            p = pack_network(self._sd_fine_np)
             _lib.check(self.lib.nsr_upload_weights(self.h, 1, _fptr(p), PACKED_FLOATS))
 
     def close(self):
@@ -127,6 +130,40 @@ class NsrModel:
         _lib.check(self.lib.nsr_render_views(self.h, _dev(c2w), v, int(H), int(W), K9, float(near), float(far),
                                              C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
         return o
+
+    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False):
+        """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each."""
+        if self.n_importance == 0:
+            raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
+        if not self._bwd_ready:                      # the transposed stream is packed on first use only
+            b = pack_network_backward(self._sd_fine_np)
+            _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
+            self._bwd_ready = True
+        rays_o = self._f32(rays_o, (-1, 3))
+        rays_d = self._f32(rays_d, (-1, 3))
+        n = rays_o.shape[0]
+        g = self._f32(grad_rgb, (n, 3))
+        go, gd = self._new(n, 3), self._new(n, 3)
+        ro, fwd = None, None
+        if with_forward:
+            fwd = dict(rgb_map=self._new(n, 3), disp_map=self._new(n), acc_map=self._new(n))
+            ro = _lib.NsrRenderOut(_dev(fwd["rgb_map"]), _dev(fwd["disp_map"]), _dev(fwd["acc_map"]), None, None,
+                                   None, None)
+        _lib.check(self.lib.nsr_render_rays_vjp(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
+                                                _dev(g), _dev(go), _dev(gd), C.byref(ro) if ro else None,
+                                                _stream_ptr(self.device)))
+        return (go, gd, fwd) if with_forward else (go, gd)
+
+    def pose_grad(self, grad_o, grad_d, H, W, K, patch):
+        """dL/d c2w[3,4] per patch of `patch` consecutive pixels, given dL/d rays of a full H x W image."""
+        grad_o = self._f32(grad_o, (int(H) * int(W), 3))
+        grad_d = self._f32(grad_d, (int(H) * int(W), 3))
+        n_patches = (int(H) * int(W) + int(patch) - 1) // int(patch)
+        out = self._new(n_patches, 3, 4)
+        K9 = (C.c_double * 9)(*[float(K[i][j]) for i in range(3) for j in range(3)])
+        _lib.check(self.lib.nsr_pose_grad(self.h, _dev(grad_o), _dev(grad_d), int(H), int(W), K9, int(patch),
+                                          _dev(out), _stream_ptr(self.device)))
+        return out
 
     def get_rays(self, H, W, K, c2w):
         c2w = self._f32(c2w)[:3, :4].contiguous()

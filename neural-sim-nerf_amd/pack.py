@@ -131,3 +131,62 @@ def pack_network(sd):
     aux[AUX_B_ALPHA] = g("alpha_linear.bias")[0]
     aux[AUX_B_RGB:AUX_B_RGB + 3] = g("rgb_linear.bias")
     return np.concatenate([stream, aux]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# backward (input-gradient) stream: the same GEMM machinery with W^T as the A operand
+# ----------------------------------------------------------------------------------------------------------
+def _enc_row(i):
+    """Row i (0..31) of an 'encoding' output block <-> (register tl, lane half h_e) of the encoding array:
+    the C fragment puts row (r&3)+8(r>>2)+4h in register r of half h, so row i is register
+    tl = (i&3) + 4*(i>>3) of half (i>>2)&1."""
+    return (i & 3) + 4 * (i >> 3), (i >> 2) & 1
+
+
+def _pack_T(M, n_mo, n_tq):
+    """M [n_mo*32 rows, K] (already transposed: rows = the GEMM's outputs, columns = its k features in
+    reference order); k-step t / half h reads column kappa(t, h).  Chunk order [tq][mo] -> [n_tq, n_mo, 64, 4]."""
+    assert M.shape[0] == n_mo * 32
+    lane = np.arange(64)
+    i, h = lane & 31, lane >> 5
+    out = np.empty((n_tq, n_mo, 64, 4), np.float32)
+    for tq in range(n_tq):
+        for kk in range(4):
+            c = kappa(4 * tq + kk, h)
+            for mo in range(n_mo):
+                out[tq, mo, :, kk] = M[32 * mo + i, c]
+    return out
+
+
+def _enc_rows_T(W_cols, n_freq, n_blocks):
+    """Rows of the transposed matrix that produce d/d(encoding register): W_cols [K_out, n_in] holds the
+    layer's columns for the encoding inputs (reference order); returns [n_blocks*32, K_out]."""
+    rows = np.zeros((n_blocks * 32, W_cols.shape[0]), np.float32)
+    for b in range(n_blocks):
+        for i in range(32):
+            tl, he = _enc_row(i)
+            col = eps(16 * b + tl, he, n_freq)
+            if col >= 0:
+                rows[32 * b + i] = W_cols[:, col]
+    return rows
+
+
+def pack_network_backward(sd):
+    """Transposed stream of one network for the input-side VJP kernel (k_render_vjp).  Order:
+    views^T (9 blocks x 16 quads) | feature^T | L7^T | L6^T | L5^T (10 blocks) | L4^T..L1^T | L0^T (2 blocks).
+    Returns float32 [STREAM_SLABS * SLAB_FLOATS] (the aux block of pack_network is shared)."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    segs = []
+    Wv = g("views_linears.0.weight")                                     # [128, 256 + 27]
+    segs.append(_pack_T(np.concatenate([Wv[:, :256].T, _enc_rows_T(Wv[:, 256:], 4, 1)], 0), 9, 16))
+    segs.append(_pack_T(g("feature_linear.weight").T, 8, 32))
+    for l in (7, 6):
+        segs.append(_pack_T(g("pts_linears.%d.weight" % l).T, 8, 32))
+    W5 = g("pts_linears.5.weight")                                       # [256, 63 + 256], input columns first
+    segs.append(_pack_T(np.concatenate([W5[:, 63:].T, _enc_rows_T(W5[:, :63], 10, 2)], 0), 10, 32))
+    for l in (4, 3, 2, 1):
+        segs.append(_pack_T(g("pts_linears.%d.weight" % l).T, 8, 32))
+    segs.append(_pack_T(_enc_rows_T(g("pts_linears.0.weight"), 10, 2), 2, 32))
+    stream = np.concatenate([x.reshape(-1) for x in segs]).astype(np.float32)
+    assert stream.size == STREAM_SLABS * SLAB_FLOATS
+    return stream

@@ -1,0 +1,96 @@
+"""Drop-in for the reference's utils/run_nerf_helpers.py (RH) -- the names neural_sim_main.py star-imports --
+backed by the native gfx950 library.  The positional encoder and the 8x256 MLP are fused into the kernels
+(csrc/nsr_kernels.hip); the classes here carry weights and shapes, they do not compute on the host.
+
+Differences from RH, all deliberate: no global torch.autograd.set_detect_anomaly(True) (RH:2: debug aid that
+slows every autograd call); no .cuda() hard-coding; unsupported configurations raise instead of running a
+different code path."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+img2mse = lambda x, y: torch.mean((x - y) ** 2)                                                  # RH:12
+mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=x.device))      # RH:13
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)                                       # RH:14 (truncation)
+
+
+class Embedder:
+    """RH:18-48.  Kept for its metadata (out_dim); the encoding itself runs inside the kernel."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        d = kwargs["input_dims"]
+        self.out_dim = (d if kwargs["include_input"] else 0) + d * 2 * kwargs["num_freqs"]
+
+    def embed(self, inputs):
+        raise NotImplementedError("the positional encoding is fused into the gfx950 kernel; call the network "
+                                  "through network_query_fn / render(), which take un-encoded points")
+
+
+def get_embedder(multires, i=0):
+    """RH:51-66.  Only the log-sampled sin/cos encoding with include_input (i == 0) is supported."""
+    if i != 0:
+        raise NotImplementedError("i_embed=%r: only the default positional encoding (0) is supported" % (i,))
+    eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                  log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return eo.embed, eo.out_dim
+
+
+class NeRF(nn.Module):
+    """RH:70-122: weight container with the reference's parameter names, so the reference's checkpoints
+    (`network_fn_state_dict` / `network_fine_state_dict`, RN:296-314) load with load_state_dict unchanged.
+    forward() evaluates the network natively; its input is the reference's [P, 90] embedded tensor, of which
+    only the raw position (columns 0:3) and direction (63:66) are read -- the kernel re-derives the rest."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        if (D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs)) != (8, 256, 63, 27, [4], True):
+            raise NotImplementedError(
+                "the gfx950 kernel is specialised to D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], "
+                "use_viewdirs=True (configs/nerf_param_ycbv_general.txt); got D=%r W=%r input_ch=%r "
+                "input_ch_views=%r skips=%r use_viewdirs=%r" % (D, W, input_ch, input_ch_views, skips, use_viewdirs))
+        self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in skips else nn.Linear(W + input_ch, W)
+                                        for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        self.feature_linear = nn.Linear(W, W)
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        self._native = None
+        self._native_key = None
+
+    def weights_version(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def forward(self, x):
+        from .engine import NsrModel
+        key = self.weights_version()
+        if self._native is None or self._native_key != key:
+            if self._native is not None:
+                self._native.close()
+            self._native = NsrModel(self.state_dict(), None, n_importance=0)
+            self._native_key = key
+        x = x.reshape(-1, x.shape[-1])
+        return self._native.run_network(x[:, :3], x[:, self.input_ch:self.input_ch + 3], 0)
+
+
+def get_rays(H, W, K, c2w):
+    """RH:156-165 on the device (native kernel).  Differentiable w.r.t. c2w (needed by RN:179)."""
+    from .run_nerf_noscale import _get_rays_autograd
+    return _get_rays_autograd(H, W, K, c2w)
+
+
+def ndc_rays(*a, **k):
+    raise NotImplementedError("NDC rays (forward-facing LLFF scenes, RH:178) are outside this path: "
+                              "LINEMOD/YCB-V uses ndc=False (RN:331-334)")
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    """RH:199-243, deterministic branch only, native kernel."""
+    if not det or pytest or N_samples != 128:
+        raise NotImplementedError("sample_pdf: only det=True, N_samples=128 (perturb=0, RN:474) is supported")
+    from .run_nerf_noscale import _util_model
+    samples, _ = _util_model(bins.device).sample_pdf(bins, weights)
+    return samples

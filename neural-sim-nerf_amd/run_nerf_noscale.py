@@ -1,0 +1,348 @@
+"""Drop-in for the reference's utils/run_nerf_noscale.py (RN): `create_nerf`, `render`, `render_path`,
+`render_path_grad`, `to8b`, `device` with the reference's signatures and return conventions, so that
+optimization/neural_sim_main.py (NM:35 star-import, call sites NM:67, NM:128, NM:184) runs unchanged on top.
+
+Everything below L1 of SURVEY.md section 1 -- batchify_rays, render_rays, run_network, raw2outputs, sample_pdf,
+Embedder, the 8x256 MLP -- is ONE persistent gfx950 kernel (csrc/nsr_kernels.hip) reached through the C ABI
+of include/nsr.h.  This file is host glue: argument checking, handle caching, reshapes, PNG side effects.
+
+Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
+different path is worse): ndc=True, lindisp, perturb>0, raw_noise_std>0, white_bkgd, c2w_staticcam,
+use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, per-ray near/far arrays."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from .run_nerf_helpers import NeRF, get_embedder, to8b, img2mse, mse2psnr, get_rays, sample_pdf  # noqa: F401
+from . import png
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")      # RN:9
+DEBUG = False
+
+
+# ------------------------------------------------------------------------------------------------------
+# native handles
+# ------------------------------------------------------------------------------------------------------
+_UTIL = {}
+
+
+def _util_model(dev=None):
+    """A weight-less handle for the stage kernels that need no network (get_rays, sample_pdf)."""
+    from .engine import NsrModel
+    from .synthetic import synth_weights
+    idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
+    if idx not in _UTIL:
+        _UTIL[idx] = NsrModel(synth_weights(0), None, device=idx, n_importance=0)
+    return _UTIL[idx]
+
+
+def _model_for(network_fn, network_fine, n_importance):
+    """One native handle per (network_fn, network_fine) pair, repacked when the parameters change."""
+    from .engine import NsrModel
+    if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
+        raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
+    key = (n_importance, network_fn.weights_version(),
+           network_fine.weights_version() if network_fine is not None else None)
+    cache = network_fn.__dict__.setdefault("_nsr_pair", {})
+    if cache.get("key") != key:
+        if cache.get("model") is not None:
+            cache["model"].close()
+        cache["model"] = NsrModel(network_fn.state_dict(), network_fine.state_dict() if network_fine is not None
+                                  else None, n_importance=n_importance)
+        cache["key"] = key
+    return cache["model"]
+
+
+# ------------------------------------------------------------------------------------------------------
+# autograd glue
+# ------------------------------------------------------------------------------------------------------
+class _GetRays(torch.autograd.Function):
+    """rays_d[p] = R dirs[p], rays_o[p] = t (RH:160-164): linear in c2w, so the VJP is a reduction over pixels."""
+
+    @staticmethod
+    def forward(ctx, c2w, H, W, K):
+        m = _util_model(c2w.device if c2w.is_cuda else None)
+        o, d = m.get_rays(H, W, K, c2w.detach())
+        ctx.geom = (H, W, K, m)
+        ctx.c2w_shape = c2w.shape
+        return o, d
+
+    @staticmethod
+    def backward(ctx, go, gd):
+        H, W, K, m = ctx.geom
+        g = m.pose_grad(go.reshape(-1, 3), gd.reshape(-1, 3), H, W, K, H * W)[0]      # [3,4]
+        out = torch.zeros(ctx.c2w_shape, dtype=torch.float32, device=g.device)
+        out[:3, :4] = g
+        return out, None, None, None
+
+
+def _get_rays_autograd(H, W, K, c2w):
+    c2w = torch.as_tensor(c2w, dtype=torch.float32)
+    if not c2w.is_cuda:
+        c2w = c2w.to(device)
+    if c2w.requires_grad:
+        return _GetRays.apply(c2w, int(H), int(W), K)
+    return _util_model(c2w.device).get_rays(int(H), int(W), K, c2w)
+
+
+class _RenderRays(torch.autograd.Function):
+    """render(rays=...) with the input-side VJP the bilevel loop needs (RN:177: d rgb / d rays; network weights
+    are frozen and z_samples is detached, RN:475, so nothing else carries gradient)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, model, near, far, want_raw):
+        out = model.render_rays(rays_o.detach(), rays_d.detach(), near, far, debug=want_raw)
+        ctx.save_for_backward(rays_o.detach(), rays_d.detach())
+        ctx.cfg = (model, near, far)
+        fine = model.n_importance > 0
+        keys = ["rgb_map", "disp_map", "acc_map"] + (["rgb0", "disp0", "acc0", "z_std"] if fine else [])
+        if want_raw:
+            keys.append("raw" if fine else "raw0")
+        ctx.n_out = len(keys)
+        ctx.mark_non_differentiable(*[out[k] for k in keys[1:]])
+        return tuple(out[k] for k in keys)
+
+    @staticmethod
+    def backward(ctx, g_rgb, *others):
+        model, near, far = ctx.cfg
+        rays_o, rays_d = ctx.saved_tensors
+        go, gd = model.render_rays_vjp(rays_o, rays_d, near, far, g_rgb)
+        return go, gd, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------
+# the reference API
+# ------------------------------------------------------------------------------------------------------
+def batchify(fn, chunk):
+    """RN:14-23.  Chunking bounds memory in the reference and does not change results (RN:67-68); the native
+    path needs no chunking, so this returns fn."""
+    return fn
+
+
+def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64):
+    """RN:26-40: inputs [..., 3] points, viewdirs [N, 3] -> [..., 4], evaluated natively (encoding fused)."""
+    if viewdirs is None:
+        raise NotImplementedError("use_viewdirs=False is not supported")
+    flat = inputs.reshape(-1, 3)
+    dirs = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
+    x = torch.zeros(flat.shape[0], 90, dtype=torch.float32, device=flat.device)
+    x[:, :3] = flat
+    x[:, 63:66] = dirs
+    out = fn(x)
+    return out.reshape(list(inputs.shape[:-1]) + [out.shape[-1]])
+
+
+def _check_kwargs(kw):
+    bad = []
+    if kw.get("perturb", 0.) not in (0, 0., False):
+        bad.append("perturb>0 (stratified jitter)")
+    if kw.get("raw_noise_std", 0.) not in (0, 0.):
+        bad.append("raw_noise_std>0")
+    if kw.get("white_bkgd", False):
+        bad.append("white_bkgd")
+    if kw.get("lindisp", False):
+        bad.append("lindisp")
+    if kw.get("N_samples", 64) != 64:
+        bad.append("N_samples=%r (kernel is specialised to 64)" % kw.get("N_samples"))
+    if kw.get("N_importance", 0) not in (0, 128):
+        bad.append("N_importance=%r (0 or 128)" % kw.get("N_importance"))
+    if kw.get("pytest", False):
+        bad.append("pytest=True")
+    if bad:
+        raise NotImplementedError("render: unsupported option(s): " + ", ".join(bad))
+
+
+def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
+           c2w_staticcam=None, **kwargs):
+    """RN:58-123.  Returns [rgb_map, disp_map, acc_map, extras] with the reference's shapes: [H,W,...] when
+    c2w is given, rays_d.shape[:-1] + ... for the rays form.  `chunk` is accepted and ignored."""
+    if ndc:
+        raise NotImplementedError("render: ndc=True (LLFF forward-facing scenes) is not supported")
+    if not use_viewdirs:
+        raise NotImplementedError("render: use_viewdirs=False is not supported")
+    if c2w_staticcam is not None:
+        raise NotImplementedError("render: c2w_staticcam is not supported")
+    if not (np.isscalar(near) and np.isscalar(far)):
+        raise NotImplementedError("render: near/far must be python scalars (per-ray bounds are not supported)")
+    _check_kwargs(kwargs)
+    n_imp = kwargs.get("N_importance", 0)
+    model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp)
+    retraw = bool(kwargs.get("retraw", False))
+    fine = n_imp > 0
+
+    if c2w is not None:
+        c2w = torch.as_tensor(c2w, dtype=torch.float32)
+        if not c2w.requires_grad:
+            out = model.render_views(c2w.to(model.device), H, W, K, near, far, debug=retraw)
+            sh = (int(H), int(W))
+            ret = {k: v.reshape(sh + tuple(v.shape[1:])) for k, v in out.items()
+                   if k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")}
+            if retraw:
+                r = out["raw" if fine else "raw0"]
+                ret["raw"] = r.reshape(sh + tuple(r.shape[1:]))
+            return _pack_ret(ret)
+        rays_o, rays_d = _get_rays_autograd(H, W, K, c2w)
+    else:
+        rays_o, rays_d = rays
+    rays_o = torch.as_tensor(rays_o, dtype=torch.float32)
+    rays_d = torch.as_tensor(rays_d, dtype=torch.float32)
+    sh = tuple(rays_d.shape[:-1])
+    ro = rays_o.reshape(-1, 3).to(model.device)
+    rd = rays_d.reshape(-1, 3).to(model.device)
+    outs = _RenderRays.apply(ro, rd, model, float(near), float(far), retraw)
+    keys = ["rgb_map", "disp_map", "acc_map"] + (["rgb0", "disp0", "acc0", "z_std"] if fine else [])
+    if retraw:
+        keys.append("raw")
+    ret = {k: v.reshape(sh + tuple(v.shape[1:])) for k, v in zip(keys, outs)}
+    return _pack_ret(ret)
+
+
+def _pack_ret(ret):
+    k_extract = ["rgb_map", "disp_map", "acc_map"]        # RN:120-123
+    return [ret[k] for k in k_extract] + [{k: v for k, v in ret.items() if k not in k_extract}]
+
+
+def _scaled_hw(hwf, render_factor):
+    H, W, focal = hwf
+    if render_factor != 0:                                 # RN:217-221 (K itself is not rescaled there either)
+        H, W, focal = H // render_factor, W // render_factor, focal / render_factor
+    return int(H), int(W), focal
+
+
+def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None,
+                object_id=2, render_factor=0):
+    """RN:213-255.  All poses are rendered by ONE persistent-kernel launch (the reference loops serially,
+    RN:229); PNGs land in savedir/<object_id>/{i:03d}.png exactly as before.  `categorical_prob` is unused
+    (as in the reference).  Returns (rgbs [K,H,W,3] float32, disps [K,H,W] float32) numpy arrays."""
+    H, W, _ = _scaled_hw(hwf, render_factor)
+    kw = dict(render_kwargs)
+    near, far = kw.pop("near", 0.), kw.pop("far", 1.)
+    if kw.pop("ndc", True):
+        raise NotImplementedError("render_path: ndc=True is not supported")
+    if not kw.pop("use_viewdirs", False):
+        raise NotImplementedError("render_path: use_viewdirs=False is not supported")
+    _check_kwargs(kw)
+    n_imp = kw.get("N_importance", 0)
+    model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp)
+    if savedir is not None:
+        os.makedirs(os.path.join(savedir, str(object_id)), exist_ok=True)
+    poses = torch.as_tensor(render_poses, dtype=torch.float32)
+    t = time.time()
+    with torch.no_grad():
+        out = model.render_views(poses[:, :3, :4].to(model.device), H, W, K, near, far)
+        rgbs = out["rgb_map"].reshape(-1, H, W, 3).cpu().numpy()
+        disps = out["disp_map"].reshape(-1, H, W).cpu().numpy()
+    print("rendered %d views in %.3f s" % (rgbs.shape[0], time.time() - t))
+    if savedir is not None:
+        for i in range(rgbs.shape[0]):
+            png.imwrite(os.path.join(savedir, str(object_id), "{:03d}.png".format(i)), to8b(rgbs[i]))
+    return rgbs, disps
+
+
+def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, render_kwargs, gt_imgs=None,
+                     savedir=None, object_id=2, render_factor=0):
+    """RN:126-210: per pose, the image and, per `chunk`-ray row-major patch, dL/d(categorical_prob) [8] for the
+    detector cotangent grad_E[i]['grad_E'][0] ([3,H,W], used in its own channel order exactly like RN:154).
+
+    The reference runs 313 forward+2 autograd calls per 400x400 image; here ONE forward+backward launch per pose
+    returns dL/d(rays) for the whole image, a second tiny kernel contracts it per patch with d(rays)/d(c2w)
+    (linear, RH:160-164) to [n_patches,3,4], and the 12x8 Jacobian d(c2w)/d(psi) of the caller's own pose graph
+    (sample_pose, LL:202-247) finishes the chain -- the same numbers as the per-patch autograd.grad of RN:177-181."""
+    H, W, _ = _scaled_hw(hwf, render_factor)
+    kw = dict(render_kwargs)
+    near, far = kw.pop("near", 0.), kw.pop("far", 1.)
+    if kw.pop("ndc", True):
+        raise NotImplementedError("render_path_grad: ndc=True is not supported")
+    if not kw.pop("use_viewdirs", False):
+        raise NotImplementedError("render_path_grad: use_viewdirs=False is not supported")
+    _check_kwargs(kw)
+    n_imp = kw.get("N_importance", 0)
+    if n_imp != 128:
+        raise NotImplementedError("render_path_grad needs the coarse+fine configuration (N_importance=128)")
+    model = _model_for(kw["network_fn"], kw.get("network_fine", None), n_imp)
+    n_rays = H * W
+    N_rand = int(chunk)
+    n_patches = (n_rays + N_rand - 1) // N_rand
+    rgbs, dLdpsis = [], []
+    for i_pose, c2w in enumerate(render_poses):
+        if i_pose >= len(grad_E):                          # RN:142
+            break
+        pose = c2w[:3, :4]
+        g = grad_E[i_pose]["grad_E"][0]
+        g = torch.as_tensor(g.detach().cpu().numpy().transpose(1, 2, 0) if isinstance(g, torch.Tensor)
+                            else np.asarray(g).transpose(1, 2, 0), dtype=torch.float32)      # RN:154 CHW -> HWC
+        cot = g.reshape(-1, 3).to(model.device).contiguous()
+        with torch.no_grad():
+            ro, rd = model.get_rays(H, W, K, pose.detach().to(model.device))
+            go, gd, out = model.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, cot,
+                                                with_forward=True)
+            g_pose = model.pose_grad(go, gd, H, W, K, N_rand)                                # [n_patches,3,4]
+        # d vec(c2w[:3,:4]) / d psi through the caller's graph: 12 rows, one batched autograd call
+        basis = torch.eye(12, dtype=pose.dtype, device=pose.device).reshape(12, 3, 4)
+        (J,) = torch.autograd.grad(pose, categorical_prob, grad_outputs=basis, retain_graph=True,
+                                   is_grads_batched=True)                                    # [12, n_cat]
+        per_patch = g_pose.reshape(n_patches, 12).to(J.device, J.dtype) @ J                  # [n_patches, n_cat]
+        dLdpsis.extend(per_patch[p].cpu().detach() for p in range(n_patches))                # RN:190
+        rgbs.append(out["rgb_map"].reshape(H, W, 3).cpu().numpy())
+        if savedir is not None:
+            d = os.path.join(savedir, str(object_id), "withgrad")
+            os.makedirs(d, exist_ok=True)
+            png.imwrite(os.path.join(d, "{:03d}.png".format(i_pose)), to8b(rgbs[-1]))       # RN:200-206
+    return np.stack(rgbs, 0), dLdpsis
+
+
+def create_nerf(args):
+    """RN:258-340: builds the coarse/fine networks, loads `args.ft_path` (or the newest .tar under
+    basedir/expname) and returns (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
+    if not args.use_viewdirs:
+        raise NotImplementedError("create_nerf: use_viewdirs=False is not supported")
+    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    output_ch = 5 if args.N_importance > 0 else 4
+    skips = [4]
+    model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,
+                 input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+    grad_vars = list(model.parameters())
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = NeRF(D=args.netdepth_fine, W=args.netwidth_fine, input_ch=input_ch, output_ch=output_ch,
+                          skips=skips, input_ch_views=input_ch_views, use_viewdirs=args.use_viewdirs).to(device)
+        grad_vars += list(model_fine.parameters())
+
+    network_query_fn = lambda inputs, viewdirs, network_fn: run_network(
+        inputs, viewdirs, network_fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, netchunk=args.netchunk)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+
+    start = 0
+    basedir, expname = args.basedir, args.expname
+    if args.ft_path is not None and args.ft_path != "None":
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(basedir, expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "tar" in f] if os.path.isdir(d) else []
+    print("Found ckpts", ckpts)
+    if len(ckpts) > 0 and not args.no_reload:
+        ckpt_path = ckpts[-1]
+        print("Reloading from", ckpt_path)
+        ckpt = torch.load(ckpt_path, map_location=device, weights_only=False)
+        start = ckpt["global_step"]
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        model.load_state_dict(ckpt["network_fn_state_dict"])
+        if model_fine is not None:
+            model_fine.load_state_dict(ckpt["network_fine_state_dict"])
+
+    render_kwargs_train = {
+        "network_query_fn": network_query_fn, "perturb": args.perturb, "N_importance": args.N_importance,
+        "network_fine": model_fine, "N_samples": args.N_samples, "network_fn": model,
+        "use_viewdirs": args.use_viewdirs, "white_bkgd": args.white_bkgd, "raw_noise_std": args.raw_noise_std,
+    }
+    if args.dataset_type != "llff" or args.no_ndc:
+        print("Not ndc!")
+        render_kwargs_train["ndc"] = False
+        render_kwargs_train["lindisp"] = args.lindisp
+    render_kwargs_test = dict(render_kwargs_train)
+    render_kwargs_test["perturb"] = False
+    render_kwargs_test["raw_noise_std"] = 0.
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer

@@ -224,10 +224,11 @@ def main():
     sel = rng.choice(160000, size=nb, replace=False)
     rays = torch.stack([o32.reshape(-1, 3)[sel], d32.reshape(-1, 3)[sel]], 0).clone().requires_grad_(True)
     cot = torch.from_numpy(rng.standard_normal((nb, 3)).astype(np.float32))
-    rgb_p, _, _, _ = RN.render(400, 400, O.YCBV_K, chunk=nb, rays=rays, retraw=True, **kwargs)
+    with Capture(RN, RH) as cap:
+        rgb_p, _, _, _ = RN.render(400, 400, O.YCBV_K, chunk=nb, rays=rays, retraw=True, **kwargs)
     (g,) = torch.autograd.grad(rgb_p, rays, grad_outputs=cot)
     save("g8_backward", seed=np.int64(SEED), rays=rays.detach().numpy(), cot=cot.numpy(),
-         rgb=rgb_p.detach().numpy(), grad_rays=g.numpy())
+         rgb=rgb_p.detach().numpy(), grad_rays=g.numpy(), z_samples=cap.log[0]["samples"])
 
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())

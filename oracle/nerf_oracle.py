@@ -378,3 +378,119 @@ def sweep_poses(n_views, seed=0):
         phi = rng.uniform(0, 360)
         poses.append(pose_spherical(theta, phi - 180.0, 1.01))
     return np.stack(poses, 0)
+
+
+# ----------------------------------------------------------------------------------------------
+# network backward (inputs only)
+# ----------------------------------------------------------------------------------------------
+def _network_forward64(sd, pts, dirs):
+    """fp64 forward of RH:99-122 on fp32 encodings, keeping what the backward needs."""
+    W = lambda k: sd[k + ".weight"].astype(f64)
+    B = lambda k: sd[k + ".bias"].astype(f64)
+    e_p = embed(pts, MULTIRES).astype(f64)
+    e_d = embed(dirs, MULTIRES_VIEWS).astype(f64)
+    pre = []
+    h = e_p
+    for i in range(NET_DEPTH):
+        a = h @ W("pts_linears.%d" % i).T + B("pts_linears.%d" % i)
+        pre.append(a)
+        h = np.maximum(a, 0)
+        if i == SKIP_AT:
+            h = np.concatenate([e_p, h], -1)
+    sigma = (h @ W("alpha_linear").T + B("alpha_linear"))[:, 0]
+    feat = h @ W("feature_linear").T + B("feature_linear")
+    av = np.concatenate([feat, e_d], -1) @ W("views_linears.0").T + B("views_linears.0")
+    rgb_raw = np.maximum(av, 0) @ W("rgb_linear").T + B("rgb_linear")
+    return dict(pre=pre, av=av, sigma=sigma, rgb_raw=rgb_raw)
+
+
+def _embed_bwd(x, G, n_freqs):
+    x = x.astype(f64)
+    out = G[:, :3].copy()
+    for l in range(n_freqs):
+        fr = 2.0 ** l
+        gs, gc = G[:, 3 + 6 * l:6 + 6 * l], G[:, 6 + 6 * l:9 + 6 * l]
+        out += fr * (gs * np.cos(x * fr) - gc * np.sin(x * fr))
+    return out
+
+
+def network_vjp(sd, pts, dirs, g_raw, fwd=None):
+    """Input-side VJP of run_network: g_raw [P,4] = dL/d(rgb logits, sigma) -> dL/d pts [P,3], dL/d dirs [P,3]
+    (weights are constants).  Manual backprop of RH:99-122 in float64."""
+    W = lambda k: sd[k + ".weight"].astype(f64)
+    if fwd is None:
+        fwd = _network_forward64(sd, pts, dirs)
+    pre, av = fwd["pre"], fwd["av"]
+    g_raw = g_raw.astype(f64)
+    G_av = (g_raw[:, :3] @ W("rgb_linear")) * (av > 0)
+    G_cat = G_av @ W("views_linears.0")
+    G_feat, G_ed = G_cat[:, :NET_WIDTH], G_cat[:, NET_WIDTH:]
+    G_h = G_feat @ W("feature_linear") + g_raw[:, 3:4] @ W("alpha_linear")
+    G_ep = np.zeros((pts.shape[0], IN_CH), f64)
+    for i in reversed(range(NET_DEPTH)):
+        if i == SKIP_AT:
+            G_ep += G_h[:, :IN_CH]
+            G_h = G_h[:, IN_CH:]
+        G_h = (G_h * (pre[i] > 0)) @ W("pts_linears.%d" % i)
+    G_ep += G_h
+    return _embed_bwd(pts, G_ep, MULTIRES), _embed_bwd(dirs, G_ed, MULTIRES_VIEWS)
+
+
+# ----------------------------------------------------------------------------------------------
+# input-side VJP of the fine render (what render_path_grad needs, RN:168-178)
+# ----------------------------------------------------------------------------------------------
+def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
+                    n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, z_fine=None):
+    """d(sum(rgb_map * grad_rgb)) / d(rays_o, rays_d), the quantity torch.autograd.grad(rgb_p, batch_rays,
+    grad_outputs=patch_grad_E) returns at RN:177.  Network weights are constants and z_samples is detached
+    (RN:475), so gradient reaches the rays only through the FINE pass: pts = o + d*z (RN:478), the view
+    direction d/|d| (RN:97) and dists*|d| (RN:361).  Manual backprop in float64 on the fp32 forward's
+    activations pattern.  Returns grad_o [N,3], grad_d [N,3] (float32) and the forward rgb_map."""
+    rays_o = rays_o.astype(f32)
+    rays_d = rays_d.astype(f32)
+    N = rays_o.shape[0]
+    sd = sd_fine if sd_fine is not None else sd_coarse
+    vd = normalize_dirs(rays_d)
+    if z_fine is None:
+        z_fine = render_rays(sd_coarse, sd_fine, rays_o, rays_d, vd, near, far, n_samples, n_importance,
+                             extras=True)["z_fine"]
+    S = z_fine.shape[1]
+    z = z_fine.astype(f32)
+    pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32)).reshape(-1, 3)
+    dirs = np.broadcast_to(vd[:, None, :], (N, S, 3)).reshape(-1, 3)
+    # ---- forward, keeping pre-activations ----
+    fwd = _network_forward64(sd, pts, dirs)
+    sigma, rgb_raw = fwd["sigma"], fwd["rgb_raw"]
+    # ---- compositing forward (float64) ----
+    sigma = sigma.reshape(N, S)
+    c = 1.0 / (1.0 + np.exp(-rgb_raw.reshape(N, S, 3)))
+    nrm = dir_norm(rays_d).astype(f64)
+    dz = np.concatenate([np.diff(z.astype(f64), axis=1), np.full((N, 1), 1e10)], 1)
+    delta = dz * nrm[:, None]
+    rs = np.maximum(sigma, 0)
+    alpha = 1.0 - np.exp(-rs * delta)
+    om = 1.0 - alpha + 1e-10
+    T = np.cumprod(np.concatenate([np.ones((N, 1)), om], 1), 1)[:, :-1]
+    w = alpha * T
+    rgb_map = (w[..., None] * c).sum(1)
+    # ---- compositing backward ----
+    g = grad_rgb.astype(f64)
+    A = (c * g[:, None, :]).sum(-1)                                     # dL/dw_i
+    Aw = A * w
+    suffix = np.concatenate([np.cumsum(Aw[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((N, 1))], 1)   # sum_{k>i}
+    d_alpha = A * T - suffix / om
+    d_sigma = d_alpha * delta * (1.0 - alpha) * (sigma > 0)
+    d_delta = d_alpha * rs * (1.0 - alpha)
+    d_nrm = (d_delta * dz).sum(1)
+    d_rgb_raw = (w[..., None] * g[:, None, :]) * c * (1.0 - c)
+    # ---- network backward (inputs only) ----
+    G_pts, G_dirs = network_vjp(sd, pts, dirs, np.concatenate([d_rgb_raw.reshape(-1, 3),
+                                                                d_sigma.reshape(-1, 1)], -1), fwd)
+    G_pts = G_pts.reshape(N, S, 3)
+    G_v = G_dirs.reshape(N, S, 3).sum(1)
+    grad_o = G_pts.sum(1)
+    v = vd.astype(f64)
+    grad_d = (G_pts * z.astype(f64)[:, :, None]).sum(1)
+    grad_d += (G_v - v * (G_v * v).sum(-1, keepdims=True)) / nrm[:, None]        # d(d/|d|)
+    grad_d += d_nrm[:, None] * v                                                 # d|d|/dd = d/|d|
+    return grad_o.astype(f32), grad_d.astype(f32), rgb_map.astype(f32)

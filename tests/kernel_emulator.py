@@ -24,15 +24,20 @@ def mfma(a, b, acc):
 
 
 class Stream:
-    def __init__(self, packed):
-        self.steps = packed[:290 * 2048].reshape(290, 8, 64, 4)
-        self.aux = packed[290 * 2048:]
+    """The packed stream as the kernel sees it: consecutive 1 KiB chunks of [64 lanes][4]."""
+
+    def __init__(self, stream_floats):
+        self.chunks = stream_floats.reshape(-1, 64, 4)
         self.pos = 0
 
-    def next_step(self):
-        s = self.steps[self.pos]
-        self.pos += 1
-        return s                       # [8 chunks][64 lanes][4]
+    def seg(self, nmo, ntq, bop, acc):
+        """csrc/nsr_kernels.hip `seg<NMO,NTQ>`: chunk n <-> (k-quad n // NMO, output block n % NMO)."""
+        for n in range(nmo * ntq):
+            frag = self.chunks[self.pos]
+            self.pos += 1
+            tq, mo = divmod(n, nmo)
+            for kk in range(4):
+                acc[mo] = mfma(frag[:, kk], bop(4 * tq + kk), acc[mo])
 
 
 def load_bias(aux, off, nmo):
@@ -46,83 +51,119 @@ def load_bias(aux, off, nmo):
     return acc
 
 
-def step8(frag, bvals, acc):
-    """frag [8][64][4]; bvals: 4 arrays [64]."""
-    for kk in range(4):
-        for mo in range(8):
-            acc[mo] = mfma(frag[mo][:, kk], bvals[kk], acc[mo])
-
-
-def step4(frag, bvals, acc):
-    for q in range(2):
-        for kk in range(4):
-            for mo in range(4):
-                acc[mo] = mfma(frag[q * 4 + mo][:, kk], bvals[q * 4 + kk], acc[mo])
-
-
-def mlp_pass(packed, pts, dirs):
-    """pts, dirs: [32,3] -> raw [32,4], emulating one wave (lane j and j+32 both own point j)."""
-    from_aux = __import__("importlib").import_module("neural_sim_nerf_amd.pack")
-    st = Stream(packed)
-    aux = st.aux
+def _encode(X, nfreq, n):
     h = LANE >> 5
-    P = np.concatenate([pts, pts], 0).astype(np.float32)      # per lane
+    e = np.zeros((n, 64), np.float32)
+    for L in range(nfreq):
+        for ax in range(3):
+            arg = (X[:, ax] * np.float32(2 ** L)).astype(np.float32)
+            e[3 * L + ax] = np.where(h == 1, np.cos(arg), np.sin(arg)).astype(np.float32)
+    e[3 * nfreq] = np.where(h == 1, X[:, 2], X[:, 0])
+    e[3 * nfreq + 1] = np.where(h == 1, 0.0, X[:, 1])
+    return e
+
+
+def mlp_pass(packed, pts, dirs, masks=None):
+    """pts, dirs: [32,3] -> raw [32,4], emulating one wave (lanes j and j+32 both own point j).
+    `masks`: optional dict filled with the relu patterns ([nmo,64,16] bool per layer), like mask capture."""
+    from neural_sim_nerf_amd import pack as PK
+    st = Stream(packed[:PK.STREAM_SLABS * PK.SLAB_FLOATS])
+    aux = packed[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
+    h = LANE >> 5
+    P = np.concatenate([pts, pts], 0).astype(np.float32)
     V = np.concatenate([dirs, dirs], 0).astype(np.float32)
-
-    def encode(X, nfreq, n):
-        e = np.zeros((n, 64), np.float32)
-        for L in range(nfreq):
-            for ax in range(3):
-                arg = (X[:, ax] * np.float32(2 ** L)).astype(np.float32)
-                e[3 * L + ax] = np.where(h == 1, np.cos(arg), np.sin(arg)).astype(np.float32)
-        e[3 * nfreq] = np.where(h == 1, X[:, 2], X[:, 0])
-        e[3 * nfreq + 1] = np.where(h == 1, 0.0, X[:, 1])
-        return e
-
-    e = encode(P, 10, 32)
-    ed = encode(V, 4, 16)
-
-    def seg_enc(acc):
-        for tq in range(8):
-            step8(st.next_step(), [e[4 * tq + kk] for kk in range(4)], acc)
-
-    def seg_main(inp, acc):
-        for tq in range(32):
-            step8(st.next_step(), [inp[(4 * tq + kk) >> 4][:, (4 * tq + kk) & 15] for kk in range(4)], acc)
-
-    acc = load_bias(aux, from_aux.AUX_BIAS, 8)
-    seg_enc(acc)
+    e = _encode(P, 10, 32)
+    ed = _encode(V, 4, 16)
+    regs = lambda arr: (lambda t: arr[t >> 4][:, t & 15])
+    acc = load_bias(aux, PK.AUX_BIAS, 8)
+    st.seg(8, 8, lambda t: e[t], acc)
+    if masks is not None:
+        masks[0] = acc > 0
     inp = np.maximum(acc, 0)
     alpha_part = np.zeros(64, np.float32)
     for L in range(1, 9):
-        acc = load_bias(aux, from_aux.AUX_BIAS + L * 256, 8)
+        acc = load_bias(aux, PK.AUX_BIAS + L * 256, 8)
         if L == 5:
-            seg_enc(acc)
+            st.seg(8, 8, lambda t: e[t], acc)
         if L == 8:
             for tq in range(32):
                 for kk in range(4):
-                    w = aux[from_aux.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk]
+                    w = aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk]
                     alpha_part = alpha_part + w * inp[(4 * tq + kk) >> 4][:, (4 * tq + kk) & 15]
-        seg_main(inp, acc)
+        st.seg(8, 32, regs(inp), acc)
+        if masks is not None and L < 8:
+            masks[L] = acc > 0
         inp = np.maximum(acc, 0) if L < 8 else acc.copy()
-    av = load_bias(aux, from_aux.AUX_BIAS_V, 4)
-    for s in range(18):
-        if s < 16:
-            b = [inp[(8 * s + i) >> 4][:, (8 * s + i) & 15] for i in range(8)]
-        else:
-            b = [ed[8 * (s - 16) + i] for i in range(8)]
-        step4(st.next_step(), b, av)
-    assert st.pos == 290
+    av = load_bias(aux, PK.AUX_BIAS_V, 4)
+    st.seg(4, 36, lambda t: inp[t >> 4][:, t & 15] if t < 128 else ed[t - 128], av)
+    if masks is not None:
+        masks[8] = av > 0
+    assert st.pos == 145 * 16
     part = np.zeros((4, 64), np.float32)
     part[3] = alpha_part
     for c in range(3):
         for mo in range(4):
             for rq in range(4):
                 for ri in range(4):
-                    w = aux[from_aux.AUX_W_RGB + c * 128 + ((mo * 4 + rq) * 2 + h) * 4 + ri]
+                    w = aux[PK.AUX_W_RGB + c * 128 + ((mo * 4 + rq) * 2 + h) * 4 + ri]
                     part[c] = part[c] + w * np.maximum(av[mo][:, rq * 4 + ri], 0)
     raw = np.zeros((32, 4), np.float32)
     for c in range(4):
-        bias = aux[from_aux.AUX_B_RGB + c] if c < 3 else aux[from_aux.AUX_B_ALPHA]
+        bias = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
         raw[:, c] = part[c][:32] + part[c][32:] + bias
     return raw
+
+
+def _embed_bwd(X, G, nfreq):
+    """csrc embed_bwd: per-lane-half contribution, then the two halves are added."""
+    h = LANE >> 5
+    out = np.zeros((3, 64), np.float64)
+    out[0] = np.where(h == 1, 0.0, G[3 * nfreq])
+    out[1] = np.where(h == 1, 0.0, G[3 * nfreq + 1])
+    out[2] = np.where(h == 1, G[3 * nfreq], 0.0)
+    for L in range(nfreq):
+        for ax in range(3):
+            f = np.float32(2 ** L)
+            arg = (X[:, ax] * f).astype(np.float32)
+            out[ax] += f * G[3 * L + ax] * np.where(h == 1, -np.sin(arg), np.cos(arg))
+    return (out[:, :32] + out[:, 32:]).T          # [32,3]
+
+
+def mlp_bwd_pass(packed_fwd, stream_bwd, masks, pts, dirs, g_raw):
+    """Emulates csrc mlp_bwd_pass for one wave: g_raw [32,4] -> (dL/dpts [32,3], dL/ddirs [32,3])."""
+    from neural_sim_nerf_amd import pack as PK
+    st = Stream(stream_bwd)
+    aux = packed_fwd[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
+    h = LANE >> 5
+    P = np.concatenate([pts, pts], 0).astype(np.float32)
+    V = np.concatenate([dirs, dirs], 0).astype(np.float32)
+    G = np.concatenate([g_raw, g_raw], 0).astype(np.float32)      # per lane
+    regs = lambda arr: (lambda t: arr[t >> 4][:, t & 15])
+    gv = np.zeros((4, 64, 16), np.float32)
+    for mo in range(4):
+        for rq in range(4):
+            for ri in range(4):
+                idx = ((mo * 4 + rq) * 2 + h) * 4 + ri
+                v = (aux[PK.AUX_W_RGB + idx] * G[:, 0] + aux[PK.AUX_W_RGB + 128 + idx] * G[:, 1]
+                     + aux[PK.AUX_W_RGB + 256 + idx] * G[:, 2])
+                gv[mo][:, rq * 4 + ri] = np.where(masks[8][mo][:, rq * 4 + ri], v, 0)
+    accv = np.zeros((9, 64, 16), np.float32)
+    st.seg(9, 16, regs(gv), accv)
+    dv = _embed_bwd(V, [accv[8][:, t] for t in range(16)], 4)
+    gin = accv[:8].copy()
+    acc = np.zeros((10, 64, 16), np.float32)
+    for idx in range(8):
+        if idx == 0:
+            for tq in range(32):
+                for kk in range(4):
+                    t = 4 * tq + kk
+                    acc[t >> 4][:, t & 15] = aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk] * G[:, 3]
+        else:
+            acc[:8] = 0
+        st.seg(10 if idx == 3 else 8, 32, regs(gin), acc)
+        gin = np.where(masks[7 - idx], acc[:8], 0).astype(np.float32)
+    genc = acc[8:]
+    st.seg(2, 32, regs(gin), genc)
+    assert st.pos == 145 * 16
+    dp = _embed_bwd(P, [genc[t >> 4][:, t & 15] for t in range(32)], 10)
+    return dp, dv
