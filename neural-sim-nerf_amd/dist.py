@@ -1,0 +1,82 @@
+"""Multi-GPU view sharding: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  Views are independent (the reference's loop RN:229 carries no state),
+so the data path has NO collective: rank r renders views r, r+world, ...; the only communication is at the
+outer-loop boundary -- one all-gather of the rendered images (1.92 MB fp32 per 400x400 view) and, for the
+bilevel gradient, one all-reduce of the 8-float psi-gradient sum plus its patch count (NM:191 takes the mean
+over all patches of all poses, and every patch has the same weight)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def shard_indices(n_items, world, rank):
+    """view i -> rank i mod world (keeps every rank within one view of the others)."""
+    return list(range(rank, n_items, world))
+
+
+def gather_views(local, n_total, group=None):
+    """local: [k_local, ...] tensor of this rank's views (in shard order).  Returns [n_total, ...] in global view
+    order on every rank.  Ranks hold ceil or floor(n_total/world) views; shorter ranks pad to the maximum."""
+    world, rank = world_info(group)
+    if world == 1:
+        return local
+    k_max = (n_total + world - 1) // world
+    pad = torch.zeros((k_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = shard_indices(n_total, world, r)
+        out[idx] = parts[r][:len(idx)]
+    return out
+
+
+def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, group=None, writer=None):
+    """render_path (RN:213-255) over all ranks.  `render_fn(poses [k,4,4]) -> (rgb [k,H,W,3], disp [k,H,W])`
+    tensors on this rank's device (production: NsrModel.render_views; tests: any deterministic function).
+    Returns (rgbs, disps) numpy arrays in pose order on every rank; rank 0 writes savedir/<object_id>/%03d.png."""
+    from .run_nerf_helpers import to8b
+    from . import png
+    world, rank = world_info(group)
+    poses = torch.as_tensor(render_poses, dtype=torch.float32)
+    n = poses.shape[0]
+    mine = shard_indices(n, world, rank)
+    rgb, disp = render_fn(poses[mine])
+    rgbs = gather_views(rgb, n, group).cpu().numpy()
+    disps = gather_views(disp, n, group).cpu().numpy()
+    if savedir is not None and rank == 0:
+        d = os.path.join(savedir, str(object_id))
+        os.makedirs(d, exist_ok=True)
+        for i in range(n):
+            (writer or png.imwrite)(os.path.join(d, "{:03d}.png".format(i)), to8b(rgbs[i]))
+    return rgbs, disps
+
+
+def mean_psi_grad(local_dLdpsis, group=None):
+    """torch.mean(torch.stack(dLdpsis), 0) (NM:191) when the per-patch gradients are spread over ranks:
+    all-reduce(sum) of [sum of local [n_cat] vectors | local count]."""
+    world, _ = world_info(group)
+    if len(local_dLdpsis):
+        s = torch.stack([torch.as_tensor(g, dtype=torch.float64) for g in local_dLdpsis]).sum(0)
+    else:
+        s = None
+    n_cat = s.numel() if s is not None else 8
+    buf = torch.zeros(n_cat + 1, dtype=torch.float64)
+    if s is not None:
+        buf[:n_cat] = s
+        buf[n_cat] = len(local_dLdpsis)
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else buf.device
+        buf = buf.to(dev)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        buf = buf.cpu()
+    return (buf[:n_cat] / buf[n_cat]).to(torch.float32)

@@ -1,0 +1,154 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/nsr.h declares, the packers
+agree with the oracle through a lane-level emulation of the kernel's MFMA data flow, the host API rejects
+unsupported configurations loudly, PNG side effects, synthetic-input recipes."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from neural_sim_nerf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nsr.h")).read()
+    declared = set(re.findall(r"\b(nsr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"nsr_handle_s"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = _lib.load()                                   # dlopen; binds every symbol or raises
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.nsr_abi_version() == _lib.ABI_VERSION
+
+
+def test_header_constants_match_packer():
+    from neural_sim_nerf_amd import pack
+    hdr = open(os.path.join(ROOT, "include", "nsr.h")).read()
+    val = lambda n: int(re.search(r"#define\s+%s\s+(\d+)" % n, hdr).group(1))
+    assert val("NSR_SLAB_FLOATS") == pack.SLAB_FLOATS
+    assert val("NSR_STREAM_SLABS") == pack.STREAM_SLABS
+    assert val("NSR_AUX_FLOATS") == pack.AUX_FLOATS
+    assert pack.PACKED_FLOATS == pack.STREAM_SLABS * pack.SLAB_FLOATS + pack.AUX_FLOATS
+
+
+def test_no_gpu_means_loud_failure(synth_nets):
+    """The product has no CPU path: without a HIP device the engine refuses to construct."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from neural_sim_nerf_amd import _lib
+    from neural_sim_nerf_amd.engine import NsrModel
+    with pytest.raises(_lib.NsrError):
+        NsrModel(synth_nets[0], synth_nets[1])
+
+
+def test_kappa_is_a_permutation():
+    from neural_sim_nerf_amd.pack import kappa, eps
+    t = np.arange(128)
+    k = np.concatenate([kappa(t, 0), kappa(t, 1)])
+    assert sorted(k.tolist()) == list(range(256))
+    cols = [eps(tt, h, 10) for tt in range(32) for h in (0, 1)]
+    assert sorted(c for c in cols if c >= 0) == list(range(63)) and cols.count(-1) == 1
+    cols = [eps(tt, h, 4) for tt in range(16) for h in (0, 1)]
+    assert sorted(c for c in cols if c >= 0) == list(range(27))
+
+
+def test_packer_through_kernel_emulation(oracle, synth_nets):
+    """Lane-level numpy emulation of one wave of the kernel's forward and backward network pass, fed with the
+    packed streams, against the oracle: pins pack.py and the kernel's fragment indexing on the CPU."""
+    from neural_sim_nerf_amd import pack
+    import kernel_emulator as E
+    sd = synth_nets[1]
+    p, b = pack.pack_network(sd), pack.pack_network_backward(sd)
+    assert p.shape == (pack.PACKED_FLOATS,) and p.dtype == np.float32
+    rng = np.random.RandomState(0)
+    pts = rng.uniform(-1.5, 1.5, (32, 3)).astype(np.float32)
+    d = rng.standard_normal((32, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    masks = {}
+    raw = E.mlp_pass(p, pts, d, masks)
+    want = oracle.mlp(sd, np.concatenate([oracle.embed(pts, 10), oracle.embed(d, 4)], -1))
+    assert np.abs(raw - want).max() < 2e-5
+    g = rng.standard_normal((32, 4)).astype(np.float32)
+    dp, dv = E.mlp_bwd_pass(p, b, masks, pts, d, g)
+    rp, rv = oracle.network_vjp(sd, pts, d, g)
+    assert np.abs(dp - rp).max() < 1e-5 * np.abs(rp).max()
+    assert np.abs(dv - rv).max() < 1e-5 * np.abs(rv).max()
+
+
+def test_packer_rejects_other_architectures(synth_nets):
+    from neural_sim_nerf_amd.pack import pack_network
+    sd = dict(synth_nets[0])
+    sd["pts_linears.3.weight"] = np.zeros((128, 256), np.float32)
+    with pytest.raises(ValueError, match="pts_linears.3.weight"):
+        pack_network(sd)
+
+
+def test_oracle_vjp_matches_reference_autograd(golden, oracle, synth_nets):
+    g = golden("g8_backward")
+    n = g["rays"].shape[1]
+    z = oracle.coarse_z(np.full(n, oracle.YCBV_NEAR, np.float32), np.full(n, oracle.YCBV_FAR, np.float32))
+    zf = np.sort(np.concatenate([z, g["z_samples"]], -1), -1)
+    go, gd, rgb = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], g["rays"][0], g["rays"][1],
+                                         oracle.YCBV_NEAR, oracle.YCBV_FAR, g["cot"], z_fine=zf)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(go, g["grad_rays"][0]) < 5e-5 and rel(gd, g["grad_rays"][1]) < 5e-5
+    assert np.abs(rgb - g["rgb"]).max() < 1e-5
+
+
+def test_synthetic_recipe_is_the_oracles(oracle):
+    from neural_sim_nerf_amd import synthetic as S
+    a, b = S.synth_weights(5), oracle.synth_weights(5)
+    assert a.keys() == b.keys() and all(np.array_equal(a[k], b[k]) for k in a)
+    fa, fb = S.synth_weights(1005, fine_of=a), oracle.synth_weights(1005, fine_of=b)
+    assert all(np.array_equal(fa[k], fb[k]) for k in fa)
+    assert np.array_equal(S.sweep_poses(3, 1), oracle.sweep_poses(3, 1))
+    assert S.FLOP_PER_POINT == 2 * oracle.MACS_PER_POINT == 1186816
+    assert (S.YCBV_NEAR, S.YCBV_FAR) == (oracle.YCBV_NEAR, oracle.YCBV_FAR)
+
+
+def test_png_roundtrip_and_to8b(tmp_path):
+    from neural_sim_nerf_amd import png
+    from neural_sim_nerf_amd.run_nerf_helpers import to8b
+    img = to8b(np.random.RandomState(0).uniform(-0.2, 1.2, (13, 7, 3)).astype(np.float32))
+    assert img.dtype == np.uint8 and img.min() == 0 and img.max() == 255
+    f = str(tmp_path / "a.png")
+    png.imwrite(f, img)
+    assert np.array_equal(png.imread(f), img)
+    with pytest.raises(TypeError):
+        png.imwrite(f, img.astype(np.float32))
+
+
+def test_api_rejects_unsupported_configurations():
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    K = [[100., 0, 4], [0, 100., 4], [0, 0, 1]]
+    base = dict(H=8, W=8, K=K, c2w=np.eye(4, dtype=np.float32)[:3], ndc=False, use_viewdirs=True,
+                network_fn=None, N_samples=64, N_importance=128)
+    for bad, pat in ((dict(ndc=True), "ndc"), (dict(use_viewdirs=False), "use_viewdirs"),
+                     (dict(c2w_staticcam=np.eye(4)[:3]), "c2w_staticcam"), (dict(perturb=1.0), "perturb"),
+                     (dict(raw_noise_std=1.0), "raw_noise_std"), (dict(white_bkgd=True), "white_bkgd"),
+                     (dict(lindisp=True), "lindisp"), (dict(N_samples=32), "N_samples"),
+                     (dict(N_importance=64), "N_importance"), (dict(near=np.zeros(3)), "near/far")):
+        kw = dict(base)
+        kw.update(bad)
+        with pytest.raises(NotImplementedError, match=pat):
+            R.render(**kw)
+    with pytest.raises(NotImplementedError, match="specialised"):
+        R.NeRF(D=4, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    with pytest.raises(NotImplementedError):
+        R.get_embedder(10, -1)
+    assert R.get_embedder(10, 0)[1] == 63 and R.get_embedder(4, 0)[1] == 27
+
+
+def test_nerf_module_has_reference_parameter_names(synth_nets):
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    assert set(n.state_dict()) == set(synth_nets[0])
+    n.load_state_dict({k: torch.from_numpy(v) for k, v in synth_nets[0].items()})
+    v0 = n.weights_version()
+    with torch.no_grad():
+        n.rgb_linear.bias.add_(1.0)
+    assert n.weights_version() != v0                     # in-place edits re-trigger packing
