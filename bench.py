@@ -44,24 +44,34 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
     """Oracle on a bounded sample (64x64 view, 64+128) -- the checker, timed; never the thing shipped."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
-    K64 = S.scaled_K(6.25)
-    n_threads = os.cpu_count() or 1
+    O.set_backend("torch")                      # MLP + encoding on multi-threaded torch-CPU ops, like the reference
+    torch.set_num_threads(os.cpu_count() or 1)
+    n_threads = torch.get_num_threads()
+    run = lambda side: O.render(sd_c, sd_f, side, side, S.scaled_K(400.0 / side), c2w=c2w[:3, :4], near=S.YCBV_NEAR,
+                                far=S.YCBV_FAR, chunk=4096)
+    run(16)                                      # warm-up (thread pools, page faults)
     t0 = time.perf_counter()
-    ref = O.render(sd_c, sd_f, 64, 64, K64, c2w=c2w[:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=4096)
+    run(32)
+    t32 = time.perf_counter() - t0
+    side = int(min(160, max(48, 16 * round(32 * (15.0 / t32) ** 0.5 / 16))))      # aim at ~15 s of CPU work
+    t0 = time.perf_counter()
+    ref = run(side)
     dt = time.perf_counter() - t0
-    got = model.render_views(c2w, 64, 64, K64, S.YCBV_NEAR, S.YCBV_FAR)
-    rgb = got["rgb_map"].cpu().numpy().reshape(64, 64, 3)
-    rgb0 = got["rgb0"].cpu().numpy().reshape(64, 64, 3)
+    O.set_backend("numpy")
+    got = model.render_views(c2w, side, side, S.scaled_K(400.0 / side), S.YCBV_NEAR, S.YCBV_FAR)
+    rgb = got["rgb_map"].cpu().numpy().reshape(side, side, 3)
+    rgb0 = got["rgb0"].cpu().numpy().reshape(side, side, 3)
     # PSNR delta against a pseudo ground truth T = oracle + N(0, 0.01^2) (SURVEY.md 8d)
     T = ref["rgb_map"] + np.random.RandomState(0).normal(0, 0.01, ref["rgb_map"].shape).astype(np.float32)
-    cpu = {"value": round(64 * 64 * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
-           "kind": "port", "sample": "one 64x64 view (4096 rays x (64+128) samples, same scene and networks), "
-           "oracle/nerf_oracle.py numpy+OpenBLAS, %.1f s" % dt}
+    cpu = {"value": round(side * side * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
+           "kind": "port", "sample": "one %dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
+           "oracle/nerf_oracle.py (MLP/encoding on torch-CPU ops, %d threads; compositing/resampling numpy), %.1f s"
+           % (side, side, side * side, n_threads, dt)}
     par = {"psnr_vs_oracle_db": round(O.psnr(rgb, ref["rgb_map"]), 2),
            "psnr_delta_db": round(abs(O.psnr(rgb, T) - O.psnr(ref["rgb_map"], T)), 4),
            "max_abs_rgb_coarse": float(np.abs(rgb0 - ref["rgb0"]).max()),
            "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
-           "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()), "sample": "64x64 view"}
+           "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()), "sample": "%dx%d view" % (side, side)}
     return cpu, par
 
 
@@ -124,6 +134,10 @@ def main():
         value = rays * SAMPLES_PER_RAY / dt / 1e6
         k_ms = float(np.mean(kernel_ms))
         achieved = H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
+        traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+        prof = os.path.join(ROOT, "profiles", "r01", "pmc_k_render.json")
+        if os.path.exists(prof):
+            traffic = json.load(open(prof))["derived"]["hbm_traffic_bytes_per_launch"]
         line = {
             "metric": "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP",
             "value": round(value, 3), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps,
@@ -136,7 +150,10 @@ def main():
                        "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
             "rays_per_s": round(rays / dt, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes "
+                                         "(profiles/r01/pmc_k_render.json); weight re-streaming past the 4 MiB XCD L2, "
+                                         "algorithmic HBM bytes are 7.0e6 per launch",
                          "kernel": "nsr::k_render", "kernel_ms": round(k_ms, 3),
                          "flop_per_launch": H * W * FLOP_PER_RAY},
         }

@@ -229,8 +229,47 @@ def mlp(sd, x_embedded, keep=None):
     return np.concatenate([rgb, alpha], -1)
 
 
+_BACKEND = "numpy"
+
+
+def set_backend(name):
+    """"numpy" (default, what the parity tests use) or "torch": the embedding + MLP of run_network executed with
+    multi-threaded torch CPU ops -- the closest stand-in for the reference's own CPU PyTorch path when the
+    oracle is timed as bench.py's cpu_baseline.  Everything else (compositing, resampling) stays numpy."""
+    global _BACKEND
+    assert name in ("numpy", "torch")
+    _BACKEND = name
+
+
+def _run_network_torch(sd, pts, viewdirs):
+    import torch
+    N, S, _ = pts.shape
+    with torch.no_grad():
+        t = lambda k: torch.from_numpy(sd[k])
+        x = torch.from_numpy(np.ascontiguousarray(pts.reshape(-1, 3)))
+        d = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(viewdirs[:, None, :], pts.shape).reshape(-1, 3)))
+
+        def enc(v, L):
+            fr = 2.0 ** torch.arange(L, dtype=torch.float32)
+            a = v[:, None, :] * fr[None, :, None]                                   # [P,L,3]
+            return torch.cat([v, torch.stack([torch.sin(a), torch.cos(a)], 2).reshape(v.shape[0], -1)], -1)
+        e, ed = enc(x, MULTIRES), enc(d, MULTIRES_VIEWS)
+        h = e
+        for i in range(NET_DEPTH):
+            h = torch.relu_(torch.addmm(t("pts_linears.%d.bias" % i), h, t("pts_linears.%d.weight" % i).T))
+            if i == SKIP_AT:
+                h = torch.cat([e, h], -1)
+        alpha = torch.addmm(t("alpha_linear.bias"), h, t("alpha_linear.weight").T)
+        feat = torch.addmm(t("feature_linear.bias"), h, t("feature_linear.weight").T)
+        hv = torch.relu_(torch.addmm(t("views_linears.0.bias"), torch.cat([feat, ed], -1), t("views_linears.0.weight").T))
+        rgb = torch.addmm(t("rgb_linear.bias"), hv, t("rgb_linear.weight").T)
+        return torch.cat([rgb, alpha], -1).numpy().reshape(N, S, 4)
+
+
 def run_network(sd, pts, viewdirs):
     """RN:26-40: pts [N,S,3], viewdirs [N,3] -> raw [N,S,4]."""
+    if _BACKEND == "torch":
+        return _run_network_torch(sd, pts, viewdirs)
     N, S, _ = pts.shape
     e = embed(pts.reshape(-1, 3), MULTIRES)
     ed = embed(np.broadcast_to(viewdirs[:, None, :], pts.shape).reshape(-1, 3), MULTIRES_VIEWS)

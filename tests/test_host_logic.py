@@ -152,3 +152,30 @@ def test_nerf_module_has_reference_parameter_names(synth_nets):
     with torch.no_grad():
         n.rgb_linear.bias.add_(1.0)
     assert n.weights_version() != v0                     # in-place edits re-trigger packing
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/optimization"), reason="needs the reference checkout")
+def test_dropin_import_shadows_only_the_render_modules():
+    """`from utils.run_nerf_noscale import *` as neural_sim_main.py:35 does, with the drop-in directory ahead of
+    the reference's optimization/ on sys.path: render symbols come from this package, pose sampling
+    (utils.load_LINEMOD_noscale, NM:36) still comes from the reference."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, types
+for m in ("imageio", "cv2"):
+    sys.modules[m] = types.ModuleType(m)
+sys.path[:0] = [%r, %r, "/root/reference/optimization"]
+ns = {}
+exec("from utils.run_nerf_noscale import *\nfrom utils.load_LINEMOD_noscale import *", ns)
+assert ns["render_path"].__module__ == "neural_sim_nerf_amd.run_nerf_noscale", ns["render_path"].__module__
+assert ns["create_nerf"].__module__ == "neural_sim_nerf_amd.run_nerf_noscale"
+for name in ("render", "render_path_grad", "to8b", "device"):
+    assert name in ns, name
+assert ns["sample_pose_nograd"].__module__ == "utils.load_LINEMOD_noscale"
+import utils.load_LINEMOD_noscale as LL
+assert LL.__file__.startswith("/root/reference/")
+print("ok")
+''' % (ROOT, os.path.join(ROOT, "neural-sim-nerf_amd", "dropin"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
