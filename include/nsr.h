@@ -143,6 +143,11 @@ int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, in
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
 
+/* Diagnostic: the 256x256 layer GEMM in isolation on every CU (mode 0: MFMAs only, 1: + LDS fragment reads,
+ * 2: + LDS-DMA ring and barriers = the production segment), `iters` layer-equivalents per wave; returns the
+ * kernel time in ms.  Used to attribute MFMA-rate losses. */
+int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream);
+
 /* Timing helper for bench.py: HIP-event time in ms of the last nsr_render_* launch on this handle
  * (events recorded on the launch stream; this call synchronises on the stop event). */
 int nsr_last_kernel_ms(nsr_handle h, float* ms);

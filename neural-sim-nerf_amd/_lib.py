@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnsr.so")
+LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "csrc", "libnsr.so"))   # override: A/B builds
 
 ABI_VERSION = 1
 PACKED_FLOATS = 145 * 4096 + 3328
@@ -51,6 +51,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_selftest": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "nsr_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "nsr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }
 

@@ -343,6 +343,30 @@ int nsr_selftest(nsr_handle h, void* stream) {
   return 0;
 }
 
+int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
+  if (!h || !ms) return fail("nsr_probe: null argument");
+  if (mode < 0 || mode > 2 || iters <= 0) return fail("nsr_probe: mode in 0..2, iters > 0");
+  if (!h->have_net[0]) return fail("nsr_probe: upload a network first");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  hipStream_t s = (hipStream_t)stream;
+  float* out = nullptr;
+  NSR_HIP(hipMalloc(&out, sizeof(float) * 256 * h->n_cu));
+  const size_t lds = nsr::kRingSlots * nsr::kSlabBytes;
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  NSR_HIP(hipEventRecord(h->ev0, s));
+  if (mode == 0) hipLaunchKernelGGL(nsr::k_probe<0>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
+  if (mode == 1) hipLaunchKernelGGL(nsr::k_probe<1>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
+  if (mode == 2) hipLaunchKernelGGL(nsr::k_probe<2>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
+  NSR_HIP(hipGetLastError());
+  NSR_HIP(hipEventRecord(h->ev1, s));
+  NSR_HIP(hipEventSynchronize(h->ev1));
+  NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  NSR_HIP(hipFree(out));
+  return 0;
+}
+
 int nsr_last_kernel_ms(nsr_handle h, float* ms) {
   if (!h || !ms) return fail("nsr_last_kernel_ms: null argument");
   if (!h->timed) return fail("nsr_last_kernel_ms: no render launched yet");

@@ -36,13 +36,18 @@ constexpr int kLdsState = kLdsAux + 2 * kAuxFloats * 4;       // 124928
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
                                    (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
-__device__ __forceinline__ f32x16 max16(f32x16 x, float lo) {
-  f32x16 r;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) r[i] = fmaxf(x[i], lo);
-  return r;
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+// relu as ONE integer max per element: negative floats are negative ints, so max_i32(bits, 0) clamps them to +0
+// and leaves non-negative values (and their NaNs) untouched; with thr = INT_MIN it is the identity (used for the
+// activation-free feature layer without a branch).  fmaxf would cost a canonicalising v_max plus the max itself.
+__device__ __forceinline__ f32x16 clamp_bits16(f32x16 x, int thr) {
+  i32x16 b = __builtin_bit_cast(i32x16, x);
+  i32x16 t = thr;
+  b = __builtin_elementwise_max(b, t);
+  return __builtin_bit_cast(f32x16, b);
 }
-__device__ __forceinline__ f32x16 relu16(f32x16 x) { return max16(x, 0.0f); }
+__device__ __forceinline__ f32x16 relu16(f32x16 x) { return clamp_bits16(x, 0); }
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   int lo = __double2loint(v), hi = __double2hiint(v);

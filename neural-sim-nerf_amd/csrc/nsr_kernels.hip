@@ -46,8 +46,10 @@ struct Ring {
 __device__ __forceinline__ void ring_issue(Ring& rg) {
   const char* g = rg.psrc + (size_t)rg.pslab * kSlabBytes;
   char* l = rg.smem + rg.pslot * kSlabBytes + rg.wave_lds;
+#ifndef NSR_EXP_NODMA        // timing experiment only
 #pragma unroll
   for (int c = 0; c < 4; ++c) NSR_GLDS16(g + c * 1024, l + c * 1024);
+#endif
   rg.pslot = (rg.pslot + 1 == kRingSlots) ? 0 : rg.pslot + 1;
   if (++rg.pslab == kStreamSlabs) {
     rg.pslab = 0;
@@ -82,8 +84,9 @@ __device__ __forceinline__ void ring_load_quarter(const Ring& rg, f32x4 (&A)[4],
 // slot of the current slab can be refilled (slab n+NS) and the next slab's first quarter can be read.
 __device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[4], int lane) {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (kRingSlots - 2)) : "memory");
+#ifndef NSR_EXP_NOBARRIER   // timing experiment only (results are wrong without the barrier)
   __builtin_amdgcn_s_barrier();
-  ring_issue(rg);  // refills the slot that was just drained (pslot == cslot here)
+#endif
   rg.cslot = (rg.cslot + 1 == kRingSlots) ? 0 : rg.cslot + 1;
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
 #pragma unroll
@@ -98,10 +101,10 @@ __device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[4], int lane) 
 // ------------------------------------------------------------------------------------------------------
 #define NSR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <int NMO, int NACC, typename BOp>
+template <int NMO, int KK0, int KK1, int NACC, typename BOp>
 __device__ __forceinline__ void consume(const f32x4 (&A)[4], int step, BOp bop, f32x16 (&acc)[NACC]) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
+  for (int kk = KK0; kk < KK1; ++kk)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int n = 4 * step + c, tq = n / NMO, mo = n % NMO;
@@ -109,20 +112,27 @@ __device__ __forceinline__ void consume(const f32x4 (&A)[4], int step, BOp bop, 
     }
 }
 
+// One step = [4 MFMAs][issue the next step's 4 fragment loads][12 MFMAs].  The loads are pinned there with
+// sched_barrier: left alone, the scheduler sinks them to just above their first use (to save registers) and the
+// waitcnt pass then waits lgkmcnt(0) right behind them, exposing the full LDS latency every 16 MFMAs (~10 % of the
+// MFMA rate, measured).  Issued after the first 4 MFMAs they have 12 MFMAs (768 cycles) to land, and any
+// lgkmcnt(0) the compiler places at the head of the next step finds nothing outstanding.
+#define NSR_PIN() __builtin_amdgcn_sched_barrier(0)
 template <int NMO, int NTQ, int NACC, typename BOp>
 __device__ __forceinline__ void seg(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], BOp bop, f32x16 (&acc)[NACC],
                                     int lane) {
   static_assert((NMO * NTQ) % 16 == 0, "a segment is a whole number of slabs");
 #pragma unroll
   for (int s = 0; s < NMO * NTQ / 4; s += 4) {
-    ring_load_quarter<1>(rg, A1, lane);
-    consume<NMO>(A0, s, bop, acc);
-    ring_load_quarter<2>(rg, A0, lane);
-    consume<NMO>(A1, s + 1, bop, acc);
-    ring_load_quarter<3>(rg, A1, lane);
-    consume<NMO>(A0, s + 2, bop, acc);
-    ring_advance(rg, A0, lane);
-    consume<NMO>(A1, s + 3, bop, acc);
+    consume<NMO, 0, 1>(A0, s, bop, acc);     NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); NSR_PIN();
+    consume<NMO, 1, 4>(A0, s, bop, acc);     NSR_PIN();
+    consume<NMO, 0, 1>(A1, s + 1, bop, acc); NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); NSR_PIN();
+    consume<NMO, 1, 4>(A1, s + 1, bop, acc); NSR_PIN();
+    consume<NMO, 0, 1>(A0, s + 2, bop, acc); NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); NSR_PIN();
+    consume<NMO, 1, 4>(A0, s + 2, bop, acc); NSR_PIN();
+    consume<NMO, 0, 1>(A1, s + 3, bop, acc); NSR_PIN(); ring_advance(rg, A0, lane);         NSR_PIN();
+    consume<NMO, 1, 2>(A1, s + 3, bop, acc); NSR_PIN(); ring_issue(rg);                     NSR_PIN();
+    consume<NMO, 2, 4>(A1, s + 3, bop, acc); NSR_PIN();   // the DMA issue (~25 SALU/VMEM) hides behind 4 queued MFMAs
   }
 }
 
@@ -188,7 +198,11 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 #pragma unroll
       for (int ax = 0; ax < 3; ++ax) {
         float s, c;
+#ifdef NSR_EXP_FASTTRIG         // timing experiment only
+        s = __sinf(p[ax] * (float)(1 << L)); c = __cosf(p[ax] * (float)(1 << L));
+#else
         sincosf(p[ax] * (float)(1 << L), &s, &c);
+#endif
         e[3 * L + ax] = h ? c : s;
       }
     e[30] = h ? pz : px;
@@ -236,9 +250,9 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
     }
     seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
     if (CAPTURE && L < 8) mask_dst[L * 256] = relu_mask<8>(acc);
-    const float lo = (L == 8) ? -__builtin_inff() : 0.0f;
+    const int thr = (L == 8) ? (int)0x80000000 : 0;      // feature_linear has no activation
 #pragma unroll
-    for (int mo = 0; mo < 8; ++mo) in[mo] = max16(acc[mo], lo);
+    for (int mo = 0; mo < 8; ++mo) in[mo] = clamp_bits16(acc[mo], thr);
   }
 
   // views_linears.0 (RH:111-115): cat([feature, input_views]) -> 128, ReLU
@@ -287,7 +301,8 @@ struct ItemState {
   float rawf[2][192][4];    // fine raw               RN:483
   float alpha[2][192];      // compositing scratch
   float wf[2][192];         // fine weights           RN:485
-  float tf[2][192];         // fine transmittance (backward only)
+  float tf[2][192];         // transmittance T_i (RN:376)
+  double om[2][192];        // 1 - alpha + 1e-10 widened to fp64 for the sequential scan
   float psum[2][6][12];     // backward: per (pass, wave) partial sums of d/dpts, z*d/dpts, d/dviewdir
   float gnorm[2];           // backward: dL/d|rays_d| from dists*|d| (RN:361)
   float res[2][8];          // rgb(3) disp acc depth
@@ -296,10 +311,15 @@ struct ItemState {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // raw2outputs RN:343-387 for both rays of the item.  z: [2][S], raw: [2][S][4] (rgb overwritten by sigmoid),
-// wout: [2][S] weights.  Results in st.res.
+// wout: [2][S] weights, tout: [2][S] transmittance.  Results in st.res.
+// Three phases: (1) per-sample alpha / sigmoid / 1-alpha+1e-10, all threads; (2) the transmittance scan -- the only
+// inherently serial part: torch-CPU cumprod is a sequential fp64 product with every prefix rounded to fp32
+// (RN:376), one lane per ray, 8 factors per LDS round trip; (3) weights and the five weighted sums, one wave per
+// ray (lane l owns samples l, l+64, l+128), xor-shuffle tree.
 template <int S>
-__device__ __forceinline__ void composite(ItemState& st, const float* z, float* raw, float* wout, int tid,
-                                          float* tout = nullptr) {
+__device__ __forceinline__ void composite(ItemState& st, const float* z, float* raw, float* wout, float* tout,
+                                          int tid) {
+  static_assert(S % 8 == 0, "scan is unrolled by 8");
   for (int idx = tid; idx < 2 * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
     const float* zr = z + r * S;
@@ -307,7 +327,9 @@ __device__ __forceinline__ void composite(ItemState& st, const float* z, float* 
     dist = dist * st.ray[r][11];                               // RN:361
     float* q = raw + (r * S + i) * 4;
     const float sigma = fmaxf(q[3], 0.0f);
-    st.alpha[r][i] = 1.0f - expf(-sigma * dist);               // RN:356
+    const float a = 1.0f - expf(-sigma * dist);                // RN:356
+    st.alpha[r][i] = a;
+    st.om[r][i] = (double)((1.0f - a) + 1e-10f);               // RN:376 factor, widened for the fp64 scan
     q[0] = sigmoidf_(q[0]);                                    // RN:363
     q[1] = sigmoidf_(q[1]);
     q[2] = sigmoidf_(q[2]);
@@ -315,29 +337,48 @@ __device__ __forceinline__ void composite(ItemState& st, const float* z, float* 
   __syncthreads();
   if ((tid & 63) == 0 && tid < 128) {
     const int r = tid >> 6;
+    double T = 1.0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < S; i0 += 8) {
+      double f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = st.om[r][i0 + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        tout[r * S + i0 + k] = (float)T;                       // exclusive product, rounded per prefix
+        T = T * f[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int r = tid >> 6, l = tid & 63;
     const float* zr = z + r * S;
     const float* q = raw + r * S * 4;
-    double T = 1.0;  // torch-CPU cumprod: sequential, fp64 accumulator, every prefix rounded to fp32 (RN:376)
     float cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, acc = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < S; ++i) {
-      const float a = st.alpha[r][i];
-      const float w = a * (float)T;
+#pragma unroll
+    for (int i = l; i < S; i += 64) {
+      const float w = st.alpha[r][i] * tout[r * S + i];        // RN:376
       wout[r * S + i] = w;
-      if (tout) tout[r * S + i] = (float)T;
-      cr = cr + w * q[i * 4 + 0];
+      cr = cr + w * q[i * 4 + 0];                              // RN:378
       cg = cg + w * q[i * 4 + 1];
       cb = cb + w * q[i * 4 + 2];
-      depth = depth + w * zr[i];
-      acc = acc + w;
-      T = T * (double)((1.0f - a) + 1e-10f);
+      depth = depth + w * zr[i];                               // RN:380
+      acc = acc + w;                                           // RN:382
     }
-    const float qd = depth / acc;
-    float disp;
-    if (qd != qd) disp = qd;                                   // 0/0 -> NaN propagates through torch.max (RN:381)
-    else disp = 1.0f / fmaxf(1e-10f, qd);
-    st.res[r][0] = cr; st.res[r][1] = cg; st.res[r][2] = cb;
-    st.res[r][3] = disp; st.res[r][4] = acc; st.res[r][5] = depth;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      cr += __shfl_xor(cr, m); cg += __shfl_xor(cg, m); cb += __shfl_xor(cb, m);
+      depth += __shfl_xor(depth, m); acc += __shfl_xor(acc, m);
+    }
+    if (l == 0) {
+      const float qd = depth / acc;
+      float disp;
+      if (qd != qd) disp = qd;                                 // 0/0 -> NaN propagates through torch.max (RN:381)
+      else disp = 1.0f / fmaxf(1e-10f, qd);
+      st.res[r][0] = cr; st.res[r][1] = cg; st.res[r][2] = cb;
+      st.res[r][3] = disp; st.res[r][4] = acc; st.res[r][5] = depth;
+    }
   }
   __syncthreads();
 }
@@ -348,12 +389,15 @@ template <typename BinsFn>
 __device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*[2][stride]*/, int wstride,
                                                 BinsFn bins, int64_t* inds_out /*[2][128] or null*/,
                                                 int64_t inds_stride, int tid, int valid_rays) {
+  // (1) x = w + 1e-5 and the 8 vector-lane partial sums of ATen's cascade, 8 lanes per ray
+  if (tid < 128 && (tid & 63) < 62) {
+    const int r = tid >> 6, i = tid & 63;
+    st.alpha[r][i] = (w + r * wstride)[i] + 1e-5f;              // RH:201 (alpha[] is free scratch here)
+  }
+  __syncthreads();
   if ((tid & 63) == 0 && tid < 128) {
     const int r = tid >> 6;
-    const float* wr = w + r * wstride;
-    float x[62];
-#pragma unroll
-    for (int i = 0; i < 62; ++i) x[i] = wr[i] + 1e-5f;          // RH:201
+    const float* x = st.alpha[r];
     // torch.sum over 62 contiguous floats: ATen's 8-lane x 4-ILP cascade (RH:202), exact association order
     float lanes[8];
 #pragma unroll
@@ -366,14 +410,29 @@ __device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*
     for (int i = 56; i < 62; ++i) total = total + x[i];
 #pragma unroll
     for (int j = 0; j < 8; ++j) total = total + lanes[j];
+    st.res[r][7] = total;
+  }
+  __syncthreads();
+  if (tid < 128 && (tid & 63) < 62) {
+    const int r = tid >> 6, i = tid & 63;
+    st.om[r][i] = (double)(st.alpha[r][i] / st.res[r][7]);     // pdf, widened (RH:202)
+  }
+  __syncthreads();
+  if ((tid & 63) == 0 && tid < 128) {
+    const int r = tid >> 6;
     // cdf = [0, cumsum(pdf)]: sequential fp64 accumulator, each prefix rounded to fp32 (RH:203-204)
     double run = 0.0;
     st.cdf[r][0] = 0.0f;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 56; i0 += 8) {
+      double f[8];
 #pragma unroll
-    for (int i = 0; i < 62; ++i) {
-      run = run + (double)(x[i] / total);
-      st.cdf[r][i + 1] = (float)run;
+      for (int k = 0; k < 8; ++k) f[k] = st.om[r][i0 + k];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { run = run + f[k]; st.cdf[r][i0 + k + 1] = (float)run; }
     }
+#pragma unroll
+    for (int i = 56; i < 62; ++i) { run = run + st.om[r][i]; st.cdf[r][i + 1] = (float)run; }
   }
   __syncthreads();
   {
@@ -578,7 +637,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
         for (int idx = tid; idx < valid * 256; idx += 256) a.dbg_raw0[ray0 * 256 + idx] = (&st.rawc[0][0][0])[idx];
         __syncthreads();
       }
-      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], tid);
+      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
       if (tid < valid * 8) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -617,7 +676,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
         for (int idx = tid; idx < valid * 768; idx += 256) a.dbg_raw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
         __syncthreads();
       }
-      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], tid);
+      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid);
       if (tid < valid * 8) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -754,21 +813,45 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
 
 // Backward of raw2outputs (RN:343-387) for both rays: dL/d raw (written over st.rawf) and dL/d|rays_d|.
 // st.rawf holds sigmoid(rgb) and the raw sigma, st.alpha / st.wf / st.tf the forward alpha, weights, T.
+//   dL/dw_i = g . c_i ;  dL/dalpha_i = A_i T_i - (sum_{k>i} A_k w_k) / (1 - alpha_i + 1e-10)
+// Only the suffix sum is serial (one lane per ray, fp32, 8 terms per LDS round trip).
 __device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /* [2][3] in LDS */, int tid) {
   constexpr int S = 192;
+  float* aw = (float*)&st.om[0][0];   // [2][S] A_i * w_i, then the exclusive suffix sums
+  float* at = aw + 2 * S;             // [2][S] A_i * T_i
+  for (int idx = tid; idx < 2 * S; idx += 256) {
+    const int r = idx / S, i = idx - r * S;
+    const float* q = st.rawf[r][i];
+    const float a_i = (grgb[r * 3 + 0] * q[0] + grgb[r * 3 + 1] * q[1]) + grgb[r * 3 + 2] * q[2];
+    aw[idx] = a_i * st.wf[r][i];
+    at[idx] = a_i * st.tf[r][i];
+  }
+  __syncthreads();
   if ((tid & 63) == 0 && tid < 128) {
     const int r = tid >> 6;
-    const float g0 = grgb[r * 3 + 0], g1 = grgb[r * 3 + 1], g2 = grgb[r * 3 + 2];
+    float suffix = 0.0f;
+#pragma unroll 1
+    for (int i0 = S - 8; i0 >= 0; i0 -= 8) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = aw[r * S + i0 + k];
+#pragma unroll
+      for (int k = 7; k >= 0; --k) { aw[r * S + i0 + k] = suffix; suffix = suffix + f[k]; }
+    }
+  }
+  __syncthreads();
+  float dn = 0.0f;
+  if (tid < 128) {
+    const int r = tid >> 6, l = tid & 63;
     const float nrm = st.ray[r][11];
-    float suffix = 0.0f, dn = 0.0f;
-    for (int i = S - 1; i >= 0; --i) {
+    const float g0 = grgb[r * 3 + 0], g1 = grgb[r * 3 + 1], g2 = grgb[r * 3 + 2];
+#pragma unroll
+    for (int i = l; i < S; i += 64) {
       float* q = st.rawf[r][i];
-      const float a = st.alpha[r][i], T = st.tf[r][i], w = st.wf[r][i];
+      const float a = st.alpha[r][i], w = st.wf[r][i];
       const float c0 = q[0], c1 = q[1], c2 = q[2], sigma = q[3];
-      const float A = (g0 * c0 + g1 * c1) + g2 * c2;                     // dL/dw_i
       const float om = (1.0f - a) + 1e-10f;
-      const float d_alpha = A * T - suffix / om;                          // T_k (k>i) carries the factor om_i
-      suffix = suffix + A * w;
+      const float d_alpha = at[r * S + i] - aw[r * S + i] / om;          // T_k (k>i) carries the factor om_i
       const float dz = (i < S - 1) ? (st.zf[r][i + 1] - st.zf[r][i]) : 1e10f;
       const float e = 1.0f - a;                                           // exp(-relu(sigma) * delta)
       const float d_sigma = (sigma > 0.0f) ? d_alpha * (dz * nrm) * e : 0.0f;
@@ -778,7 +861,9 @@ __device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /
       q[2] = w * g2 * c2 * (1.0f - c2);
       q[3] = d_sigma;
     }
-    st.gnorm[r] = dn;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dn += __shfl_xor(dn, m);
+    if (l == 0) st.gnorm[r] = dn;
   }
   __syncthreads();
 }
@@ -904,7 +989,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
 
     if (pass == 0) {
       __syncthreads();
-      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], tid);
+      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
       int64_t* none = nullptr;
       sample_pdf_item(st, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid);
@@ -914,7 +999,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       ++pass;
     } else if (pass == 3) {
       __syncthreads();
-      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], tid, &st.tf[0][0]);
+      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid);
       if (tid < valid * 8) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -993,6 +1078,73 @@ __global__ void __launch_bounds__(256) k_pose_grad(const float* __restrict__ go,
     __syncthreads();
   }
   if (threadIdx.x < 12) out[blockIdx.x * 12 + threadIdx.x] = (float)red[0][threadIdx.x];
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Diagnostic micro-kernels (nsr_probe): the layer GEMM in isolation, to attribute MFMA-rate losses.
+//   mode 0: 1024 MFMAs per iteration, A operands from registers (no LDS, no ring)  -> MFMA issue ceiling
+//   mode 1: A fragments read from a static LDS slab with the production step structure (no DMA, no barrier)
+//   mode 2: the production segment seg<8,32> with the LDS-DMA ring and barriers
+// ------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_probe(const float* __restrict__ stream, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x16 in[8], acc[8];
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
+  }
+  Ring rg;
+  rg.smem = smem;
+  rg.base = (const char*)stream;
+  rg.stride = 0;
+  rg.lane_off = wave * 4096 + lane * 16;
+  rg.wave_lds = wave * 4096;
+  rg.psrc = rg.base + rg.lane_off;
+  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.ppi = 1;
+  f32x4 A0[4], A1[4];
+  if (MODE == 2) {
+    ring_start(rg, A0, lane);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (MODE == 1) {
+    for (int i = tid; i < 4096; i += 256) ((float*)smem)[i] = stream[i];
+    __syncthreads();
+    ring_load_quarter<0>(rg, A0, lane);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 64; s += 2) {
+        consume<8, 0, 1>(A0, s, BRegs16<8>{in}, acc);     NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); NSR_PIN();
+        consume<8, 1, 4>(A0, s, BRegs16<8>{in}, acc);     NSR_PIN();
+        consume<8, 0, 1>(A1, s + 1, BRegs16<8>{in}, acc); NSR_PIN(); ring_load_quarter<0>(rg, A0, lane); NSR_PIN();
+        consume<8, 1, 4>(A1, s + 1, BRegs16<8>{in}, acc); NSR_PIN();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { A0[c] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(lane + c); A1[c] = A0[c] * 0.5f; }
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int s = 0; s < 64; s += 2) {
+        consume<8, 0, 4>(A0, s, BRegs16<8>{in}, acc);
+        consume<8, 0, 4>(A1, s + 1, BRegs16<8>{in}, acc);
+      }
+    }
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += acc[mo][r];
+  out[blockIdx.x * 256 + tid] = sum;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1085,7 +1237,7 @@ __global__ void __launch_bounds__(256) k_raw2outputs(R2OArgs a) {
       st.ray[tid][11] = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
     }
     __syncthreads();
-    composite<S>(st, zbuf, rawbuf, wbuf, tid);
+    composite<S>(st, zbuf, rawbuf, wbuf, &st.tf[0][0], tid);
     for (int idx = tid; idx < valid * S; idx += 256) a.weights[ray0 * S + idx] = wbuf[idx];
     if (tid < valid * 8) {
       const int r = tid >> 3, c = tid & 7;
