@@ -33,7 +33,6 @@ struct Ring {
   char* smem;            // LDS base (generic pointer)
   const char* base;      // packed networks (global), consecutive at `stride` bytes: coarse | fine | fine^T (backward)
   long long stride;
-  const char* psrc;      // producer: current net base + this lane's offset (wave*4096 + lane*16)
   int lane_off;          // wave*4096 + lane*16
   int wave_lds;          // wave*4096
   int pslab;             // producer: next slab index within the pass stream
@@ -41,21 +40,41 @@ struct Ring {
   int pphase;            // producer: pass index within the item (0 = coarse net)
   int ppi;               // passes per item: 1 (coarse only), 4 (coarse + 3 fine) or 7 (+ 3 backward)
   int cslot;             // consumer: slot of the slab being consumed
+  int pnet_off;          // producer: byte offset of the current net within `base` (buffer-descriptor form)
+  __amdgpu_buffer_rsrc_t rsrc;
 };
 
+__device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base, long long stride, int ppi, int wave,
+                                          int lane) {
+  rg.smem = smem;
+  rg.base = (const char*)base;
+  rg.stride = stride;
+  rg.lane_off = wave * 4096 + lane * 16;
+  rg.wave_lds = wave * 4096;
+  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.pnet_off = 0;
+  rg.ppi = ppi;
+  rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+
 __device__ __forceinline__ void ring_issue(Ring& rg) {
-  const char* g = rg.psrc + (size_t)rg.pslab * kSlabBytes;
   char* l = rg.smem + rg.pslot * kSlabBytes + rg.wave_lds;
-#ifndef NSR_EXP_NODMA        // timing experiment only
-#pragma unroll
-  for (int c = 0; c < 4; ++c) NSR_GLDS16(g + c * 1024, l + c * 1024);
+#ifndef NSR_EXP_NODMA        // (NODMA: timing experiment only)
+  // MUBUF LDS-DMA (buffer_load_dwordx4 ... lds): per-lane offset is a loop-invariant VGPR, everything that changes
+  // (network, slab, chunk) sits in the scalar offset / immediate -> no per-instruction VALU address math; measured
+  // +1 % on the layer GEMM over the flat global_load_lds form with 64-bit per-lane addresses.
+  const int soff = rg.pnet_off + rg.pslab * kSlabBytes;
+#define NSR_BUFDMA(C)                                                                                      \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rg.rsrc, (__attribute__((address_space(3))) void*)l, 16, rg.lane_off, \
+                                           soff, (C) * 1024, 0) /* the immediate offsets BOTH the source and LDS */
+  NSR_BUFDMA(0); NSR_BUFDMA(1); NSR_BUFDMA(2); NSR_BUFDMA(3);
+#undef NSR_BUFDMA
 #endif
   rg.pslot = (rg.pslot + 1 == kRingSlots) ? 0 : rg.pslot + 1;
   if (++rg.pslab == kStreamSlabs) {
     rg.pslab = 0;
     rg.pphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
     const int net = rg.pphase == 0 ? 0 : (rg.pphase <= 3 ? 1 : 2);   // arithmetic, not a pointer table: keeps Ring in SGPRs
-    rg.psrc = rg.base + net * rg.stride + rg.lane_off;
+    rg.pnet_off = net * (int)rg.stride;
   }
 }
 
@@ -556,14 +575,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   const int fine = a.fine;
 
   Ring rg;
-  rg.smem = smem;
-  rg.base = (const char*)a.nets;
-  rg.stride = a.net_stride;
-  rg.lane_off = wave * 4096 + lane * 16;
-  rg.wave_lds = wave * 4096;
-  rg.psrc = rg.base + rg.lane_off;
-  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0;
-  rg.ppi = fine ? 4 : 1;
+  ring_init(rg, smem, a.nets, a.net_stride, fine ? 4 : 1, wave, lane);
 
   f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
@@ -901,14 +913,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
   if ((long long)blockIdx.x >= n_items) return;
 
   Ring rg;
-  rg.smem = smem;
-  rg.base = (const char*)a.nets;
-  rg.stride = a.net_stride;
-  rg.lane_off = wave * 4096 + lane * 16;
-  rg.wave_lds = wave * 4096;
-  rg.psrc = rg.base + rg.lane_off;
-  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0;
-  rg.ppi = 7;
+  ring_init(rg, smem, a.nets, a.net_stride, 7, wave, lane);
 
   f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);
@@ -1100,13 +1105,7 @@ __global__ void __launch_bounds__(256, 1) k_probe(const float* __restrict__ stre
     for (int r = 0; r < 16; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
   }
   Ring rg;
-  rg.smem = smem;
-  rg.base = (const char*)stream;
-  rg.stride = 0;
-  rg.lane_off = wave * 4096 + lane * 16;
-  rg.wave_lds = wave * 4096;
-  rg.psrc = rg.base + rg.lane_off;
-  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.ppi = 1;
+  ring_init(rg, smem, stream, 0, 1, wave, lane);
   f32x4 A0[4], A1[4];
   if (MODE == 2) {
     ring_start(rg, A0, lane);
@@ -1168,13 +1167,7 @@ __global__ void __launch_bounds__(256, 1) k_run_network(NetArgs a) {
   if ((long long)blockIdx.x >= n_tiles) return;
 
   Ring rg;
-  rg.smem = smem;
-  rg.base = (const char*)a.stream;
-  rg.stride = 0;
-  rg.lane_off = wave * 4096 + lane * 16;
-  rg.wave_lds = wave * 4096;
-  rg.psrc = rg.base + rg.lane_off;
-  rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.ppi = 1;
+  ring_init(rg, smem, a.stream, 0, 1, wave, lane);
   f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);
   float* auxl = (float*)(smem + kLdsAux);
