@@ -491,7 +491,9 @@ __device__ __forceinline__ float zstd_wave(const ItemState& st, int r, int lane)
   return (float)sqrt(v * (1.0 / 128.0));
 }
 
-// z_vals = sort(cat([z_coarse, z_samples])) RN:477 by rank counting (no sortedness assumption).
+// z_vals = sort(cat([z_coarse, z_samples])) RN:477 by exact, stable rank counting: no sortedness assumption about
+// z_samples (adjacent inverse-CDF bins can produce 1-ulp inversions).  Measured cost 0.7 % of a render; float4 /
+// 64-bit-key variants were within noise (interleaved A/B on one box), so the plain form stays.
 __device__ __forceinline__ void merge_sort_item(ItemState& st, int tid) {
   for (int e = tid; e < 384; e += 256) {
     const int r = e / 192, k = e - r * 192;
@@ -560,9 +562,19 @@ __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int ti
 // spills inside the MFMA passes.
 __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; }
 
+#ifdef NSR_PHASE_TIMING      // diagnostic build: per-workgroup cycle totals of the item phases (thread 0), see tools
+#define NSR_T(i) do { if (tid == 0) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define NSR_T(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RenderArgs& a = *ap;
+#ifdef NSR_PHASE_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -618,6 +630,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
         st.zc[r][i] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
       }
       __syncthreads();
+      NSR_T(0);
     }
 
     // ---- one network pass: 128 points -------------------------------------------------------------
@@ -642,6 +655,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
+    NSR_T(1);
 
     if (pass == 0) {
       __syncthreads();
@@ -664,21 +678,29 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
       if (a.dbg_w0)
         for (int idx = tid; idx < valid * 64; idx += 256) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
       if (!fine) { __syncthreads(); item += gridDim.x; continue; }
+      NSR_T(2);
 
       // ---- hierarchical resampling ----------------------------------------------------------------
+#ifdef NSR_PHASE_TIMING
+      int64_t* inds = nullptr;                 // dbg_inds carries the cycle totals in this build
+#else
       int64_t* inds = (int64_t*)a.dbg_inds;
+#endif
       sample_pdf_item(st, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
                       inds ? inds + ray0 * 128 : nullptr, 128, tid, valid);
+      NSR_T(3);
       if (wave < 2) {
         const float sd = zstd_wave(st, wave, lane);
         if (lane == 0 && wave < valid && a.z_std) a.z_std[ray0 + wave] = sd;
       }
       if (a.dbg_zs)
         for (int idx = tid; idx < valid * 128; idx += 256) a.dbg_zs[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
+      NSR_T(4);
       merge_sort_item(st, tid);
       if (a.dbg_zf)
         for (int idx = tid; idx < valid * 192; idx += 256) a.dbg_zf[ray0 * 192 + idx] = (&st.zf[0][0])[idx];
+      NSR_T(5);
       pass = 1;
     } else if (pass < 3) {
       ++pass;
@@ -698,11 +720,16 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
         else if (c == 4) { if (a.acc) a.acc[rr] = v; }
       }
       __syncthreads();
+      NSR_T(6);
       pass = 0;
       item += gridDim.x;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+#ifdef NSR_PHASE_TIMING
+  if (tid == 0 && a.dbg_raw == nullptr && a.dbg_inds)      // diagnostic hijack: dbg_inds receives [grid][8] cycle totals
+    for (int i = 0; i < 8; ++i) a.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------

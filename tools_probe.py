@@ -5,7 +5,7 @@ from neural_sim_nerf_amd import synthetic as S
 from neural_sim_nerf_amd.engine import NsrModel
 sd_c = S.synth_weights(0); sd_f = S.synth_weights(1000, fine_of=sd_c)
 m = NsrModel(sd_c, sd_f)
-P = 160000 * 256
+P = 160000 * 256 if len(sys.argv) < 2 else 1024
 pts = torch.rand(P, 3, device=m.device) * 2 - 1
 dirs = torch.nn.functional.normalize(torch.randn(P, 3, device=m.device), dim=-1)
 for _ in range(2):
