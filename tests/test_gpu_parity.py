@@ -295,3 +295,30 @@ def test_render_api_autograd_and_render_path_grad(model, oracle, synth_nets, tmp
         # 16-ray patch sums cancel heavily: bound the error by the largest component (VJP itself: 2e-4 rel.)
         assert np.abs(dLdpsis[p].numpy() - want).max() < 2e-3 * np.abs(want).max(), p
     assert np.allclose(rgbs[0].reshape(-1, 3), cpu(fwd["rgb_map"]))
+
+
+def test_models_on_concurrent_streams(oracle):
+    """BASELINE config 5 in miniature: one handle per (model, stream), kernels of different models co-resident
+    (max_workgroups caps each persistent grid), results identical to running them one after the other."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    K = oracle.scaled_K(12.5)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    poses = oracle.sweep_poses(3, seed=11)
+    models, streams, seq = [], [], []
+    for i in range(3):
+        sd_c = oracle.synth_weights(100 + i)
+        models.append(NsrModel(sd_c, oracle.synth_weights(1100 + i, fine_of=sd_c), max_workgroups=64))
+        streams.append(torch.cuda.Stream())
+        seq.append(cpu(models[i].render_views(poses[i], 32, 32, K, near, far)["rgb_map"]))
+    torch.cuda.synchronize()
+    outs = []
+    for m, st, p in zip(models, streams, poses):
+        with torch.cuda.stream(st):
+            outs.append(m.render_views(p, 32, 32, K, near, far)["rgb_map"])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert np.array_equal(cpu(outs[i]), seq[i])
+    assert not np.array_equal(seq[0], seq[1])            # the models really differ
+    for m in models:
+        m.close()

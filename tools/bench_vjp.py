@@ -1,6 +1,6 @@
 """Timing of the forward+input-gradient kernel (render_path_grad's per-pose work): one 400x400 image."""
 import sys, json, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from neural_sim_nerf_amd import synthetic as S
 from neural_sim_nerf_amd.engine import NsrModel
 H = W = int(sys.argv[1]) if len(sys.argv) > 1 else 400

@@ -1,6 +1,6 @@
 """Per-phase cycle totals of k_render from the NSR_PHASE_TIMING diagnostic build (thread 0 of every workgroup)."""
 import sys, ctypes as C, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from neural_sim_nerf_amd import synthetic as S, _lib
 from neural_sim_nerf_amd.engine import NsrModel, _dev, _stream_ptr
 sd_c = S.synth_weights(0); sd_f = S.synth_weights(1000, fine_of=sd_c)

@@ -1,5 +1,5 @@
 import sys, ctypes as C
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from neural_sim_nerf_amd import synthetic as S, _lib
 from neural_sim_nerf_amd.engine import NsrModel
 m = NsrModel(S.synth_weights(0), None, n_importance=0)

@@ -1,6 +1,6 @@
 """Perf probes: run_network alone (no per-item phases) vs the fused render, per network pass."""
 import sys, json, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from neural_sim_nerf_amd import synthetic as S
 from neural_sim_nerf_amd.engine import NsrModel
 sd_c = S.synth_weights(0); sd_f = S.synth_weights(1000, fine_of=sd_c)
