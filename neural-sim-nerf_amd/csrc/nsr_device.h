@@ -31,11 +31,6 @@ constexpr int kLdsRing = 0;
 constexpr int kLdsAux = kRingSlots * kSlabBytes;              //  98304
 constexpr int kLdsState = kLdsAux + 2 * kAuxFloats * 4;       // 124928
 
-// global -> LDS DMA, 16 B per lane: LDS destination = wave-uniform base + lane*16 (M0), source per lane.
-#define NSR_GLDS16(gptr, lptr)                                                                        \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),             \
-                                   (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 // relu as ONE integer max per element: negative floats are negative ints, so max_i32(bits, 0) clamps them to +0
