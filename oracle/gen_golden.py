@@ -230,6 +230,27 @@ def main():
     save("g8_backward", seed=np.int64(SEED), rays=rays.detach().numpy(), cot=cot.numpy(),
          rgb=rgb_p.detach().numpy(), grad_rays=g.numpy(), z_samples=cap.log[0]["samples"])
 
+    # ---- G10 the bilevel gradient end to end: psi -> poses (LL:202-301) -> render_path_grad (RN:126-210) -------
+    class _FixedSecond:                       # LL:273 seeds numpy with datetime.now().second
+        @staticmethod
+        def now():
+            return types.SimpleNamespace(second=5)
+    LL.datetime = _FixedSecond
+    psi = torch.tensor([0.02, 0.02, 0.02, 0.86, 0.02, 0.02, 0.02, 0.02])
+    prob16 = np.array(torch.softmax(psi / 0.25, 0), dtype=np.float16)               # NM:85-87
+    poses_ng, log = LL.sample_pose_nograd(prob16, 2, 0.1)
+    prob = torch.softmax(psi / 0.25, 0).requires_grad_()                             # NM:141-142
+    poses_g = LL.sample_pose(prob, 2, 0.1, log)
+    Hs = 8
+    Ks = O.scaled_K(50.0)
+    gE = [{"grad_E": [torch.from_numpy(rng.standard_normal((3, Hs, Hs)).astype(np.float32))]} for _ in range(2)]
+    kw10 = {k: v for k, v in kwargs.items()}
+    rgbs10, dl = RN.render_path_grad(prob, poses_g, [Hs, Hs, Ks[0][0]], Ks, 16, gE, kw10, savedir=None)
+    save("g10_path_grad", psi=psi.numpy(), prob16=prob16, gumbel=np.array(log["gumbel_noises"]),
+         uniform=np.array(log["uniform_noises"]), thetas=np.array(log["thetas"]), poses_nograd=poses_ng.numpy(),
+         poses_grad=poses_g.detach().numpy(), K=np.array(Ks), grad_E=np.stack([g["grad_E"][0].numpy() for g in gE]),
+         rgbs=rgbs10, dLdpsis=np.stack([d.numpy() for d in dl]), seed=np.int64(SEED))
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

@@ -322,3 +322,36 @@ def test_models_on_concurrent_streams(oracle):
     assert not np.array_equal(seq[0], seq[1])            # the models really differ
     for m in models:
         m.close()
+
+
+def test_bilevel_gradient_end_to_end_vs_reference(synth_nets, oracle, tmp_path):
+    """BASELINE config 4's render leg, end to end: psi -> poses (pose.py, LL:202-247) -> render_path_grad, against
+    what the REFERENCE's sample_pose + render_path_grad returned for the same psi, noise log and cotangents
+    (tests/golden/g10_path_grad.npz).  Tolerance: every per-patch dL/dpsi within 2 % of the largest component
+    (the reference runs 4 autograd patches per pose on CPU; a few rays resample differently)."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd import pose as P
+    g = load_golden("g10_path_grad")
+    nets = []
+    for sd in synth_nets:
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=oracle.YCBV_NEAR, far=oracle.YCBV_FAR)
+    log = {"gumbel_noises": g["gumbel"].tolist(), "uniform_noises": g["uniform"].tolist(),
+           "thetas": g["thetas"].tolist()}
+    prob = torch.softmax(torch.tensor(g["psi"]) / 0.25, 0).requires_grad_()             # NM:141-142
+    poses = P.sample_pose(prob, 2, 0.1, log)
+    grad_E = [{"grad_E": [torch.from_numpy(x)]} for x in g["grad_E"]]
+    K = g["K"].tolist()
+    rgbs, dl = R.render_path_grad(prob, poses, [8, 8, K[0][0]], K, 16, grad_E, kw, savedir=str(tmp_path))
+    assert rgbs.shape == (2, 8, 8, 3) and len(dl) == 8
+    assert oracle.psnr(rgbs, g["rgbs"]) > 50.0
+    got = np.stack([d.numpy() for d in dl])
+    scale = np.abs(g["dLdpsis"]).max()
+    assert np.abs(got - g["dLdpsis"]).max() < 2e-2 * scale, np.abs(got - g["dLdpsis"]).max() / scale
+    mean_ref = g["dLdpsis"].mean(0)                                                      # NM:191
+    assert np.abs(got.mean(0) - mean_ref).max() < 2e-2 * np.abs(mean_ref).max()

@@ -179,3 +179,19 @@ print("ok")
 ''' % (ROOT, os.path.join(ROOT, "neural-sim-nerf_amd", "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_pose_module_matches_reference(golden):
+    """psi -> poses (LL:202-301) against what the reference produced for the same noise: exact."""
+    import torch
+    from neural_sim_nerf_amd import pose as P
+    g = golden("g10_path_grad")
+    poses, log = P.sample_pose_nograd(g["prob16"], 2, 0.1, seed=5)          # the reference seeded numpy with 5
+    assert np.array_equal(poses.numpy(), g["poses_nograd"])
+    assert np.allclose(log["gumbel_noises"], g["gumbel"]) and np.allclose(log["thetas"], g["thetas"])
+    prob = torch.softmax(torch.tensor(g["psi"]) / 0.25, 0).requires_grad_()
+    pg = P.sample_pose(prob, 2, 0.1, log)
+    assert np.array_equal(pg.detach().numpy(), g["poses_grad"])
+    assert np.abs(g["poses_grad"] - g["poses_nograd"]).max() < 1e-6          # the two paths agree to fp32 rounding
+    (gr,) = torch.autograd.grad(pg.sum(), prob)
+    assert gr.shape == (8,) and torch.isfinite(gr).all()
