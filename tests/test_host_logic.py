@@ -192,6 +192,6 @@ def test_pose_module_matches_reference(golden):
     prob = torch.softmax(torch.tensor(g["psi"]) / 0.25, 0).requires_grad_()
     pg = P.sample_pose(prob, 2, 0.1, log)
     assert np.array_equal(pg.detach().numpy(), g["poses_grad"])
-    assert np.abs(g["poses_grad"] - g["poses_nograd"]).max() < 1e-6          # the two paths agree to fp32 rounding
+    assert np.abs(g["poses_grad"] - g["poses_nograd"]).max() < 1e-5          # fp64-trig vs fp32-trig construction
     (gr,) = torch.autograd.grad(pg.sum(), prob)
     assert gr.shape == (8,) and torch.isfinite(gr).all()
