@@ -355,3 +355,44 @@ def test_bilevel_gradient_end_to_end_vs_reference(synth_nets, oracle, tmp_path):
     assert np.abs(got - g["dLdpsis"]).max() < 2e-2 * scale, np.abs(got - g["dLdpsis"]).max() / scale
     # NM:191 takes the mean over patches; the patch values (+-10) cancel to ~0.6, so the bound stays relative to them
     assert np.abs(got.mean(0) - g["dLdpsis"].mean(0)).max() < 1e-2 * scale
+
+
+def test_render_path_api_and_png_side_effects(oracle, synth_nets, tmp_path):
+    """render_path (RN:213-255) through the reference-shaped API built by create_nerf from a checkpoint file:
+    shapes, numpy returns, savedir/<object_id>/%03d.png written with to8b truncation, one launch for all poses
+    equal to per-pose render(c2w=...) calls, render_factor honoured."""
+    import argparse
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd import png
+    mk = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+    ckpt = str(tmp_path / "ycbvid2.tar")
+    torch.save({"global_step": 7, "optimizer_state_dict": None, "network_fn_state_dict": mk(synth_nets[0]),
+                "network_fine_state_dict": mk(synth_nets[1])}, ckpt)
+    args = argparse.Namespace(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128,
+                              netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
+                              lrate=5e-4, basedir=str(tmp_path), expname="exp", ft_path=ckpt, no_reload=False,
+                              perturb=1.0, N_samples=64, white_bkgd=False, raw_noise_std=0.0,
+                              dataset_type="LINEMOD", no_ndc=False, lindisp=False)
+    orig = torch.optim.Adam.load_state_dict
+    torch.optim.Adam.load_state_dict = lambda self, sd: None          # the synthetic checkpoint has no optimizer state
+    try:
+        _, kw_test, start, _, _ = R.create_nerf(args)
+    finally:
+        torch.optim.Adam.load_state_dict = orig
+    assert start == 7
+    kw_test.update({"near": oracle.YCBV_NEAR, "far": oracle.YCBV_FAR})                    # NM:109-114
+    poses = torch.tensor(load_golden("g9_pose")["c2w"][:3])
+    K = oracle.scaled_K(25.0)
+    rgbs, disps = R.render_path(None, poses, [16, 16, K[0][0]], K, 512, kw_test, savedir=str(tmp_path), object_id=2)
+    assert rgbs.shape == (3, 16, 16, 3) and disps.shape == (3, 16, 16) and rgbs.dtype == np.float32
+    for i in range(3):
+        img = png.imread(str(tmp_path / "2" / ("%03d.png" % i)))
+        assert np.array_equal(img, R.to8b(rgbs[i]))
+        rgb, disp, acc, extras = R.render(16, 16, K, chunk=512, c2w=poses[i][:3, :4], **kw_test)
+        assert rgb.shape == (16, 16, 3) and set(extras) == {"rgb0", "disp0", "acc0", "z_std"}
+        assert np.array_equal(cpu(rgb), rgbs[i]) and np.array_equal(cpu(disp), disps[i], equal_nan=True)
+    g = load_golden("g7_render")                                                        # same pose/K as the 32x32 golden
+    rgbs32, _ = R.render_path(None, torch.tensor(g["c2w_b"])[None], [64, 64, 0.0], g["K32"].tolist(), 512, kw_test,
+                              savedir=None, render_factor=2)
+    assert rgbs32.shape == (1, 32, 32, 3) and oracle.psnr(rgbs32[0], g["rgb_c2"]) > 55.0

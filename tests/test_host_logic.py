@@ -195,3 +195,45 @@ def test_pose_module_matches_reference(golden):
     assert np.abs(g["poses_grad"] - g["poses_nograd"]).max() < 1e-5          # fp64-trig vs fp32-trig construction
     (gr,) = torch.autograd.grad(pg.sum(), prob)
     assert gr.shape == (8,) and torch.isfinite(gr).all()
+
+
+def test_load_data_param(oracle):
+    """LL:166-199 on the reference's own nerf_traindata_info.json (committed as a data fixture)."""
+    from neural_sim_nerf_amd.data import load_data_param
+    d = os.path.join(ROOT, "tests", "golden")
+    hwf, K, near, far = load_data_param(d, half_res=False)
+    assert hwf == [400, 400, 1333.3333740234375] and K == oracle.YCBV_K
+    assert (near, far) == (oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    hwf, K, near, far = load_data_param(d, half_res=True)                   # the config default (CF:24)
+    assert hwf == [100, 100, 1333.3333740234375 / 4] and K[:2] == oracle.scaled_K(4.0)[:2] and K[2] == [0.0, 0.0, 1.0]
+
+
+def _args(tmp_path, ckpt):
+    import argparse
+    return argparse.Namespace(multires=10, i_embed=0, use_viewdirs=True, multires_views=4, N_importance=128,
+                              netdepth=8, netwidth=256, netdepth_fine=8, netwidth_fine=256, netchunk=65536,
+                              lrate=5e-4, basedir=str(tmp_path), expname="exp", ft_path=ckpt, no_reload=False,
+                              perturb=1.0, N_samples=64, white_bkgd=False, raw_noise_std=0.0,
+                              dataset_type="LINEMOD", no_ndc=False, lindisp=False)
+
+
+def test_create_nerf_loads_reference_checkpoints(tmp_path, synth_nets):
+    """RN:258-340: a checkpoint with the reference's keys (RN:296-314) loads; the returned dicts carry the
+    reference's keys and the test kwargs are deterministic (perturb False, raw_noise_std 0)."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    mk = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
+    nets = [R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+            for _ in range(2)]
+    opt = torch.optim.Adam([p for n in nets for p in n.parameters()], lr=5e-4, betas=(0.9, 0.999))
+    ckpt = str(tmp_path / "ycbvid2.tar")
+    torch.save({"global_step": 1234, "optimizer_state_dict": opt.state_dict(),
+                "network_fn_state_dict": mk(synth_nets[0]), "network_fine_state_dict": mk(synth_nets[1])}, ckpt)
+    train, test, start, grad_vars, optimizer = R.create_nerf(_args(tmp_path, ckpt))
+    assert start == 1234 and len(grad_vars) == 2 * 24
+    assert set(train) == {"network_query_fn", "perturb", "N_importance", "network_fine", "N_samples", "network_fn",
+                          "use_viewdirs", "white_bkgd", "raw_noise_std", "ndc", "lindisp"}
+    assert test["perturb"] is False and test["raw_noise_std"] == 0. and train["perturb"] == 1.0
+    for net, sd in zip((test["network_fn"], test["network_fine"]), synth_nets):
+        got = net.state_dict()
+        assert all(np.array_equal(got[k].cpu().numpy(), sd[k]) for k in sd)
