@@ -50,8 +50,10 @@ typedef struct NsrConfig {
   int32_t device;          /* HIP device ordinal                                                   */
   int32_t n_samples;       /* must be 64                                                           */
   int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1)               */
-  int32_t max_workgroups;  /* 0 = one persistent workgroup per CU                                  */
-  int32_t reserved[3];
+  int32_t max_workgroups;  /* 0 = fill the chip (one workgroup per CU for x32, two for x16)        */
+  int32_t variant;         /* forward kernel: 0 = library default, 32 = 32 points/wave (1 workgroup per CU),
+                              16 = 16 points/wave, two workgroups per CU (needs nsr_upload_weights16)   */
+  int32_t reserved[2];
 } NsrConfig;
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
@@ -84,6 +86,9 @@ int nsr_destroy(nsr_handle h);
 /* Weight upload: `packed` is a HOST buffer of NSR_PACKED_FLOATS floats in the kernel layout
  * (pack.py).  net_id 0 = network_fn (coarse), 1 = network_fine.  Replaces the .to(device) of RN:269-278. */
 int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_floats);
+
+/* The same networks in the layout of the x16 forward kernel (pack.py: pack_network16). */
+int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n_floats);
 
 /* Transposed stream of the FINE network for the input-gradient kernel (pack.py: pack_network_backward);
  * host buffer of NSR_STREAM_SLABS*NSR_SLAB_FLOATS floats.  Needed only by nsr_render_rays_vjp. */

@@ -13,7 +13,7 @@ PACKED_FLOATS = 145 * 4096 + 3328
 
 class NsrConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_samples", C.c_int32),
-                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class NsrDebugOut(C.Structure):
@@ -33,6 +33,7 @@ SIGNATURES = {
     "nsr_create": (C.c_int, [C.POINTER(NsrConfig), C.POINTER(C.c_void_p)]),
     "nsr_destroy": (C.c_int, [C.c_void_p]),
     "nsr_upload_weights": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "nsr_upload_weights16": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
     "nsr_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,

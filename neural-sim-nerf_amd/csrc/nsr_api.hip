@@ -30,6 +30,7 @@ int fail(const std::string& m) {
   } while (0)
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
+constexpr size_t kRender16Lds = nsr::kLds16State + sizeof(nsr::ItemState16);
 constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
 
 }  // namespace
@@ -40,6 +41,8 @@ struct nsr_handle_s {
   float* d_nets = nullptr;
   float* d_packed[3] = {nullptr, nullptr, nullptr};   // views into d_nets: coarse, fine, fine transposed
   bool have_net[3] = {false, false, false};
+  float* d_nets16 = nullptr;                            // coarse | fine in the x16 layout
+  bool have_net16[2] = {false, false};
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
@@ -61,6 +64,8 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
   if (cfg->n_samples != NSR_N_SAMPLES)
     return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
+  if (cfg->variant != 0 && cfg->variant != 16 && cfg->variant != 32)
+    return fail("nsr_create: variant must be 0 (default), 16 or 32");
   if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0)
     return fail("nsr_create: unsupported N_importance (128, or 0 for coarse-only)");
   int ndev = 0;
@@ -77,6 +82,8 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
   NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
   for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
+  NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 2 * NSR_PACKED_FLOATS));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
@@ -95,6 +102,7 @@ int nsr_destroy(nsr_handle h) {
   hipSetDevice(h->cfg.device);
   hipDeviceSynchronize();
   hipFree(h->d_nets);
+  hipFree(h->d_nets16);
   hipFree(h->d_tables);
   hipFree(h->d_scratch);
   hipFree(h->d_args);
@@ -113,6 +121,17 @@ int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_f
   NSR_HIP(hipSetDevice(h->cfg.device));
   NSR_HIP(hipMemcpy(h->d_packed[net_id], packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   h->have_net[net_id] = true;
+  return 0;
+}
+
+int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n_floats) {
+  if (!h || !packed) return fail("nsr_upload_weights16: null argument");
+  if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights16: net_id must be 0 (coarse) or 1 (fine)");
+  if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights16: wrong packed size");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_HIP(hipMemcpy(h->d_nets16 + (size_t)net_id * NSR_PACKED_FLOATS, packed, sizeof(float) * n_floats,
+                    hipMemcpyHostToDevice));
+  h->have_net16[net_id] = true;
   return 0;
 }
 
@@ -149,17 +168,23 @@ static int grid_for(nsr_handle h, long long n_items) {
   return (int)(g < 1 ? 1 : g);
 }
 
+static bool use_x16(nsr_handle h) { return h->cfg.variant == 16; }
+
 static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* out, const NsrDebugOut* dbg,
                          void* stream) {
   const bool fine = h->cfg.n_importance > 0;
+  const bool x16 = use_x16(h);
   if (int e = check_ready(h, fine)) return e;
+  if (x16 && (!h->have_net16[0] || (fine && !h->have_net16[1])))
+    return fail("variant 16 needs nsr_upload_weights16 for every network");
   if (!out || !out->d_rgb || !out->d_disp || !out->d_acc) return fail("render: rgb/disp/acc outputs are required");
   if (a.n_rays <= 0) return 0;
   NSR_HIP(hipSetDevice(h->cfg.device));
-  a.nets = h->d_nets;
+  float* nets = x16 ? h->d_nets16 : h->d_nets;
+  a.nets = nets;
   a.net_stride = (long long)sizeof(float) * NSR_PACKED_FLOATS;
-  a.aux[0] = h->d_packed[0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
-  a.aux[1] = h->d_packed[fine ? 1 : 0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.aux[0] = nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.aux[1] = nets + (fine ? (size_t)NSR_PACKED_FLOATS : 0) + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = fine ? 1 : 0;
@@ -171,12 +196,18 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   a.dbg_raw0 = dbg ? dbg->d_raw0 : nullptr;
   a.dbg_raw = dbg ? dbg->d_raw : nullptr;
   a.dbg_inds = dbg ? (long long*)dbg->d_inds : nullptr;
-  const long long n_items = (a.n_rays + 1) / 2;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);
   NSR_HIP(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(nsr::k_render, dim3(grid_for(h, n_items)), dim3(256), kRenderLds, s,
-                     (const nsr::RenderArgs*)h->d_args);
+  if (x16) {
+    long long g = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;   // two workgroups per CU
+    if (g > a.n_rays) g = a.n_rays;
+    hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
+  } else {
+    const long long n_items = (a.n_rays + 1) / 2;
+    hipLaunchKernelGGL(nsr::k_render, dim3(grid_for(h, n_items)), dim3(256), kRenderLds, s,
+                       (const nsr::RenderArgs*)h->d_args);
+  }
   NSR_HIP(hipGetLastError());
   NSR_HIP(hipEventRecord(h->ev1, s));
   h->timed = true;

@@ -56,6 +56,7 @@ __device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base
   rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
 
+template <int NS = kRingSlots>
 __device__ __forceinline__ void ring_issue(Ring& rg) {
   char* l = rg.smem + rg.pslot * kSlabBytes + rg.wave_lds;
 #ifndef NSR_EXP_NODMA        // (NODMA: timing experiment only)
@@ -69,7 +70,7 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   NSR_BUFDMA(0); NSR_BUFDMA(1); NSR_BUFDMA(2); NSR_BUFDMA(3);
 #undef NSR_BUFDMA
 #endif
-  rg.pslot = (rg.pslot + 1 == kRingSlots) ? 0 : rg.pslot + 1;
+  rg.pslot = (rg.pslot + 1 == NS) ? 0 : rg.pslot + 1;
   // branch-free advance (scalar selects only): a branch here would split the basic block and stop the scheduler
   // from interleaving the DMA issue with the MFMAs around it
   const int nslab = rg.pslab + 1;
@@ -83,10 +84,11 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
 
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
 // A step = 4 chunks of 1 KiB = 4 float4 fragments per lane = 16 MFMAs; a slab = 4 steps.
+template <int NS = kRingSlots>
 __device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[4], int lane) {
 #pragma unroll 1
-  for (int s = 0; s < kRingSlots; ++s) ring_issue(rg);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (kRingSlots - 1)) : "memory");
+  for (int s = 0; s < NS; ++s) ring_issue<NS>(rg);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
 #pragma unroll
@@ -104,12 +106,13 @@ __device__ __forceinline__ void ring_load_quarter(const Ring& rg, f32x4 (&A)[4],
 // Last step of a slab: all of this wave's reads of the current slab are complete after lgkmcnt(0); my share of
 // the next slab has landed after the counted vmcnt; the barrier makes both true for the whole workgroup, so the
 // slot of the current slab can be refilled (slab n+NS) and the next slab's first quarter can be read.
+template <int NS = kRingSlots>
 __device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[4], int lane) {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (kRingSlots - 2)) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * (NS - 2)) : "memory");
 #ifndef NSR_EXP_NOBARRIER   // timing experiment only (results are wrong without the barrier)
   __builtin_amdgcn_s_barrier();
 #endif
-  rg.cslot = (rg.cslot + 1 == kRingSlots) ? 0 : rg.cslot + 1;
+  rg.cslot = (rg.cslot + 1 == NS) ? 0 : rg.cslot + 1;
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
 #pragma unroll
   for (int c = 0; c < 4; ++c) A[c] = *(const f32x4*)(p + c * 1024);
@@ -122,15 +125,19 @@ __device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[4], int lane) 
 // every index is a compile-time constant after unrolling.
 // ------------------------------------------------------------------------------------------------------
 #define NSR_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// one name for both fp32 MFMA shapes: 32x32x2 (16 accumulator registers, 32 points per wave) and 16x16x4 (4 registers,
+// 16 points per wave); exact fp32 products, fmaf-chain accumulate, 64 FLOP/clk/SIMD either way
+__device__ __forceinline__ f32x16 mfma_op(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma_op(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <int NMO, int KK0, int KK1, int NACC, typename BOp>
-__device__ __forceinline__ void consume(const f32x4 (&A)[4], int step, BOp bop, f32x16 (&acc)[NACC]) {
+template <int NMO, int KK0, int KK1, int NACC, typename BOp, typename AccT>
+__device__ __forceinline__ void consume(const f32x4 (&A)[4], int step, BOp bop, AccT (&acc)[NACC]) {
 #pragma unroll
   for (int kk = KK0; kk < KK1; ++kk)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int n = 4 * step + c, tq = n / NMO, mo = n % NMO;
-      acc[mo] = NSR_MFMA(A[c][kk], bop(4 * tq + kk), acc[mo]);
+      acc[mo] = mfma_op(A[c][kk], bop(4 * tq + kk), acc[mo]);
     }
 }
 
@@ -173,8 +180,8 @@ __device__ __forceinline__ void step_pattern_dma() {
   }
 }
 
-template <int NMO, int NTQ, int NACC, typename BOp>
-__device__ __forceinline__ void seg(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], BOp bop, f32x16 (&acc)[NACC],
+template <int NMO, int NTQ, int NS = kRingSlots, int NACC, typename BOp, typename AccT>
+__device__ __forceinline__ void seg(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], BOp bop, AccT (&acc)[NACC],
                                     int lane) {
   static_assert((NMO * NTQ) % 16 == 0, "a segment is a whole number of slabs");
 #pragma unroll
@@ -183,8 +190,8 @@ __device__ __forceinline__ void seg(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], BO
     NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<NMO, 0, 4>(A1, s + 1, bop, acc); step_pattern<16>();
     NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<NMO, 0, 4>(A0, s + 2, bop, acc); step_pattern<16>();
     NSR_PIN(); consume<NMO, 0, 1>(A1, s + 3, bop, acc);
-    NSR_PIN(); ring_advance(rg, A0, lane);          // counted wait + s_barrier, then the next slab's first loads
-    ring_issue(rg); consume<NMO, 1, 4>(A1, s + 3, bop, acc); step_pattern_dma<12>();
+    NSR_PIN(); ring_advance<NS>(rg, A0, lane);      // counted wait + s_barrier, then the next slab's first loads
+    ring_issue<NS>(rg); consume<NMO, 1, 4>(A1, s + 3, bop, acc); step_pattern_dma<12>();
     NSR_PIN();
   }
 }
@@ -355,7 +362,8 @@ struct ItemState {
   float alpha[2][192];      // compositing scratch
   float wf[2][192];         // fine weights           RN:485
   float tf[2][192];         // transmittance T_i (RN:376)
-  double om[2][192];        // 1 - alpha + 1e-10 widened to fp64 for the sequential scan
+  float om[2][192];         // 1 - alpha + 1e-10 (RN:376) / pdf (RH:202): fp32 values, widened to fp64 inside the scans
+  float bwd_scratch[2][192][2];   // backward compositing: A_i*w_i suffix sums and A_i*T_i
   float psum[2][6][12];     // backward: per (pass, wave) partial sums of d/dpts, z*d/dpts, d/dviewdir
   float gnorm[2];           // backward: dL/d|rays_d| from dists*|d| (RN:361)
   float res[2][8];          // rgb(3) disp acc depth
@@ -369,11 +377,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // inherently serial part: torch-CPU cumprod is a sequential fp64 product with every prefix rounded to fp32
 // (RN:376), one lane per ray, 8 factors per LDS round trip; (3) weights and the five weighted sums, one wave per
 // ray (lane l owns samples l, l+64, l+128), xor-shuffle tree.
-template <int S>
-__device__ __forceinline__ void composite(ItemState& st, const float* z, float* raw, float* wout, float* tout,
-                                          int tid) {
+template <int S, int R = 2, typename ST>
+__device__ __forceinline__ void composite(ST& st, const float* z, float* raw, float* wout, float* tout, int tid) {
   static_assert(S % 8 == 0, "scan is unrolled by 8");
-  for (int idx = tid; idx < 2 * S; idx += 256) {
+  for (int idx = tid; idx < R * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
     const float* zr = z + r * S;
     float dist = (i < S - 1) ? (zr[i + 1] - zr[i]) : 1e10f;   // RN:358-359
@@ -382,20 +389,20 @@ __device__ __forceinline__ void composite(ItemState& st, const float* z, float* 
     const float sigma = fmaxf(q[3], 0.0f);
     const float a = 1.0f - expf(-sigma * dist);                // RN:356
     st.alpha[r][i] = a;
-    st.om[r][i] = (double)((1.0f - a) + 1e-10f);               // RN:376 factor, widened for the fp64 scan
+    st.om[r][i] = (1.0f - a) + 1e-10f;                         // RN:376 factor (widened to fp64 in the scan)
     q[0] = sigmoidf_(q[0]);                                    // RN:363
     q[1] = sigmoidf_(q[1]);
     q[2] = sigmoidf_(q[2]);
   }
   __syncthreads();
-  if ((tid & 63) == 0 && tid < 128) {
+  if ((tid & 63) == 0 && tid < 64 * R) {
     const int r = tid >> 6;
     double T = 1.0;
 #pragma unroll 1
     for (int i0 = 0; i0 < S; i0 += 8) {
       double f[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = st.om[r][i0 + k];
+      for (int k = 0; k < 8; ++k) f[k] = (double)st.om[r][i0 + k];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         tout[r * S + i0 + k] = (float)T;                       // exclusive product, rounded per prefix
@@ -404,7 +411,7 @@ __device__ __forceinline__ void composite(ItemState& st, const float* z, float* 
     }
   }
   __syncthreads();
-  if (tid < 128) {
+  if (tid < 64 * R) {
     const int r = tid >> 6, l = tid & 63;
     const float* zr = z + r * S;
     const float* q = raw + r * S * 4;
@@ -438,17 +445,18 @@ __device__ __forceinline__ void composite(ItemState& st, const float* z, float* 
 
 // sample_pdf RH:199-243 (det=True) for both rays: weights w[r][0..61] (= coarse weights[1:-1]), bins = mid-points.
 // Writes st.cdf, st.zs; optional inds.  `bins` is a callable: bins(r, k), k in 0..62.
-template <typename BinsFn>
-__device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*[2][stride]*/, int wstride,
-                                                BinsFn bins, int64_t* inds_out /*[2][128] or null*/,
-                                                int64_t inds_stride, int tid, int valid_rays) {
+template <int R = 2, typename ST, typename BinsFn>
+__device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[128], LDS or global*/,
+                                                const float* w /*[R][stride]*/, int wstride, BinsFn bins,
+                                                int64_t* inds_out /*[R][128] or null*/, int64_t inds_stride, int tid,
+                                                int valid_rays) {
   // (1) x = w + 1e-5 and the 8 vector-lane partial sums of ATen's cascade, 8 lanes per ray
-  if (tid < 128 && (tid & 63) < 62) {
+  if (tid < 64 * R && (tid & 63) < 62) {
     const int r = tid >> 6, i = tid & 63;
     st.alpha[r][i] = (w + r * wstride)[i] + 1e-5f;              // RH:201 (alpha[] is free scratch here)
   }
   __syncthreads();
-  if ((tid & 63) == 0 && tid < 128) {
+  if ((tid & 63) == 0 && tid < 64 * R) {
     const int r = tid >> 6;
     const float* x = st.alpha[r];
     // torch.sum over 62 contiguous floats: ATen's 8-lane x 4-ILP cascade (RH:202), exact association order
@@ -466,12 +474,12 @@ __device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*
     st.res[r][7] = total;
   }
   __syncthreads();
-  if (tid < 128 && (tid & 63) < 62) {
+  if (tid < 64 * R && (tid & 63) < 62) {
     const int r = tid >> 6, i = tid & 63;
-    st.om[r][i] = (double)(st.alpha[r][i] / st.res[r][7]);     // pdf, widened (RH:202)
+    st.om[r][i] = st.alpha[r][i] / st.res[r][7];               // pdf (RH:202), widened to fp64 in the scan
   }
   __syncthreads();
-  if ((tid & 63) == 0 && tid < 128) {
+  if ((tid & 63) == 0 && tid < 64 * R) {
     const int r = tid >> 6;
     // cdf = [0, cumsum(pdf)]: sequential fp64 accumulator, each prefix rounded to fp32 (RH:203-204)
     double run = 0.0;
@@ -480,17 +488,17 @@ __device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*
     for (int i0 = 0; i0 < 56; i0 += 8) {
       double f[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = st.om[r][i0 + k];
+      for (int k = 0; k < 8; ++k) f[k] = (double)st.om[r][i0 + k];
 #pragma unroll
       for (int k = 0; k < 8; ++k) { run = run + f[k]; st.cdf[r][i0 + k + 1] = (float)run; }
     }
 #pragma unroll
-    for (int i = 56; i < 62; ++i) { run = run + st.om[r][i]; st.cdf[r][i + 1] = (float)run; }
+    for (int i = 56; i < 62; ++i) { run = run + (double)st.om[r][i]; st.cdf[r][i + 1] = (float)run; }
   }
   __syncthreads();
-  {
+  if (tid < 128 * R) {
     const int r = tid >> 7, k = tid & 127;
-    const float u = st.ufine[k];
+    const float u = ufine[k];
     const float* cdf = st.cdf[r];
     // searchsorted(cdf, u, right=True): number of entries <= u among 63 (RH:227)
     int lo = 0, hi = 63;
@@ -513,7 +521,8 @@ __device__ __forceinline__ void sample_pdf_item(ItemState& st, const float* w /*
 }
 
 // std(z_samples, unbiased=False) RN:495, fp64 two-pass; result valid in lane 0 of waves 0 / 1 (ray = wave).
-__device__ __forceinline__ float zstd_wave(const ItemState& st, int r, int lane) {
+template <typename ST>
+__device__ __forceinline__ float zstd_wave(const ST& st, int r, int lane) {
   double s = (double)st.zs[r][lane] + (double)st.zs[r][lane + 64];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += shfl_xor_f64(s, m);
@@ -528,8 +537,9 @@ __device__ __forceinline__ float zstd_wave(const ItemState& st, int r, int lane)
 // z_vals = sort(cat([z_coarse, z_samples])) RN:477 by exact, stable rank counting: no sortedness assumption about
 // z_samples (adjacent inverse-CDF bins can produce 1-ulp inversions).  Measured cost 0.7 % of a render; float4 /
 // 64-bit-key variants were within noise (interleaved A/B on one box), so the plain form stays.
-__device__ __forceinline__ void merge_sort_item(ItemState& st, int tid) {
-  for (int e = tid; e < 384; e += 256) {
+template <int R = 2, typename ST>
+__device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
+  for (int e = tid; e < 192 * R; e += 256) {
     const int r = e / 192, k = e - r * 192;
     const float x = (k < 64) ? st.zc[r][k] : st.zs[r][k - 64];
     int rank = 0;
@@ -720,7 +730,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
 #else
       int64_t* inds = (int64_t*)a.dbg_inds;
 #endif
-      sample_pdf_item(st, &st.w0[0][1], 64,
+      sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
                       inds ? inds + ray0 * 128 : nullptr, 128, tid, valid);
       NSR_T(3);
@@ -890,8 +900,8 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
 // Only the suffix sum is serial (one lane per ray, fp32, 8 terms per LDS round trip).
 __device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /* [2][3] in LDS */, int tid) {
   constexpr int S = 192;
-  float* aw = (float*)&st.om[0][0];   // [2][S] A_i * w_i, then the exclusive suffix sums
-  float* at = aw + 2 * S;             // [2][S] A_i * T_i
+  float* aw = &st.bwd_scratch[0][0][0];   // [2][S] A_i * w_i, then the exclusive suffix sums
+  float* at = aw + 2 * S;                 // [2][S] A_i * T_i
   for (int idx = tid; idx < 2 * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
     const float* q = st.rawf[r][i];
@@ -1057,7 +1067,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       __syncthreads();
       composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
       int64_t* none = nullptr;
-      sample_pdf_item(st, &st.w0[0][1], 64,
+      sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid);
       merge_sort_item(st, tid);
       pass = 1;
@@ -1146,6 +1156,261 @@ __global__ void __launch_bounds__(256) k_pose_grad(const float* __restrict__ go,
   if (threadIdx.x < 12) out[blockIdx.x * 12 + threadIdx.x] = (float)red[0][threadIdx.x];
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// x16 variant of the forward kernel: v_mfma_f32_16x16x4_f32, 16 points per wave, 64 per workgroup, registers
+// <= 256 per lane so that TWO workgroups share a CU (two waves per SIMD).  Each workgroup still runs its four
+// waves in lock-step on its own 3-slab weight ring, but the two workgroups of a CU drift against each other, so
+// one's VALU-only stretches (encoding, layer epilogues, heads, compositing, resampling) run in the shadow of the
+// other's MFMAs.  Work item = ONE ray: a coarse pass (64 points) + 3 fine passes.  Weight layout: pack_network16
+// (no K permutation: register (block mo, r) of lane group g holds feature 16*mo + 4*g + r, which is what k-step
+// 4*mo + r reads in group g; biases and heads in natural order).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRing16 = 3;
+constexpr int kAux16Floats = 3080;                                     // 3076 used, 16-byte multiple
+constexpr int kLds16Aux = kRing16 * kSlabBytes;                        // 49152
+constexpr int kLds16State = kLds16Aux + 2 * kAux16Floats * 4;          // 73792
+
+struct ItemState16 {            // one ray; 7520 bytes
+  float ray[1][16];
+  float zc[1][64];
+  float w0[1][64];
+  float cdf[1][64];
+  float zs[1][128];
+  float zf[1][192];
+  float rawf[1][192][4];        // the coarse pass uses the first 64 entries
+  float alpha[1][192];
+  float om[1][192];
+  float tf[1][192];
+  float res[1][8];
+};
+static_assert(kLds16State + sizeof(ItemState16) <= 81920, "two workgroups must fit in the 160 KiB LDS of a CU");
+
+template <int NG>
+struct BRegs4 {    // previous layer's C fragment (16x16x4): k-step t <-> register (t>>2, t&3)
+  const f32x4 (&v)[NG];
+  __device__ __forceinline__ float operator()(int t) const { return v[t >> 2][t & 3]; }
+};
+struct BViews4 {   // cat([feature, input_views]) (RH:111): 64 k-steps of registers, then 8 of direction encoding
+  const f32x4 (&v)[16];
+  const float (&ed)[8];
+  __device__ __forceinline__ float operator()(int t) const { return t < 64 ? v[(t & 63) >> 2][t & 3] : ed[t & 7]; }
+};
+
+__device__ __forceinline__ f32x4 clamp_bits4(f32x4 x, int thr) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 b = __builtin_bit_cast(i32x4, x);
+  i32x4 t = thr;
+  b = __builtin_elementwise_max(b, t);
+  return __builtin_bit_cast(f32x4, b);
+}
+
+// One network pass for this lane's point: lane (j = lane&15, g = lane>>4), the four lanes of a point hold
+// complementary quarters of every feature vector.  Embedder RH:18-48, NeRF.forward RH:99-122.
+__device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
+                                           float px, float py, float pz, float vx, float vy, float vz,
+                                           float (&raw)[4]) {
+  const int g = lane >> 4;
+  float e[16];   // 60 sin/cos columns dealt 15 per lane group (reference order), then the identity column g
+  float ed[8];   // directions: group g holds frequency 2^g (sin xyz, cos xyz), then the identity column g
+  {
+    const float p[3] = {px, py, pz};
+#pragma unroll
+    for (int t = 0; t < 15; ++t) {
+      const int q = 15 * g + t, L = q / 6, sc = (q % 6) / 3, ax = q % 3;
+      const float x = ax == 0 ? p[0] : (ax == 1 ? p[1] : p[2]);
+      float s, c;
+      sincosf(ldexpf(x, L), &s, &c);
+      e[t] = sc ? c : s;
+    }
+    e[15] = g == 0 ? px : (g == 1 ? py : (g == 2 ? pz : 0.0f));
+    const float v[3] = {vx, vy, vz};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      float s, c;
+      sincosf(ldexpf(v[t % 3], g), &s, &c);
+      ed[t] = (t >= 3) ? c : s;
+    }
+    ed[6] = g == 0 ? vx : (g == 1 ? vy : (g == 2 ? vz : 0.0f));
+    ed[7] = 0.0f;
+  }
+
+  f32x4 acc[16], in[16];
+  const float* bias_g = aux + kAuxBias + 4 * g;
+  auto load_bias16 = [&](const float* b) {
+#pragma unroll
+    for (int mo = 0; mo < 16; ++mo) acc[mo] = *(const f32x4*)(b + 16 * mo);
+  };
+  load_bias16(bias_g);
+  seg<16, 4, kRing16>(rg, A0, A1, BArr<16>{e}, acc, lane);
+#pragma unroll
+  for (int mo = 0; mo < 16; ++mo) in[mo] = clamp_bits4(acc[mo], 0);
+
+  float alpha_part = 0.0f;
+#pragma unroll 1
+  for (int L = 1; L <= 8; ++L) {
+    load_bias16(bias_g + L * 256);
+    if (L == 5) seg<16, 4, kRing16>(rg, A0, A1, BArr<16>{e}, acc, lane);   // skip columns first (RH:105)
+    if (L == 8) {                                                           // alpha_linear on h7 (RH:109)
+      const float* wa = aux + kAuxWAlpha + 4 * g;
+#pragma unroll
+      for (int mo = 0; mo < 16; ++mo) {
+        const f32x4 w = *(const f32x4*)(wa + 16 * mo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) alpha_part = __builtin_fmaf(w[r], in[mo][r], alpha_part);
+      }
+    }
+    seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
+    const int thr = (L == 8) ? (int)0x80000000 : 0;                         // feature_linear has no activation
+#pragma unroll
+    for (int mo = 0; mo < 16; ++mo) in[mo] = clamp_bits4(acc[mo], thr);
+  }
+
+  f32x4 av[8];                                                              // views_linears.0 (RH:111-115)
+#pragma unroll
+  for (int mo = 0; mo < 8; ++mo) av[mo] = *(const f32x4*)(aux + kAuxBiasV + 4 * g + 16 * mo);
+  seg<8, 18, kRing16>(rg, A0, A1, BViews4{in, ed}, av, lane);
+
+  float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};                           // rgb_linear (RH:117)
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) {
+      const f32x4 w = *(const f32x4*)(aux + kAuxWRgb + c * 128 + 4 * g + 16 * mo);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[c] = __builtin_fmaf(w[r], fmaxf(av[mo][r], 0.0f), part[c]);
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float x = part[c];
+    x = x + __shfl_xor(x, 16);
+    x = x + __shfl_xor(x, 32);
+    raw[c] = x + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha];
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RenderArgs& a = *ap;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15;
+  ItemState16& st = *(ItemState16*)(smem + kLds16State);
+
+  const long long n_items = a.n_rays;
+  if ((long long)blockIdx.x >= n_items) return;
+  const int fine = a.fine;
+
+  Ring rg;
+  ring_init(rg, smem, a.nets, a.net_stride, fine ? 4 : 1, wave, lane);
+  f32x4 A0[4], A1[4];
+  ring_start<kRing16>(rg, A0, lane);
+  {
+    float* dst = (float*)(smem + kLds16Aux);
+    for (int i = tid; i < kAux16Floats; i += 256) {
+      dst[i] = a.aux[0][i];
+      dst[kAux16Floats + i] = a.aux[1][i];
+    }
+  }
+  __syncthreads();
+  const float* aux_c = (const float*)(smem + kLds16Aux);
+
+  long long item = blockIdx.x;
+  int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current ray
+#pragma unroll 1
+  while (item < n_items) {
+    const long long rr = item;
+    if (pass == 0) {
+      const float near_ = a.near_, far_ = a.far_;
+      if (tid == 0) {
+        float o[3], d[3];
+        if (a.camera) {
+          const long long hw = (long long)a.H * a.W;
+          const long long v = rr / hw;
+          const int pix = (int)(rr - v * hw);
+          gen_ray(a.c2w + v * 12, a.fx, a.fy, a.cx, a.cy, pix / a.W, pix % a.W, o, d);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
+        }
+        const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));   // torch.norm RN:97, RN:361
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { st.ray[0][c] = o[c]; st.ray[0][3 + c] = d[c]; st.ray[0][6 + c] = d[c] / nrm; }
+        st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
+      }
+      if (tid < 64) {
+        const float t = a.tcoarse[tid];
+        st.zc[0][tid] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
+      }
+      __syncthreads();
+    }
+
+    // one network pass: 64 points; coarse: sample 16w + j; fine p: sample 64(p-1) + 16w + j
+    {
+      const int i = (pass == 0 ? 0 : 64 * (pass - 1)) + 16 * wave + j;
+      const float z = (pass == 0) ? st.zc[0][i] : st.zf[0][i];
+      const float* ry = st.ray[0];
+      float raw[4];
+      mlp_pass16(rg, aux_c + (pass == 0 ? 0 : kAux16Floats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+                 ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
+      if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    }
+
+    if (pass == 0) {
+      __syncthreads();
+      if (a.dbg_raw0) {
+        for (int idx = tid; idx < 256; idx += 256) a.dbg_raw0[rr * 256 + idx] = (&st.rawf[0][0][0])[idx];
+        __syncthreads();
+      }
+      composite<64, 1>(st, &st.zc[0][0], &st.rawf[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
+      if (tid < 8) {
+        const int c = tid;
+        const float v = st.res[0][c];
+        float* rgb_dst = fine ? a.rgb0 : a.rgb;
+        float* disp_dst = fine ? a.disp0 : a.disp;
+        float* acc_dst = fine ? a.acc0 : a.acc;
+        if (c < 3) { if (rgb_dst) rgb_dst[rr * 3 + c] = v; }
+        else if (c == 3) { if (disp_dst) disp_dst[rr] = v; }
+        else if (c == 4) { if (acc_dst) acc_dst[rr] = v; }
+      }
+      if (a.dbg_w0 && tid < 64) a.dbg_w0[rr * 64 + tid] = st.w0[0][tid];
+      if (!fine) { __syncthreads(); item += gridDim.x; continue; }
+      int64_t* inds = (int64_t*)a.dbg_inds;
+      sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
+                         [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
+                         inds ? inds + rr * 128 : nullptr, 128, tid, 1);
+      if (wave == 0) {
+        const float sd = zstd_wave(st, 0, lane);
+        if (lane == 0 && a.z_std) a.z_std[rr] = sd;
+      }
+      if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
+      merge_sort_item<1>(st, tid);
+      if (a.dbg_zf && tid < 192) a.dbg_zf[rr * 192 + tid] = st.zf[0][tid];
+      pass = 1;
+    } else if (pass < 3) {
+      ++pass;
+    } else {
+      __syncthreads();
+      if (a.dbg_raw) {
+        for (int idx = tid; idx < 768; idx += 256) a.dbg_raw[rr * 768 + idx] = (&st.rawf[0][0][0])[idx];
+        __syncthreads();
+      }
+      composite<192, 1>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.alpha[0][0], &st.tf[0][0], tid);
+      if (tid < 8) {
+        const int c = tid;
+        const float v = st.res[0][c];
+        if (c < 3) { if (a.rgb) a.rgb[rr * 3 + c] = v; }
+        else if (c == 3) { if (a.disp) a.disp[rr] = v; }
+        else if (c == 4) { if (a.acc) a.acc[rr] = v; }
+      }
+      __syncthreads();
+      pass = 0;
+      item += gridDim.x;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Diagnostic micro-kernels (nsr_probe): the layer GEMM in isolation, to attribute MFMA-rate losses.
@@ -1330,7 +1595,7 @@ __global__ void __launch_bounds__(256) k_sample_pdf(PdfArgs a) {
       wbuf[r * 64 + i] = (i < 62) ? a.weights[rr * 62 + i] : 0.0f;
     }
     __syncthreads();
-    sample_pdf_item(st, wbuf, 64, [&](int r, int k) { return binbuf[r * 64 + k]; },
+    sample_pdf_item(st, st.ufine, wbuf, 64, [&](int r, int k) { return binbuf[r * 64 + k]; },
                     a.inds ? (int64_t*)a.inds + ray0 * 128 : nullptr, 128, tid, valid);
     for (int idx = tid; idx < valid * 128; idx += 256) a.samples[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
     __syncthreads();

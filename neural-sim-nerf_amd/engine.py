@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .pack import pack_network, pack_network_backward, PACKED_FLOATS
+from .pack import pack_network, pack_network16, pack_network_backward, PACKED_FLOATS
 
 N_SAMPLES = 64
 N_IMPORTANCE = 128
@@ -35,7 +35,7 @@ def _stream_ptr(device):
 
 
 class NsrModel:
-    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0):
+    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0):
         """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu)."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
@@ -47,7 +47,10 @@ class NsrModel:
         if n_importance > 0 and sd_fine is None:
             sd_fine = sd_coarse          # RN:482: run_fn = network_fn if network_fine is None
         self.n_importance = n_importance
-        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups)
+        if variant not in (0, 16, 32):
+            raise NotImplementedError("variant must be 0 (library default), 16 or 32")
+        self.variant = variant
+        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant)
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -58,14 +61,21 @@ class NsrModel:
     def upload(self, sd_coarse, sd_fine=None):
         to_np = lambda sd: {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
                             for k, v in sd.items()}
-        p = pack_network(to_np(sd_coarse))
+        sd_c = to_np(sd_coarse)
+        p = pack_network(sd_c)
         _lib.check(self.lib.nsr_upload_weights(self.h, 0, _fptr(p), PACKED_FLOATS))
+        if self.variant == 16:
+            p = pack_network16(sd_c)
+            _lib.check(self.lib.nsr_upload_weights16(self.h, 0, _fptr(p), PACKED_FLOATS))
         self._sd_fine_np = None
         self._bwd_ready = False
         if sd_fine is not None:
             self._sd_fine_np = to_np(sd_fine)
             p = pack_network(self._sd_fine_np)
             _lib.check(self.lib.nsr_upload_weights(self.h, 1, _fptr(p), PACKED_FLOATS))
+            if self.variant == 16:
+                p = pack_network16(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights16(self.h, 1, _fptr(p), PACKED_FLOATS))
 
     def close(self):
         if getattr(self, "h", None):

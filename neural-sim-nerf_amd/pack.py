@@ -190,3 +190,76 @@ def pack_network_backward(sd):
     stream = np.concatenate([x.reshape(-1) for x in segs]).astype(np.float32)
     assert stream.size == STREAM_SLABS * SLAB_FLOATS
     return stream
+
+
+# ----------------------------------------------------------------------------------------------------------
+# "x16" forward layout: v_mfma_f32_16x16x4_f32, 16 points per wave, TWO workgroups per CU (k_render16)
+# ----------------------------------------------------------------------------------------------------------
+# One MFMA consumes, per lane l, A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; its C/D fragment holds, in
+# register r of lane l, output row 4*(l>>4) + r of column l&15.  With the weights as A and 16-row output blocks,
+# register (block mo, r) of lane group g = l>>4 holds feature 16*mo + 4*g + r -- which is also the feature k-step
+# t = 4*mo + r reads in group g.  The K permutation of the 32x32 layout disappears: kappa16(t, g) = 16*(t>>2) + 4g +
+# (t&3), biases and head weights stay in natural order.  A chunk is [64 lanes][4 k-steps] for one 16-row block; a
+# 256-wide layer is 16 k-quads x 16 blocks = 256 chunks = 16 slabs, the stream is 145 slabs as before.
+def kappa16(t, g):
+    t = np.asarray(t)
+    return 16 * (t >> 2) + 4 * g + (t & 3)
+
+
+def eps16(t, g, n_freq):
+    """Reference embedding column held in encoding register t of lane group g (-1 = padding).  The 6*n_freq
+    sin/cos columns (reference order, after the 3 identity columns) are dealt 6*n_freq/4 per group; the next
+    register holds the identity column g (x, y, z, pad)."""
+    per_group = 6 * n_freq // 4
+    if t < per_group:
+        return 3 + per_group * g + t
+    if t == per_group:
+        return g if g < 3 else -1
+    return -1
+
+
+def _pack16(W, cols, n_mo):
+    """W [16*n_mo, K]; cols [n_ksteps, 4 groups] -> [n_ksteps/4, n_mo, 64, 4]."""
+    n_k = cols.shape[0]
+    assert W.shape[0] == 16 * n_mo and n_k % 4 == 0
+    Wp = np.concatenate([W, np.zeros((W.shape[0], 1), W.dtype)], 1)
+    lane = np.arange(64)
+    i, g = lane & 15, lane >> 4
+    out = np.empty((n_k // 4, n_mo, 64, 4), np.float32)
+    for tq in range(n_k // 4):
+        for kk in range(4):
+            c = cols[4 * tq + kk][g]
+            for mo in range(n_mo):
+                out[tq, mo, :, kk] = Wp[16 * mo + i, c]
+    return out
+
+
+def pack_network16(sd):
+    """Forward stream + natural-order aux block for k_render16.  float32 [PACKED_FLOATS]."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    t = np.arange(64)
+    cols_main = np.stack([kappa16(t, gg) for gg in range(4)], 1)                              # [64,4]
+    cols_enc = np.array([[eps16(tt, gg, 10) for gg in range(4)] for tt in range(16)])
+    cols_dir = np.array([[eps16(tt, gg, 4) for gg in range(4)] for tt in range(8)])
+    segs = [_pack16(g("pts_linears.0.weight"), cols_enc, 16)]
+    for i in range(1, 8):
+        W = g("pts_linears.%d.weight" % i)
+        if i == 5:
+            segs.append(_pack16(W[:, :63], cols_enc, 16))
+            W = W[:, 63:]
+        segs.append(_pack16(W, cols_main, 16))
+    segs.append(_pack16(g("feature_linear.weight"), cols_main, 16))
+    cols_views = np.concatenate([cols_main, np.where(cols_dir >= 0, cols_dir + 256, -1)], 0)   # [72,4]
+    segs.append(_pack16(g("views_linears.0.weight"), cols_views, 8))
+    stream = np.concatenate([x.reshape(-1) for x in segs])
+    assert stream.size == STREAM_SLABS * SLAB_FLOATS
+    aux = np.zeros(AUX_FLOATS, np.float32)
+    for L in range(8):
+        aux[AUX_BIAS + L * 256:AUX_BIAS + (L + 1) * 256] = g("pts_linears.%d.bias" % L)
+    aux[AUX_BIAS + 8 * 256:AUX_BIAS + 9 * 256] = g("feature_linear.bias")
+    aux[AUX_BIAS_V:AUX_BIAS_V + 128] = g("views_linears.0.bias")
+    aux[AUX_W_ALPHA:AUX_W_ALPHA + 256] = g("alpha_linear.weight")[0]
+    aux[AUX_W_RGB:AUX_W_RGB + 384] = g("rgb_linear.weight").reshape(-1)
+    aux[AUX_B_ALPHA] = g("alpha_linear.bias")[0]
+    aux[AUX_B_RGB:AUX_B_RGB + 3] = g("rgb_linear.bias")
+    return np.concatenate([stream, aux]).astype(np.float32)

@@ -167,3 +167,87 @@ def mlp_bwd_pass(packed_fwd, stream_bwd, masks, pts, dirs, g_raw):
     assert st.pos == 145 * 16
     dp = _embed_bwd(P, [genc[t >> 4][:, t & 15] for t in range(32)], 10)
     return dp, dv
+
+
+# ----------------------------------------------------------------------------------------------------------
+# x16 variant: v_mfma_f32_16x16x4_f32, 16 points per wave (csrc mlp_pass16)
+#   A[i][k] = a[lane = i + 16k], B[k][j] = b[lane = j + 16k], D[4*(lane>>4) + r][lane&15] = acc[lane][r]
+# ----------------------------------------------------------------------------------------------------------
+ROW16 = 4 * (LANE >> 4)[:, None] + np.arange(4)[None, :]          # [64,4]
+COL16 = (LANE & 15)[:, None].repeat(4, 1)
+
+
+def mfma16(a, b, acc):
+    A = a.reshape(4, 16).T            # [i, k]
+    B = b.reshape(4, 16)              # [k, j]
+    D = A.astype(np.float64) @ B.astype(np.float64)
+    return acc + D[ROW16, COL16].astype(np.float32)
+
+
+class Stream16(Stream):
+    def seg(self, nmo, ntq, bop, acc):
+        for n in range(nmo * ntq):
+            frag = self.chunks[self.pos]
+            self.pos += 1
+            tq, mo = divmod(n, nmo)
+            for kk in range(4):
+                acc[mo] = mfma16(frag[:, kk], bop(4 * tq + kk), acc[mo])
+
+
+def _encode16(X, nfreq, n):
+    g = LANE >> 4
+    per = 6 * nfreq // 4
+    e = np.zeros((n, 64), np.float32)
+    for t in range(per):
+        q = per * g + t
+        L, sc, ax = q // 6, (q % 6) // 3, q % 3
+        arg = (X[LANE, ax] * np.exp2(L).astype(np.float32)).astype(np.float32)
+        e[t] = np.where(sc == 1, np.cos(arg), np.sin(arg)).astype(np.float32)
+    e[per] = np.where(g < 3, X[LANE, np.minimum(g, 2)], 0.0)
+    return e
+
+
+def mlp_pass16(packed16, pts, dirs):
+    """pts, dirs [16,3] -> raw [16,4]; lanes j, j+16, j+32, j+48 all own point j."""
+    from neural_sim_nerf_amd import pack as PK
+    st = Stream16(packed16[:PK.STREAM_SLABS * PK.SLAB_FLOATS])
+    aux = packed16[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
+    g = LANE >> 4
+    P = np.tile(pts, (4, 1)).astype(np.float32)
+    V = np.tile(dirs, (4, 1)).astype(np.float32)
+    e, ed = _encode16(P, 10, 16), _encode16(V, 4, 8)
+    regs = lambda arr: (lambda t: arr[t >> 2][:, t & 3])
+
+    def bias(off, nmo):
+        acc = np.zeros((nmo, 64, 4), np.float32)
+        for mo in range(nmo):
+            for r in range(4):
+                acc[mo][:, r] = aux[off + 16 * mo + 4 * g + r]
+        return acc
+    acc = bias(PK.AUX_BIAS, 16)
+    st.seg(16, 4, lambda t: e[t], acc)
+    inp = np.maximum(acc, 0)
+    alpha_part = np.zeros(64, np.float32)
+    for L in range(1, 9):
+        acc = bias(PK.AUX_BIAS + L * 256, 16)
+        if L == 5:
+            st.seg(16, 4, lambda t: e[t], acc)
+        if L == 8:
+            for t in range(64):
+                alpha_part = alpha_part + aux[PK.AUX_W_ALPHA + 16 * (t >> 2) + 4 * g + (t & 3)] * inp[t >> 2][:, t & 3]
+        st.seg(16, 16, regs(inp), acc)
+        inp = np.maximum(acc, 0) if L < 8 else acc.copy()
+    av = bias(PK.AUX_BIAS_V, 8)
+    st.seg(8, 18, lambda t: inp[t >> 2][:, t & 3] if t < 64 else ed[t - 64], av)
+    assert st.pos == 145 * 16
+    part = np.zeros((4, 64), np.float32)
+    part[3] = alpha_part
+    for c in range(3):
+        for mo in range(8):
+            for r in range(4):
+                part[c] = part[c] + aux[PK.AUX_W_RGB + c * 128 + 16 * mo + 4 * g + r] * np.maximum(av[mo][:, r], 0)
+    raw = np.zeros((16, 4), np.float32)
+    for c in range(4):
+        b = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
+        raw[:, c] = part[c].reshape(4, 16).sum(0) + b
+    return raw

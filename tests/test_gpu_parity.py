@@ -396,3 +396,51 @@ def test_render_path_api_and_png_side_effects(oracle, synth_nets, tmp_path):
     rgbs32, _ = R.render_path(None, torch.tensor(g["c2w_b"])[None], [64, 64, 0.0], g["K32"].tolist(), 512, kw_test,
                               savedir=None, render_factor=2)
     assert rgbs32.shape == (1, 32, 32, 3) and oracle.psnr(rgbs32[0], g["rgb_c2"]) > 55.0
+
+
+# ------------------------------------------------------------------------------------------------------
+# x16 forward kernel (16 points per wave, two workgroups per CU): same parity bar as the default kernel
+# ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def model16(synth_nets):
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1], variant=16)
+    yield m
+    m.close()
+
+
+def test_x16_stagewise_and_golden(model16, oracle, synth_nets):
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    r = model16.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
+    _stagewise(model16, oracle, synth_nets, r, g["rays_o"], g["rays_d"], near, far)
+    assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+    assert (cpu(r["inds"]) == g["inds"]).mean() > 0.99
+    assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0
+
+
+def test_x16_chunk_invariance_and_views(model16, model, oracle):
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    full = model16.render_rays(g["rays_o"], g["rays_d"], near, far)
+    for n in (1, 3, 77):
+        r = model16.render_rays(g["rays_o"][:n], g["rays_d"][:n], near, far)
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+            assert np.array_equal(cpu(r[k]), cpu(full[k])[:n], equal_nan=True), (k, n)
+    g7 = load_golden("g7_render")
+    r = model16.render_views(g7["c2w_b"], 32, 32, g7["K32"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    assert_close(cpu(r["rgb0"]).reshape(32, 32, 3), g7["rgb0_c2"], atol=1e-5, what="rgb0")
+    assert oracle.psnr(cpu(r["rgb_map"]).reshape(32, 32, 3), g7["rgb_c2"]) > 55.0
+    # the two kernels differ only in the summation order inside the MFMA chains
+    r32 = model.render_views(g7["c2w_b"], 32, 32, g7["K32"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    assert np.abs(cpu(r["rgb0"]) - cpu(r32["rgb0"])).max() < 1e-5
+
+
+def test_x16_coarse_only_config1(oracle, synth_nets):
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g7_render")
+    m1 = NsrModel(synth_nets[0], None, n_importance=0, variant=16)
+    r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    assert_close(cpu(r["rgb_map"]).reshape(64, 64, 3), g["rgb_c1"], atol=1e-5, what="config-1 rgb")
+    assert_close(cpu(r["acc_map"]).reshape(64, 64), g["acc_c1"], atol=1e-5, what="config-1 acc")
+    m1.close()
