@@ -168,7 +168,8 @@ static int grid_for(nsr_handle h, long long n_items) {
   return (int)(g < 1 ? 1 : g);
 }
 
-static bool use_x16(nsr_handle h) { return h->cfg.variant == 16; }
+// library default (variant 0) = x16: measured 145.0 vs 141.5 TFLOP/s for x32 on one 400x400 view (tools/compare_variants.py)
+static bool use_x16(nsr_handle h) { return h->cfg.variant != 32; }
 
 static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* out, const NsrDebugOut* dbg,
                          void* stream) {
@@ -376,12 +377,12 @@ int nsr_selftest(nsr_handle h, void* stream) {
 
 int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
   if (!h || !ms) return fail("nsr_probe: null argument");
-  if (mode < 0 || mode > 2 || iters <= 0) return fail("nsr_probe: mode in 0..2, iters > 0");
+  if (mode < 0 || mode > 3 || iters <= 0) return fail("nsr_probe: mode in 0..3, iters > 0");
   if (!h->have_net[0]) return fail("nsr_probe: upload a network first");
   NSR_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = (hipStream_t)stream;
   float* out = nullptr;
-  NSR_HIP(hipMalloc(&out, sizeof(float) * 256 * h->n_cu));
+  NSR_HIP(hipMalloc(&out, sizeof(float) * 512 * h->n_cu));
   const size_t lds = nsr::kRingSlots * nsr::kSlabBytes;
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -390,6 +391,10 @@ int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
   if (mode == 0) hipLaunchKernelGGL(nsr::k_probe<0>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
   if (mode == 1) hipLaunchKernelGGL(nsr::k_probe<1>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
   if (mode == 2) hipLaunchKernelGGL(nsr::k_probe<2>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
+  if (mode == 3) {
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe16, hipFuncAttributeMaxDynamicSharedMemorySize, nsr::kRing16 * nsr::kSlabBytes));
+    hipLaunchKernelGGL(nsr::k_probe16, dim3(2 * h->n_cu), dim3(256), nsr::kRing16 * nsr::kSlabBytes, s, h->d_packed[0], out, iters);
+  }
   NSR_HIP(hipGetLastError());
   NSR_HIP(hipEventRecord(h->ev1, s));
   NSR_HIP(hipEventSynchronize(h->ev1));

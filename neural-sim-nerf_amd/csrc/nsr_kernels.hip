@@ -1472,6 +1472,33 @@ __global__ void __launch_bounds__(256, 1) k_probe(const float* __restrict__ stre
   out[blockIdx.x * 256 + tid] = sum;
 }
 
+// mode 3: the x16 layer GEMM (seg<16,16> on the 3-slab ring), two workgroups per CU
+__global__ void __launch_bounds__(256, 2) k_probe16(const float* __restrict__ stream, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x4 in[16], acc[16];
+#pragma unroll
+  for (int mo = 0; mo < 16; ++mo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
+  }
+  Ring rg;
+  ring_init(rg, smem, stream, 0, 1, wave, lane);
+  f32x4 A0[4], A1[4];
+  ring_start<kRing16>(rg, A0, lane);
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float sum = 0.0f;
+#pragma unroll
+  for (int mo = 0; mo < 16; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum += acc[mo][r];
+  out[blockIdx.x * 256 + tid] = sum;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // run_network (RN:26-40) as a stage kernel: 128 points per workgroup pass.
 // ------------------------------------------------------------------------------------------------------
