@@ -51,8 +51,8 @@ typedef struct NsrConfig {
   int32_t n_samples;       /* must be 64                                                           */
   int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1)               */
   int32_t max_workgroups;  /* 0 = fill the chip (one workgroup per CU for x32, two for x16)        */
-  int32_t variant;         /* forward kernel: 0 = library default, 32 = 32 points/wave (1 workgroup per CU),
-                              16 = 16 points/wave, two workgroups per CU (needs nsr_upload_weights16)   */
+  int32_t variant;         /* forward kernel: 0 = library default (= 16), 16 = 16 points/wave, two workgroups
+                              per CU (needs nsr_upload_weights16), 32 = 32 points/wave, one workgroup/CU  */
   int32_t reserved[2];
 } NsrConfig;
 

@@ -64,7 +64,7 @@ class NsrModel:
         sd_c = to_np(sd_coarse)
         p = pack_network(sd_c)
         _lib.check(self.lib.nsr_upload_weights(self.h, 0, _fptr(p), PACKED_FLOATS))
-        if self.variant == 16:
+        if self.variant != 32:                       # 0 = library default = x16
             p = pack_network16(sd_c)
             _lib.check(self.lib.nsr_upload_weights16(self.h, 0, _fptr(p), PACKED_FLOATS))
         self._sd_fine_np = None
@@ -73,7 +73,7 @@ class NsrModel:
             self._sd_fine_np = to_np(sd_fine)
             p = pack_network(self._sd_fine_np)
             _lib.check(self.lib.nsr_upload_weights(self.h, 1, _fptr(p), PACKED_FLOATS))
-            if self.variant == 16:
+            if self.variant != 32:
                 p = pack_network16(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights16(self.h, 1, _fptr(p), PACKED_FLOATS))
 

@@ -21,7 +21,7 @@ def model(synth_nets):
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     from neural_sim_nerf_amd.engine import NsrModel
     sd_c, sd_f = synth_nets
-    m = NsrModel(sd_c, sd_f)
+    m = NsrModel(sd_c, sd_f, variant=32)      # the x32 kernels (forward, VJP, stage entry points)
     yield m
     m.close()
 
@@ -153,7 +153,7 @@ def test_render_views_config1_and_2(model, oracle, synth_nets):
     g = load_golden("g7_render")
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     # BASELINE config 1: 64x64, coarse only
-    m1 = NsrModel(synth_nets[0], None, n_importance=0)
+    m1 = NsrModel(synth_nets[0], None, n_importance=0, variant=32)
     r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), near, far)
     assert_close(cpu(r["rgb_map"]).reshape(64, 64, 3), g["rgb_c1"], atol=1e-5, what="config-1 rgb")
     assert_close(cpu(r["acc_map"]).reshape(64, 64), g["acc_c1"], atol=1e-5, what="config-1 acc")
@@ -404,7 +404,7 @@ def test_render_path_api_and_png_side_effects(oracle, synth_nets, tmp_path):
 @pytest.fixture(scope="module")
 def model16(synth_nets):
     from neural_sim_nerf_amd.engine import NsrModel
-    m = NsrModel(synth_nets[0], synth_nets[1], variant=16)
+    m = NsrModel(synth_nets[0], synth_nets[1])                   # variant 0 = library default = x16
     yield m
     m.close()
 
