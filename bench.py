@@ -12,7 +12,7 @@ are all-gathered over RCCL once, at the outer-loop boundary, inside the timed re
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     -- dominant kernel nsr::k_render: algorithmic FLOP per launch / HIP-event kernel time, against
+  roofline     -- dominant kernel nsr::k_render16: algorithmic FLOP per launch / HIP-event kernel time, against
                   the fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
   cpu_baseline -- the oracle (CPU numpy restatement of the reference path, "port") timed on this host's cores
                   on a bounded sample (a 64x64 view of the same scene: same per-ray work), rank 0, N=1 only;
@@ -149,7 +149,7 @@ def main():
         traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
         prof = os.path.join(ROOT, "profiles", "r01", "pmc_k_render.json")
         if os.path.exists(prof):
-            traffic = json.load(open(prof))["derived"]["hbm_traffic_bytes_per_launch"]
+            traffic = json.load(open(prof))["x16_default"]["derived"]["hbm_traffic_bytes_per_launch"]
         line = {
             "metric": "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP",
             "value": round(value, 3), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps,
@@ -157,16 +157,17 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
                                    "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), fp32, fused "
-                                   "persistent kernel, rays generated in-kernel",
+                                   "persistent kernel (x16: 2 workgroups per CU), rays generated in-kernel",
                        "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
                        "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
             "rays_per_s": round(rays / dt, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes "
-                                         "(profiles/r01/pmc_k_render.json); weight re-streaming past the 4 MiB XCD L2, "
-                                         "algorithmic HBM bytes are 7.0e6 per launch",
-                         "kernel": "nsr::k_render", "kernel_ms": round(k_ms, 3),
+                                         "(profiles/r01/pmc_k_render.json); weight re-streaming of 512 workgroups past "
+                                         "the 4 MiB XCD L2s (served by Infinity Cache, 0.24 TB/s); algorithmic HBM "
+                                         "bytes are 7.0e6 per launch",
+                         "kernel": "nsr::k_render16", "kernel_ms": round(k_ms, 3),
                          "flop_per_launch": H * W * FLOP_PER_RAY},
         }
         if world == 1 and not args.no_cpu_baseline:
