@@ -131,6 +131,12 @@ int nsr_pose_grad(nsr_handle h, const float* d_grad_o, const float* d_grad_d, in
 int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K9,
                  float* d_rays_o, float* d_rays_d, void* stream);
 
+/* Embedder.embed (RH:18-48, get_embedder RH:51-66 with i_embed = 0): d_x [n,3] -> d_out [n, 3 + 6*multires] in the
+ * reference's channel order [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)].  This is the
+ * encoding the fused kernels evaluate in registers; coordinates with 2^(L-1)|x| >= 2^24 (outside any NeRF scene)
+ * encode to NaN rather than to an inaccurate value. */
+int nsr_embed(nsr_handle h, const float* d_x, int64_t n, int multires, float* d_out, void* stream);
+
 /* run_network (RN:26-40) = Embedder (RH:18-48) + NeRF MLP (RH:99-122): d_pts [P,3], d_viewdirs [P,3]
  * (already unit length) -> d_raw [P,4]. */
 int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts,

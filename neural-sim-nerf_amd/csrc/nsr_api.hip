@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/nsr.h"
@@ -301,6 +302,18 @@ int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K
   return 0;
 }
 
+int nsr_embed(nsr_handle h, const float* d_x, int64_t n, int multires, float* d_out, void* stream) {
+  if (!h || !d_x || !d_out) return fail("nsr_embed: null argument");
+  if (multires < 1 || multires > 16) return fail("nsr_embed: multires in 1..16");
+  if (n <= 0) return n == 0 ? 0 : fail("nsr_embed: negative point count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const long long work = (long long)n * (multires + 1);
+  hipLaunchKernelGGL(nsr::k_embed, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x,
+                     (long long)n, multires, d_out);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
 int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts,
                     float* d_raw, void* stream) {
   if (!h || !d_pts || !d_viewdirs || !d_raw) return fail("nsr_run_network: null argument");
@@ -377,7 +390,7 @@ int nsr_selftest(nsr_handle h, void* stream) {
 
 int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
   if (!h || !ms) return fail("nsr_probe: null argument");
-  if (mode < 0 || mode > 3 || iters <= 0) return fail("nsr_probe: mode in 0..3, iters > 0");
+  if (mode < 0 || mode > 8 || iters <= 0) return fail("nsr_probe: mode in 0..8, iters > 0");
   if (!h->have_net[0]) return fail("nsr_probe: upload a network first");
   NSR_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = (hipStream_t)stream;
@@ -395,10 +408,39 @@ int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe16, hipFuncAttributeMaxDynamicSharedMemorySize, nsr::kRing16 * nsr::kSlabBytes));
     hipLaunchKernelGGL(nsr::k_probe16, dim3(2 * h->n_cu), dim3(256), nsr::kRing16 * nsr::kSlabBytes, s, h->d_packed[0], out, iters);
   }
+  int* done = nullptr;
+  if (mode >= 4) {
+    NSR_HIP(hipMalloc(&done, sizeof(int)));
+    NSR_HIP(hipMemsetAsync(done, 0, sizeof(int), s));
+    const size_t l16 = nsr::kRing16 * nsr::kSlabBytes;
+    const dim3 g(2 * h->n_cu), b(256);
+#define NSR_PAIR(P)                                                                                              \
+  if (mode == 4 + P) {                                                                                           \
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe16_pair<P>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)l16));                                                                      \
+    hipLaunchKernelGGL(nsr::k_probe16_pair<P>, g, b, l16, s, h->d_packed[0], out, iters, done, h->n_cu,        \
+                       getenv("NSR_PROBE_PARTNER_PRIO") ? atoi(getenv("NSR_PROBE_PARTNER_PRIO")) : 0);                   \
+  }
+    NSR_PAIR(0) NSR_PAIR(1) NSR_PAIR(2) NSR_PAIR(3) NSR_PAIR(4)
+#undef NSR_PAIR
+  }
   NSR_HIP(hipGetLastError());
   NSR_HIP(hipEventRecord(h->ev1, s));
   NSR_HIP(hipEventSynchronize(h->ev1));
   NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  if (mode >= 4) {        // mean duration of the GEMM workgroups (100 MHz ticks -> ms), not the whole kernel
+    std::vector<float> host(2 * h->n_cu);
+    NSR_HIP(hipMemcpy(host.data(), out, sizeof(float) * host.size(), hipMemcpyDeviceToHost));
+    double sum = 0.0; int n = 0;
+    for (float v : host) if (v > 0.0f) { sum += v; ++n; }
+    *ms = n ? (float)(sum / n * 1e-5) : 0.0f;
+    double ps = 0.0; int pn = 0;
+    for (float v : host) if (v < 0.0f) { ps -= v; ++pn; }
+    if (pn && getenv("NSR_PROBE_VERBOSE"))
+      fprintf(stderr, "nsr_probe mode %d: partner workgroups ran %.4f loop iterations per 10 ns tick\n", mode, ps / pn);
+    if (n != h->n_cu) { hipFree(out); hipFree(done); return fail("nsr_probe: the dispatcher did not place one first workgroup per CU"); }
+    NSR_HIP(hipFree(done));
+  }
   NSR_HIP(hipFree(out));
   return 0;
 }

@@ -244,38 +244,67 @@ __device__ __forceinline__ uint4 relu_mask(const f32x16 (&acc)[NMO]) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// sin(a + k pi/2) for the encodings (RH:39-48; k = 0: sin, 1: cos, 2: -sin).  The library sincosf costs ~100
+// VALU instructions per call (plus a Payne-Hanek path that cannot be kept out of the register budget), and a
+// VALU instruction is never free here: it takes matrix-pipe issue time from the other wave on the SIMD
+// (tools/probe_pairing.py).  So: one fp64 reduction -- t = a*(2/pi) has >= 24 spare bits for |a| < 2^24, and
+// the split into quadrant n and fraction f is exact -- then the Cephes single-precision minimax polynomials on
+// [-pi/4, pi/4] (1 ulp).  ~20 instructions.  Domain: |a| < 2^24; enc_domain() turns coordinates beyond it into
+// NaN so that an out-of-range scene shows up as NaN pixels rather than as slightly wrong ones.
+__device__ __forceinline__ float enc_trig(float a, int k) {
+  const double kMagic = 6755399441055744.0;                 // 1.5 * 2^52: t + kMagic holds rint(t) in its low word
+  const double t = (double)a * 0.63661977236758134308;      // a * 2/pi
+  const double tm = t + kMagic;
+  const int n = __double2loint(tm) + k;
+  const double f = t - (tm - kMagic);                       // [-0.5, 0.5], exact
+  const float r = (float)(f * 1.57079632679489661923);
+  const float z = r * r;
+  float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * z, r, r);
+  float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const float v = (n & 1) ? pc : ps;
+  return __uint_as_float(__float_as_uint(v) ^ ((unsigned)(n & 2) << 30));
+}
+
+// x if 2^(nfreq-1) |x| < 2^24 (the domain of enc_trig), NaN otherwise (also for inf / NaN inputs)
+__device__ __forceinline__ float enc_domain(float x, int nfreq) {
+  return __builtin_fabsf(x) < ldexpf(1.0f, 25 - nfreq) ? x : __builtin_nanf("");
+}
+
+// 0 if the point and direction are inside the encoder's domain, NaN otherwise.  Added to the network outputs so
+// that a NaN / out-of-range input reaches the caller as NaN, as it does through torch's relu in the reference
+// (the integer-max relu and v_max_f32 used here both let a NaN activation collapse to 0).
+__device__ __forceinline__ float enc_poison(float px, float py, float pz, float vx, float vy, float vz) {
+  const float a = (enc_domain(px, kMultires) * 0.0f + enc_domain(py, kMultires) * 0.0f) + enc_domain(pz, kMultires) * 0.0f;
+  const float b = (enc_domain(vx, kMultiresViews) * 0.0f + enc_domain(vy, kMultiresViews) * 0.0f) +
+                  enc_domain(vz, kMultiresViews) * 0.0f;
+  return __builtin_fabsf(a + b);      // +0 or NaN
+}
+
 template <bool CAPTURE>
 __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                          float px, float py, float pz, float vx, float vy, float vz,
                                          float (&raw)[4], uint4* mask_dst = nullptr) {
   const int h = lane >> 5;
+  const float poison = enc_poison(px, py, pz, vx, vy, vz);
   float e[32];   // position encoding, k-step t: h=0 -> sin(2^L p_ax), h=1 -> cos(2^L p_ax), t = 3L+ax
   float ed[16];  // direction encoding, same scheme with L < 4
   {
     const float p[3] = {px, py, pz};
+    const float v[3] = {vx, vy, vz};
 #pragma unroll
     for (int L = 0; L < kMultires; ++L)
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        float s, c;
-#ifdef NSR_EXP_FASTTRIG         // timing experiment only
-        s = __sinf(p[ax] * (float)(1 << L)); c = __cosf(p[ax] * (float)(1 << L));
-#else
-        sincosf(p[ax] * (float)(1 << L), &s, &c);
-#endif
-        e[3 * L + ax] = h ? c : s;
-      }
-    e[30] = h ? pz : px;
-    e[31] = h ? 0.0f : py;
-    const float v[3] = {vx, vy, vz};
+      for (int ax = 0; ax < 3; ++ax) e[3 * L + ax] = enc_trig(enc_domain(p[ax], kMultires) * (float)(1 << L), h);
 #pragma unroll
     for (int L = 0; L < kMultiresViews; ++L)
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        float s, c;
-        sincosf(v[ax] * (float)(1 << L), &s, &c);
-        ed[3 * L + ax] = h ? c : s;
-      }
+      for (int ax = 0; ax < 3; ++ax) ed[3 * L + ax] = enc_trig(enc_domain(v[ax], kMultiresViews) * (float)(1 << L), h);
+    e[30] = h ? pz : px;
+    e[31] = h ? 0.0f : py;
     ed[12] = h ? vz : vx;
     ed[13] = h ? 0.0f : vy;
     ed[14] = 0.0f;
@@ -341,7 +370,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
     float other = __shfl_xor(part[c], 32);
     float lo_half = h ? other : part[c];
     float hi_half = h ? part[c] : other;
-    raw[c] = (lo_half + hi_half) + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha];
+    raw[c] = ((lo_half + hi_half) + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha]) + poison;
   }
 }
 
@@ -802,12 +831,9 @@ __device__ __forceinline__ void embed_bwd(const float (&x)[3], const float* G /*
 #pragma unroll
   for (int L = 0; L < NFREQ; ++L)
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
+    for (int ax = 0; ax < 3; ++ax) {     // d sin = f cos, d cos = -f sin
       const float f = (float)(1 << L);
-      float sn, cs;
-      sincosf(x[ax] * f, &sn, &cs);
-      const float g = G[3 * L + ax];
-      out[ax] = __builtin_fmaf(f * g, h ? -sn : cs, out[ax]);     // d sin = f cos, d cos = -f sin
+      out[ax] = __builtin_fmaf(f * G[3 * L + ax], enc_trig(enc_domain(x[ax], NFREQ) * f, 1 + h), out[ax]);
     }
 }
 
@@ -1211,26 +1237,21 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
                                            float px, float py, float pz, float vx, float vy, float vz,
                                            float (&raw)[4]) {
   const int g = lane >> 4;
+  const float poison = enc_poison(px, py, pz, vx, vy, vz);
   float e[16];   // 60 sin/cos columns dealt 15 per lane group (reference order), then the identity column g
   float ed[8];   // directions: group g holds frequency 2^g (sin xyz, cos xyz), then the identity column g
   {
-    const float p[3] = {px, py, pz};
+    const float p[3] = {enc_domain(px, kMultires), enc_domain(py, kMultires), enc_domain(pz, kMultires)};
+    const float v[3] = {enc_domain(vx, kMultiresViews), enc_domain(vy, kMultiresViews), enc_domain(vz, kMultiresViews)};
 #pragma unroll
     for (int t = 0; t < 15; ++t) {
       const int q = 15 * g + t, L = q / 6, sc = (q % 6) / 3, ax = q % 3;
       const float x = ax == 0 ? p[0] : (ax == 1 ? p[1] : p[2]);
-      float s, c;
-      sincosf(ldexpf(x, L), &s, &c);
-      e[t] = sc ? c : s;
+      e[t] = enc_trig(ldexpf(x, L), sc);
     }
-    e[15] = g == 0 ? px : (g == 1 ? py : (g == 2 ? pz : 0.0f));
-    const float v[3] = {vx, vy, vz};
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
-      float s, c;
-      sincosf(ldexpf(v[t % 3], g), &s, &c);
-      ed[t] = (t >= 3) ? c : s;
-    }
+    for (int t = 0; t < 6; ++t) ed[t] = enc_trig(ldexpf(v[t % 3], g), t >= 3);
+    e[15] = g == 0 ? px : (g == 1 ? py : (g == 2 ? pz : 0.0f));
     ed[6] = g == 0 ? vx : (g == 1 ? vy : (g == 2 ? vz : 0.0f));
     ed[7] = 0.0f;
   }
@@ -1285,13 +1306,17 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
     float x = part[c];
     x = x + __shfl_xor(x, 16);
     x = x + __shfl_xor(x, 32);
-    raw[c] = x + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha];
+    raw[c] = (x + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha]) + poison;
   }
 }
 
 __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RenderArgs& a = *ap;
+#ifdef NSR_PHASE_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1344,6 +1369,7 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
         st.zc[0][tid] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
       }
       __syncthreads();
+      NSR_T(0);
     }
 
     // one network pass: 64 points; coarse: sample 16w + j; fine p: sample 64(p-1) + 16w + j
@@ -1356,6 +1382,7 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
                  ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
+    NSR_T(1);
 
     if (pass == 0) {
       __syncthreads();
@@ -1376,7 +1403,12 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
       }
       if (a.dbg_w0 && tid < 64) a.dbg_w0[rr * 64 + tid] = st.w0[0][tid];
       if (!fine) { __syncthreads(); item += gridDim.x; continue; }
+      NSR_T(2);
+#ifdef NSR_PHASE_TIMING
+      int64_t* inds = nullptr;                 // dbg_inds carries the cycle totals in this build
+#else
       int64_t* inds = (int64_t*)a.dbg_inds;
+#endif
       sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
                          [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
                          inds ? inds + rr * 128 : nullptr, 128, tid, 1);
@@ -1385,8 +1417,10 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
         if (lane == 0 && a.z_std) a.z_std[rr] = sd;
       }
       if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
+      NSR_T(3);
       merge_sort_item<1>(st, tid);
       if (a.dbg_zf && tid < 192) a.dbg_zf[rr * 192 + tid] = st.zf[0][tid];
+      NSR_T(5);
       pass = 1;
     } else if (pass < 3) {
       ++pass;
@@ -1405,11 +1439,16 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
         else if (c == 4) { if (a.acc) a.acc[rr] = v; }
       }
       __syncthreads();
+      NSR_T(6);
       pass = 0;
       item += gridDim.x;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+#ifdef NSR_PHASE_TIMING
+  if (tid == 0 && a.dbg_raw == nullptr && a.dbg_inds)
+    for (int i = 0; i < 8; ++i) a.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1499,6 +1538,81 @@ __global__ void __launch_bounds__(256, 2) k_probe16(const float* __restrict__ st
   out[blockIdx.x * 256 + tid] = sum;
 }
 
+// modes 4..8: what the x16 layer GEMM of the FIRST workgroup on a CU loses to a second workgroup that runs
+// PARTNER = 0 nothing, 1 dense fp32 VALU, 2 transcendentals, 3 an LDS latency chain, 4 an fp64 chain.
+// out[blockIdx] = 100 MHz ticks the GEMM workgroup took (0 for partners); partners spin until all GEMMs are done.
+template <int PARTNER>
+__global__ void __launch_bounds__(256, 2) k_probe16_pair(const float* __restrict__ stream, float* out, int iters,
+                                                         int* done, int n_first, int prio) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned ldsb = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11));      // HW_REG_LDS_ALLOC.LDS_BASE
+  if (ldsb != 0) {
+    if (tid == 0) out[blockIdx.x] = 0.0f;
+    if (PARTNER == 0) return;
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    float x = 1e-3f * (float)tid, y = 0.5f;
+    double d = 1.0 + 1e-9 * tid;
+    float* l = (float*)smem;
+    l[tid] = (float)((tid * 17) & 255);
+    const long long t0 = wall_clock64();
+    int it = 0;
+#pragma unroll 1
+    for (; it < (1 << 24); ++it) {
+      if (PARTNER == 1) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { x = x * 1.0001f + y; y = y * 0.9999f + x; }
+      } else if (PARTNER == 2) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) { x = __sinf(x) + 1.0f; y = __cosf(y + x); }
+      } else if (PARTNER == 3) {
+        int idx = tid;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) idx = (int)l[idx & 255];
+        x += (float)idx;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) d = d * 1.000000001 + 1e-12;
+      }
+      if ((it & 15) == 0) {
+        if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_first) break;
+        if (wall_clock64() - t0 > 300000000LL) break;       // 3 s safety net
+      }
+    }
+    const long long t1 = wall_clock64();
+    if (tid == 0) out[blockIdx.x] = (x + y + (float)d == 123.456f) ? x : -(float)it / (float)(t1 - t0);   // -(iterations per tick)
+    return;
+  }
+  f32x4 in[16], acc[16];
+#pragma unroll
+  for (int mo = 0; mo < 16; ++mo) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
+  }
+  Ring rg;
+  ring_init(rg, smem, stream, 0, 1, wave, lane);
+  f32x4 A0[4], A1[4];
+  ring_start<kRing16>(rg, A0, lane);
+  const long long t0 = wall_clock64();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (iters == 1) while (wall_clock64() - t0 < 500000) __builtin_amdgcn_s_sleep(64);     // partner baseline: idle 5 ms
+  const long long t1 = wall_clock64();
+  float sum = 0.0f;
+#pragma unroll
+  for (int mo = 0; mo < 16; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum += acc[mo][r];
+  __syncthreads();
+  if (tid == 0) {
+    out[blockIdx.x] = (sum == 123.456f) ? sum : (float)(t1 - t0);
+    __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // run_network (RN:26-40) as a stage kernel: 128 points per workgroup pass.
 // ------------------------------------------------------------------------------------------------------
@@ -1550,6 +1664,23 @@ __global__ void k_get_rays(const float* __restrict__ c2w, float fx, float fy, fl
   gen_ray(c2w, fx, fy, cx, cy, pix / W, pix % W, o, d);
 #pragma unroll
   for (int c = 0; c < 3; ++c) { rays_o[pix * 3 + c] = o[c]; rays_d[pix * 3 + c] = d[c]; }
+}
+
+// Embedder.embed (RH:39-48): [n,3] -> [n, 3 + 6 L] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]
+__global__ void k_embed(const float* __restrict__ x, long long n, int L, float* __restrict__ out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (point, frequency)
+  if (idx >= n * (L + 1)) return;
+  const long long pt = idx / (L + 1);
+  const int f = (int)(idx - pt * (L + 1));       // 0 = identity block, f >= 1: frequency 2^(f-1)
+  float* o = out + pt * (3 + 6 * L);
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const float v = x[pt * 3 + ax];
+    if (f == 0) { o[ax] = v; continue; }
+    const float a = ldexpf(enc_domain(v, L), f - 1);
+    o[3 + 6 * (f - 1) + ax] = enc_trig(a, 0);
+    o[3 + 6 * (f - 1) + 3 + ax] = enc_trig(a, 1);
+  }
 }
 
 struct R2OArgs {

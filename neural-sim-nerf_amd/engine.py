@@ -183,6 +183,16 @@ class NsrModel:
                                          _stream_ptr(self.device)))
         return o, d
 
+    def embed(self, x, multires):
+        """Embedder.embed (RH:39-48): [..., 3] -> [..., 3 + 6*multires]."""
+        x = self._f32(x)
+        lead = tuple(x.shape[:-1])
+        flat = x.reshape(-1, 3).contiguous()
+        out = self._new(flat.shape[0], 3 + 6 * int(multires))
+        _lib.check(self.lib.nsr_embed(self.h, _dev(flat), flat.shape[0], int(multires), _dev(out),
+                                      _stream_ptr(self.device)))
+        return out.reshape(*lead, 3 + 6 * int(multires))
+
     def run_network(self, pts, viewdirs, net_id=0):
         pts = self._f32(pts, (-1, 3))
         viewdirs = self._f32(viewdirs, (-1, 3))

@@ -15,7 +15,8 @@ to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)                      
 
 
 class Embedder:
-    """RH:18-48.  Kept for its metadata (out_dim); the encoding itself runs inside the kernel."""
+    """RH:18-48.  Inside render() the encoding is evaluated in registers by the fused kernels; embed() exposes
+    the same device code as a stand-alone op (nsr_embed), forward only."""
 
     def __init__(self, **kwargs):
         self.kwargs = kwargs
@@ -23,8 +24,12 @@ class Embedder:
         self.out_dim = (d if kwargs["include_input"] else 0) + d * 2 * kwargs["num_freqs"]
 
     def embed(self, inputs):
-        raise NotImplementedError("the positional encoding is fused into the gfx950 kernel; call the network "
-                                  "through network_query_fn / render(), which take un-encoded points")
+        if torch.is_tensor(inputs) and inputs.requires_grad:
+            raise NotImplementedError("Embedder.embed is forward-only here; gradients w.r.t. points flow through "
+                                      "render(rays=...) (nsr_render_rays_vjp)")
+        from .run_nerf_noscale import _util_model
+        dev = inputs.device if torch.is_tensor(inputs) and inputs.is_cuda else None
+        return _util_model(dev).embed(inputs, self.kwargs["num_freqs"])
 
 
 def get_embedder(multires, i=0):

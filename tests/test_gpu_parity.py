@@ -70,6 +70,44 @@ def test_run_network_vs_oracle_ragged(model, oracle, synth_nets, n):
     assert_close(cpu(model.run_network(pts, dirs, 0)), want, atol=3e-5, rtol=2e-5, what="run_network n=%d" % n)
 
 
+def test_embed_vs_golden(model):
+    g = load_golden("g2_embed")
+    pts, dirs = g["pts"], g["dirs"]
+    assert_close(cpu(model.embed(pts, 10)), g["e_pts"], atol=2.5e-7, rtol=0, what="embed L=10")
+    assert_close(cpu(model.embed(dirs, 4)), g["e_dirs"], atol=2.5e-7, rtol=0, what="embed L=4")
+
+
+def test_embed_large_arguments(model, oracle):
+    """enc_trig's fp64 reduction: encodings of coordinates far outside a NeRF scene (2^9 |x| up to 1.6e7) still
+    match sin/cos of the exact fp32 argument, like the reference's torch.sin (RH:39-48), to 2 ulp of 1."""
+    rng = np.random.RandomState(5)
+    n = 20000
+    mag = np.exp(rng.uniform(np.log(1e-3), np.log(32000.0), (n, 3)))
+    pts = (mag * rng.choice([-1.0, 1.0], (n, 3))).astype(np.float32)
+    pts[:8] = [[0, -0.0, 1e-30], [32767.99, -32767.99, 1.0], [np.pi, -np.pi / 2, np.pi / 4]] + [[0.5, 1.5, 2.5]] * 5
+    assert_close(cpu(model.embed(pts, 10)), oracle.embed(pts, 10), atol=2.5e-7, rtol=0, what="embed, large |x|")
+
+
+def test_embed_out_of_domain_is_nan(model):
+    """Coordinates whose largest encoding argument reaches 2^24 (|x| >= 32768 for L=10) encode to NaN -- loud --
+    instead of to an inaccurate value (csrc/nsr_kernels.hip enc_domain); the rest is unaffected, also in the
+    network (the fused kernels share the device function)."""
+    pts = np.zeros((256, 3), np.float32)
+    pts[:, 0] = np.linspace(-1, 1, 256)
+    dirs = np.tile(np.array([[0.0, 0.6, 0.8]], np.float32), (256, 1))
+    bad = pts.copy()
+    bad[7, 1] = 40000.0
+    bad[100, 2] = -np.inf
+    e = cpu(model.embed(bad, 10))
+    assert np.isnan(e[7, 4::3]).all() and np.isnan(e[100, 5::3]).all()        # the y / z trig channels
+    assert e[7, 1] == 40000.0 and np.isfinite(e[7, 3::3]).all()               # identity channel and x channels intact
+    ref = cpu(model.run_network(pts, dirs, 0))
+    got = cpu(model.run_network(bad, dirs, 0))
+    assert np.isnan(got[7]).all() and np.isnan(got[100]).all()
+    keep = np.ones(256, bool); keep[[7, 100]] = False
+    assert np.array_equal(got[keep], ref[keep]) and np.isfinite(ref).all()
+
+
 def test_raw2outputs_vs_golden(model):
     g = load_golden("g4_raw2outputs")
     for s in (64, 192):

@@ -4,20 +4,24 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(_
 from neural_sim_nerf_amd import synthetic as S, _lib
 from neural_sim_nerf_amd.engine import NsrModel, _dev, _stream_ptr
 sd_c = S.synth_weights(0); sd_f = S.synth_weights(1000, fine_of=sd_c)
-m = NsrModel(sd_c, sd_f)
+import os
+V = int(os.environ.get('V', '32')); WG = int(os.environ.get('WG', '0'))
+m = NsrModel(sd_c, sd_f, variant=V, max_workgroups=WG)
 H = W = 400
 c2w = torch.as_tensor(S.sweep_poses(1, 0)[0][:3, :4], device=m.device)[None].contiguous()
 n = H * W
 o, ro, _ = m._outs(n, False)
-t = torch.zeros(256 * 8, dtype=torch.int64, device=m.device)
+t = torch.zeros(512 * 8, dtype=torch.int64, device=m.device)
 dbg = _lib.NsrDebugOut(None, None, _dev(t), None, None, None)
 K9 = (C.c_double * 9)(*[float(S.YCBV_K[i][j]) for i in range(3) for j in range(3)])
 for _ in range(2):
     _lib.check(m.lib.nsr_render_views(m.h, _dev(c2w), 1, H, W, K9, S.YCBV_NEAR, S.YCBV_FAR, C.byref(ro), C.byref(dbg), _stream_ptr(m.device)))
     ms = m.last_kernel_ms()
-tt = t.cpu().numpy().reshape(256, 8).astype(np.float64)
+tt = t.cpu().numpy().reshape(512, 8).astype(np.float64)
+tt = tt[tt.sum(1) > 0]
+print('variant', V, 'workgroups', len(tt))
 names = ["stage rays", "network passes", "coarse composite+out", "sample_pdf", "z_std+dbg", "merge sort", "fine composite+out", "-"]
 tot = tt.sum(1).mean()
 print("kernel ms %.2f  total cycles/WG %.3e (100 MHz counter? ratio to ms: %.1f MHz)" % (ms, tot, tot / ms / 1e3))
 for i, nm in enumerate(names):
-    print("%-22s %6.2f %%" % (nm, 100 * tt[:, i].mean() / tot))
+    print("%-22s %6.2f %%   %.3e cycles/WG" % (nm, 100 * tt[:, i].mean() / tot, tt[:, i].mean()))
