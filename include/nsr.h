@@ -151,6 +151,18 @@ int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const fl
 int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, int64_t n_rays,
                    float* d_samples, int64_t* d_inds, void* stream);
 
+/* Image hand-off to the detector's loader without the PNG round trip.
+ * nsr_to8b: to8b (RH:14) = (255 * clip(x, 0, 1)).astype(uint8) over n floats (truncation; NaN -> 0).
+ * nsr_find_bbox: what get_annotation / find_bbox (NM:786-797) derive from the PNG read back with cv2, for
+ *   d_rgb8 [n_images,H,W,3] uint8 RGB: gray = cv2.cvtColor(BGR image, COLOR_RGB2GRAY) (the reference's channel
+ *   swap kept), mask = gray > 1, 8-connected components with statistics, the largest-area row dropped, then the row
+ *   with the largest w*h (NM:691-692).  d_bbox [n_images,4] int32 = x, y, w, h; d_count [n_images] = number of rows
+ *   left after the drop (0 = the reference would raise on this image; the box is then 0,0,0,0); d_mask (nullable)
+ *   [n_images,H,W] uint8 0/255.  H*W <= 2^20. */
+int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* stream);
+int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int W, int32_t* d_bbox,
+                  int32_t* d_count, uint8_t* d_mask, void* stream);
+
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
 

@@ -2,6 +2,7 @@
 // checking, weight/table residency, launches, HIP-event timing.  No torch types, no hidden synchronisation on
 // the hot path.
 #include "nsr_kernels.hip"
+#include "nsr_handoff.hip"
 
 #include <string>
 #include <vector>
@@ -51,6 +52,8 @@ struct nsr_handle_s {
   nsr::VjpArgs* d_vjp_args = nullptr;
   uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [grid][3][9][256]
   int mask_grid = 0;
+  int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images
+  size_t box_scratch_ints = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
 };
@@ -109,6 +112,7 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_args);
   hipFree(h->d_vjp_args);
   hipFree(h->d_mask_scratch);
+  hipFree(h->d_box_scratch);
   hipEventDestroy(h->ev0);
   hipEventDestroy(h->ev1);
   delete h;
@@ -298,6 +302,54 @@ int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K
   const int n = H * W;
   hipLaunchKernelGGL(nsr::k_get_rays, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_c2w, (float)K9[0],
                      (float)K9[4], (float)K9[2], (float)K9[5], H, W, d_rays_o, d_rays_d);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* stream) {
+  if (!h || !d_x || !d_out) return fail("nsr_to8b: null argument");
+  if (n <= 0) return n == 0 ? 0 : fail("nsr_to8b: negative element count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const long long groups = (n + 3) / 4;
+  hipLaunchKernelGGL(nsr::k_to8b, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x,
+                     (long long)n, d_out);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int W, int32_t* d_bbox,
+                  int32_t* d_count, uint8_t* d_mask, void* stream) {
+  if (!h || !d_rgb8 || !d_bbox || !d_count) return fail("nsr_find_bbox: null argument");
+  if (H <= 0 || W <= 0 || (long long)H * W > (1 << 20)) return fail("nsr_find_bbox: image must have 1..2^20 pixels");
+  if (n_images <= 0) return n_images == 0 ? 0 : fail("nsr_find_bbox: negative image count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const long long hw = (long long)H * W;
+  const int batch = n_images < 16 ? n_images : 16;           // bounds the scratch: 24 B per pixel per image in flight
+  const size_t need = (size_t)batch * (hw + (hw + 1) * 5);
+  if (need > h->box_scratch_ints) {
+    if (h->d_box_scratch) { NSR_HIP(hipStreamSynchronize((hipStream_t)stream)); NSR_HIP(hipFree(h->d_box_scratch)); }
+    h->d_box_scratch = nullptr; h->box_scratch_ints = 0;
+    NSR_HIP(hipMalloc(&h->d_box_scratch, need * sizeof(int)));
+    h->box_scratch_ints = need;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  for (int i0 = 0; i0 < n_images; i0 += batch) {
+    nsr::BoxArgs a;
+    a.K = (n_images - i0) < batch ? (n_images - i0) : batch;
+    a.H = H; a.W = W;
+    a.rgb8 = d_rgb8 + (size_t)i0 * hw * 3;
+    a.mask = d_mask ? d_mask + (size_t)i0 * hw : nullptr;
+    a.parent = h->d_box_scratch;
+    a.stats = h->d_box_scratch + (size_t)batch * hw;
+    a.bbox = d_bbox + (size_t)i0 * 4;
+    a.count = d_count + i0;
+    const long long n_init = (long long)a.K * (hw + 1), n_pix = (long long)a.K * hw;
+    hipLaunchKernelGGL(nsr::k_box_init, dim3((unsigned)((n_init + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nsr::k_box_union, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nsr::k_box_flatten, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nsr::k_box_stats, dim3((unsigned)((n_pix + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nsr::k_box_select, dim3(a.K), dim3(256), 0, s, a);
+  }
   NSR_HIP(hipGetLastError());
   return 0;
 }

@@ -183,6 +183,27 @@ class NsrModel:
                                          _stream_ptr(self.device)))
         return o, d
 
+    def to8b(self, x):
+        """to8b (RH:14) on device: float tensor -> uint8 tensor of the same shape."""
+        x = self._f32(x)
+        out = torch.empty(x.shape, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.nsr_to8b(self.h, _dev(x), x.numel(), _dev(out), _stream_ptr(self.device)))
+        return out
+
+    def find_bbox(self, rgb8, with_mask=False):
+        """get_annotation / find_bbox (NM:786-797) on device: uint8 [K,H,W,3] RGB -> (bbox [K,4] int32 XYWH,
+        count [K] int32[, mask [K,H,W] uint8])."""
+        rgb8 = torch.as_tensor(rgb8, dtype=torch.uint8, device=self.device).contiguous()
+        if rgb8.dim() == 3:
+            rgb8 = rgb8[None]
+        k, hh, ww, _ = rgb8.shape
+        bbox = torch.empty((k, 4), dtype=torch.int32, device=self.device)
+        count = torch.empty((k,), dtype=torch.int32, device=self.device)
+        mask = torch.empty((k, hh, ww), dtype=torch.uint8, device=self.device) if with_mask else None
+        _lib.check(self.lib.nsr_find_bbox(self.h, _dev(rgb8), k, hh, ww, _dev(bbox), _dev(count),
+                                          _dev(mask) if with_mask else None, _stream_ptr(self.device)))
+        return (bbox, count, mask) if with_mask else (bbox, count)
+
     def embed(self, x, multires):
         """Embedder.embed (RH:39-48): [..., 3] -> [..., 3 + 6*multires]."""
         x = self._f32(x)
