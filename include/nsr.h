@@ -166,9 +166,12 @@ int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int 
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
 
-/* Diagnostic: the 256x256 layer GEMM in isolation on every CU (mode 0: MFMAs only, 1: + LDS fragment reads,
- * 2: + LDS-DMA ring and barriers = the production segment), `iters` layer-equivalents per wave; returns the
- * kernel time in ms.  Used to attribute MFMA-rate losses. */
+/* Diagnostic: the 256x256 layer GEMM in isolation on every CU, `iters` layer-equivalents per wave; returns ms.
+ * mode 0: MFMAs only, 1: + LDS fragment reads, 2: + LDS-DMA ring and barriers = the production x32 segment,
+ * 3: the x16 segment with two workgroups per CU (ms = kernel time).  Modes 4..8: the x16 segment in the first
+ * workgroup of every CU while the second one runs nothing / a dense fp32 VALU chain / sin-cos / an LDS pointer
+ * chase / an fp64 chain (ms = mean duration of the GEMM workgroups; NSR_PROBE_VERBOSE=1 prints the partner's
+ * loop rate, NSR_PROBE_PARTNER_PRIO=1 raises its priority).  Used to attribute MFMA-rate losses. */
 int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream);
 
 /* Timing helper for bench.py: HIP-event time in ms of the last nsr_render_* launch on this handle

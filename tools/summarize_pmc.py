@@ -1,0 +1,50 @@
+"""gpurun_out/prof (tools/collect_profiles.sh) -> profiles/<round>/pmc_k_render.json + kernel stats + bench line.
+    python tools/summarize_pmc.py r01"""
+import csv, glob, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
+os.makedirs(dst, exist_ok=True)
+out = {}
+for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_render(")):
+    tot, disp, ns = {}, {}, None
+    for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
+        if not os.path.isdir(d):
+            continue
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if kname in r["Kernel_Name"]:
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    disp = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
+        for f in glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")):
+            for r in csv.DictReader(open(f)):
+                if kname in r["Kernel_Name"]:
+                    ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    if not tot:
+        continue
+    n_simd = 256 * 4
+    der = {}
+    if "GRBM_GUI_ACTIVE" in tot and ns:
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs of the dispatch
+        der["clock_GHz"] = tot["GRBM_GUI_ACTIVE"] / 8 / ns
+        der["mfma_busy_frac"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (n_simd * tot["GRBM_GUI_ACTIVE"] / 8)
+    if "SQ_WAVE_CYCLES" in tot:
+        der["wait_any_frac_of_wave_cycles"] = tot.get("SQ_WAIT_ANY", 0) / tot["SQ_WAVE_CYCLES"]
+        der["wait_inst_frac"] = tot.get("SQ_WAIT_INST_ANY", 0) / tot["SQ_WAVE_CYCLES"]
+    if "SQ_INSTS_VALU" in tot and "SQ_INSTS_MFMA" in tot:
+        der["valu_insts_per_mfma_inst"] = (tot["SQ_INSTS_VALU"] - tot["SQ_INSTS_MFMA"]) / tot["SQ_INSTS_MFMA"]
+    if "SQ_LDS_IDX_ACTIVE" in tot:
+        der["lds_bank_conflict_frac_of_lds_active"] = tot.get("SQ_LDS_BANK_CONFLICT", 0) / tot["SQ_LDS_IDX_ACTIVE"]
+    if "FETCH_SIZE" in tot:
+        der["hbm_traffic_bytes_per_launch"] = (2 * tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0)) * 1024
+    der["note"] = ("one 400x400x(64+128) view per launch; separate rocprofv3 --pmc passes with --kernel-trace only "
+                   "(tools/collect_profiles.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; counters summed over the XCDs")
+    out[key] = {"counters": tot, "dispatch": disp, "kernel_ns_under_pmc": ns, "derived": der}
+json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
+for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, "kernel_stats_bench_steps3.csv"))
+if os.path.exists(os.path.join(src, "bench.json")):
+    lines = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
+    if lines:
+        open(os.path.join(dst, "bench_final_kernel.json"), "w").write(lines[-1])
+print(json.dumps({k: v["derived"] for k, v in out.items()}, indent=1))
