@@ -130,14 +130,17 @@ __device__ __forceinline__ void ring_advance(Ring& rg, f32x4 (&A)[4], int lane) 
 __device__ __forceinline__ f32x16 mfma_op(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma_op(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <int NMO, int KK0, int KK1, int NACC, typename BOp, typename AccT>
+// ZERO: the accumulators start from 0 -- the first MFMA of every output block takes the inline constant 0 as its C
+// operand instead of a register block that 16 VALU writes per block would have to clear first.
+template <int NMO, int KK0, int KK1, bool ZERO = false, int NACC, typename BOp, typename AccT>
 __device__ __forceinline__ void consume(const f32x4 (&A)[4], int step, BOp bop, AccT (&acc)[NACC]) {
 #pragma unroll
   for (int kk = KK0; kk < KK1; ++kk)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int n = 4 * step + c, tq = n / NMO, mo = n % NMO;
-      acc[mo] = mfma_op(A[c][kk], bop(4 * tq + kk), acc[mo]);
+      if (ZERO && tq == 0 && kk == 0) acc[mo] = mfma_op(A[c][kk], bop(4 * tq + kk), AccT{0});
+      else acc[mo] = mfma_op(A[c][kk], bop(4 * tq + kk), acc[mo]);
     }
 }
 
@@ -180,18 +183,18 @@ __device__ __forceinline__ void step_pattern_dma() {
   }
 }
 
-template <int NMO, int NTQ, int NS = kRingSlots, int NACC, typename BOp, typename AccT>
+template <int NMO, int NTQ, int NS = kRingSlots, bool ZERO = false, int NACC, typename BOp, typename AccT>
 __device__ __forceinline__ void seg(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], BOp bop, AccT (&acc)[NACC],
                                     int lane) {
   static_assert((NMO * NTQ) % 16 == 0, "a segment is a whole number of slabs");
 #pragma unroll
   for (int s = 0; s < NMO * NTQ / 4; s += 4) {
-    NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<NMO, 0, 4>(A0, s, bop, acc);     step_pattern<16>();
-    NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<NMO, 0, 4>(A1, s + 1, bop, acc); step_pattern<16>();
-    NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<NMO, 0, 4>(A0, s + 2, bop, acc); step_pattern<16>();
-    NSR_PIN(); consume<NMO, 0, 1>(A1, s + 3, bop, acc);
+    NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<NMO, 0, 4, ZERO>(A0, s, bop, acc);     step_pattern<16>();
+    NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<NMO, 0, 4, ZERO>(A1, s + 1, bop, acc); step_pattern<16>();
+    NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<NMO, 0, 4, ZERO>(A0, s + 2, bop, acc); step_pattern<16>();
+    NSR_PIN(); consume<NMO, 0, 1, ZERO>(A1, s + 3, bop, acc);
     NSR_PIN(); ring_advance<NS>(rg, A0, lane);      // counted wait + s_barrier, then the next slab's first loads
-    ring_issue<NS>(rg); consume<NMO, 1, 4>(A1, s + 3, bop, acc); step_pattern_dma<12>();
+    ring_issue<NS>(rg); consume<NMO, 1, 4, ZERO>(A1, s + 3, bop, acc); step_pattern_dma<12>();
     NSR_PIN();
   }
 }
@@ -864,9 +867,7 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
   }
   // views^T: 256 feature rows (blocks 0-7) + 32 direction-encoding rows (block 8), K = 128
   f32x16 accv[9];
-#pragma unroll
-  for (int mo = 0; mo < 9; ++mo) accv[mo] = f32x16{0};
-  seg<9, 16>(rg, A0, A1, BRegs16<4>{gv}, accv, lane);
+  seg<9, 16, kRingSlots, true>(rg, A0, A1, BRegs16<4>{gv}, accv, lane);
   {
     float Gd[16];
 #pragma unroll
@@ -882,26 +883,23 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
   f32x16 acc[10];   // 0-7: gradient w.r.t. the 256 hidden features; 8-9: gradient w.r.t. the 64 encoding registers
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) gin[mo] = accv[mo];          // feature_linear has no activation
-  acc[8] = f32x16{0};
-  acc[9] = f32x16{0};
-  // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (10 blocks), 4..7 L4^T..L1^T
+  // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (10 blocks: first use of acc[8..9]), 4..7 L4^T..L1^T
 #pragma unroll 1
   for (int idx = 0; idx < 8; ++idx) {
     const uint4 mk = mask_src[(7 - idx) * 256];              // relu pattern of the layer this GEMM feeds back to
+    if (idx == 3) seg<10, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+    else seg<8, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
     if (idx == 0) {
       const float* wa = aux + kAuxWAlpha;                    // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
 #pragma unroll
       for (int tq = 0; tq < 32; ++tq) {
         const f32x4 w = *(const f32x4*)(wa + (tq * 2 + h) * 4);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc[(4 * tq + kk) >> 4][(4 * tq + kk) & 15] = w[kk] * gs;
+        for (int kk = 0; kk < 4; ++kk)
+          acc[(4 * tq + kk) >> 4][(4 * tq + kk) & 15] =
+              __builtin_fmaf(w[kk], gs, acc[(4 * tq + kk) >> 4][(4 * tq + kk) & 15]);
       }
-    } else {
-#pragma unroll
-      for (int mo = 0; mo < 8; ++mo) acc[mo] = f32x16{0};
     }
-    if (idx == 3) seg<10, 32>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
-    else seg<8, 32>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
     const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
     for (int mo = 0; mo < 8; ++mo) gin[mo] = apply_mask(acc[mo], mw[mo >> 1], (mo & 1) * 16);
