@@ -14,9 +14,10 @@ are all-gathered over RCCL once, at the outer-loop boundary, inside the timed re
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     -- dominant kernel nsr::k_render16: algorithmic FLOP per launch / HIP-event kernel time, against
                   the fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
-  cpu_baseline -- the oracle (CPU numpy restatement of the reference path, "port") timed on this host's cores
-                  on a bounded sample (a 64x64 view of the same scene: same per-ray work), rank 0, N=1 only;
-  parity       -- PSNR / max-abs of the GPU render vs the oracle on that sample.
+  cpu_baseline -- the oracle (CPU restatement of the reference path, "port") timed on this host's cores on a
+                  bounded sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
+  parity       -- PSNR / max-abs of the GPU render vs the oracle on that sample, and the exact-match rate of
+                  the resampling indices.
 """
 import argparse
 import json
@@ -70,9 +71,21 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
     ref = run(side)
     dt = time.perf_counter() - t0
     O.set_backend("numpy")
-    got = model.render_views(c2w, side, side, S.scaled_K(400.0 / side), S.YCBV_NEAR, S.YCBV_FAR)
+    got = model.render_views(c2w, side, side, S.scaled_K(400.0 / side), S.YCBV_NEAR, S.YCBV_FAR, debug=True)
     rgb = got["rgb_map"].cpu().numpy().reshape(side, side, 3)
     rgb0 = got["rgb0"].cpu().numpy().reshape(side, side, 3)
+    # resampling indices (the bit-exact quantity): the oracle's sample_pdf on the kernel's own coarse weights
+    n = side * side
+    z = O.coarse_z(np.full(n, S.YCBV_NEAR, np.float32), np.full(n, S.YCBV_FAR, np.float32))
+    zs, inds, _ = O.sample_pdf((np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32),
+                               got["weights0"].cpu().numpy()[:, 1:-1])
+    inds_match = float((got["inds"].cpu().numpy() == inds).mean())
+    zs_match = float((got["z_samples"].cpu().numpy() == zs).mean())
+
+    def maxabs(key, shape):
+        a, b = got[key].cpu().numpy().reshape(shape), ref[key].reshape(shape)
+        with np.errstate(invalid="ignore"):
+            return float(np.nanmax(np.abs(a - b)))
     # PSNR delta against a pseudo ground truth T = oracle + N(0, 0.01^2)
     T = ref["rgb_map"] + np.random.RandomState(0).normal(0, 0.01, ref["rgb_map"].shape).astype(np.float32)
     cpu = {"value": round(side * side * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
@@ -83,7 +96,11 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
            "psnr_delta_db": round(abs(O.psnr(rgb, T) - O.psnr(ref["rgb_map"], T)), 4),
            "max_abs_rgb_coarse": float(np.abs(rgb0 - ref["rgb0"]).max()),
            "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
-           "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()), "sample": "%dx%d view" % (side, side)}
+           "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()),
+           "max_abs_acc": maxabs("acc_map", (side, side)), "max_abs_disp": maxabs("disp_map", (side, side)),
+           "max_abs_z_std": maxabs("z_std", (side, side)),
+           "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
+           "sample": "%dx%d view; indices/samples: oracle sample_pdf on the kernel's own coarse weights" % (side, side)}
     return cpu, par
 
 
@@ -164,7 +181,7 @@ def main():
                                    "persistent kernel (x16: 2 workgroups per CU), rays generated in-kernel",
                        "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
                        "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
-            "rays_per_s": round(rays / dt, 1),
+            "rays_per_s": round(rays / dt, 1), "mlp_evals_per_s": round(rays * EVALS_PER_RAY / dt, 1),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes "

@@ -222,6 +222,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
 
 int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                     float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
+  if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!d_rays_o || !d_rays_d) return fail("nsr_render_rays: null rays");
   if (n_rays < 0) return fail("nsr_render_rays: negative ray count");
   nsr::RenderArgs a;
@@ -232,6 +233,7 @@ int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, 
 
 int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9, float near_,
                      float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
+  if (h && n_views == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!d_c2w || !K9) return fail("nsr_render_views: null argument");
   if (n_views < 0 || H <= 0 || W <= 0) return fail("nsr_render_views: bad image geometry");
   nsr::RenderArgs a;
@@ -245,6 +247,7 @@ int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W
 int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                         float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
                         const NsrRenderOut* out, void* stream) {
+  if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h) return fail("nsr_render_rays_vjp: null handle");
   if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
   if (int e = check_ready(h, true)) return e;
@@ -307,6 +310,7 @@ int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K
 }
 
 int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* stream) {
+  if (h && n == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_x || !d_out) return fail("nsr_to8b: null argument");
   if (n <= 0) return n == 0 ? 0 : fail("nsr_to8b: negative element count");
   NSR_HIP(hipSetDevice(h->cfg.device));
@@ -319,6 +323,7 @@ int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* st
 
 int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int W, int32_t* d_bbox,
                   int32_t* d_count, uint8_t* d_mask, void* stream) {
+  if (h && n_images == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_rgb8 || !d_bbox || !d_count) return fail("nsr_find_bbox: null argument");
   if (H <= 0 || W <= 0 || (long long)H * W > (1 << 20)) return fail("nsr_find_bbox: image must have 1..2^20 pixels");
   if (n_images <= 0) return n_images == 0 ? 0 : fail("nsr_find_bbox: negative image count");
@@ -355,6 +360,7 @@ int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int 
 }
 
 int nsr_embed(nsr_handle h, const float* d_x, int64_t n, int multires, float* d_out, void* stream) {
+  if (h && n == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_x || !d_out) return fail("nsr_embed: null argument");
   if (multires < 1 || multires > 16) return fail("nsr_embed: multires in 1..16");
   if (n <= 0) return n == 0 ? 0 : fail("nsr_embed: negative point count");
@@ -368,6 +374,7 @@ int nsr_embed(nsr_handle h, const float* d_x, int64_t n, int multires, float* d_
 
 int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts,
                     float* d_raw, void* stream) {
+  if (h && n_pts == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_pts || !d_viewdirs || !d_raw) return fail("nsr_run_network: null argument");
   if (net_id < 0 || net_id > 1 || !h->have_net[net_id]) return fail("nsr_run_network: network not uploaded");
   if (n_pts <= 0) return n_pts == 0 ? 0 : fail("nsr_run_network: negative point count");
@@ -385,6 +392,7 @@ int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d
 int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const float* d_rays_d, int64_t n_rays,
                     int n_samples, float* d_rgb, float* d_disp, float* d_acc, float* d_weights, float* d_depth,
                     void* stream) {
+  if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_raw || !d_z || !d_rays_d || !d_rgb || !d_disp || !d_acc || !d_weights || !d_depth)
     return fail("nsr_raw2outputs: null argument");
   if (n_samples != 64 && n_samples != 192) return fail("nsr_raw2outputs: n_samples must be 64 or 192");
@@ -403,6 +411,7 @@ int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const fl
 
 int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, int64_t n_rays, float* d_samples,
                    int64_t* d_inds, void* stream) {
+  if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_bins || !d_weights || !d_samples) return fail("nsr_sample_pdf: null argument");
   if (!h->have_tables) return fail("nsr_sample_pdf: tables not uploaded");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_sample_pdf: negative ray count");
