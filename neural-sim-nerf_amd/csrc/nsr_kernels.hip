@@ -239,11 +239,18 @@ __device__ __forceinline__ void load_bias(const float* bias, int h, f32x16 (&acc
 // relu pattern of one layer output (lane-private C fragment) as a bit mask: bit (mo&1)*16 + r of word mo>>1
 template <int NMO>
 __device__ __forceinline__ uint4 relu_mask(const f32x16 (&acc)[NMO]) {
+  // One v_alignbit per element shifts a sign bit into the word: element e = 16 (mo & 1) + r of word mo >> 1 ends
+  // up at bit 31 - e, SET when the unit is OFF (x <= +0).  The sign comes from max(int(x), 0) - 1, which is -1
+  // exactly for the units relu zeroes (negative floats, -0 and +0 have integer patterns <= 0) -- the same
+  // predicate as torch's relu' (x > 0), without a compare + select + shift + or per element.
   unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int mo = 0; mo < NMO; ++mo)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) w[mo >> 1] |= (acc[mo][r] > 0.0f ? 1u : 0u) << ((mo & 1) * 16 + r);
+    for (int r = 0; r < 16; ++r) {
+      const int on = max(__float_as_int(acc[mo][r]), 0) - 1;
+      w[mo >> 1] = __builtin_amdgcn_alignbit(w[mo >> 1], (unsigned)on, 31);
+    }
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -819,7 +826,8 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
 __device__ __forceinline__ f32x16 apply_mask(f32x16 x, unsigned word, int shift) {
   f32x16 r;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) r[i] = ((word >> (shift + i)) & 1u) ? x[i] : 0.0f;
+  for (int i = 0; i < 16; ++i)                        // bit 31 - (shift + i) set = unit off (relu_mask)
+    r[i] = ((word >> (31 - (shift + i))) & 1u) ? 0.0f : x[i];
   return r;
 }
 
@@ -861,7 +869,7 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
         for (int ri = 0; ri < 4; ++ri) {
           const float v = __builtin_fmaf(w2[ri], g2, __builtin_fmaf(w1[ri], g1, w0[ri] * g0));
           const int r = rq * 4 + ri;
-          gv[mo][r] = ((mw[mo >> 1] >> ((mo & 1) * 16 + r)) & 1u) ? v : 0.0f;
+          gv[mo][r] = ((mw[mo >> 1] >> (31 - ((mo & 1) * 16 + r))) & 1u) ? 0.0f : v;     // set bit = unit off
         }
       }
   }
