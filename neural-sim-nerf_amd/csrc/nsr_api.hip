@@ -52,6 +52,8 @@ struct nsr_handle_s {
   nsr::VjpArgs* d_vjp_args = nullptr;
   uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [grid][3][9][256]
   int mask_grid = 0;
+  float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk
+  int zf_grid = 0, zf_chunk = 0;
   int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images
   size_t box_scratch_ints = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -113,6 +115,7 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_vjp_args);
   hipFree(h->d_mask_scratch);
   hipFree(h->d_box_scratch);
+  hipFree(h->d_zf_scratch);
   hipEventDestroy(h->ev0);
   hipEventDestroy(h->ev1);
   delete h;
@@ -202,6 +205,23 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   a.dbg_raw0 = dbg ? dbg->d_raw0 : nullptr;
   a.dbg_raw = dbg ? dbg->d_raw : nullptr;
   a.dbg_inds = dbg ? (long long*)dbg->d_inds : nullptr;
+  if (x16) {
+    long long g = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;
+    if (g > a.n_rays) g = a.n_rays;
+    // rays per workgroup per phase (see k_render16): large enough that a phase streams one network for a long
+    // time, small enough that the z scratch of an XCD's workgroups stays in its L2 next to that network
+    int chunk = 16;
+    if (const char* e = getenv("NSR_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= 256) chunk = v; }
+    if (g > h->zf_grid || chunk > h->zf_chunk) {
+      if (h->d_zf_scratch) { NSR_HIP(hipDeviceSynchronize()); NSR_HIP(hipFree(h->d_zf_scratch)); }
+      h->d_zf_scratch = nullptr;
+      const int ng = g > h->zf_grid ? (int)g : h->zf_grid, nc = chunk > h->zf_chunk ? chunk : h->zf_chunk;
+      NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * (size_t)ng * nc));
+      h->zf_grid = ng; h->zf_chunk = nc;
+    }
+    a.zf_scratch = h->d_zf_scratch;
+    a.chunk = chunk;
+  }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);
   NSR_HIP(hipEventRecord(h->ev0, s));

@@ -29,6 +29,8 @@ namespace nsr {
 // ------------------------------------------------------------------------------------------------------
 // ring (LDS weight stream)
 // ------------------------------------------------------------------------------------------------------
+constexpr int kRing16 = 3;          // ring slots of the x16 kernels (k_render16); also selects their chunked producer
+
 struct Ring {
   char* smem;            // LDS base (generic pointer)
   const char* base;      // packed networks (global), consecutive at `stride` bytes: coarse | fine | fine^T (backward)
@@ -41,6 +43,8 @@ struct Ring {
   int ppi;               // passes per item: 1 (coarse only), 4 (coarse + 3 fine) or 7 (+ 3 backward)
   int cslot;             // consumer: slot of the slab being consumed
   int pnet_off;          // producer: byte offset of the current net within `base` (buffer-descriptor form)
+  int pn0, pn1;          // producer: passes [0,pn0) of a cycle stream net 0, [pn0,pn1) net 1, the rest net 2
+  int pk, pmul, prem;    // chunked schedule (x16): rays per chunk, passes per ray (1 or 4), rays not yet scheduled
   __amdgpu_buffer_rsrc_t rsrc;
 };
 
@@ -53,6 +57,8 @@ __device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base
   rg.wave_lds = wave * 4096;
   rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.pnet_off = 0;
   rg.ppi = ppi;
+  rg.pn0 = 1; rg.pn1 = 4;            // coarse pass, 3 fine passes, then (ppi = 7) 3 backward passes
+  rg.pk = 0; rg.pmul = 0; rg.prem = 0;
   rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
 
@@ -76,9 +82,22 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   const int nslab = rg.pslab + 1;
   const bool wrap = nslab == kStreamSlabs;
   rg.pslab = wrap ? 0 : nslab;
+  const bool cyc = wrap && (rg.pphase + 1 == rg.ppi);
   const int nphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
   rg.pphase = wrap ? nphase : rg.pphase;
-  const int net = rg.pphase == 0 ? 0 : (rg.pphase <= 3 ? 1 : 2);   // arithmetic, not a pointer table: keeps Ring in SGPRs
+  if (NS == kRing16) {
+    // chunked schedule (k_render16): a cycle is pk coarse passes followed by 3 pk fine passes; when a cycle ends
+    // the next chunk's size takes effect (the last chunk of a workgroup may be short; past the end the producer
+    // keeps the old shape and its prefetches are simply never consumed)
+    const int nk = rg.prem < rg.pk ? rg.prem : rg.pk;
+    const bool sel = cyc && nk > 0;
+    rg.pn0 = sel ? nk : rg.pn0;
+    rg.pn1 = sel ? nk * rg.pmul : rg.pn1;
+    rg.ppi = sel ? nk * rg.pmul : rg.ppi;
+    rg.prem = sel ? rg.prem - nk : rg.prem;
+  }
+  // arithmetic, not a pointer table: keeps Ring in SGPRs
+  const int net = rg.pphase < rg.pn0 ? 0 : (rg.pphase < rg.pn1 ? 1 : 2);
   rg.pnet_off = net * (int)rg.stride;
 }
 
@@ -626,6 +645,8 @@ struct RenderArgs {
   float *rgb, *disp, *acc, *rgb0, *disp0, *acc0, *z_std;
   float *dbg_w0, *dbg_zs, *dbg_zf, *dbg_raw0, *dbg_raw;
   long long* dbg_inds;
+  float* zf_scratch;        // k_render16: [grid][chunk][192] sorted fine z values between the two phases of a chunk
+  int chunk;                // k_render16: rays per workgroup per phase
 };
 
 __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
@@ -1198,7 +1219,6 @@ __global__ void __launch_bounds__(256) k_pose_grad(const float* __restrict__ go,
 // (no K permutation: register (block mo, r) of lane group g holds feature 16*mo + 4*g + r, which is what k-step
 // 4*mo + r reads in group g; biases and heads in natural order).
 // ------------------------------------------------------------------------------------------------------
-constexpr int kRing16 = 3;
 constexpr int kAux16Floats = 3080;                                     // 3076 used, 16-byte multiple
 constexpr int kLds16Aux = kRing16 * kSlabBytes;                        // 49152
 constexpr int kLds16State = kLds16Aux + 2 * kAux16Floats * 4;          // 73792
@@ -1316,6 +1336,11 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
   }
 }
 
+// Schedule: a workgroup owns rays b, b+G, b+2G, ...; it processes them in chunks of `chunk` rays, and inside a
+// chunk in two phases: (A) the coarse pass + compositing + resampling + sort of every ray of the chunk (the 192
+// sorted z values go to a small global scratch, 768 B per ray), then (B) the three fine passes + compositing of
+// the same rays.  All workgroups start together and every ray costs the same, so at any time the whole GPU streams
+// ONE network: 2.3 MiB against the 4 MiB L2 of an XCD, instead of both networks (4.6 MiB) thrashing it.
 __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RenderArgs& a = *ap;
@@ -1332,9 +1357,19 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   const long long n_items = a.n_rays;
   if ((long long)blockIdx.x >= n_items) return;
   const int fine = a.fine;
+  const long long grid = gridDim.x;
+  const long long my_count = (n_items - blockIdx.x + grid - 1) / grid;      // rays of this workgroup
+  const int K = a.chunk;
+  float* zscr = a.zf_scratch + (size_t)blockIdx.x * K * 192;
 
   Ring rg;
-  ring_init(rg, smem, a.nets, a.net_stride, fine ? 4 : 1, wave, lane);
+  ring_init(rg, smem, a.nets, a.net_stride, 1, wave, lane);
+  {
+    const int k0 = my_count < K ? (int)my_count : K;
+    rg.pk = K; rg.pmul = fine ? 4 : 1;
+    rg.pn0 = k0; rg.pn1 = k0 * rg.pmul; rg.ppi = rg.pn1;
+    rg.prem = (int)(my_count - k0);
+  }
   f32x4 A0[4], A1[4];
   ring_start<kRing16>(rg, A0, lane);
   {
@@ -1347,12 +1382,14 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLds16Aux);
 
-  long long item = blockIdx.x;
-  int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current ray
+  long long c0 = 0;                                        // local index of the chunk's first ray
+  int kc = my_count < K ? (int)my_count : K;               // rays in the current chunk
+  int jr = 0;                                              // ray within the chunk
+  int pass = 0;                                            // 0 = coarse pass (phase A), 1..3 = fine passes (phase B)
 #pragma unroll 1
-  while (item < n_items) {
-    const long long rr = item;
-    if (pass == 0) {
+  while (c0 < my_count) {
+    const long long rr = blockIdx.x + (c0 + jr) * grid;
+    if (pass <= 1) {                                       // a new ray enters the workgroup state
       const float near_ = a.near_, far_ = a.far_;
       if (tid == 0) {
         float o[3], d[3];
@@ -1370,9 +1407,14 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
         for (int c = 0; c < 3; ++c) { st.ray[0][c] = o[c]; st.ray[0][3 + c] = d[c]; st.ray[0][6 + c] = d[c] / nrm; }
         st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
       }
-      if (tid < 64) {
-        const float t = a.tcoarse[tid];
-        st.zc[0][tid] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
+      if (pass == 0) {
+        if (tid < 64) {
+          const float t = a.tcoarse[tid];
+          st.zc[0][tid] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
+        }
+      } else if (tid < 192) {                              // phase B: the sorted z values phase A left for this ray
+        st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)zscr + jr * 192 + tid, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT));
       }
       __syncthreads();
       NSR_T(0);
@@ -1408,26 +1450,38 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
         else if (c == 4) { if (acc_dst) acc_dst[rr] = v; }
       }
       if (a.dbg_w0 && tid < 64) a.dbg_w0[rr * 64 + tid] = st.w0[0][tid];
-      if (!fine) { __syncthreads(); item += gridDim.x; continue; }
-      NSR_T(2);
+      if (fine) {
+        NSR_T(2);
 #ifdef NSR_PHASE_TIMING
-      int64_t* inds = nullptr;                 // dbg_inds carries the cycle totals in this build
+        int64_t* inds = nullptr;                 // dbg_inds carries the cycle totals in this build
 #else
-      int64_t* inds = (int64_t*)a.dbg_inds;
+        int64_t* inds = (int64_t*)a.dbg_inds;
 #endif
-      sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
-                         [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
-                         inds ? inds + rr * 128 : nullptr, 128, tid, 1);
-      if (wave == 0) {
-        const float sd = zstd_wave(st, 0, lane);
-        if (lane == 0 && a.z_std) a.z_std[rr] = sd;
+        sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
+                           [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
+                           inds ? inds + rr * 128 : nullptr, 128, tid, 1);
+        if (wave == 0) {
+          const float sd = zstd_wave(st, 0, lane);
+          if (lane == 0 && a.z_std) a.z_std[rr] = sd;
+        }
+        if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
+        NSR_T(3);
+        merge_sort_item<1>(st, tid);
+        if (tid < 192) {
+          const float zv = st.zf[0][tid];
+          __hip_atomic_store((unsigned*)zscr + jr * 192 + tid, __float_as_uint(zv), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          if (a.dbg_zf) a.dbg_zf[rr * 192 + tid] = zv;
+        }
+        NSR_T(5);
       }
-      if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
-      NSR_T(3);
-      merge_sort_item<1>(st, tid);
-      if (a.dbg_zf && tid < 192) a.dbg_zf[rr * 192 + tid] = st.zf[0][tid];
-      NSR_T(5);
-      pass = 1;
+      __syncthreads();
+      ++jr;
+      if (jr == kc) {                                      // phase A of the chunk is done
+        jr = 0;
+        if (fine) pass = 1;
+        else { c0 += kc; kc = (my_count - c0) < K ? (int)(my_count - c0) : K; }
+      }
     } else if (pass < 3) {
       ++pass;
     } else {
@@ -1446,8 +1500,13 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
       }
       __syncthreads();
       NSR_T(6);
-      pass = 0;
-      item += gridDim.x;
+      pass = 1;
+      ++jr;
+      if (jr == kc) {                                      // phase B of the chunk is done: next chunk
+        jr = 0; pass = 0;
+        c0 += kc;
+        kc = (my_count - c0) < K ? (int)(my_count - c0) : K;
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup

@@ -11,12 +11,13 @@ for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
         if not os.path.isdir(d):
             continue
-        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        newest = lambda pat: sorted(glob.glob(os.path.join(d, "*", pat)), key=os.path.getmtime)[-1:]   # gpurun merges runs
+        for f in newest("*_counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if kname in r["Kernel_Name"]:
                     tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     disp = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
-        for f in glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")):
+        for f in newest("*_kernel_trace.csv"):
             for r in csv.DictReader(open(f)):
                 if kname in r["Kernel_Name"]:
                     ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -41,7 +42,7 @@ for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_
                    "(tools/collect_profiles.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; counters summed over the XCDs")
     out[key] = {"counters": tot, "dispatch": disp, "kernel_ns_under_pmc": ns, "derived": der}
 json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
-for f in glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")):
+for f in sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
     shutil.copy(f, os.path.join(dst, "kernel_stats_bench_steps3.csv"))
 if os.path.exists(os.path.join(src, "bench.json")):
     lines = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
