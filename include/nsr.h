@@ -151,6 +151,12 @@ int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const fl
 int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, int64_t n_rays,
                    float* d_samples, int64_t* d_inds, void* stream);
 
+/* z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1) (RN:477): d_z_coarse [N,64], d_z_samples [N,128]
+ * -> d_z_sorted [N,192].  Exact for any input (a merge when both halves are already ordered, a full rank count
+ * otherwise). */
+int nsr_sort_merge(nsr_handle h, const float* d_z_coarse, const float* d_z_samples, int64_t n_rays,
+                   float* d_z_sorted, void* stream);
+
 /* Image hand-off to the detector's loader without the PNG round trip.
  * nsr_to8b: to8b (RH:14) = (255 * clip(x, 0, 1)).astype(uint8) over n floats (truncation; NaN -> 0).
  * nsr_find_bbox: what get_annotation / find_bbox (NM:786-797) derive from the PNG read back with cv2, for

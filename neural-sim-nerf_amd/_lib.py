@@ -55,6 +55,7 @@ SIGNATURES = {
     "nsr_raw2outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsr_sort_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsr_selftest": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nsr_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "nsr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -444,6 +444,20 @@ int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, in
   return 0;
 }
 
+int nsr_sort_merge(nsr_handle h, const float* d_z_coarse, const float* d_z_samples, int64_t n_rays, float* d_z_sorted,
+                   void* stream) {
+  if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
+  if (!h || !d_z_coarse || !d_z_samples || !d_z_sorted) return fail("nsr_sort_merge: null argument");
+  if (n_rays < 0) return fail("nsr_sort_merge: negative ray count");
+  NSR_HIP(hipSetDevice(h->cfg.device));
+  const long long items = (n_rays + 1) / 2;
+  const int grid = (int)(items < 4096 ? items : 4096);
+  hipLaunchKernelGGL(nsr::k_sort_merge, dim3(grid), dim3(256), sizeof(nsr::ItemState), (hipStream_t)stream,
+                     d_z_coarse, d_z_samples, (long long)n_rays, d_z_sorted);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
 int nsr_selftest(nsr_handle h, void* stream) {
   if (!h) return fail("nsr_selftest: null handle");
   NSR_HIP(hipSetDevice(h->cfg.device));

@@ -243,6 +243,18 @@ class NsrModel:
                                            _stream_ptr(self.device)))
         return samples, inds
 
+    def sort_merge(self, z_coarse, z_samples):
+        """torch.sort(torch.cat([z_vals, z_samples], -1), -1) values (RN:477): [N,64] + [N,128] -> [N,192]."""
+        z_coarse = self._f32(z_coarse)
+        n = z_coarse.shape[0]
+        z_samples = self._f32(z_samples, (n, 128))
+        if z_coarse.shape[1] != 64:
+            raise NotImplementedError("sort_merge is specialised to 64 + 128 samples")
+        out = self._new(n, 192)
+        _lib.check(self.lib.nsr_sort_merge(self.h, _dev(z_coarse), _dev(z_samples), n, _dev(out),
+                                           _stream_ptr(self.device)))
+        return out
+
     def selftest(self):
         _lib.check(self.lib.nsr_selftest(self.h, _stream_ptr(self.device)))
 

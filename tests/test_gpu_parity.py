@@ -186,6 +186,26 @@ def test_render_rays_odd_and_single(model, oracle, synth_nets):
             assert np.array_equal(cpu(r[k]), cpu(full[k])[:n], equal_nan=True), (k, n)   # chunk-invariant (RN:67-68)
 
 
+def test_sort_merge_both_paths(model):
+    """RN:477 as a stage: ordered inputs take the merge path, anything else the rank count; both must equal a
+    sort of the concatenation bit for bit (ties, duplicates across the halves, inversions, descending input)."""
+    rng = np.random.RandomState(9)
+    n = 301
+    zc = np.sort(rng.uniform(0.3, 1.9, (n, 64)).astype(np.float32), -1)
+    zs = np.sort(rng.uniform(0.3, 1.9, (n, 128)).astype(np.float32), -1)
+    zs[1, 10:40] = zs[1, 10]                       # run of equal samples
+    zs[2, :64] = zc[2]                             # every coarse value duplicated in the samples
+    zc[3] = zc[3, 0]; zs[3] = zc[3, 0]             # everything equal
+    zs[4, 50], zs[4, 51] = zs[4, 51], zs[4, 50]    # a one-position inversion -> rank-count path
+    zs[5] = zs[5, ::-1]                            # descending samples
+    zc[6] = zc[6, ::-1]                            # descending coarse values (near > far)
+    zs[7] = rng.permutation(zs[7])                 # arbitrary order
+    zs[8, :] = np.float32(0.1); zc[8, :] = np.float32(5.0)      # all samples before all coarse values
+    got = cpu(model.sort_merge(zc, zs))
+    want = np.sort(np.concatenate([zc, zs], -1), -1)
+    assert np.array_equal(got, want)
+
+
 def test_empty_inputs(model):
     """Zero rays / points / images are valid calls that return empty tensors (the reference's ops accept them)."""
     import torch
