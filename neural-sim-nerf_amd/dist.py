@@ -61,6 +61,13 @@ def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, 
     return rgbs, disps
 
 
+def gather_handoff(ann, n_total, group=None):
+    """The in-memory hand-off (handoff.annotate / render_path_inmemory) of this rank's views -> the same dict for all
+    n_total views in pose order on every rank: uint8 images (0.48 MB per 400x400 view instead of 1.92 MB fp32),
+    boxes, row counts and, if present, masks."""
+    return {k: gather_views(v, n_total, group) for k, v in ann.items()}
+
+
 def mean_psi_grad(local_dLdpsis, group=None):
     """torch.mean(torch.stack(dLdpsis), 0) (NM:191) when the per-patch gradients are spread over ranks:
     all-reduce(sum) of [sum of local [n_cat] vectors | local count]."""

@@ -41,6 +41,16 @@ def _worker(rank, world, port, n_views, tmp, q):
     rgbs, disps = D.render_path_distributed(_fake_render, poses, savedir=tmp, object_id=7)
     want_rgb, want_disp = _fake_render(poses)
     ok = np.array_equal(rgbs, want_rgb.numpy()) and np.array_equal(disps, want_disp.numpy())
+    # in-memory hand-off (uint8 images + int32 boxes) gathered in pose order
+    mine = D.shard_indices(n_views, world, rank)
+    ann = {"images": torch.stack([torch.full((4, 5, 3), i, dtype=torch.uint8) for i in mine]) if mine else
+           torch.zeros((0, 4, 5, 3), dtype=torch.uint8),
+           "bbox": torch.tensor([[i, i + 1, i + 2, i + 3] for i in mine], dtype=torch.int32).reshape(-1, 4),
+           "count": torch.tensor([i + 1 for i in mine], dtype=torch.int32)}
+    allv = D.gather_handoff(ann, n_views)
+    ok = ok and allv["images"].dtype == torch.uint8 and allv["bbox"].dtype == torch.int32
+    ok = ok and all(int(allv["images"][i, 0, 0, 0]) == i and allv["bbox"][i].tolist() == [i, i + 1, i + 2, i + 3]
+                    and int(allv["count"][i]) == i + 1 for i in range(n_views))
     local = [torch.full((8,), float(i)) for i in D.shard_indices(n_views, world, rank)]   # "patch gradients"
     g = D.mean_psi_grad(local)
     ok = ok and torch.allclose(g, torch.full((8,), (n_views - 1) / 2.0))

@@ -95,6 +95,24 @@ def test_oracle_selection_rules():
     assert HO.get_annotation(empty)[:2] == (None, 0)
 
 
+def test_dataset_dicts_records():
+    """Host logic of the hand-off: the detectron2-style records built from an annotation dict (no GPU needed)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from neural_sim_nerf_amd import handoff
+    imgs = torch.arange(2 * 4 * 5 * 3, dtype=torch.uint8).reshape(2, 4, 5, 3)
+    ann = {"bbox": torch.tensor([[1, 0, 3, 2], [0, 1, 2, 2]], dtype=torch.int32), "count": torch.tensor([1, 3], dtype=torch.int32),
+           "mask": torch.zeros((2, 4, 5), dtype=torch.uint8)}
+    recs = handoff.dataset_dicts(imgs, ann, category_id=15, first_image_id=10)
+    assert [r["image_id"] for r in recs] == [10, 11] and recs[0]["height"] == 4 and recs[0]["width"] == 5
+    assert recs[1]["annotations"][0] == {"bbox": [0, 1, 2, 2], "bbox_mode": 1, "category_id": 15,
+                                         "segmentation_mask": recs[1]["annotations"][0]["segmentation_mask"]}
+    assert np.array_equal(recs[0]["image"], imgs[0].numpy()[..., ::-1])          # BGR, like read_image(format="BGR")
+    ann["count"][0] = 0
+    with pytest.raises(ValueError):                                                # the reference's np.argmax([]) error
+        handoff.dataset_dicts(imgs, ann, category_id=15)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # GPU: the product path against the oracle, bit-exact
 # ---------------------------------------------------------------------------------------------------------
