@@ -177,7 +177,9 @@ int nsr_selftest(nsr_handle h, void* stream);
  * 3: the x16 segment with two workgroups per CU (ms = kernel time).  Modes 4..8: the x16 segment in the first
  * workgroup of every CU while the second one runs nothing / a dense fp32 VALU chain / sin-cos / an LDS pointer
  * chase / an fp64 chain (ms = mean duration of the GEMM workgroups; NSR_PROBE_VERBOSE=1 prints the partner's
- * loop rate, NSR_PROBE_PARTNER_PRIO=1 raises its priority).  Used to attribute MFMA-rate losses. */
+ * loop rate, NSR_PROBE_PARTNER_PRIO=1 raises its priority).  Mode 10: the x32 layer followed by its relu + re-bias
+ * epilogue; mode 9: the two-tiles-per-wave 16x16x4 scheme with the epilogue of one tile interleaved into the other
+ * tile's MFMAs.  Used to attribute MFMA-rate losses. */
 int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream);
 
 /* Timing helper for bench.py: HIP-event time in ms of the last nsr_render_* launch on this handle

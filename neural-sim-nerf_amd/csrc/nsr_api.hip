@@ -485,7 +485,7 @@ int nsr_selftest(nsr_handle h, void* stream) {
 
 int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
   if (!h || !ms) return fail("nsr_probe: null argument");
-  if (mode < 0 || mode > 8 || iters <= 0) return fail("nsr_probe: mode in 0..8, iters > 0");
+  if (mode < 0 || mode > 10 || iters <= 0) return fail("nsr_probe: mode in 0..10, iters > 0");
   if (!h->have_net[0]) return fail("nsr_probe: upload a network first");
   NSR_HIP(hipSetDevice(h->cfg.device));
   hipStream_t s = (hipStream_t)stream;
@@ -503,8 +503,18 @@ int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe16, hipFuncAttributeMaxDynamicSharedMemorySize, nsr::kRing16 * nsr::kSlabBytes));
     hipLaunchKernelGGL(nsr::k_probe16, dim3(2 * h->n_cu), dim3(256), nsr::kRing16 * nsr::kSlabBytes, s, h->d_packed[0], out, iters);
   }
+  if (mode == 9 || mode == 10) {
+    const size_t l = nsr::kRingSlots * nsr::kSlabBytes + 1024;
+    if (mode == 9) {
+      NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe_epi<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+      hipLaunchKernelGGL(nsr::k_probe_epi<9>, dim3(h->n_cu), dim3(256), l, s, h->d_nets16, out, iters);
+    } else {
+      NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe_epi<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
+      hipLaunchKernelGGL(nsr::k_probe_epi<10>, dim3(h->n_cu), dim3(256), l, s, h->d_packed[0], out, iters);
+    }
+  }
   int* done = nullptr;
-  if (mode >= 4) {
+  if (mode >= 4 && mode <= 8) {
     NSR_HIP(hipMalloc(&done, sizeof(int)));
     NSR_HIP(hipMemsetAsync(done, 0, sizeof(int), s));
     const size_t l16 = nsr::kRing16 * nsr::kSlabBytes;
@@ -523,7 +533,7 @@ int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
   NSR_HIP(hipEventRecord(h->ev1, s));
   NSR_HIP(hipEventSynchronize(h->ev1));
   NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
-  if (mode >= 4) {        // mean duration of the GEMM workgroups (100 MHz ticks -> ms), not the whole kernel
+  if (mode >= 4 && mode <= 8) {        // mean duration of the GEMM workgroups (100 MHz ticks -> ms), not the whole kernel
     std::vector<float> host(2 * h->n_cu);
     NSR_HIP(hipMemcpy(host.data(), out, sizeof(float) * host.size(), hipMemcpyDeviceToHost));
     double sum = 0.0; int n = 0;

@@ -1712,6 +1712,116 @@ __global__ void __launch_bounds__(256, 2) k_probe16_pair(const float* __restrict
   }
 }
 
+// modes 9 / 10: can the layer epilogue (relu + re-bias) be hidden?  Mode 10 is the x32 layer as the kernels run it
+// (GEMM, then the epilogue).  Mode 9 is the "two 16-point tiles per wave" scheme: 16x16x4 MFMAs, the two tiles
+// share every weight fragment in the 14 middle slabs of a layer; in the last slab tile A runs ahead and its
+// epilogue is interleaved with tile B's MFMAs, in the first slab of the next layer tile B's epilogue is interleaved
+// with tile A's MFMAs.  Tiles are independent accumulator sets, so the epilogues are in place (no extra registers).
+template <int Q>
+__device__ __forceinline__ void epi_chunk(f32x4 (&acc)[16], f32x4 (&in)[16], const float* bias_g) {
+#pragma unroll
+  for (int mo = 4 * Q; mo < 4 * Q + 4; ++mo) {
+    in[mo] = clamp_bits4(acc[mo], 0);
+    acc[mo] = *(const f32x4*)(bias_g + 16 * mo);
+  }
+}
+
+__device__ __forceinline__ void layer16x2(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], f32x4 (&inA)[16], f32x4 (&inB)[16],
+                                          f32x4 (&accA)[16], f32x4 (&accB)[16], const float* bias_g, int lane) {
+  // slab 0: tile A, with tile B's epilogue of the previous layer
+  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 0, BRegs4<16>{inA}, accA); epi_chunk<0>(accB, inB, bias_g); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 1, BRegs4<16>{inA}, accA); epi_chunk<1>(accB, inB, bias_g); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 2, BRegs4<16>{inA}, accA); epi_chunk<2>(accB, inB, bias_g); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<0>(rg, A0, lane); consume<16, 0, 4>(A1, 3, BRegs4<16>{inA}, accA); epi_chunk<3>(accB, inB, bias_g); step_pattern<16>();
+  // slab 0: tile B
+  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 0, BRegs4<16>{inB}, accB); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 1, BRegs4<16>{inB}, accB); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 2, BRegs4<16>{inB}, accB); step_pattern<16>();
+  NSR_PIN(); consume<16, 0, 1>(A1, 3, BRegs4<16>{inB}, accB);
+  NSR_PIN(); ring_advance(rg, A0, lane);
+  ring_issue(rg); consume<16, 1, 4>(A1, 3, BRegs4<16>{inB}, accB); step_pattern_dma<12>();
+  // slabs 1..14: both tiles on every fragment
+#pragma unroll
+  for (int s = 4; s < 60; s += 4) {
+    NSR_PIN(); ring_load_quarter<1>(rg, A1, lane);
+    consume<16, 0, 4>(A0, s, BRegs4<16>{inA}, accA); consume<16, 0, 4>(A0, s, BRegs4<16>{inB}, accB); step_pattern<32>();
+    NSR_PIN(); ring_load_quarter<2>(rg, A0, lane);
+    consume<16, 0, 4>(A1, s + 1, BRegs4<16>{inA}, accA); consume<16, 0, 4>(A1, s + 1, BRegs4<16>{inB}, accB); step_pattern<32>();
+    NSR_PIN(); ring_load_quarter<3>(rg, A1, lane);
+    consume<16, 0, 4>(A0, s + 2, BRegs4<16>{inA}, accA); consume<16, 0, 4>(A0, s + 2, BRegs4<16>{inB}, accB); step_pattern<32>();
+    NSR_PIN(); consume<16, 0, 1>(A1, s + 3, BRegs4<16>{inA}, accA); consume<16, 0, 1>(A1, s + 3, BRegs4<16>{inB}, accB);
+    NSR_PIN(); ring_advance(rg, A0, lane);
+    ring_issue(rg);
+    consume<16, 1, 4>(A1, s + 3, BRegs4<16>{inA}, accA); consume<16, 1, 4>(A1, s + 3, BRegs4<16>{inB}, accB); step_pattern_dma<24>();
+  }
+  // slab 15: tile A
+  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 60, BRegs4<16>{inA}, accA); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 61, BRegs4<16>{inA}, accA); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 62, BRegs4<16>{inA}, accA); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<0>(rg, A0, lane); consume<16, 0, 4>(A1, 63, BRegs4<16>{inA}, accA); step_pattern<16>();
+  // slab 15: tile B, with tile A's epilogue
+  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 60, BRegs4<16>{inB}, accB); epi_chunk<0>(accA, inA, bias_g); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 61, BRegs4<16>{inB}, accB); epi_chunk<1>(accA, inA, bias_g); step_pattern<16>();
+  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 62, BRegs4<16>{inB}, accB); epi_chunk<2>(accA, inA, bias_g); step_pattern<16>();
+  NSR_PIN(); consume<16, 0, 1>(A1, 63, BRegs4<16>{inB}, accB);
+  NSR_PIN(); ring_advance(rg, A0, lane);
+  ring_issue(rg); consume<16, 1, 4>(A1, 63, BRegs4<16>{inB}, accB); epi_chunk<3>(accA, inA, bias_g); step_pattern_dma<12>();
+  NSR_PIN();
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256, 1) k_probe_epi(const float* __restrict__ stream, float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* bias = (float*)(smem + kRingSlots * kSlabBytes);
+  bias[tid] = -1e-3f * (float)(tid & 31);
+  Ring rg;
+  ring_init(rg, smem, stream, 0, 1, wave, lane);
+  f32x4 A0[4], A1[4];
+  ring_start(rg, A0, lane);
+  float sum = 0.0f;
+  if (MODE == 9) {
+    f32x4 inA[16], inB[16], accA[16], accB[16];
+#pragma unroll
+    for (int mo = 0; mo < 16; ++mo) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        inA[mo][r] = 1e-3f * (float)(lane + r + mo); inB[mo][r] = 2e-3f * (float)(lane + r + mo);
+        accA[mo][r] = 0.0f; accB[mo][r] = 0.0f;
+      }
+    }
+    const float* bias_g = bias + 4 * (lane >> 4);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) layer16x2(rg, A0, A1, inA, inB, accA, accB, bias_g, lane);
+#pragma unroll
+    for (int mo = 0; mo < 16; ++mo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sum += accA[mo][r] + accB[mo][r] + inA[mo][r] + inB[mo][r];
+  } else {
+    f32x16 in[8], acc[8];
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+      seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
+#pragma unroll
+      for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
+      load_bias<8>(bias, lane >> 5, acc);
+    }
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sum += acc[mo][r] + in[mo][r];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  out[blockIdx.x * 256 + tid] = sum;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // run_network (RN:26-40) as a stage kernel: 128 points per workgroup pass.
 // ------------------------------------------------------------------------------------------------------
