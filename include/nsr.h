@@ -53,8 +53,12 @@ typedef struct NsrConfig {
   int32_t max_workgroups;  /* 0 = fill the chip (one workgroup per CU for x32, two for x16)        */
   int32_t variant;         /* forward kernel: 0 = library default (= 16), 16 = 16 points/wave, two workgroups
                               per CU (needs nsr_upload_weights16), 32 = 32 points/wave, one workgroup/CU  */
-  int32_t reserved[2];
+  int32_t flags;           /* NSR_FLAG_* render options (0 = the YCB-V configuration)                */
+  int32_t reserved;        /* must be 0                                                            */
 } NsrConfig;
+
+#define NSR_FLAG_WHITE_BKGD 1   /* white_bkgd (RN:384-385): rgb_map += 1 - acc_map, coarse and fine; also in the VJP */
+#define NSR_FLAG_LINDISP    2   /* lindisp (RN:443): coarse samples linear in inverse depth                          */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {

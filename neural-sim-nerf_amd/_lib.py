@@ -13,7 +13,7 @@ PACKED_FLOATS = 145 * 4096 + 3328
 
 class NsrConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_samples", C.c_int32),
-                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("variant", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("variant", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class NsrDebugOut(C.Structure):

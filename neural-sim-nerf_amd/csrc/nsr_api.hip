@@ -70,6 +70,8 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
   if (cfg->n_samples != NSR_N_SAMPLES)
     return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
+  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP)) return fail("nsr_create: unknown bits in flags");
+  if (cfg->reserved != 0) return fail("nsr_create: reserved must be 0");
   if (cfg->variant != 0 && cfg->variant != 16 && cfg->variant != 32)
     return fail("nsr_create: variant must be 0 (default), 16 or 32");
   if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0)
@@ -197,6 +199,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = fine ? 1 : 0;
+  a.white_bkgd = (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0;
+  a.lindisp = (h->cfg.flags & NSR_FLAG_LINDISP) ? 1 : 0;
   a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc;
   a.rgb0 = out->d_rgb0; a.disp0 = out->d_disp0; a.acc0 = out->d_acc0; a.z_std = out->d_z_std;
   a.dbg_w0 = dbg ? dbg->d_weights0 : nullptr;
@@ -293,6 +297,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = 1;
+  a.white_bkgd = (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0;
+  a.lindisp = (h->cfg.flags & NSR_FLAG_LINDISP) ? 1 : 0;
   if (out) { a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc; }
   v.grad_rgb = d_grad_rgb; v.grad_o = d_grad_o; v.grad_d = d_grad_d; v.mask_scratch = h->d_mask_scratch;
   hipStream_t s = (hipStream_t)stream;
@@ -418,7 +424,8 @@ int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const fl
   if (n_samples != 64 && n_samples != 192) return fail("nsr_raw2outputs: n_samples must be 64 or 192");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_raw2outputs: negative ray count");
   NSR_HIP(hipSetDevice(h->cfg.device));
-  nsr::R2OArgs a{d_raw, d_z, d_rays_d, n_rays, d_rgb, d_disp, d_acc, d_weights, d_depth};
+  nsr::R2OArgs a{d_raw, d_z, d_rays_d, n_rays, (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0,
+                 d_rgb, d_disp, d_acc, d_weights, d_depth};
   const long long items = (n_rays + 1) / 2;
   const int grid = (int)(items < 4096 ? items : 4096);
   if (n_samples == 64)

@@ -494,6 +494,10 @@ __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, fl
       float disp;
       if (qd != qd) disp = qd;                                 // 0/0 -> NaN propagates through torch.max (RN:381)
       else disp = 1.0f / fmaxf(1e-10f, qd);
+      if (st.ray[r][12] != 0.0f) {                             // white_bkgd, RN:384-385
+        const float bg = 1.0f - acc;
+        cr = cr + bg; cg = cg + bg; cb = cb + bg;
+      }
       st.res[r][0] = cr; st.res[r][1] = cg; st.res[r][2] = cb;
       st.res[r][3] = disp; st.res[r][4] = acc; st.res[r][5] = depth;
     }
@@ -648,6 +652,12 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
   __syncthreads();
 }
 
+// RN:441 / RN:443: the coarse sample depth for table value t
+__device__ __forceinline__ float coarse_z(float near_, float far_, float t, int lindisp) {
+  if (lindisp) return 1.0f / (((1.0f / near_) * (1.0f - t)) + ((1.0f / far_) * t));
+  return (near_ * (1.0f - t)) + (far_ * t);
+}
+
 // get_rays RH:156-165 for pixel (row, col); cam = {c2w[12], fx, fy, cx, cy}
 __device__ __forceinline__ void gen_ray(const float* __restrict__ c2w, float fx, float fy, float cx, float cy,
                                         int row, int col, float (&o)[3], float (&d)[3]) {
@@ -676,6 +686,8 @@ struct RenderArgs {
   float near_, far_;
   int fine;                 // 0: coarse only
   int camera;               // 1: generate rays in-kernel
+  int white_bkgd;           // RN:384-385: rgb_map += 1 - acc_map
+  int lindisp;              // RN:443: coarse samples linear in inverse depth
   float *rgb, *disp, *acc, *rgb0, *disp0, *acc0, *z_std;
   float *dbg_w0, *dbg_zs, *dbg_zf, *dbg_raw0, *dbg_raw;
   long long* dbg_inds;
@@ -761,11 +773,12 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
 #pragma unroll
         for (int c = 0; c < 3; ++c) { st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c]; st.ray[tid][6 + c] = d[c] / nrm; }
         st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
+        st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
-        st.zc[r][i] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
+        st.zc[r][i] = coarse_z(near_, far_, t, a.lindisp);
       }
       __syncthreads();
       NSR_T(0);
@@ -992,7 +1005,8 @@ __device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /
   for (int idx = tid; idx < 2 * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
     const float* q = st.rawf[r][i];
-    const float a_i = (grgb[r * 3 + 0] * q[0] + grgb[r * 3 + 1] * q[1]) + grgb[r * 3 + 2] * q[2];
+    float a_i = (grgb[r * 3 + 0] * q[0] + grgb[r * 3 + 1] * q[1]) + grgb[r * 3 + 2] * q[2];
+    if (st.ray[r][12] != 0.0f) a_i = a_i - ((grgb[r * 3 + 0] + grgb[r * 3 + 1]) + grgb[r * 3 + 2]);   // d(1 - acc)/dw
     aw[idx] = a_i * st.wf[r][i];
     at[idx] = a_i * st.tf[r][i];
   }
@@ -1101,11 +1115,12 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
 #pragma unroll
         for (int c = 0; c < 3; ++c) { st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c]; st.ray[tid][6 + c] = d[c] / nrm; }
         st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
+        st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
-        st.zc[r][i] = (near_ * (1.0f - t)) + (far_ * t);
+        st.zc[r][i] = coarse_z(near_, far_, t, a.lindisp);
       }
       __syncthreads();
     }
@@ -1440,11 +1455,12 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
 #pragma unroll
         for (int c = 0; c < 3; ++c) { st.ray[0][c] = o[c]; st.ray[0][3 + c] = d[c]; st.ray[0][6 + c] = d[c] / nrm; }
         st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
+        st.ray[0][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (pass == 0) {
         if (tid < 64) {
           const float t = a.tcoarse[tid];
-          st.zc[0][tid] = (near_ * (1.0f - t)) + (far_ * t);      // RN:441
+          st.zc[0][tid] = coarse_z(near_, far_, t, a.lindisp);
         }
       } else if (tid < 192) {                              // phase B: the sorted z values phase A left for this ray
         st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)zscr + jr * 192 + tid, __ATOMIC_RELAXED,
@@ -1895,6 +1911,7 @@ __global__ void k_embed(const float* __restrict__ x, long long n, int L, float* 
 struct R2OArgs {
   const float *raw, *z, *rays_d;
   long long n_rays;
+  int white_bkgd;
   float *rgb, *disp, *acc, *weights, *depth;
 };
 
@@ -1921,6 +1938,7 @@ __global__ void __launch_bounds__(256) k_raw2outputs(R2OArgs a) {
       const long long rr = ray0 + (tid < valid ? tid : 0);
       const float dx = a.rays_d[rr * 3], dy = a.rays_d[rr * 3 + 1], dz = a.rays_d[rr * 3 + 2];
       st.ray[tid][11] = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
+      st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
     }
     __syncthreads();
     composite<S>(st, zbuf, rawbuf, wbuf, &st.tf[0][0], tid);

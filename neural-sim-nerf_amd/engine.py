@@ -35,8 +35,10 @@ def _stream_ptr(device):
 
 
 class NsrModel:
-    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0):
-        """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu)."""
+    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0,
+                 white_bkgd=False, lindisp=False):
+        """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu).
+        white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration)."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
@@ -50,7 +52,9 @@ class NsrModel:
         if variant not in (0, 16, 32):
             raise NotImplementedError("variant must be 0 (library default), 16 or 32")
         self.variant = variant
-        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant)
+        self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
+        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant,
+                             (1 if white_bkgd else 0) | (2 if lindisp else 0), 0)
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h

@@ -49,7 +49,7 @@ def render_path_inmemory(render_poses, hwf, K, render_kwargs, render_factor=0, w
         raise NotImplementedError("render_path_inmemory: use_viewdirs=False is not supported")
     _rn._check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
-    model = _rn._model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp)
+    model = _rn._model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
     poses = torch.as_tensor(render_poses, dtype=torch.float32)
     with torch.no_grad():
         out = model.render_views(poses[:, :3, :4].to(model.device), H, W, K, near, far)

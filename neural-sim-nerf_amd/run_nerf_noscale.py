@@ -7,8 +7,9 @@ Embedder, the 8x256 MLP -- is ONE persistent gfx950 kernel (csrc/nsr_kernels.hip
 of include/nsr.h.  This file is host glue: argument checking, handle caching, reshapes, PNG side effects.
 
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
-different path is worse): ndc=True, lindisp, perturb>0, raw_noise_std>0, white_bkgd, c2w_staticcam,
-use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, per-ray near/far arrays."""
+different path is worse): ndc=True, perturb>0, raw_noise_std>0, c2w_staticcam,
+use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, per-ray near/far arrays.  white_bkgd (RN:384-385)
+and lindisp (RN:443) are supported (one native handle per option pair)."""
 import os
 import time
 
@@ -38,19 +39,21 @@ def _util_model(dev=None):
     return _UTIL[idx]
 
 
-def _model_for(network_fn, network_fine, n_importance):
-    """One native handle per (network_fn, network_fine) pair, repacked when the parameters change."""
+def _model_for(network_fn, network_fine, n_importance, kw=None):
+    """One native handle per (network_fn, network_fine, render options) tuple, repacked when the parameters change.
+    `kw`: the render kwargs, read for white_bkgd / lindisp (RN:384-385, RN:443)."""
     from .engine import NsrModel
     if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
         raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
+    white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
     key = (n_importance, network_fn.weights_version(),
            network_fine.weights_version() if network_fine is not None else None)
-    cache = network_fn.__dict__.setdefault("_nsr_pair", {})
+    cache = network_fn.__dict__.setdefault("_nsr_pair", {}).setdefault((white, lindisp), {})
     if cache.get("key") != key:
         if cache.get("model") is not None:
             cache["model"].close()
         cache["model"] = NsrModel(network_fn.state_dict(), network_fine.state_dict() if network_fine is not None
-                                  else None, n_importance=n_importance)
+                                  else None, n_importance=n_importance, white_bkgd=white, lindisp=lindisp)
         cache["key"] = key
     return cache["model"]
 
@@ -140,10 +143,6 @@ def _check_kwargs(kw):
         bad.append("perturb>0 (stratified jitter)")
     if kw.get("raw_noise_std", 0.) not in (0, 0.):
         bad.append("raw_noise_std>0")
-    if kw.get("white_bkgd", False):
-        bad.append("white_bkgd")
-    if kw.get("lindisp", False):
-        bad.append("lindisp")
     if kw.get("N_samples", 64) != 64:
         bad.append("N_samples=%r (kernel is specialised to 64)" % kw.get("N_samples"))
     if kw.get("N_importance", 0) not in (0, 128):
@@ -168,7 +167,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
         raise NotImplementedError("render: near/far must be python scalars (per-ray bounds are not supported)")
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
-    model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp)
+    model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
 
@@ -225,7 +224,7 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
         raise NotImplementedError("render_path: use_viewdirs=False is not supported")
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
-    model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp)
+    model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
     if savedir is not None:
         os.makedirs(os.path.join(savedir, str(object_id)), exist_ok=True)
     poses = torch.as_tensor(render_poses, dtype=torch.float32)
@@ -261,7 +260,7 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
     n_imp = kw.get("N_importance", 0)
     if n_imp != 128:
         raise NotImplementedError("render_path_grad needs the coarse+fine configuration (N_importance=128)")
-    model = _model_for(kw["network_fn"], kw.get("network_fine", None), n_imp)
+    model = _model_for(kw["network_fn"], kw.get("network_fine", None), n_imp, kw)
     n_rays = H * W
     N_rand = int(chunk)
     n_patches = (n_rays + N_rand - 1) // N_rand

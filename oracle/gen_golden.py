@@ -93,7 +93,12 @@ class Capture:
         torch.searchsorted = self.orig_ss
 
 
+ONLY = os.environ.get("GOLDEN_ONLY")          # e.g. GOLDEN_ONLY=g11_options: leave the other fixtures untouched
+
+
 def save(name, **arrs):
+    if ONLY and name != ONLY:
+        return
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrs)
     print("%-28s %8.1f KB" % (name, os.path.getsize(path) / 1024))
@@ -250,6 +255,27 @@ def main():
          uniform=np.array(log["uniform_noises"]), thetas=np.array(log["thetas"]), poses_nograd=poses_ng.numpy(),
          poses_grad=poses_g.detach().numpy(), K=np.array(Ks), grad_E=np.stack([g["grad_E"][0].numpy() for g in gE]),
          rgbs=rgbs10, dLdpsis=np.stack([d.numpy() for d in dl]), seed=np.int64(SEED))
+
+    # ---- G11 render options: white_bkgd (RN:384-385) and lindisp (RN:443), forward and VJP ------
+    kw11 = dict(kwargs, white_bkgd=True, lindisp=True)
+    sel = rng.choice(160000, size=160, replace=False)
+    ro11 = o32.reshape(-1, 3)[sel]
+    rd11 = d32.reshape(-1, 3)[sel]
+    with Capture(RN, RH) as cap:
+        with torch.no_grad():
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=160, rays=torch.stack([ro11, rd11], 0),
+                                           retraw=True, **kw11)
+    fwd11 = dict(rays_o=ro11.numpy(), rays_d=rd11.numpy(), rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(),
+                 rgb0=ex["rgb0"].numpy(), disp0=ex["disp0"].numpy(), acc0=ex["acc0"].numpy(),
+                 z_std=ex["z_std"].numpy(), raw=ex["raw"].numpy(), inds=cap.log[0]["inds"],
+                 z_samples=cap.log[0]["samples"])
+    rays = torch.stack([ro11[:64], rd11[:64]], 0).clone().requires_grad_(True)
+    cot = torch.from_numpy(rng.standard_normal((64, 3)).astype(np.float32))
+    with Capture(RN, RH) as cap:
+        rgb_p, _, _, _ = RN.render(400, 400, O.YCBV_K, chunk=64, rays=rays, retraw=True, **kw11)
+    (g,) = torch.autograd.grad(rgb_p, rays, grad_outputs=cot)
+    save("g11_options", seed=np.int64(SEED), cot=cot.numpy(), vjp_rgb=rgb_p.detach().numpy(), grad_rays=g.numpy(),
+         vjp_z_samples=cap.log[0]["samples"], **fwd11)
 
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())

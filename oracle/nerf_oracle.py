@@ -276,8 +276,8 @@ def run_network(sd, pts, viewdirs):
     return mlp(sd, np.concatenate([e, ed], -1)).reshape(N, S, 4)
 
 
-def raw2outputs(raw, z_vals, rays_d):
-    """RN:343-387 with raw_noise_std=0, white_bkgd=False.
+def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
+    """RN:343-387 with raw_noise_std=0.
     Returns rgb_map [N,3], disp_map [N], acc_map [N], weights [N,S], depth_map [N]."""
     raw = raw.astype(f32)
     z = z_vals.astype(f32)
@@ -297,6 +297,8 @@ def raw2outputs(raw, z_vals, rays_d):
     with np.errstate(invalid="ignore", divide="ignore"):
         q = (depth_map / acc_map).astype(f32)
         disp_map = (f32(1) / np.where(np.isnan(q), q, np.maximum(f32(1e-10), q))).astype(f32)
+    if white_bkgd:                                                        # RN:384-385
+        rgb_map = _add(rgb_map, (f32(1) - acc_map[..., None]).astype(f32))
     return rgb_map, disp_map, acc_map, weights, depth_map
 
 
@@ -323,26 +325,30 @@ def sample_pdf(bins, weights, n_samples=N_IMPORTANCE, u=None):
     return samples, inds, cdf
 
 
-def coarse_z(near, far, n=N_SAMPLES):
-    """RN:439-441: z = near*(1-t) + far*t, per ray (near/far [N])."""
+def coarse_z(near, far, n=N_SAMPLES, lindisp=False):
+    """RN:439-443: z = near*(1-t) + far*t, or 1/(1/near*(1-t) + 1/far*t) with lindisp, per ray (near/far [N])."""
     t = torch_linspace01(n)
     near = np.asarray(near, f32).reshape(-1, 1)
     far = np.asarray(far, f32).reshape(-1, 1)
+    if lindisp:
+        inv = _add(((f32(1) / near).astype(f32) * (f32(1) - t).astype(f32)).astype(f32),
+                   ((f32(1) / far).astype(f32) * t).astype(f32))
+        return (f32(1) / inv).astype(f32)
     return _add((near * (f32(1) - t).astype(f32)).astype(f32), (far * t).astype(f32))
 
 
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
-                n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, extras=False):
-    """RN:390-501 with perturb=0, lindisp=False, raw_noise_std=0, white_bkgd=False.
+                n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, extras=False, white_bkgd=False, lindisp=False):
+    """RN:390-501 with perturb=0, raw_noise_std=0.
     rays_o/rays_d/viewdirs [N,3], near/far scalars or [N]."""
     rays_o, rays_d, viewdirs = (a.astype(f32) for a in (rays_o, rays_d, viewdirs))
     N = rays_o.shape[0]
     near = np.broadcast_to(np.asarray(near, f32), (N,))
     far = np.broadcast_to(np.asarray(far, f32), (N,))
-    z = coarse_z(near, far, n_samples)
+    z = coarse_z(near, far, n_samples, lindisp)
     pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32))
     raw = run_network(sd_coarse, pts, viewdirs)
-    rgb_map, disp_map, acc_map, weights, _ = raw2outputs(raw, z, rays_d)
+    rgb_map, disp_map, acc_map, weights, _ = raw2outputs(raw, z, rays_d, white_bkgd)
     ret = {}
     if n_importance > 0:
         ret.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
@@ -351,7 +357,7 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
         z_fine = np.sort(np.concatenate([z, z_samples], -1), -1)
         pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z_fine[:, :, None]).astype(f32))
         raw = run_network(sd_fine if sd_fine is not None else sd_coarse, pts, viewdirs)
-        rgb_map, disp_map, acc_map, weights_f, _ = raw2outputs(raw, z_fine, rays_d)
+        rgb_map, disp_map, acc_map, weights_f, _ = raw2outputs(raw, z_fine, rays_d, white_bkgd)
         ret["z_std"] = np.std(z_samples.astype(f64), -1).astype(f32)   # RN:495 (unbiased=False)
         if extras:
             ret.update(z_samples=z_samples, inds=inds, cdf=cdf, z_fine=z_fine, weights0=weights,
@@ -361,7 +367,7 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
 
 
 def render(sd_coarse, sd_fine, H, W, K, c2w=None, rays=None, near=0.0, far=1.0,
-           n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, chunk=4096, extras=False):
+           n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, chunk=4096, extras=False, white_bkgd=False, lindisp=False):
     """RN:58-123 with use_viewdirs=True, ndc=False.  Returns dict of [H,W,...] (c2w form) or [N,...]."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, K, c2w)
@@ -375,7 +381,7 @@ def render(sd_coarse, sd_fine, H, W, K, c2w=None, rays=None, near=0.0, far=1.0,
     for i in range(0, rays_o.shape[0], chunk):
         s = slice(i, i + chunk)
         outs.append(render_rays(sd_coarse, sd_fine, rays_o[s], rays_d[s], viewdirs[s], near, far,
-                                n_samples, n_importance, extras))
+                                n_samples, n_importance, extras, white_bkgd, lindisp))
     ret = {k: np.concatenate([o[k] for o in outs], 0) for k in outs[0]}
     return {k: v.reshape(sh + v.shape[1:]) for k, v in ret.items()}
 
@@ -479,7 +485,7 @@ def network_vjp(sd, pts, dirs, g_raw, fwd=None):
 # input-side VJP of the fine render (what render_path_grad needs, RN:168-178)
 # ----------------------------------------------------------------------------------------------
 def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
-                    n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, z_fine=None):
+                    n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, z_fine=None, white_bkgd=False, lindisp=False):
     """d(sum(rgb_map * grad_rgb)) / d(rays_o, rays_d), the quantity torch.autograd.grad(rgb_p, batch_rays,
     grad_outputs=patch_grad_E) returns at RN:177.  Network weights are constants and z_samples is detached
     (RN:475), so gradient reaches the rays only through the FINE pass: pts = o + d*z (RN:478), the view
@@ -492,7 +498,7 @@ def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
     vd = normalize_dirs(rays_d)
     if z_fine is None:
         z_fine = render_rays(sd_coarse, sd_fine, rays_o, rays_d, vd, near, far, n_samples, n_importance,
-                             extras=True)["z_fine"]
+                             extras=True, white_bkgd=white_bkgd, lindisp=lindisp)["z_fine"]
     S = z_fine.shape[1]
     z = z_fine.astype(f32)
     pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32)).reshape(-1, 3)
@@ -512,9 +518,13 @@ def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
     T = np.cumprod(np.concatenate([np.ones((N, 1)), om], 1), 1)[:, :-1]
     w = alpha * T
     rgb_map = (w[..., None] * c).sum(1)
+    if white_bkgd:
+        rgb_map = rgb_map + (1.0 - w.sum(1))[:, None]                   # RN:384-385
     # ---- compositing backward ----
     g = grad_rgb.astype(f64)
     A = (c * g[:, None, :]).sum(-1)                                     # dL/dw_i
+    if white_bkgd:
+        A = A - g.sum(-1)[:, None]                                      # d(1 - acc)/dw_i = -1 per channel
     Aw = A * w
     suffix = np.concatenate([np.cumsum(Aw[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((N, 1))], 1)   # sum_{k>i}
     d_alpha = A * T - suffix / om

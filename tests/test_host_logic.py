@@ -128,8 +128,7 @@ def test_api_rejects_unsupported_configurations():
                 network_fn=None, N_samples=64, N_importance=128)
     for bad, pat in ((dict(ndc=True), "ndc"), (dict(use_viewdirs=False), "use_viewdirs"),
                      (dict(c2w_staticcam=np.eye(4)[:3]), "c2w_staticcam"), (dict(perturb=1.0), "perturb"),
-                     (dict(raw_noise_std=1.0), "raw_noise_std"), (dict(white_bkgd=True), "white_bkgd"),
-                     (dict(lindisp=True), "lindisp"), (dict(N_samples=32), "N_samples"),
+                     (dict(raw_noise_std=1.0), "raw_noise_std"), (dict(N_samples=32), "N_samples"),
                      (dict(N_importance=64), "N_importance"), (dict(near=np.zeros(3)), "near/far")):
         kw = dict(base)
         kw.update(bad)

@@ -100,6 +100,35 @@ def test_render_rays_end_to_end(golden, oracle, synth_nets):
     assert oracle.psnr(r["rgb_map"], g["rgb"]) > 60.0
 
 
+def test_render_options_white_bkgd_lindisp(golden, oracle, synth_nets):
+    """RN:384-385 / RN:443 against the reference (g11): coarse outputs tight, the lindisp samples bit-exact, fine
+    outputs to the usual end-to-end tolerance; then the oracle's VJP against the reference's autograd."""
+    g = golden("g11_options")
+    sd_c, sd_f = synth_nets
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    vd = oracle.normalize_dirs(g["rays_d"])
+    r = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, extras=True, white_bkgd=True,
+                           lindisp=True)
+    assert_close(r["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
+    assert_close(r["acc0"], g["acc0"], atol=1e-5, what="acc0")
+    assert (r["inds"] == g["inds"]).mean() > 0.99
+    assert_close(r["z_samples"], g["z_samples"], atol=3e-3, what="z_samples")
+    # (same ill-conditioning as in test_render_rays_end_to_end: 0.3 % of the indices flip and move a few rays)
+    assert np.abs(r["rgb_map"] - g["rgb"]).mean() < 3e-4 and oracle.psnr(r["rgb_map"], g["rgb"]) > 58.0
+    assert_close(r["z_std"], g["z_std"], atol=2e-3, what="z_std")
+    # the white background really is in there: rgb0 - (1 - acc0) is the plain composite, inside [0, 1]
+    plain = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, lindisp=True)
+    assert_close(r["rgb0"], plain["rgb0"] + (1 - plain["acc0"])[:, None], atol=1e-6, what="white composite")
+    n = g["cot"].shape[0]
+    z = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32), lindisp=True)
+    zf = np.sort(np.concatenate([z, g["vjp_z_samples"]], -1), -1)
+    go, gd, rgb = oracle.render_rays_vjp(sd_c, sd_f, g["rays_o"][:n], g["rays_d"][:n], near, far, g["cot"], z_fine=zf,
+                                         white_bkgd=True, lindisp=True)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(go, g["grad_rays"][0]) < 5e-5 and rel(gd, g["grad_rays"][1]) < 5e-5
+    assert np.abs(rgb - g["vjp_rgb"]).max() < 1e-5
+
+
 def test_render_image(golden, oracle, synth_nets):
     g = golden("g7_render")
     sd_c, sd_f = synth_nets
