@@ -43,7 +43,8 @@ def gather_views(local, n_total, group=None):
 def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, group=None, writer=None):
     """render_path (RN:213-255) over all ranks.  `render_fn(poses [k,4,4]) -> (rgb [k,H,W,3], disp [k,H,W])`
     tensors on this rank's device (production: NsrModel.render_views; tests: any deterministic function).
-    Returns (rgbs, disps) numpy arrays in pose order on every rank; rank 0 writes savedir/<object_id>/%03d.png."""
+    Returns (rgbs, disps) numpy arrays in pose order on every rank; savedir/<object_id>/%03d.png are written by the
+    rank that rendered them (pose index in the name, as RN:248-249)."""
     from .run_nerf_helpers import to8b
     from . import png
     world, rank = world_info(group)
@@ -51,13 +52,16 @@ def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, 
     n = poses.shape[0]
     mine = shard_indices(n, world, rank)
     rgb, disp = render_fn(poses[mine])
+    if savedir is not None:                      # every rank writes its own views (one node, one file system):
+        d = os.path.join(savedir, str(object_id))         # 6.5 ms of zlib per 400x400 PNG would otherwise serialise
+        os.makedirs(d, exist_ok=True)                     # on rank 0 (100 views: 0.65 s against 4.2 s of rendering)
+        local = rgb.cpu().numpy()
+        for k, i in enumerate(mine):
+            (writer or png.imwrite)(os.path.join(d, "{:03d}.png".format(i)), to8b(local[k]))
     rgbs = gather_views(rgb, n, group).cpu().numpy()
     disps = gather_views(disp, n, group).cpu().numpy()
-    if savedir is not None and rank == 0:
-        d = os.path.join(savedir, str(object_id))
-        os.makedirs(d, exist_ok=True)
-        for i in range(n):
-            (writer or png.imwrite)(os.path.join(d, "{:03d}.png".format(i)), to8b(rgbs[i]))
+    if savedir is not None and world > 1:
+        dist.barrier(group=group)                # the files of all ranks exist when any rank returns
     return rgbs, disps
 
 

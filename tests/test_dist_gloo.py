@@ -76,7 +76,7 @@ def test_view_sharding_gather_and_grad_allreduce(tmp_path, n_views):
     seen = sorted(i for _, _, idx in res for i in idx)
     assert seen == list(range(n_views))                       # every view rendered exactly once
     files = sorted(os.listdir(tmp_path / "7"))
-    assert files == ["%03d.png" % i for i in range(n_views)]  # rank 0 wrote them, in pose order
+    assert files == ["%03d.png" % i for i in range(n_views)]  # each rank wrote its own views, named by pose index
 
 
 def test_single_process_paths():
