@@ -52,6 +52,7 @@ struct nsr_handle_s {
   nsr::VjpArgs* d_vjp_args = nullptr;
   uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [grid][3][9][256]
   int mask_grid = 0;
+  unsigned* d_chunk_counter = nullptr;  // k_render16: chunk queue head
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk
   int zf_grid = 0, zf_chunk = 0;
   int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images
@@ -95,6 +96,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
+  NSR_HIP(hipMalloc(&h->d_chunk_counter, sizeof(unsigned)));
   NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   NSR_HIP(hipEventCreate(&h->ev0));
@@ -118,6 +120,7 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_mask_scratch);
   hipFree(h->d_box_scratch);
   hipFree(h->d_zf_scratch);
+  hipFree(h->d_chunk_counter);
   hipEventDestroy(h->ev0);
   hipEventDestroy(h->ev1);
   delete h;
@@ -216,6 +219,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     // time, small enough that the z scratch of an XCD's workgroups stays in its L2 next to that network
     int chunk = 16;
     if (const char* e = getenv("NSR_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= 256) chunk = v; }
+    if ((long long)chunk * g > a.n_rays) chunk = (int)(a.n_rays / g > 1 ? a.n_rays / g : 1);   // small batches: keep every CU busy
     if (g > h->zf_grid || chunk > h->zf_chunk) {
       if (h->d_zf_scratch) { NSR_HIP(hipDeviceSynchronize()); NSR_HIP(hipFree(h->d_zf_scratch)); }
       h->d_zf_scratch = nullptr;
@@ -225,13 +229,16 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     }
     a.zf_scratch = h->d_zf_scratch;
     a.chunk = chunk;
+    a.chunk_counter = h->d_chunk_counter;
+    NSR_HIP(hipMemsetAsync(h->d_chunk_counter, 0, sizeof(unsigned), (hipStream_t)stream));
   }
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);
   NSR_HIP(hipEventRecord(h->ev0, s));
   if (x16) {
     long long g = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;   // two workgroups per CU
-    if (g > a.n_rays) g = a.n_rays;
+    const long long n_chunks = (a.n_rays + a.chunk - 1) / a.chunk;
+    if (g > n_chunks) g = n_chunks;
     hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   } else {
     const long long n_items = (a.n_rays + 1) / 2;

@@ -29,7 +29,7 @@ namespace nsr {
 // ------------------------------------------------------------------------------------------------------
 // ring (LDS weight stream)
 // ------------------------------------------------------------------------------------------------------
-constexpr int kRing16 = 3;          // ring slots of the x16 kernels (k_render16); also selects their chunked producer
+constexpr int kRing16 = 3;          // ring slots of the x16 kernels
 
 struct Ring {
   char* smem;            // LDS base (generic pointer)
@@ -44,7 +44,6 @@ struct Ring {
   int cslot;             // consumer: slot of the slab being consumed
   int pnet_off;          // producer: byte offset of the current net within `base` (buffer-descriptor form)
   int pn0, pn1;          // producer: passes [0,pn0) of a cycle stream net 0, [pn0,pn1) net 1, the rest net 2
-  int pk, pmul, prem;    // chunked schedule (x16): rays per chunk, passes per ray (1 or 4), rays not yet scheduled
   __amdgpu_buffer_rsrc_t rsrc;
 };
 
@@ -58,7 +57,6 @@ __device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base
   rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.pnet_off = 0;
   rg.ppi = ppi;
   rg.pn0 = 1; rg.pn1 = 4;            // coarse pass, 3 fine passes, then (ppi = 7) 3 backward passes
-  rg.pk = 0; rg.pmul = 0; rg.prem = 0;
   rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
 
@@ -82,20 +80,8 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   const int nslab = rg.pslab + 1;
   const bool wrap = nslab == kStreamSlabs;
   rg.pslab = wrap ? 0 : nslab;
-  const bool cyc = wrap && (rg.pphase + 1 == rg.ppi);
   const int nphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
   rg.pphase = wrap ? nphase : rg.pphase;
-  if (NS == kRing16) {
-    // chunked schedule (k_render16): a cycle is pk coarse passes followed by 3 pk fine passes; when a cycle ends
-    // the next chunk's size takes effect (the last chunk of a workgroup may be short; past the end the producer
-    // keeps the old shape and its prefetches are simply never consumed)
-    const int nk = rg.prem < rg.pk ? rg.prem : rg.pk;
-    const bool sel = cyc && nk > 0;
-    rg.pn0 = sel ? nk : rg.pn0;
-    rg.pn1 = sel ? nk * rg.pmul : rg.pn1;
-    rg.ppi = sel ? nk * rg.pmul : rg.ppi;
-    rg.prem = sel ? rg.prem - nk : rg.prem;
-  }
   // arithmetic, not a pointer table: keeps Ring in SGPRs
   const int net = rg.pphase < rg.pn0 ? 0 : (rg.pphase < rg.pn1 ? 1 : 2);
   rg.pnet_off = net * (int)rg.stride;
@@ -693,6 +679,7 @@ struct RenderArgs {
   long long* dbg_inds;
   float* zf_scratch;        // k_render16: [grid][chunk][192] sorted fine z values between the two phases of a chunk
   int chunk;                // k_render16: rays per workgroup per phase
+  unsigned* chunk_counter;  // k_render16: next chunk to hand out (zeroed before the launch)
 };
 
 __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
@@ -1385,11 +1372,14 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
   }
 }
 
-// Schedule: a workgroup owns rays b, b+G, b+2G, ...; it processes them in chunks of `chunk` rays, and inside a
-// chunk in two phases: (A) the coarse pass + compositing + resampling + sort of every ray of the chunk (the 192
-// sorted z values go to a small global scratch, 768 B per ray), then (B) the three fine passes + compositing of
-// the same rays.  All workgroups start together and every ray costs the same, so at any time the whole GPU streams
-// ONE network: 2.3 MiB against the 4 MiB L2 of an XCD, instead of both networks (4.6 MiB) thrashing it.
+// Schedule: the rays are cut into chunks of `chunk` consecutive rays; workgroups take chunks from a global counter
+// (the two workgroups of a CU share its matrix pipe unevenly, so a static split would leave the slower one
+// finishing alone) and process a chunk in two phases: (A) the coarse pass + compositing + resampling + sort of every
+// ray of the chunk (the 192 sorted z values go to a small global scratch, 768 B per ray), then (B) the three fine
+// passes + compositing of the same rays.  Every chunk has the same shape (a short last chunk is padded with
+// repeats of the last ray whose results are dropped), so the LDS-DMA producer can run ahead across chunk
+// boundaries without knowing which chunk comes next; and workgroups that start together stream ONE network at a
+// time: 2.3 MiB against the 4 MiB L2 of an XCD, instead of both networks (4.6 MiB) thrashing it.
 __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RenderArgs& a = *ap;
@@ -1404,21 +1394,17 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   ItemState16& st = *(ItemState16*)(smem + kLds16State);
 
   const long long n_items = a.n_rays;
-  if ((long long)blockIdx.x >= n_items) return;
   const int fine = a.fine;
-  const long long grid = gridDim.x;
-  const long long my_count = (n_items - blockIdx.x + grid - 1) / grid;      // rays of this workgroup
   const int K = a.chunk;
+  const long long n_chunks = (n_items + K - 1) / K;
   float* zscr = a.zf_scratch + (size_t)blockIdx.x * K * 192;
+  int* chunk_slot = (int*)&st.res[0][7];                   // LDS word that broadcasts the chunk id
 
   Ring rg;
   ring_init(rg, smem, a.nets, a.net_stride, 1, wave, lane);
-  {
-    const int k0 = my_count < K ? (int)my_count : K;
-    rg.pk = K; rg.pmul = fine ? 4 : 1;
-    rg.pn0 = k0; rg.pn1 = k0 * rg.pmul; rg.ppi = rg.pn1;
-    rg.prem = (int)(my_count - k0);
-  }
+  rg.pn0 = fine ? K : 0x7fffffff;                          // K coarse passes, then 3K fine passes, repeating
+  rg.pn1 = fine ? 4 * K : 0x7fffffff;
+  rg.ppi = fine ? 4 * K : 1;
   f32x4 A0[4], A1[4];
   ring_start<kRing16>(rg, A0, lane);
   {
@@ -1431,13 +1417,22 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLds16Aux);
 
-  long long c0 = 0;                                        // local index of the chunk's first ray
-  int kc = my_count < K ? (int)my_count : K;               // rays in the current chunk
+  long long c0;                                            // first ray of the current chunk
   int jr = 0;                                              // ray within the chunk
   int pass = 0;                                            // 0 = coarse pass (phase A), 1..3 = fine passes (phase B)
+  auto next_chunk = [&]() -> bool {
+    if (tid == 0) *chunk_slot = (int)atomicAdd(a.chunk_counter, 1u);
+    __syncthreads();
+    const long long c = *chunk_slot;
+    __syncthreads();
+    c0 = c * K;
+    return c < n_chunks;
+  };
+  bool more = next_chunk();
 #pragma unroll 1
-  while (c0 < my_count) {
-    const long long rr = blockIdx.x + (c0 + jr) * grid;
+  while (more) {
+    // a short last chunk is padded with repeats of the last ray (recomputed and rewritten with identical values)
+    const long long rr = (c0 + jr) < n_items ? (c0 + jr) : n_items - 1;
     if (pass <= 1) {                                       // a new ray enters the workgroup state
       const float near_ = a.near_, far_ = a.far_;
       if (tid == 0) {
@@ -1527,10 +1522,10 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
       }
       __syncthreads();
       ++jr;
-      if (jr == kc) {                                      // phase A of the chunk is done
+      if (jr == K) {                                       // phase A of the chunk is done
         jr = 0;
         if (fine) pass = 1;
-        else { c0 += kc; kc = (my_count - c0) < K ? (int)(my_count - c0) : K; }
+        else more = next_chunk();
       }
     } else if (pass < 3) {
       ++pass;
@@ -1552,10 +1547,9 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
       NSR_T(6);
       pass = 1;
       ++jr;
-      if (jr == kc) {                                      // phase B of the chunk is done: next chunk
+      if (jr == K) {                                       // phase B of the chunk is done: next chunk
         jr = 0; pass = 0;
-        c0 += kc;
-        kc = (my_count - c0) < K ? (int)(my_count - c0) : K;
+        more = next_chunk();
       }
     }
   }
