@@ -186,8 +186,8 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes "
                                          "(profiles/r01/pmc_k_render.json); L2 misses of the weight streams (4.6 MiB of "
-                                         "networks vs 4 MiB L2 per XCD), served by Infinity Cache at 0.14 TB/s, not by "
-                                         "HBM; 2.9e9 with one workgroup per CU (DESIGN.md, L2-aware schedule); "
+                                         "networks vs 4 MiB L2 per XCD), served by Infinity Cache at 0.28 TB/s, not by "
+                                         "HBM; a schedule with 2.9e9 exists and is 2.4 % slower (DESIGN.md, chunk queue); "
                                          "algorithmic HBM bytes are 7.0e6 per launch",
                          "kernel": "nsr::k_render16", "kernel_ms": round(k_ms, 3),
                          "flop_per_launch": H * W * FLOP_PER_RAY},
