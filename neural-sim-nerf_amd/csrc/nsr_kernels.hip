@@ -1433,7 +1433,8 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   while (more) {
     // a short last chunk is padded with repeats of the last ray (recomputed and rewritten with identical values)
     const long long rr = (c0 + jr) < n_items ? (c0 + jr) : n_items - 1;
-    if (pass <= 1) {                                       // a new ray enters the workgroup state
+    if (pass == 0 || (pass == 1 && K > 1)) {               // a new ray enters the workgroup state (with one ray
+                                                           // per chunk phase B simply continues in LDS)
       const float near_ = a.near_, far_ = a.far_;
       if (tid == 0) {
         float o[3], d[3];
@@ -1514,8 +1515,9 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
         merge_sort_item<1>(st, tid);
         if (tid < 192) {
           const float zv = st.zf[0][tid];
-          __hip_atomic_store((unsigned*)zscr + jr * 192 + tid, __float_as_uint(zv), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+          if (K > 1)
+            __hip_atomic_store((unsigned*)zscr + jr * 192 + tid, __float_as_uint(zv), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
           if (a.dbg_zf) a.dbg_zf[rr * 192 + tid] = zv;
         }
         NSR_T(5);
