@@ -230,9 +230,9 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     }
     a.zf_scratch = h->d_zf_scratch;
     a.chunk = chunk;
-    a.chunk_counter = h->d_chunk_counter;
-    NSR_HIP(hipMemsetAsync(h->d_chunk_counter, 0, sizeof(unsigned), (hipStream_t)stream));
   }
+  a.chunk_counter = h->d_chunk_counter;
+  NSR_HIP(hipMemsetAsync(h->d_chunk_counter, 0, sizeof(unsigned), (hipStream_t)stream));
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);
   NSR_HIP(hipEventRecord(h->ev0, s));
@@ -305,6 +305,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = 1;
+  a.chunk_counter = h->d_chunk_counter;
+  NSR_HIP(hipMemsetAsync(h->d_chunk_counter, 0, sizeof(unsigned), (hipStream_t)stream));
   a.white_bkgd = (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0;
   a.lindisp = (h->cfg.flags & NSR_FLAG_LINDISP) ? 1 : 0;
   if (out) { a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc; }

@@ -735,7 +735,16 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
 
-  long long item = blockIdx.x;
+  // items come from a global counter: nothing forces the workgroups to progress at the same rate
+  int* item_slot = (int*)&st.ray[0][15];
+  auto next_item = [&]() -> long long {
+    if (tid == 0) *item_slot = (int)atomicAdd(a.chunk_counter, 1u);
+    __syncthreads();
+    const long long v = *item_slot;
+    __syncthreads();
+    return v;
+  };
+  long long item = next_item();
   int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current item
 #pragma unroll 1
   while (item < n_items) {
@@ -815,7 +824,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
       }
       if (a.dbg_w0)
         for (int idx = tid; idx < valid * 64; idx += 256) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
-      if (!fine) { __syncthreads(); item += gridDim.x; continue; }
+      if (!fine) { __syncthreads(); item = next_item(); continue; }
       NSR_T(2);
 
       // ---- hierarchical resampling ----------------------------------------------------------------
@@ -860,7 +869,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
       __syncthreads();
       NSR_T(6);
       pass = 0;
-      item += gridDim.x;
+      item = next_item();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
@@ -1085,7 +1094,15 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
   uint4* my_masks = va.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256) + tid;
   float* grgb = &st.res[0][0];   // [2][3] cotangent staged here during the backward half (res is free then)
 
-  long long item = blockIdx.x;
+  int* item_slot = (int*)&st.ray[0][15];
+  auto next_item = [&]() -> long long {
+    if (tid == 0) *item_slot = (int)atomicAdd(a.chunk_counter, 1u);
+    __syncthreads();
+    const long long v = *item_slot;
+    __syncthreads();
+    return v;
+  };
+  long long item = next_item();
   int pass = 0;
 #pragma unroll 1
   while (item < n_items) {
@@ -1207,7 +1224,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       }
       __syncthreads();
       pass = 0;
-      item += gridDim.x;
+      item = next_item();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
