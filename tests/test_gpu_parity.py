@@ -562,6 +562,22 @@ def test_x16_chunk_invariance_and_views(model16, model, oracle):
     assert np.abs(cpu(r["rgb0"]) - cpu(r32["rgb0"])).max() < 1e-5
 
 
+def test_x16_chunked_schedule_is_result_invariant(model16, monkeypatch):
+    """k_render16's chunk queue: any chunk size (two-phase schedule with the z scratch, padded last chunk, fewer
+    workgroups than chunks and the reverse) gives bit-identical results to the default one-ray chunks."""
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    ro = np.tile(g["rays_o"], (8, 1))[:1500 + 7]
+    rd = np.tile(g["rays_d"], (8, 1))[:1500 + 7]
+    monkeypatch.delenv("NSR_CHUNK", raising=False)
+    want = model16.render_rays(ro, rd, near, far, debug=True)
+    for chunk in ("2", "5", "16", "64"):
+        monkeypatch.setenv("NSR_CHUNK", chunk)
+        got = model16.render_rays(ro, rd, near, far, debug=True)
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std", "z_fine", "inds", "raw"):
+            assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), (chunk, k)
+
+
 def test_x16_coarse_only_config1(oracle, synth_nets):
     from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g7_render")
