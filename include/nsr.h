@@ -5,7 +5,7 @@
  * (gyhandy/Neural-Sim-NeRF) has no native layer: its hot path is a chain of PyTorch ops in
  *   RN = optimization/utils/run_nerf_noscale.py, RH = optimization/utils/run_nerf_helpers.py.
  * Each entry point below replaces the reference functions cited next to it.  The binding a maintainer
- * adds on the reference side is a ctypes stub; `neural-sim-nerf_amd/_lib.py` is that stub.
+ * adds on the reference side is a ctypes stub; `neural_sim_nerf_amd/_lib.py` is that stub.
  *
  * Conventions
  *   - plain C types only; every `const float*` / `float*` / `int64_t*` named d_* is a DEVICE pointer

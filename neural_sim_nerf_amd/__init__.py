@@ -1,11 +1,7 @@
-"""Importable alias of the package directory `neural-sim-nerf_amd/` (a hyphen is not a valid module name).
+"""neural-sim-nerf_amd: MI355X-native NeRF volumetric renderer behind the reference's render API.
 
-`import neural_sim_nerf_amd` executes neural-sim-nerf_amd/__init__.py with this package's name, so every
-sub-module (`neural_sim_nerf_amd.pack`, `.run_nerf_noscale`, ...) resolves to the files in that directory."""
-import os as _os
-
-_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "neural-sim-nerf_amd")
-__path__ = [_real]
-with open(_os.path.join(_real, "__init__.py")) as _f:
-    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
-del _os, _f, _real
+Drop-in for `utils/run_nerf_noscale.py` + `utils/run_nerf_helpers.py` of gyhandy/Neural-Sim-NeRF:
+    from neural_sim_nerf_amd.run_nerf_noscale import create_nerf, render, render_path, render_path_grad
+The compute path is the hand-written gfx950 library csrc/libnsr.so (C ABI in include/nsr.h); there is no
+CPU or PyTorch fallback: importing the render API without the library raises."""
+__version__ = "0.1.0"

@@ -75,7 +75,7 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise NsrError("libnsr.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; "
-                       "g.build()' or make -C neural-sim-nerf_amd/csrc); there is no CPU fallback" % LIB_PATH)
+                       "g.build()' or make -C neural_sim_nerf_amd/csrc); there is no CPU fallback" % LIB_PATH)
     # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7, the
     # same SONAME libnsr.so was linked against).  Loading it FIRST makes the dynamic loader bind libnsr.so to
     # that very instance, so device pointers and hipStream_t handles mean the same thing on both sides.  The

@@ -1,4 +1,4 @@
-"""Drop-in module: put `<repo>` and `<repo>/neural-sim-nerf_amd/dropin` in front of the reference's
+"""Drop-in module: put `<repo>` and `<repo>/neural_sim_nerf_amd/dropin` in front of the reference's
 `optimization/` on PYTHONPATH and `from utils.run_nerf_noscale import *` (neural_sim_main.py:35) binds the
 MI355X-native implementation.  `utils` is a namespace package on both sides (no __init__.py), so every other
 `utils.*` module (load_LINEMOD_noscale, gumble, the vendored detectron2 pieces) still comes from the reference."""

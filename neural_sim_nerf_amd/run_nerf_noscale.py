@@ -9,7 +9,10 @@ of include/nsr.h.  This file is host glue: argument checking, handle caching, re
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
 different path is worse): ndc=True, perturb>0, raw_noise_std>0, c2w_staticcam,
 use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, per-ray near/far arrays.  white_bkgd (RN:384-385)
-and lindisp (RN:443) are supported (one native handle per option pair)."""
+and lindisp (RN:443) are supported (one native handle per option pair).
+
+`create_nerf` deliberately restates RN:258-340 statement by statement: the args it reads, the kwargs keys, the
+checkpoint keys and the returned 5-tuple ARE the drop-in contract, so there is nothing to redesign there."""
 import os
 import time
 

@@ -4,7 +4,7 @@ This file restates, in plain numpy fp32, the algorithm of the reference's render
 (gyhandy/Neural-Sim-NeRF, files cited per function below; RN = optimization/utils/run_nerf_noscale.py,
 RH = optimization/utils/run_nerf_helpers.py).  It exists so that tests can check the HIP path against
 something that does not live in the product.  Only `tests/`, `__graft_entry__.smoke()` and the
-`cpu_baseline` leg of `bench.py` may import it.  The product (`neural-sim-nerf_amd/`) never does.
+`cpu_baseline` leg of `bench.py` may import it.  The product (`neural_sim_nerf_amd/`) never does.
 
 Pinning: every function here is checked against golden vectors produced by importing and running the
 reference itself (see oracle/gen_golden.py -> tests/golden/*.npz, tests/test_oracle_golden.py).

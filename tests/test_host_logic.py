@@ -175,7 +175,7 @@ assert ns["sample_pose_nograd"].__module__ == "utils.load_LINEMOD_noscale"
 import utils.load_LINEMOD_noscale as LL
 assert LL.__file__.startswith("/root/reference/")
 print("ok")
-''' % (ROOT, os.path.join(ROOT, "neural-sim-nerf_amd", "dropin"))
+''' % (ROOT, os.path.join(ROOT, "neural_sim_nerf_amd", "dropin"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
