@@ -10,10 +10,16 @@
  * Conventions
  *   - plain C types only; every `const float*` / `float*` / `int64_t*` named d_* is a DEVICE pointer
  *     owned by the caller (e.g. a PyTorch-ROCm tensor's data_ptr); the library never frees them;
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered,
- *     no hidden synchronisation except in nsr_create/nsr_destroy/nsr_upload_* (setup, not hot path);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered.
+ *     SETUP calls (nsr_create, nsr_destroy, nsr_upload_*, nsr_reserve_bbox, nsr_selftest, nsr_last_kernel_ms)
+ *     may allocate and synchronise.  LAUNCH calls (everything else) only enqueue kernels on `stream`: no
+ *     allocation, no synchronisation, no environment reads, the calling thread's current HIP device is left as
+ *     it was found -- they can be captured into a hipGraph and replayed (tests/test_gpu_parity.py);
  *   - return value: 0 = OK, non-zero = error, message via nsr_last_error() (thread-local);
- *   - one handle per (model, stream); a handle is not thread-safe, distinct handles are;
+ *   - one handle per (model, stream): a handle owns one argument block, one work-queue head and its scratch
+ *     buffers, so launches are ordered by the stream they are issued on; a launch on a DIFFERENT stream while the
+ *     handle's previous launch is still running is refused with an error (never a silent race).  A handle is not
+ *     thread-safe, distinct handles are;
  *   - the arithmetic is fp32 end to end (MFMA v_mfma_f32_32x32x2_f32 for the MLP GEMMs), fp64 only
  *     inside the two sequential scans where torch-CPU accumulates in fp64 (RN:376 cumprod, RH:203 cumsum).
  */
@@ -27,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NSR_ABI_VERSION 1
+#define NSR_ABI_VERSION 2
 
 /* Fixed architecture of the path (configs/nerf_param_ycbv_general.txt:12-13; NM:1232-1272). */
 #define NSR_N_SAMPLES     64   /* N_samples    (coarse, RN:439)          */
@@ -54,7 +60,8 @@ typedef struct NsrConfig {
   int32_t variant;         /* forward kernel: 0 = library default (= 16), 16 = 16 points/wave, two workgroups
                               per CU (needs nsr_upload_weights16), 32 = 32 points/wave, one workgroup/CU  */
   int32_t flags;           /* NSR_FLAG_* render options (0 = the YCB-V configuration)                */
-  int32_t reserved;        /* must be 0                                                            */
+  int32_t chunk;           /* x16 kernel: rays per chunk of the work queue; 0 = default (1).  Larger chunks trade
+                              load balance for L2 locality of the weight streams ("Chunk queue")  */
 } NsrConfig;
 
 #define NSR_FLAG_WHITE_BKGD 1   /* white_bkgd (RN:384-385): rgb_map += 1 - acc_map, coarse and fine; also in the VJP */
@@ -119,10 +126,13 @@ int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W
  * torch.autograd.grad(rgb_p, batch_rays, grad_outputs=patch_grad_E) (RN:168-178).  Network weights are
  * constants and z_samples is detached (RN:475), so the gradient reaches the rays only through the fine pass.
  * d_grad_rgb [N,3] cotangent of rgb_map -> d_grad_o, d_grad_d [N,3].  `out` (optional, may be NULL; only
- * d_rgb/d_disp/d_acc are written) receives the forward render of the same launch. */
+ * d_rgb/d_disp/d_acc are written) receives the forward render of the same launch.
+ * d_z_fine (optional, may be NULL) [N,192]: sorted fine sample depths (RN:477) to use INSTEAD of the kernel's own
+ * resampling -- they are constants of the backward pass (RN:475), so a caller that already holds them (or a parity
+ * test holding the reference's) gets the gradient at exactly those depths. */
 int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                         float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
-                        const NsrRenderOut* out, void* stream);
+                        const float* d_z_fine, const NsrRenderOut* out, void* stream);
 
 /* Chain rule through get_rays (RH:160-164, linear in c2w): per patch of `patch` consecutive pixels (row-major,
  * the order of RN:150-157), d_out[p] = dL/d c2w[3][4] given dL/d rays.  n_patches = ceil(H*W / patch). */
@@ -168,26 +178,19 @@ int nsr_sort_merge(nsr_handle h, const float* d_z_coarse, const float* d_z_sampl
  *   swap kept), mask = gray > 1, 8-connected components with statistics, the largest-area row dropped, then the row
  *   with the largest w*h (NM:691-692).  d_bbox [n_images,4] int32 = x, y, w, h; d_count [n_images] = number of rows
  *   left after the drop (0 = the reference would raise on this image; the box is then 0,0,0,0); d_mask (nullable)
- *   [n_images,H,W] uint8 0/255.  H*W <= 2^20. */
+ *   [n_images,H,W] uint8 0/255.  H*W <= 2^20.  Its scratch (24 B per pixel for 16 images in flight) is allocated by
+ *   the SETUP call nsr_reserve_bbox(h, H, W), which must have been made for an image at least this large. */
 int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* stream);
 int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int W, int32_t* d_bbox,
                   int32_t* d_count, uint8_t* d_mask, void* stream);
+int nsr_reserve_bbox(nsr_handle h, int H, int W);
 
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
 
-/* Diagnostic: the 256x256 layer GEMM in isolation on every CU, `iters` layer-equivalents per wave; returns ms.
- * mode 0: MFMAs only, 1: + LDS fragment reads, 2: + LDS-DMA ring and barriers = the production x32 segment,
- * 3: the x16 segment with two workgroups per CU (ms = kernel time).  Modes 4..8: the x16 segment in the first
- * workgroup of every CU while the second one runs nothing / a dense fp32 VALU chain / sin-cos / an LDS pointer
- * chase / an fp64 chain (ms = mean duration of the GEMM workgroups; NSR_PROBE_VERBOSE=1 prints the partner's
- * loop rate, NSR_PROBE_PARTNER_PRIO=1 raises its priority).  Mode 10: the x32 layer followed by its relu + re-bias
- * epilogue; mode 9: the two-tiles-per-wave 16x16x4 scheme with the epilogue of one tile interleaved into the other
- * tile's MFMAs.  Used to attribute MFMA-rate losses. */
-int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream);
-
-/* Timing helper for bench.py: HIP-event time in ms of the last nsr_render_* launch on this handle
- * (events recorded on the launch stream; this call synchronises on the stop event). */
+/* Timing helper for bench.py: HIP-event time in ms of the last EAGER nsr_render_* launch on this handle
+ * (events recorded on the launch stream; this call synchronises on the stop event).  Launches made while the
+ * stream is being captured into a graph are not timed. */
 int nsr_last_kernel_ms(nsr_handle h, float* ms);
 
 #ifdef __cplusplus

@@ -7,13 +7,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "csrc", "libnsr.so"))   # override: A/B builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 PACKED_FLOATS = 145 * 4096 + 3328
 
 
 class NsrConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_samples", C.c_int32),
-                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("variant", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("n_importance", C.c_int32), ("max_workgroups", C.c_int32), ("variant", C.c_int32), ("flags", C.c_int32), ("chunk", C.c_int32)]
 
 
 class NsrDebugOut(C.Structure):
@@ -42,7 +42,8 @@ SIGNATURES = {
                                    C.c_float, C.c_float, C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut),
                                    C.c_void_p]),
     "nsr_render_rays_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NsrRenderOut), C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NsrRenderOut),
+                                      C.c_void_p]),
     "nsr_pose_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double),
                                 C.c_int, C.c_void_p, C.c_void_p]),
     "nsr_get_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p,
@@ -57,7 +58,7 @@ SIGNATURES = {
     "nsr_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_sort_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsr_selftest": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "nsr_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "nsr_reserve_bbox": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "nsr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
 }
 

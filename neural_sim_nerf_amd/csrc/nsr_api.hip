@@ -1,6 +1,9 @@
 // nsr_api.hip -- C ABI (include/nsr.h) over the kernels in nsr_kernels.hip.  Host side only: argument
-// checking, weight/table residency, launches, HIP-event timing.  No torch types, no hidden synchronisation on
-// the hot path.
+// checking, weight/table residency, launches, HIP-event timing.  No torch types.
+// Launch entry points (nsr_render_*, nsr_pose_grad, nsr_to8b, nsr_find_bbox, stage kernels) only enqueue work on the
+// caller's stream: every scratch buffer they need is allocated by the setup calls (nsr_create, nsr_upload_weights_bwd,
+// nsr_reserve_bbox), they read no environment variables, they leave the calling thread's current device as they found
+// it, and they can be captured into a hipGraph.
 #include "nsr_kernels.hip"
 #include "nsr_handoff.hip"
 
@@ -31,6 +34,19 @@ int fail(const std::string& m) {
     if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
   } while (0)
 
+// current device := `dev` for the lifetime of the guard; restored on exit (libnsr shares the caller's HIP runtime, so
+// a bare hipSetDevice would silently move e.g. PyTorch's current device)
+struct DeviceGuard {
+  int prev = -1, dev;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int d) : dev(d) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+#define NSR_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSR_HIP(guard_.err)
+
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
 constexpr size_t kRender16Lds = nsr::kLds16State + sizeof(nsr::ItemState16);
 constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
@@ -40,6 +56,7 @@ constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
 struct nsr_handle_s {
   NsrConfig cfg;
   int n_cu = 0;
+  int chunk = 1;                                        // k_render16: rays per chunk of the work queue
   float* d_nets = nullptr;
   float* d_packed[3] = {nullptr, nullptr, nullptr};   // views into d_nets: coarse, fine, fine transposed
   bool have_net[3] = {false, false, false};
@@ -48,18 +65,43 @@ struct nsr_handle_s {
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
-  nsr::RenderArgs* d_args = nullptr;  // kernel argument block (device), one per handle
+  nsr::RenderArgs* d_args = nullptr;  // kernel argument block (device), written stream-ordered by k_set_args
   nsr::VjpArgs* d_vjp_args = nullptr;
-  uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [grid][3][9][256]
+  uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [n_cu][3][9][256] (nsr_upload_weights_bwd)
   int mask_grid = 0;
-  unsigned* d_chunk_counter = nullptr;  // k_render16: chunk queue head
-  float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk
-  int zf_grid = 0, zf_chunk = 0;
-  int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images
+  unsigned long long* d_work_counter = nullptr;  // work-queue head
+  float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
+  int zf_grid = 0;
+  int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images (nsr_reserve_bbox)
   size_t box_scratch_ints = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel timing (eager launches only)
+  hipEvent_t ev_busy = nullptr;              // completion of the last launch that used the per-handle scratch
+  hipStream_t last_stream = nullptr;
+  bool launched = false;
   bool timed = false;
 };
+
+// One handle = one argument block, one work counter, one set of scratch buffers: launches on ONE stream are ordered
+// by the stream; a launch on a different stream while the previous one is still running would race on them and
+// is refused (include/nsr.h: one handle per (model, stream)).  Never blocks, never queried while capturing.
+static int claim_stream(nsr_handle h, hipStream_t s, bool capturing) {
+  if (h->launched && s != h->last_stream && !capturing) {
+    const hipError_t q = hipEventQuery(h->ev_busy);
+    if (q == hipErrorNotReady)
+      return fail("handle is busy on another stream (one handle per (model, stream); use a second handle or order the "
+                  "streams with an event)");
+    if (q != hipSuccess) return fail(std::string("hipEventQuery: ") + hipGetErrorString(q));
+  }
+  h->last_stream = s;
+  return 0;
+}
+
+static int stream_capturing(hipStream_t s, bool* capturing) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  NSR_HIP(hipStreamIsCapturing(s, &st));
+  *capturing = st != hipStreamCaptureStatusNone;
+  return 0;
+}
 
 extern "C" {
 
@@ -72,7 +114,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->n_samples != NSR_N_SAMPLES)
     return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
   if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP)) return fail("nsr_create: unknown bits in flags");
-  if (cfg->reserved != 0) return fail("nsr_create: reserved must be 0");
+  if (cfg->chunk < 0 || cfg->chunk > 256) return fail("nsr_create: chunk must be 0 (default) or 1..256");
   if (cfg->variant != 0 && cfg->variant != 16 && cfg->variant != 32)
     return fail("nsr_create: variant must be 0 (default), 16 or 32");
   if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0)
@@ -80,7 +122,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   int ndev = 0;
   NSR_HIP(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail("nsr_create: no such HIP device");
-  NSR_HIP(hipSetDevice(cfg->device));
+  DeviceGuard guard_(cfg->device); NSR_HIP(guard_.err);
   hipDeviceProp_t prop;
   NSR_HIP(hipGetDeviceProperties(&prop, cfg->device));
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
@@ -88,6 +130,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   nsr_handle h = new nsr_handle_s();
   h->cfg = *cfg;
   h->n_cu = prop.multiProcessorCount;
+  h->chunk = cfg->chunk > 0 ? cfg->chunk : 1;
   // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
   NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
   for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
@@ -96,7 +139,11 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
-  NSR_HIP(hipMalloc(&h->d_chunk_counter, sizeof(unsigned)));
+  NSR_HIP(hipMalloc(&h->d_work_counter, sizeof(unsigned long long)));
+  // k_render16's inter-phase scratch: bounded by the grid (2 workgroups per CU, or max_workgroups) x chunk
+  h->zf_grid = cfg->max_workgroups > 0 ? cfg->max_workgroups : 2 * h->n_cu;
+  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * (size_t)h->zf_grid * h->chunk));
+  NSR_HIP(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
   NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   NSR_HIP(hipEventCreate(&h->ev0));
@@ -109,7 +156,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
 
 int nsr_destroy(nsr_handle h) {
   if (!h) return 0;
-  hipSetDevice(h->cfg.device);
+  DeviceGuard guard_(h->cfg.device);
   hipDeviceSynchronize();
   hipFree(h->d_nets);
   hipFree(h->d_nets16);
@@ -120,9 +167,10 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_mask_scratch);
   hipFree(h->d_box_scratch);
   hipFree(h->d_zf_scratch);
-  hipFree(h->d_chunk_counter);
+  hipFree(h->d_work_counter);
   hipEventDestroy(h->ev0);
   hipEventDestroy(h->ev1);
+  hipEventDestroy(h->ev_busy);
   delete h;
   return 0;
 }
@@ -131,7 +179,7 @@ int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_f
   if (!h || !packed) return fail("nsr_upload_weights: null argument");
   if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights: net_id must be 0 (coarse) or 1 (fine)");
   if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights: wrong packed size");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   NSR_HIP(hipMemcpy(h->d_packed[net_id], packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   h->have_net[net_id] = true;
   return 0;
@@ -141,7 +189,7 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
   if (!h || !packed) return fail("nsr_upload_weights16: null argument");
   if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights16: net_id must be 0 (coarse) or 1 (fine)");
   if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights16: wrong packed size");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   NSR_HIP(hipMemcpy(h->d_nets16 + (size_t)net_id * NSR_PACKED_FLOATS, packed, sizeof(float) * n_floats,
                     hipMemcpyHostToDevice));
   h->have_net16[net_id] = true;
@@ -151,8 +199,12 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
 int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats) {
   if (!h || !stream) return fail("nsr_upload_weights_bwd: null argument");
   if (n_floats != (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd: wrong stream size");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   NSR_HIP(hipMemcpy(h->d_packed[2], stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  if (!h->d_mask_scratch) {          // setup call: the VJP kernel's relu-pattern scratch, one block per workgroup
+    h->mask_grid = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : h->n_cu;
+    NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)h->mask_grid * 3 * 9 * 256));
+  }
   h->have_net[2] = true;
   return 0;
 }
@@ -160,7 +212,7 @@ int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats) {
 int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine) {
   if (!h || !t_coarse || !u_fine) return fail("nsr_upload_tables: null argument");
   if (n_coarse != 64 || n_fine != 128) return fail("nsr_upload_tables: tables must have 64 and 128 entries");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   NSR_HIP(hipMemcpy(h->d_tables, t_coarse, sizeof(float) * 64, hipMemcpyHostToDevice));
   NSR_HIP(hipMemcpy(h->d_tables + 64, u_fine, sizeof(float) * 128, hipMemcpyHostToDevice));
   h->have_tables = true;
@@ -193,7 +245,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     return fail("variant 16 needs nsr_upload_weights16 for every network");
   if (!out || !out->d_rgb || !out->d_disp || !out->d_acc) return fail("render: rgb/disp/acc outputs are required");
   if (a.n_rays <= 0) return 0;
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   float* nets = x16 ? h->d_nets16 : h->d_nets;
   a.nets = nets;
   a.net_stride = (long long)sizeof(float) * NSR_PACKED_FLOATS;
@@ -212,43 +264,40 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   a.dbg_raw0 = dbg ? dbg->d_raw0 : nullptr;
   a.dbg_raw = dbg ? dbg->d_raw : nullptr;
   a.dbg_inds = dbg ? (long long*)dbg->d_inds : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  bool capturing = false;
+  if (int e = stream_capturing(s, &capturing)) return e;
+  if (int e = claim_stream(h, s, capturing)) return e;
+  long long g = 0;
   if (x16) {
-    long long g = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;
-    if (g > a.n_rays) g = a.n_rays;
+    g = h->zf_grid;                                        // two workgroups per CU (or max_workgroups)
     // rays per chunk (see k_render16).  Larger chunks keep one network per L2 for longer (less fabric traffic), but
     // the chunk is also the granularity of the dynamic load balance between the unevenly progressing workgroups:
-    // measured 1 -> 148.2, 2 -> 148.0, 4 -> 148.0, 8 -> 147.9, 16 -> 145.9 TFLOP/s.  Speed wins: 1.
-    int chunk = 1;
-    if (const char* e = getenv("NSR_CHUNK")) { const int v = atoi(e); if (v >= 1 && v <= 256) chunk = v; }
+    // measured 1 -> 148.2, 2 -> 148.0, 4 -> 148.0, 8 -> 147.9, 16 -> 145.9 TFLOP/s.  Speed wins: the default is 1
+    // (NsrConfig.chunk).
+    int chunk = h->chunk;
     if ((long long)chunk * g > a.n_rays) chunk = (int)(a.n_rays / g > 1 ? a.n_rays / g : 1);   // small batches: keep every CU busy
-    if (g > h->zf_grid || chunk > h->zf_chunk) {
-      if (h->d_zf_scratch) { NSR_HIP(hipDeviceSynchronize()); NSR_HIP(hipFree(h->d_zf_scratch)); }
-      h->d_zf_scratch = nullptr;
-      const int ng = g > h->zf_grid ? (int)g : h->zf_grid, nc = chunk > h->zf_chunk ? chunk : h->zf_chunk;
-      NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * (size_t)ng * nc));
-      h->zf_grid = ng; h->zf_chunk = nc;
-    }
+    const long long n_chunks = (a.n_rays + chunk - 1) / chunk;
+    if (g > n_chunks) g = n_chunks;
     a.zf_scratch = h->d_zf_scratch;
     a.chunk = chunk;
-  }
-  a.chunk_counter = h->d_chunk_counter;
-  NSR_HIP(hipMemsetAsync(h->d_chunk_counter, 0, sizeof(unsigned), (hipStream_t)stream));
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);
-  NSR_HIP(hipEventRecord(h->ev0, s));
-  if (x16) {
-    long long g = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;   // two workgroups per CU
-    const long long n_chunks = (a.n_rays + a.chunk - 1) / a.chunk;
-    if (g > n_chunks) g = n_chunks;
-    hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   } else {
-    const long long n_items = (a.n_rays + 1) / 2;
-    hipLaunchKernelGGL(nsr::k_render, dim3(grid_for(h, n_items)), dim3(256), kRenderLds, s,
-                       (const nsr::RenderArgs*)h->d_args);
+    g = grid_for(h, (a.n_rays + 1) / 2);
   }
+  a.work_counter = h->d_work_counter;
+  hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);     // also zeroes the work counter
+  if (!capturing) NSR_HIP(hipEventRecord(h->ev0, s));
+  if (x16)
+    hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
+  else
+    hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   NSR_HIP(hipGetLastError());
-  NSR_HIP(hipEventRecord(h->ev1, s));
-  h->timed = true;
+  if (!capturing) {
+    NSR_HIP(hipEventRecord(h->ev1, s));
+    NSR_HIP(hipEventRecord(h->ev_busy, s));
+  }
+  h->launched = true;
+  h->timed = !capturing;
   return 0;
 }
 
@@ -278,7 +327,7 @@ int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W
 
 int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                         float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
-                        const NsrRenderOut* out, void* stream) {
+                        const float* d_z_fine, const NsrRenderOut* out, void* stream) {
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h) return fail("nsr_render_rays_vjp: null handle");
   if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
@@ -286,14 +335,14 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   if (!h->have_net[2]) return fail("nsr_render_rays_vjp: backward stream not uploaded (nsr_upload_weights_bwd)");
   if (!d_rays_o || !d_rays_d || !d_grad_rgb || !d_grad_o || !d_grad_d) return fail("nsr_render_rays_vjp: null argument");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_render_rays_vjp: negative ray count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
+  hipStream_t s = (hipStream_t)stream;
+  bool capturing = false;
+  if (int e = stream_capturing(s, &capturing)) return e;
+  if (int e = claim_stream(h, s, capturing)) return e;
   const long long n_items = (n_rays + 1) / 2;
-  const int grid = grid_for(h, n_items);
-  if (grid > h->mask_grid) {
-    if (h->d_mask_scratch) NSR_HIP(hipFree(h->d_mask_scratch));
-    NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)grid * 3 * 9 * 256));
-    h->mask_grid = grid;
-  }
+  int grid = grid_for(h, n_items);
+  if (grid > h->mask_grid) grid = h->mask_grid;          // the relu-pattern scratch was sized at upload time
   nsr::VjpArgs v;
   memset(&v, 0, sizeof(v));
   nsr::RenderArgs& a = v.r;
@@ -305,19 +354,22 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = 1;
-  a.chunk_counter = h->d_chunk_counter;
-  NSR_HIP(hipMemsetAsync(h->d_chunk_counter, 0, sizeof(unsigned), (hipStream_t)stream));
+  a.work_counter = h->d_work_counter;
   a.white_bkgd = (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0;
   a.lindisp = (h->cfg.flags & NSR_FLAG_LINDISP) ? 1 : 0;
   if (out) { a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc; }
   v.grad_rgb = d_grad_rgb; v.grad_o = d_grad_o; v.grad_d = d_grad_d; v.mask_scratch = h->d_mask_scratch;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);
-  NSR_HIP(hipEventRecord(h->ev0, s));
+  v.z_fine = d_z_fine;
+  hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);   // also zeroes the work counter
+  if (!capturing) NSR_HIP(hipEventRecord(h->ev0, s));
   hipLaunchKernelGGL(nsr::k_render_vjp, dim3(grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   NSR_HIP(hipGetLastError());
-  NSR_HIP(hipEventRecord(h->ev1, s));
-  h->timed = true;
+  if (!capturing) {
+    NSR_HIP(hipEventRecord(h->ev1, s));
+    NSR_HIP(hipEventRecord(h->ev_busy, s));
+  }
+  h->launched = true;
+  h->timed = !capturing;
   return 0;
 }
 
@@ -325,7 +377,7 @@ int nsr_pose_grad(nsr_handle h, const float* d_grad_o, const float* d_grad_d, in
                   int patch, float* d_out, void* stream) {
   if (!h || !d_grad_o || !d_grad_d || !K9 || !d_out) return fail("nsr_pose_grad: null argument");
   if (H <= 0 || W <= 0 || patch <= 0) return fail("nsr_pose_grad: bad geometry");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   const int n = H * W, n_patches = (n + patch - 1) / patch;
   hipLaunchKernelGGL(nsr::k_pose_grad, dim3(n_patches), dim3(256), 0, (hipStream_t)stream, d_grad_o, d_grad_d,
                      (float)K9[0], (float)K9[4], (float)K9[2], (float)K9[5], W, n, patch, d_out);
@@ -337,7 +389,7 @@ int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K
                  float* d_rays_d, void* stream) {
   if (!h || !d_c2w || !K9 || !d_rays_o || !d_rays_d) return fail("nsr_get_rays: null argument");
   if (H <= 0 || W <= 0) return fail("nsr_get_rays: bad image geometry");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   const int n = H * W;
   hipLaunchKernelGGL(nsr::k_get_rays, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_c2w, (float)K9[0],
                      (float)K9[4], (float)K9[2], (float)K9[5], H, W, d_rays_o, d_rays_d);
@@ -349,7 +401,7 @@ int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* st
   if (h && n == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_x || !d_out) return fail("nsr_to8b: null argument");
   if (n <= 0) return n == 0 ? 0 : fail("nsr_to8b: negative element count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   const long long groups = (n + 3) / 4;
   hipLaunchKernelGGL(nsr::k_to8b, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x,
                      (long long)n, d_out);
@@ -363,16 +415,14 @@ int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int 
   if (!h || !d_rgb8 || !d_bbox || !d_count) return fail("nsr_find_bbox: null argument");
   if (H <= 0 || W <= 0 || (long long)H * W > (1 << 20)) return fail("nsr_find_bbox: image must have 1..2^20 pixels");
   if (n_images <= 0) return n_images == 0 ? 0 : fail("nsr_find_bbox: negative image count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   const long long hw = (long long)H * W;
-  const int batch = n_images < 16 ? n_images : 16;           // bounds the scratch: 24 B per pixel per image in flight
-  const size_t need = (size_t)batch * (hw + (hw + 1) * 5);
-  if (need > h->box_scratch_ints) {
-    if (h->d_box_scratch) { NSR_HIP(hipStreamSynchronize((hipStream_t)stream)); NSR_HIP(hipFree(h->d_box_scratch)); }
-    h->d_box_scratch = nullptr; h->box_scratch_ints = 0;
-    NSR_HIP(hipMalloc(&h->d_box_scratch, need * sizeof(int)));
-    h->box_scratch_ints = need;
-  }
+  const int batch = (int)(h->box_scratch_ints / (size_t)(hw + (hw + 1) * 5));   // images per round of the 5 kernels
+  if (batch < 1)
+    return fail("nsr_find_bbox: scratch not reserved for this image size (call nsr_reserve_bbox(h, H, W) once, at setup)");
+  bool capturing = false;
+  if (int e = stream_capturing((hipStream_t)stream, &capturing)) return e;
+  if (int e = claim_stream(h, (hipStream_t)stream, capturing)) return e;
   hipStream_t s = (hipStream_t)stream;
   for (int i0 = 0; i0 < n_images; i0 += batch) {
     nsr::BoxArgs a;
@@ -392,6 +442,22 @@ int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int 
     hipLaunchKernelGGL(nsr::k_box_select, dim3(a.K), dim3(256), 0, s, a);
   }
   NSR_HIP(hipGetLastError());
+  if (!capturing) NSR_HIP(hipEventRecord(h->ev_busy, s));
+  h->launched = true;
+  return 0;
+}
+
+int nsr_reserve_bbox(nsr_handle h, int H, int W) {
+  if (!h) return fail("nsr_reserve_bbox: null handle");
+  if (H <= 0 || W <= 0 || (long long)H * W > (1 << 20)) return fail("nsr_reserve_bbox: image must have 1..2^20 pixels");
+  NSR_DEVICE(h);
+  const long long hw = (long long)H * W;
+  const size_t need = (size_t)16 * (hw + (hw + 1) * 5);     // 16 images in flight: 24 B per pixel each
+  if (need <= h->box_scratch_ints) return 0;
+  if (h->d_box_scratch) { NSR_HIP(hipDeviceSynchronize()); NSR_HIP(hipFree(h->d_box_scratch)); }   // setup call
+  h->d_box_scratch = nullptr; h->box_scratch_ints = 0;
+  NSR_HIP(hipMalloc(&h->d_box_scratch, need * sizeof(int)));
+  h->box_scratch_ints = need;
   return 0;
 }
 
@@ -400,7 +466,7 @@ int nsr_embed(nsr_handle h, const float* d_x, int64_t n, int multires, float* d_
   if (!h || !d_x || !d_out) return fail("nsr_embed: null argument");
   if (multires < 1 || multires > 16) return fail("nsr_embed: multires in 1..16");
   if (n <= 0) return n == 0 ? 0 : fail("nsr_embed: negative point count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   const long long work = (long long)n * (multires + 1);
   hipLaunchKernelGGL(nsr::k_embed, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_x,
                      (long long)n, multires, d_out);
@@ -414,7 +480,7 @@ int nsr_run_network(nsr_handle h, int net_id, const float* d_pts, const float* d
   if (!h || !d_pts || !d_viewdirs || !d_raw) return fail("nsr_run_network: null argument");
   if (net_id < 0 || net_id > 1 || !h->have_net[net_id]) return fail("nsr_run_network: network not uploaded");
   if (n_pts <= 0) return n_pts == 0 ? 0 : fail("nsr_run_network: negative point count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   nsr::NetArgs a;
   a.stream = h->d_packed[net_id];
   a.aux = h->d_packed[net_id] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
@@ -433,7 +499,7 @@ int nsr_raw2outputs(nsr_handle h, const float* d_raw, const float* d_z, const fl
     return fail("nsr_raw2outputs: null argument");
   if (n_samples != 64 && n_samples != 192) return fail("nsr_raw2outputs: n_samples must be 64 or 192");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_raw2outputs: negative ray count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   nsr::R2OArgs a{d_raw, d_z, d_rays_d, n_rays, (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0,
                  d_rgb, d_disp, d_acc, d_weights, d_depth};
   const long long items = (n_rays + 1) / 2;
@@ -452,7 +518,7 @@ int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, in
   if (!h || !d_bins || !d_weights || !d_samples) return fail("nsr_sample_pdf: null argument");
   if (!h->have_tables) return fail("nsr_sample_pdf: tables not uploaded");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_sample_pdf: negative ray count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   nsr::PdfArgs a{d_bins, d_weights, h->d_tables + 64, n_rays, d_samples, (long long*)d_inds};
   const long long items = (n_rays + 1) / 2;
   const int grid = (int)(items < 4096 ? items : 4096);
@@ -466,7 +532,7 @@ int nsr_sort_merge(nsr_handle h, const float* d_z_coarse, const float* d_z_sampl
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h || !d_z_coarse || !d_z_samples || !d_z_sorted) return fail("nsr_sort_merge: null argument");
   if (n_rays < 0) return fail("nsr_sort_merge: negative ray count");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   const long long items = (n_rays + 1) / 2;
   const int grid = (int)(items < 4096 ? items : 4096);
   hipLaunchKernelGGL(nsr::k_sort_merge, dim3(grid), dim3(256), sizeof(nsr::ItemState), (hipStream_t)stream,
@@ -477,7 +543,7 @@ int nsr_sort_merge(nsr_handle h, const float* d_z_coarse, const float* d_z_sampl
 
 int nsr_selftest(nsr_handle h, void* stream) {
   if (!h) return fail("nsr_selftest: null handle");
-  NSR_HIP(hipSetDevice(h->cfg.device));
+  NSR_DEVICE(h);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(nsr::k_selftest, dim3(1), dim3(64), 0, s, h->d_scratch);
   NSR_HIP(hipGetLastError());
@@ -500,76 +566,10 @@ int nsr_selftest(nsr_handle h, void* stream) {
   return 0;
 }
 
-int nsr_probe(nsr_handle h, int mode, int iters, float* ms, void* stream) {
-  if (!h || !ms) return fail("nsr_probe: null argument");
-  if (mode < 0 || mode > 10 || iters <= 0) return fail("nsr_probe: mode in 0..10, iters > 0");
-  if (!h->have_net[0]) return fail("nsr_probe: upload a network first");
-  NSR_HIP(hipSetDevice(h->cfg.device));
-  hipStream_t s = (hipStream_t)stream;
-  float* out = nullptr;
-  NSR_HIP(hipMalloc(&out, sizeof(float) * 512 * h->n_cu));
-  const size_t lds = nsr::kRingSlots * nsr::kSlabBytes;
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  NSR_HIP(hipEventRecord(h->ev0, s));
-  if (mode == 0) hipLaunchKernelGGL(nsr::k_probe<0>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
-  if (mode == 1) hipLaunchKernelGGL(nsr::k_probe<1>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
-  if (mode == 2) hipLaunchKernelGGL(nsr::k_probe<2>, dim3(h->n_cu), dim3(256), lds, s, h->d_packed[0], out, iters);
-  if (mode == 3) {
-    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe16, hipFuncAttributeMaxDynamicSharedMemorySize, nsr::kRing16 * nsr::kSlabBytes));
-    hipLaunchKernelGGL(nsr::k_probe16, dim3(2 * h->n_cu), dim3(256), nsr::kRing16 * nsr::kSlabBytes, s, h->d_packed[0], out, iters);
-  }
-  if (mode == 9 || mode == 10) {
-    const size_t l = nsr::kRingSlots * nsr::kSlabBytes + 1024;
-    if (mode == 9) {
-      NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe_epi<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
-      hipLaunchKernelGGL(nsr::k_probe_epi<9>, dim3(h->n_cu), dim3(256), l, s, h->d_nets16, out, iters);
-    } else {
-      NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe_epi<10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l));
-      hipLaunchKernelGGL(nsr::k_probe_epi<10>, dim3(h->n_cu), dim3(256), l, s, h->d_packed[0], out, iters);
-    }
-  }
-  int* done = nullptr;
-  if (mode >= 4 && mode <= 8) {
-    NSR_HIP(hipMalloc(&done, sizeof(int)));
-    NSR_HIP(hipMemsetAsync(done, 0, sizeof(int), s));
-    const size_t l16 = nsr::kRing16 * nsr::kSlabBytes;
-    const dim3 g(2 * h->n_cu), b(256);
-#define NSR_PAIR(P)                                                                                              \
-  if (mode == 4 + P) {                                                                                           \
-    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_probe16_pair<P>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)l16));                                                                      \
-    hipLaunchKernelGGL(nsr::k_probe16_pair<P>, g, b, l16, s, h->d_packed[0], out, iters, done, h->n_cu,        \
-                       getenv("NSR_PROBE_PARTNER_PRIO") ? atoi(getenv("NSR_PROBE_PARTNER_PRIO")) : 0);                   \
-  }
-    NSR_PAIR(0) NSR_PAIR(1) NSR_PAIR(2) NSR_PAIR(3) NSR_PAIR(4)
-#undef NSR_PAIR
-  }
-  NSR_HIP(hipGetLastError());
-  NSR_HIP(hipEventRecord(h->ev1, s));
-  NSR_HIP(hipEventSynchronize(h->ev1));
-  NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
-  if (mode >= 4 && mode <= 8) {        // mean duration of the GEMM workgroups (100 MHz ticks -> ms), not the whole kernel
-    std::vector<float> host(2 * h->n_cu);
-    NSR_HIP(hipMemcpy(host.data(), out, sizeof(float) * host.size(), hipMemcpyDeviceToHost));
-    double sum = 0.0; int n = 0;
-    for (float v : host) if (v > 0.0f) { sum += v; ++n; }
-    *ms = n ? (float)(sum / n * 1e-5) : 0.0f;
-    double ps = 0.0; int pn = 0;
-    for (float v : host) if (v < 0.0f) { ps -= v; ++pn; }
-    if (pn && getenv("NSR_PROBE_VERBOSE"))
-      fprintf(stderr, "nsr_probe mode %d: partner workgroups ran %.4f loop iterations per 10 ns tick\n", mode, ps / pn);
-    if (n != h->n_cu) { hipFree(out); hipFree(done); return fail("nsr_probe: the dispatcher did not place one first workgroup per CU"); }
-    NSR_HIP(hipFree(done));
-  }
-  NSR_HIP(hipFree(out));
-  return 0;
-}
-
 int nsr_last_kernel_ms(nsr_handle h, float* ms) {
   if (!h || !ms) return fail("nsr_last_kernel_ms: null argument");
-  if (!h->timed) return fail("nsr_last_kernel_ms: no render launched yet");
+  if (!h->timed) return fail("nsr_last_kernel_ms: no timed render launch yet (launches captured into a graph are not timed)");
+  NSR_DEVICE(h);
   NSR_HIP(hipEventSynchronize(h->ev1));
   NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
   return 0;

@@ -679,7 +679,7 @@ struct RenderArgs {
   long long* dbg_inds;
   float* zf_scratch;        // k_render16: [grid][chunk][192] sorted fine z values between the two phases of a chunk
   int chunk;                // k_render16: rays per workgroup per phase
-  unsigned* chunk_counter;  // k_render16: next chunk to hand out (zeroed before the launch)
+  unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays
 };
 
 __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
@@ -697,7 +697,7 @@ __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int ti
 // (stream-ordered, no host staging buffer to keep alive), and the render kernel reads its fields with scalar
 // loads at the point of use -- by-value kernel arguments were all preloaded into SGPRs and cost 70 more SGPR
 // spills inside the MFMA passes.
-__global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; }
+__global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; *a.work_counter = 0ull; }
 
 #ifdef NSR_PHASE_TIMING      // diagnostic build: per-workgroup cycle totals of the item phases (thread 0), see tools
 #define NSR_T(i) do { if (tid == 0) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
@@ -736,9 +736,9 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   const float* aux_c = (const float*)(smem + kLdsAux);
 
   // items come from a global counter: nothing forces the workgroups to progress at the same rate
-  int* item_slot = (int*)&st.ray[0][15];
+  long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
   auto next_item = [&]() -> long long {
-    if (tid == 0) *item_slot = (int)atomicAdd(a.chunk_counter, 1u);
+    if (tid == 0) *item_slot = (long long)atomicAdd(a.work_counter, 1ull);
     __syncthreads();
     const long long v = *item_slot;
     __syncthreads();
@@ -1054,9 +1054,11 @@ struct VjpArgs {
   float* grad_o;            // [N,3]
   float* grad_d;            // [N,3]
   uint4* mask_scratch;      // [gridDim][3 passes][9 layers][256 threads]
+  const float* z_fine;      // optional [N,192]: sorted fine sample depths to use instead of the kernel's own resampling
+                            // (z_samples is detached, RN:475: the depths are constants of the backward pass)
 };
 
-__global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; }
+__global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; *a.r.work_counter = 0ull; }
 
 // ------------------------------------------------------------------------------------------------------
 // Fused forward + input-gradient kernel (render_path_grad, RN:168-178).  Per item (2 rays):
@@ -1094,9 +1096,9 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
   uint4* my_masks = va.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256) + tid;
   float* grgb = &st.res[0][0];   // [2][3] cotangent staged here during the backward half (res is free then)
 
-  int* item_slot = (int*)&st.ray[0][15];
+  long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
   auto next_item = [&]() -> long long {
-    if (tid == 0) *item_slot = (int)atomicAdd(a.chunk_counter, 1u);
+    if (tid == 0) *item_slot = (long long)atomicAdd(a.work_counter, 1ull);
     __syncthreads();
     const long long v = *item_slot;
     __syncthreads();
@@ -1176,6 +1178,13 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid);
       merge_sort_item(st, tid);
+      if (va.z_fine) {                                       // caller-supplied depths replace the resampled ones
+        for (int idx = tid; idx < 2 * 192; idx += 256) {
+          const int r = idx / 192, k = idx - r * 192;
+          st.zf[r][k] = va.z_fine[(ray0 + (r < valid ? r : 0)) * 192 + k];
+        }
+        __syncthreads();
+      }
       pass = 1;
     } else if (pass < 3) {
       ++pass;
@@ -1415,7 +1424,7 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   const int K = a.chunk;
   const long long n_chunks = (n_items + K - 1) / K;
   float* zscr = a.zf_scratch + (size_t)blockIdx.x * K * 192;
-  int* chunk_slot = (int*)&st.res[0][7];                   // LDS word that broadcasts the chunk id
+  long long* chunk_slot = (long long*)&st.res[0][6];       // 8-byte LDS slot that broadcasts the chunk id
 
   Ring rg;
   ring_init(rg, smem, a.nets, a.net_stride, 1, wave, lane);
@@ -1438,7 +1447,7 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   int jr = 0;                                              // ray within the chunk
   int pass = 0;                                            // 0 = coarse pass (phase A), 1..3 = fine passes (phase B)
   auto next_chunk = [&]() -> bool {
-    if (tid == 0) *chunk_slot = (int)atomicAdd(a.chunk_counter, 1u);
+    if (tid == 0) *chunk_slot = (long long)atomicAdd(a.work_counter, 1ull);
     __syncthreads();
     const long long c = *chunk_slot;
     __syncthreads();
@@ -1577,278 +1586,6 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   if (tid == 0 && a.dbg_raw == nullptr && a.dbg_inds)
     for (int i = 0; i < 8; ++i) a.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
 #endif
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Diagnostic micro-kernels (nsr_probe): the layer GEMM in isolation, to attribute MFMA-rate losses.
-//   mode 0: 1024 MFMAs per iteration, A operands from registers (no LDS, no ring)  -> MFMA issue ceiling
-//   mode 1: A fragments read from a static LDS slab with the production step structure (no DMA, no barrier)
-//   mode 2: the production segment seg<8,32> with the LDS-DMA ring and barriers
-// ------------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(256, 1) k_probe(const float* __restrict__ stream, float* out, int iters) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  f32x16 in[8], acc[8];
-#pragma unroll
-  for (int mo = 0; mo < 8; ++mo) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
-  }
-  Ring rg;
-  ring_init(rg, smem, stream, 0, 1, wave, lane);
-  f32x4 A0[4], A1[4];
-  if (MODE == 2) {
-    ring_start(rg, A0, lane);
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else if (MODE == 1) {
-    for (int i = tid; i < 4096; i += 256) ((float*)smem)[i] = stream[i];
-    __syncthreads();
-    ring_load_quarter<0>(rg, A0, lane);
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int s = 0; s < 64; s += 2) {
-        consume<8, 0, 1>(A0, s, BRegs16<8>{in}, acc);     NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); NSR_PIN();
-        consume<8, 1, 4>(A0, s, BRegs16<8>{in}, acc);     NSR_PIN();
-        consume<8, 0, 1>(A1, s + 1, BRegs16<8>{in}, acc); NSR_PIN(); ring_load_quarter<0>(rg, A0, lane); NSR_PIN();
-        consume<8, 1, 4>(A1, s + 1, BRegs16<8>{in}, acc); NSR_PIN();
-      }
-    }
-  } else {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { A0[c] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(lane + c); A1[c] = A0[c] * 0.5f; }
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int s = 0; s < 64; s += 2) {
-        consume<8, 0, 4>(A0, s, BRegs16<8>{in}, acc);
-        consume<8, 0, 4>(A1, s + 1, BRegs16<8>{in}, acc);
-      }
-    }
-  }
-  float sum = 0.0f;
-#pragma unroll
-  for (int mo = 0; mo < 8; ++mo)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sum += acc[mo][r];
-  out[blockIdx.x * 256 + tid] = sum;
-}
-
-// mode 3: the x16 layer GEMM (seg<16,16> on the 3-slab ring), two workgroups per CU
-__global__ void __launch_bounds__(256, 2) k_probe16(const float* __restrict__ stream, float* out, int iters) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  f32x4 in[16], acc[16];
-#pragma unroll
-  for (int mo = 0; mo < 16; ++mo) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
-  }
-  Ring rg;
-  ring_init(rg, smem, stream, 0, 1, wave, lane);
-  f32x4 A0[4], A1[4];
-  ring_start<kRing16>(rg, A0, lane);
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  float sum = 0.0f;
-#pragma unroll
-  for (int mo = 0; mo < 16; ++mo)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sum += acc[mo][r];
-  out[blockIdx.x * 256 + tid] = sum;
-}
-
-// modes 4..8: what the x16 layer GEMM of the FIRST workgroup on a CU loses to a second workgroup that runs
-// PARTNER = 0 nothing, 1 dense fp32 VALU, 2 transcendentals, 3 an LDS latency chain, 4 an fp64 chain.
-// out[blockIdx] = 100 MHz ticks the GEMM workgroup took (0 for partners); partners spin until all GEMMs are done.
-template <int PARTNER>
-__global__ void __launch_bounds__(256, 2) k_probe16_pair(const float* __restrict__ stream, float* out, int iters,
-                                                         int* done, int n_first, int prio) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned ldsb = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11));      // HW_REG_LDS_ALLOC.LDS_BASE
-  if (ldsb != 0) {
-    if (tid == 0) out[blockIdx.x] = 0.0f;
-    if (PARTNER == 0) return;
-    if (prio) __builtin_amdgcn_s_setprio(3);
-    float x = 1e-3f * (float)tid, y = 0.5f;
-    double d = 1.0 + 1e-9 * tid;
-    float* l = (float*)smem;
-    l[tid] = (float)((tid * 17) & 255);
-    const long long t0 = wall_clock64();
-    int it = 0;
-#pragma unroll 1
-    for (; it < (1 << 24); ++it) {
-      if (PARTNER == 1) {
-#pragma unroll
-        for (int k = 0; k < 64; ++k) { x = x * 1.0001f + y; y = y * 0.9999f + x; }
-      } else if (PARTNER == 2) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) { x = __sinf(x) + 1.0f; y = __cosf(y + x); }
-      } else if (PARTNER == 3) {
-        int idx = tid;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) idx = (int)l[idx & 255];
-        x += (float)idx;
-      } else {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) d = d * 1.000000001 + 1e-12;
-      }
-      if ((it & 15) == 0) {
-        if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_first) break;
-        if (wall_clock64() - t0 > 300000000LL) break;       // 3 s safety net
-      }
-    }
-    const long long t1 = wall_clock64();
-    if (tid == 0) out[blockIdx.x] = (x + y + (float)d == 123.456f) ? x : -(float)it / (float)(t1 - t0);   // -(iterations per tick)
-    return;
-  }
-  f32x4 in[16], acc[16];
-#pragma unroll
-  for (int mo = 0; mo < 16; ++mo) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
-  }
-  Ring rg;
-  ring_init(rg, smem, stream, 0, 1, wave, lane);
-  f32x4 A0[4], A1[4];
-  ring_start<kRing16>(rg, A0, lane);
-  const long long t0 = wall_clock64();
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (iters == 1) while (wall_clock64() - t0 < 500000) __builtin_amdgcn_s_sleep(64);     // partner baseline: idle 5 ms
-  const long long t1 = wall_clock64();
-  float sum = 0.0f;
-#pragma unroll
-  for (int mo = 0; mo < 16; ++mo)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sum += acc[mo][r];
-  __syncthreads();
-  if (tid == 0) {
-    out[blockIdx.x] = (sum == 123.456f) ? sum : (float)(t1 - t0);
-    __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
-// modes 9 / 10: can the layer epilogue (relu + re-bias) be hidden?  Mode 10 is the x32 layer as the kernels run it
-// (GEMM, then the epilogue).  Mode 9 is the "two 16-point tiles per wave" scheme: 16x16x4 MFMAs, the two tiles
-// share every weight fragment in the 14 middle slabs of a layer; in the last slab tile A runs ahead and its
-// epilogue is interleaved with tile B's MFMAs, in the first slab of the next layer tile B's epilogue is interleaved
-// with tile A's MFMAs.  Tiles are independent accumulator sets, so the epilogues are in place (no extra registers).
-template <int Q>
-__device__ __forceinline__ void epi_chunk(f32x4 (&acc)[16], f32x4 (&in)[16], const float* bias_g) {
-#pragma unroll
-  for (int mo = 4 * Q; mo < 4 * Q + 4; ++mo) {
-    in[mo] = clamp_bits4(acc[mo], 0);
-    acc[mo] = *(const f32x4*)(bias_g + 16 * mo);
-  }
-}
-
-__device__ __forceinline__ void layer16x2(Ring& rg, f32x4 (&A0)[4], f32x4 (&A1)[4], f32x4 (&inA)[16], f32x4 (&inB)[16],
-                                          f32x4 (&accA)[16], f32x4 (&accB)[16], const float* bias_g, int lane) {
-  // slab 0: tile A, with tile B's epilogue of the previous layer
-  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 0, BRegs4<16>{inA}, accA); epi_chunk<0>(accB, inB, bias_g); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 1, BRegs4<16>{inA}, accA); epi_chunk<1>(accB, inB, bias_g); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 2, BRegs4<16>{inA}, accA); epi_chunk<2>(accB, inB, bias_g); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<0>(rg, A0, lane); consume<16, 0, 4>(A1, 3, BRegs4<16>{inA}, accA); epi_chunk<3>(accB, inB, bias_g); step_pattern<16>();
-  // slab 0: tile B
-  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 0, BRegs4<16>{inB}, accB); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 1, BRegs4<16>{inB}, accB); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 2, BRegs4<16>{inB}, accB); step_pattern<16>();
-  NSR_PIN(); consume<16, 0, 1>(A1, 3, BRegs4<16>{inB}, accB);
-  NSR_PIN(); ring_advance(rg, A0, lane);
-  ring_issue(rg); consume<16, 1, 4>(A1, 3, BRegs4<16>{inB}, accB); step_pattern_dma<12>();
-  // slabs 1..14: both tiles on every fragment
-#pragma unroll
-  for (int s = 4; s < 60; s += 4) {
-    NSR_PIN(); ring_load_quarter<1>(rg, A1, lane);
-    consume<16, 0, 4>(A0, s, BRegs4<16>{inA}, accA); consume<16, 0, 4>(A0, s, BRegs4<16>{inB}, accB); step_pattern<32>();
-    NSR_PIN(); ring_load_quarter<2>(rg, A0, lane);
-    consume<16, 0, 4>(A1, s + 1, BRegs4<16>{inA}, accA); consume<16, 0, 4>(A1, s + 1, BRegs4<16>{inB}, accB); step_pattern<32>();
-    NSR_PIN(); ring_load_quarter<3>(rg, A1, lane);
-    consume<16, 0, 4>(A0, s + 2, BRegs4<16>{inA}, accA); consume<16, 0, 4>(A0, s + 2, BRegs4<16>{inB}, accB); step_pattern<32>();
-    NSR_PIN(); consume<16, 0, 1>(A1, s + 3, BRegs4<16>{inA}, accA); consume<16, 0, 1>(A1, s + 3, BRegs4<16>{inB}, accB);
-    NSR_PIN(); ring_advance(rg, A0, lane);
-    ring_issue(rg);
-    consume<16, 1, 4>(A1, s + 3, BRegs4<16>{inA}, accA); consume<16, 1, 4>(A1, s + 3, BRegs4<16>{inB}, accB); step_pattern_dma<24>();
-  }
-  // slab 15: tile A
-  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 60, BRegs4<16>{inA}, accA); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 61, BRegs4<16>{inA}, accA); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 62, BRegs4<16>{inA}, accA); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<0>(rg, A0, lane); consume<16, 0, 4>(A1, 63, BRegs4<16>{inA}, accA); step_pattern<16>();
-  // slab 15: tile B, with tile A's epilogue
-  NSR_PIN(); ring_load_quarter<1>(rg, A1, lane); consume<16, 0, 4>(A0, 60, BRegs4<16>{inB}, accB); epi_chunk<0>(accA, inA, bias_g); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<2>(rg, A0, lane); consume<16, 0, 4>(A1, 61, BRegs4<16>{inB}, accB); epi_chunk<1>(accA, inA, bias_g); step_pattern<16>();
-  NSR_PIN(); ring_load_quarter<3>(rg, A1, lane); consume<16, 0, 4>(A0, 62, BRegs4<16>{inB}, accB); epi_chunk<2>(accA, inA, bias_g); step_pattern<16>();
-  NSR_PIN(); consume<16, 0, 1>(A1, 63, BRegs4<16>{inB}, accB);
-  NSR_PIN(); ring_advance(rg, A0, lane);
-  ring_issue(rg); consume<16, 1, 4>(A1, 63, BRegs4<16>{inB}, accB); epi_chunk<3>(accA, inA, bias_g); step_pattern_dma<12>();
-  NSR_PIN();
-}
-
-template <int MODE>
-__global__ void __launch_bounds__(256, 1) k_probe_epi(const float* __restrict__ stream, float* out, int iters) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* bias = (float*)(smem + kRingSlots * kSlabBytes);
-  bias[tid] = -1e-3f * (float)(tid & 31);
-  Ring rg;
-  ring_init(rg, smem, stream, 0, 1, wave, lane);
-  f32x4 A0[4], A1[4];
-  ring_start(rg, A0, lane);
-  float sum = 0.0f;
-  if (MODE == 9) {
-    f32x4 inA[16], inB[16], accA[16], accB[16];
-#pragma unroll
-    for (int mo = 0; mo < 16; ++mo) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        inA[mo][r] = 1e-3f * (float)(lane + r + mo); inB[mo][r] = 2e-3f * (float)(lane + r + mo);
-        accA[mo][r] = 0.0f; accB[mo][r] = 0.0f;
-      }
-    }
-    const float* bias_g = bias + 4 * (lane >> 4);
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) layer16x2(rg, A0, A1, inA, inB, accA, accB, bias_g, lane);
-#pragma unroll
-    for (int mo = 0; mo < 16; ++mo)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sum += accA[mo][r] + accB[mo][r] + inA[mo][r] + inB[mo][r];
-  } else {
-    f32x16 in[8], acc[8];
-#pragma unroll
-    for (int mo = 0; mo < 8; ++mo) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { in[mo][r] = 1e-3f * (float)(lane + r + mo); acc[mo][r] = 0.0f; }
-    }
-#pragma unroll 1
-    for (int it = 0; it < iters; ++it) {
-      seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
-#pragma unroll
-      for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
-      load_bias<8>(bias, lane >> 5, acc);
-    }
-#pragma unroll
-    for (int mo = 0; mo < 8; ++mo)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sum += acc[mo][r] + in[mo][r];
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  out[blockIdx.x * 256 + tid] = sum;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@ PyTorch is plumbing here: it owns the device buffers (torch tensors -> raw devic
 all arithmetic happens inside the hand-written gfx950 kernels.  Mirrors what the reference keeps in its
 `render_kwargs` dict (network_fn, network_fine, N_samples, N_importance; RN:318-334)."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -36,14 +37,20 @@ def _stream_ptr(device):
 
 class NsrModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0,
-                 white_bkgd=False, lindisp=False):
+                 white_bkgd=False, lindisp=False, chunk=None):
         """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu).
-        white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration)."""
+        white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration).
+        chunk: rays per work-queue chunk of the x16 kernel (None: $NSR_CHUNK, read HERE once, else the library default)."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
-        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else
-                                   (device.index if isinstance(device, torch.device) else int(device)))
+        if isinstance(device, torch.device):
+            device = device.index                       # torch.device("cuda") has no index: use the current device
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        if chunk is None:
+            chunk = int(os.environ.get("NSR_CHUNK", "0") or 0)
+        if not 0 <= int(chunk) <= 256:
+            raise ValueError("chunk must be in 0..256")
         if n_importance not in (0, N_IMPORTANCE):
             raise NotImplementedError("N_importance must be 128 (or 0 for coarse-only); got %r" % (n_importance,))
         if n_importance > 0 and sd_fine is None:
@@ -54,7 +61,8 @@ class NsrModel:
         self.variant = variant
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant,
-                             (1 if white_bkgd else 0) | (2 if lindisp else 0), 0)
+                             (1 if white_bkgd else 0) | (2 if lindisp else 0), int(chunk))
+        self._bbox_reserved = (0, 0)
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -145,8 +153,10 @@ class NsrModel:
                                              C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
         return o
 
-    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False):
-        """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each."""
+    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None):
+        """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each.
+        z_fine (optional [N,192]): sorted fine sample depths to differentiate at, instead of the kernel's own
+        resampling (they are constants of the backward, RN:475)."""
         if self.n_importance == 0:
             raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
         if not self._bwd_ready:                      # the transposed stream is packed on first use only
@@ -157,6 +167,7 @@ class NsrModel:
         rays_d = self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
         g = self._f32(grad_rgb, (n, 3))
+        zf = self._f32(z_fine, (n, 192)) if z_fine is not None else None
         go, gd = self._new(n, 3), self._new(n, 3)
         ro, fwd = None, None
         if with_forward:
@@ -164,7 +175,7 @@ class NsrModel:
             ro = _lib.NsrRenderOut(_dev(fwd["rgb_map"]), _dev(fwd["disp_map"]), _dev(fwd["acc_map"]), None, None,
                                    None, None)
         _lib.check(self.lib.nsr_render_rays_vjp(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
-                                                _dev(g), _dev(go), _dev(gd), C.byref(ro) if ro else None,
+                                                _dev(g), _dev(go), _dev(gd), _dev(zf), C.byref(ro) if ro else None,
                                                 _stream_ptr(self.device)))
         return (go, gd, fwd) if with_forward else (go, gd)
 
@@ -201,6 +212,9 @@ class NsrModel:
         if rgb8.dim() == 3:
             rgb8 = rgb8[None]
         k, hh, ww, _ = rgb8.shape
+        if hh * ww > self._bbox_reserved[0] * self._bbox_reserved[1]:       # setup, once per image size
+            _lib.check(self.lib.nsr_reserve_bbox(self.h, hh, ww))
+            self._bbox_reserved = (hh, ww)
         bbox = torch.empty((k, 4), dtype=torch.int32, device=self.device)
         count = torch.empty((k,), dtype=torch.int32, device=self.device)
         mask = torch.empty((k, hh, ww), dtype=torch.uint8, device=self.device) if with_mask else None

@@ -67,7 +67,31 @@ class NeRF(nn.Module):
         self._native_key = None
 
     def weights_version(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        """Key of the packed-weight cache: storage identity + autograd version of every parameter (catches
+        load_state_dict, optimizer steps, `.data = ...`) AND a content fingerprint, because in-place writes through
+        `.data` (p.data.copy_(), legacy loaders filling weight.data) change neither.  The fingerprint is three
+        reductions over the concatenated parameters (sum, abs-sum, position-weighted sum) and one host read-back."""
+        ps = list(self.parameters())
+        ident = tuple((p.data_ptr(), p._version) for p in ps)
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in ps])
+            ramp = getattr(self, "_fp_ramp", None)
+            if ramp is None or ramp.shape != flat.shape or ramp.device != flat.device:
+                ramp = torch.linspace(1.0, 2.0, flat.numel(), device=flat.device)
+                self.__dict__["_fp_ramp"] = ramp
+            fp = torch.stack([flat.sum(), flat.abs().sum(), (flat * ramp).sum()]).tolist()
+        return ident, tuple(fp)
+
+    def invalidate(self):
+        """Drop every native handle packed from this module (they are rebuilt on the next render)."""
+        for cache in self.__dict__.get("_nsr_pair", {}).values():
+            if cache.get("model") is not None:
+                cache["model"].close()
+            cache.clear()
+        if self._native is not None:
+            self._native.close()
+        self._native = None
+        self._native_key = None
 
     def forward(self, x):
         from .engine import NsrModel

@@ -51,12 +51,19 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
     key = (n_importance, network_fn.weights_version(),
            network_fine.weights_version() if network_fine is not None else None)
-    cache = network_fn.__dict__.setdefault("_nsr_pair", {}).setdefault((white, lindisp), {})
+    # a native handle owns ONE argument block / work queue / scratch set (include/nsr.h: one handle per (model,
+    # stream)), so the cache is also keyed on the device and on the torch stream the launch will be issued on
+    p0 = next(network_fn.parameters())
+    dev = p0.device.index if p0.is_cuda else torch.cuda.current_device()
+    stream_id = torch.cuda.current_stream(dev).cuda_stream
+    cache = network_fn.__dict__.setdefault("_nsr_pair", {}).setdefault((white, lindisp, dev, stream_id), {})
     if cache.get("key") != key:
         if cache.get("model") is not None:
             cache["model"].close()
-        cache["model"] = NsrModel(network_fn.state_dict(), network_fine.state_dict() if network_fine is not None
-                                  else None, n_importance=n_importance, white_bkgd=white, lindisp=lindisp)
+        with torch.cuda.device(dev):
+            cache["model"] = NsrModel(network_fn.state_dict(), network_fine.state_dict() if network_fine is not None
+                                      else None, device=dev, n_importance=n_importance, white_bkgd=white,
+                                      lindisp=lindisp)
         cache["key"] = key
     return cache["model"]
 

@@ -214,11 +214,15 @@ def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
         want_o, want_d, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro[:n], rd[:n], near, far, g["cot"],
                                                    z_fine=cpu(fwd["z_fine"]), white_bkgd=True, lindisp=True)
         assert _relfro(cpu(go), want_o) < 2e-4 and _relfro(cpu(gd), want_d) < 2e-4
-        # vs the reference's autograd (RN:177): 64 rays only, and a ray whose importance samples land differently
-        # (ill-conditioned inverse CDF) moves the Frobenius norm, so the bulk is held by the median
-        assert _relfro(cpu(go), g["grad_rays"][0]) < 0.15 and _relfro(cpu(gd), g["grad_rays"][1]) < 0.15
-        assert np.median(np.abs(cpu(gd) - g["grad_rays"][1]) / (np.abs(g["grad_rays"][1]) + 1e-6)) < 1e-3
-        assert np.median(np.abs(cpu(go) - g["grad_rays"][0]) / (np.abs(g["grad_rays"][0]) + 1e-6)) < 1e-3
+        # vs the reference's autograd (RN:177) AT THE REFERENCE'S OWN SAMPLE DEPTHS: z_samples is detached (RN:475),
+        # so handing the kernel sort(cat(z_coarse, reference z_samples)) removes the only ill-conditioned step (the
+        # inverse CDF) from the comparison.  Tolerance: relative Frobenius error 1e-4 (fp32 MFMA chains both ways).
+        zc = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32), lindisp=True)
+        zf_ref = np.sort(np.concatenate([zc, g["vjp_z_samples"]], -1), -1)
+        go, gd, f3 = m.render_rays_vjp(ro[:n], rd[:n], near, far, g["cot"], with_forward=True, z_fine=zf_ref)
+        assert _relfro(cpu(go), g["grad_rays"][0]) < 1e-4, _relfro(cpu(go), g["grad_rays"][0])
+        assert _relfro(cpu(gd), g["grad_rays"][1]) < 1e-4, _relfro(cpu(gd), g["grad_rays"][1])
+        assert_close(cpu(f3["rgb_map"]), g["vjp_rgb"], atol=2e-5, what="VJP-launch forward vs reference at its depths")
     # the options are per handle: the default handle is unaffected
     plain = NsrModel(synth_nets[0], synth_nets[1], variant=variant)
     p = plain.render_rays(ro[:8], rd[:8], near, far)
@@ -338,8 +342,9 @@ def _relfro(a, b):
 
 def test_render_rays_vjp(model, oracle, synth_nets):
     """Tolerance: relative Frobenius error 2e-4 against the oracle's float64 backprop evaluated on the kernel's
-    OWN sample positions (fp32 MFMA chains forward and backward); against the reference's autograd output the
-    bound is 3e-2 because a handful of rays resample differently (ill-conditioned inverse CDF, see above)."""
+    OWN sample positions (fp32 MFMA chains forward and backward); against the reference's autograd output 1e-4
+    when the kernel is handed the reference's own sample depths (nsr_render_rays_vjp d_z_fine), 3e-2 end to end
+    because a handful of rays resample differently (ill-conditioned inverse CDF, see above)."""
     g = load_golden("g8_backward")
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     ro, rd, cot = g["rays"][0], g["rays"][1], g["cot"]
@@ -353,10 +358,18 @@ def test_render_rays_vjp(model, oracle, synth_nets):
     assert _relfro(cpu(gd), want_d) < 2e-4, _relfro(cpu(gd), want_d)
     scale = np.abs(want_d).max(1, keepdims=True) + 1e-3
     assert (np.abs(cpu(gd) - want_d) / scale).max() < 5e-3
-    # what the reference's torch.autograd.grad returned (RN:177)
+    # what the reference's torch.autograd.grad returned (RN:177), end to end (the kernel's own resampling): a handful
+    # of rays resample differently, so this bound stays loose ...
     assert _relfro(cpu(go), g["grad_rays"][0]) < 3e-2
     assert _relfro(cpu(gd), g["grad_rays"][1]) < 3e-2
-    assert np.median(np.abs(cpu(gd) - g["grad_rays"][1]) / (np.abs(g["grad_rays"][1]) + 1e-6)) < 1e-3
+    # ... and at the reference's own sample depths (z_samples is detached, RN:475): relative Frobenius error <= 1e-4
+    n = ro.shape[0]
+    zc = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32))
+    zf_ref = np.sort(np.concatenate([zc, g["z_samples"]], -1), -1)
+    go, gd, f3 = model.render_rays_vjp(ro, rd, near, far, cot, with_forward=True, z_fine=zf_ref)
+    assert _relfro(cpu(go), g["grad_rays"][0]) < 1e-4, _relfro(cpu(go), g["grad_rays"][0])
+    assert _relfro(cpu(gd), g["grad_rays"][1]) < 1e-4, _relfro(cpu(gd), g["grad_rays"][1])
+    assert_close(cpu(f3["rgb_map"]), g["rgb"], atol=2e-5, what="VJP-launch forward vs reference at its depths")
 
 
 def test_vjp_odd_ray_count_and_linearity(model, oracle):
@@ -593,20 +606,98 @@ def test_x16_chunk_invariance_and_views(model16, model, oracle):
     assert np.abs(cpu(r["rgb0"]) - cpu(r32["rgb0"])).max() < 1e-5
 
 
-def test_x16_chunked_schedule_is_result_invariant(model16, monkeypatch):
+def test_x16_chunked_schedule_is_result_invariant(model16, synth_nets, monkeypatch):
     """k_render16's chunk queue: any chunk size (two-phase schedule with the z scratch, padded last chunk, fewer
-    workgroups than chunks and the reverse) gives bit-identical results to the default one-ray chunks."""
+    workgroups than chunks and the reverse) gives bit-identical results to the default one-ray chunks.  The chunk is
+    a per-handle setting (NsrConfig.chunk; $NSR_CHUNK is read once by the Python constructor, never by a launch)."""
+    from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
     ro = np.tile(g["rays_o"], (8, 1))[:1500 + 7]
     rd = np.tile(g["rays_d"], (8, 1))[:1500 + 7]
     monkeypatch.delenv("NSR_CHUNK", raising=False)
     want = model16.render_rays(ro, rd, near, far, debug=True)
-    for chunk in ("2", "5", "16", "64"):
-        monkeypatch.setenv("NSR_CHUNK", chunk)
-        got = model16.render_rays(ro, rd, near, far, debug=True)
+    for chunk in (2, 5, 16, 64):
+        if chunk == 5:
+            monkeypatch.setenv("NSR_CHUNK", "5")
+            m = NsrModel(synth_nets[0], synth_nets[1], variant=16)
+            monkeypatch.delenv("NSR_CHUNK")
+        else:
+            m = NsrModel(synth_nets[0], synth_nets[1], variant=16, chunk=chunk)
+        got = m.render_rays(ro, rd, near, far, debug=True)
         for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std", "z_fine", "inds", "raw"):
             assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), (chunk, k)
+        m.close()
+
+
+def test_launch_is_graph_capturable_and_replays_bit_identically(synth_nets, oracle):
+    """include/nsr.h: launch calls only enqueue kernels (no allocation, synchronisation or environment reads), so
+    nsr_render_views and nsr_render_rays_vjp can be captured into a hipGraph; replays equal the eager launch bit
+    for bit, also after the camera buffer the graph reads has been rewritten in place."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g7_render")
+    g8 = load_golden("g8_backward")
+    K = g["K32"].tolist() if "K32" in g else oracle.scaled_K(400.0 / 32)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    for variant in (16, 32):
+        m = NsrModel(synth_nets[0], synth_nets[1], variant=variant)
+        poses = torch.as_tensor(np.asarray(oracle.sweep_poses(2, seed=11))[:, :3, :4], dtype=torch.float32, device=m.device)
+        cam = poses[0:1].clone()
+        eager = [cpu(m.render_views(poses[i], 32, 32, K, near, far)["rgb_map"]) for i in range(2)]
+        ro, rd, cot = (torch.as_tensor(x, device=m.device) for x in (g8["rays"][0], g8["rays"][1], g8["cot"]))
+        e_go, e_gd = m.render_rays_vjp(ro, rd, near, far, cot)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            m.render_views(cam, 32, 32, K, near, far)               # warm-up on the capture stream
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                out = m.render_views(cam, 32, 32, K, near, far)
+                go, gd = m.render_rays_vjp(ro, rd, near, far, cot)
+        for rep in range(3):
+            i = rep % 2
+            cam.copy_(poses[i:i + 1])
+            out["rgb_map"].zero_(); go.zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert np.array_equal(cpu(out["rgb_map"]), eager[i]), (variant, rep)
+            assert np.array_equal(cpu(go), cpu(e_go)) and np.array_equal(cpu(gd), cpu(e_gd)), (variant, rep)
+        m.close()
+
+
+def test_second_stream_on_a_busy_handle_is_refused(synth_nets, oracle):
+    """One handle = one argument block + work queue + scratch: a launch on another stream while the previous launch
+    is still running must fail loudly instead of racing; once the first launch has finished it is accepted."""
+    import torch
+    from neural_sim_nerf_amd import _lib
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1])
+    pose = np.asarray(oracle.sweep_poses(1, seed=2))[0]
+    K = oracle.scaled_K(2.0)
+    a = m.render_views(pose, 200, 200, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)          # ~80 ms of work in flight
+    other = torch.cuda.Stream()
+    with torch.cuda.stream(other):
+        with pytest.raises(_lib.NsrError, match="busy on another stream"):
+            m.render_views(pose, 8, 8, oracle.scaled_K(50.0), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(other):
+        b = m.render_views(pose, 8, 8, oracle.scaled_K(50.0), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    torch.cuda.synchronize()
+    assert np.isfinite(cpu(a["acc_map"])).all() and np.isfinite(cpu(b["acc_map"])).all()
+    m.close()
+
+
+def test_calls_leave_the_current_device_alone(synth_nets):
+    """libnsr shares torch's HIP runtime: entry points must restore the calling thread's current device."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1], device=torch.device("cuda"))        # index-less device: current device
+    assert m.device.index == torch.cuda.current_device()
+    m.selftest()
+    assert torch.cuda.current_device() == m.device.index
+    m.close()
 
 
 def test_x16_coarse_only_config1(oracle, synth_nets):

@@ -151,6 +151,11 @@ def test_nerf_module_has_reference_parameter_names(synth_nets):
     with torch.no_grad():
         n.rgb_linear.bias.add_(1.0)
     assert n.weights_version() != v0                     # in-place edits re-trigger packing
+    v1 = n.weights_version()
+    n.pts_linears[3].weight.data[17, 5] += 0.25          # through .data: neither data_ptr nor _version changes ...
+    assert n.weights_version()[0] == v1[0]
+    assert n.weights_version() != v1                     # ... the content fingerprint does
+    n.invalidate()                                       # explicit hook: no native handle yet, must be a no-op
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/optimization"), reason="needs the reference checkout")

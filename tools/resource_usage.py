@@ -12,7 +12,7 @@ def main():
     p = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
     rows, cur = [], None
     for line in p.stderr.splitlines():
-        m = re.search(r"remark: .*?:\s+(Function Name|[A-Za-z ]+(?:\[[^\]]*\])?):\s+(\S+)", line)
+        m = re.search(r"remark:\s+(Function Name|[A-Za-z ]+(?:\[[^\]]*\])?):\s+(\S+)", line)
         if not m:
             if "error" in line: print(line)
             continue
