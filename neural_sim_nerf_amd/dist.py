@@ -22,6 +22,45 @@ def shard_indices(n_items, world, rank):
     return list(range(rank, n_items, world))
 
 
+def shard_models(n_models, world, rank):
+    """BASELINE config 5 (all 21 YCB-V NeRFs): model m -> rank m mod world; on a rank every model gets its own
+    native handle and HIP stream.  Same rule as the views, kept separate because it is a different contract."""
+    return list(range(rank, n_models, world))
+
+
+def auto_shard_enabled():
+    """The drop-in render_path / render_path_grad shard their poses over the default process group when one is
+    initialised with more than one rank (so neural_sim_main.py runs unchanged under torchrun); NSR_AUTO_SHARD=0
+    turns that off (every rank then renders everything, like the reference would)."""
+    return (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            and os.environ.get("NSR_AUTO_SHARD", "1") != "0")
+
+
+def _comm_device(group=None):
+    """Where collectives' buffers must live: the GPU for nccl (= RCCL), the host for gloo."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def check_same_poses(poses, group=None, tol=1e-6):
+    """Sharding by index only makes sense if every rank holds the SAME pose list.  The reference seeds its pose
+    sampler from the wall clock (LL:273), so ranks of an unchanged script can disagree: fail loudly then."""
+    world, rank = world_info(group)
+    if world == 1:
+        return
+    dev = _comm_device(group)
+    p0 = torch.as_tensor(poses, dtype=torch.float32).detach().to(dev).contiguous().clone()
+    mine = p0.clone()
+    dist.broadcast(p0, src=0, group=group)
+    bad = ((mine - p0).abs().max() > tol).to(torch.int32).reshape(1) if mine.numel() else torch.zeros(1, dtype=torch.int32, device=dev)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()):
+        raise RuntimeError("view sharding: ranks hold different render_poses (the reference seeds sample_pose from "
+                           "the wall clock, LL:273) -- seed the pose sampler identically on every rank, or set "
+                           "NSR_AUTO_SHARD=0")
+
+
 def gather_views(local, n_total, group=None):
     """local: [k_local, ...] tensor of this rank's views (in shard order).  Returns [n_total, ...] in global view
     order on every rank.  Ranks hold ceil or floor(n_total/world) views; shorter ranks pad to the maximum."""
@@ -29,6 +68,8 @@ def gather_views(local, n_total, group=None):
     if world == 1:
         return local
     k_max = (n_total + world - 1) // world
+    if local.device != _comm_device(group):
+        local = local.to(_comm_device(group))
     pad = torch.zeros((k_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
@@ -48,8 +89,9 @@ def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, 
     from .run_nerf_helpers import to8b
     from . import png
     world, rank = world_info(group)
-    poses = torch.as_tensor(render_poses, dtype=torch.float32)
+    poses = torch.as_tensor(render_poses, dtype=torch.float32).detach()
     n = poses.shape[0]
+    check_same_poses(poses, group)
     mine = shard_indices(n, world, rank)
     rgb, disp = render_fn(poses[mine])
     if savedir is not None:                      # every rank writes its own views (one node, one file system):
@@ -72,6 +114,13 @@ def gather_handoff(ann, n_total, group=None):
     return {k: gather_views(v, n_total, group) for k, v in ann.items()}
 
 
+def gather_patch_grads(local, n_poses, group=None):
+    """render_path_grad's list of per-patch [n_cat] gradients (RN:190) when poses are sharded: `local`
+    [k_local, n_patches, n_cat] for this rank's poses (shard order) -> [n_poses, n_patches, n_cat] in pose order on
+    every rank (the reference appends pose-major, patch-minor, which is this tensor flattened)."""
+    return gather_views(local, n_poses, group)
+
+
 def mean_psi_grad(local_dLdpsis, group=None):
     """torch.mean(torch.stack(dLdpsis), 0) (NM:191) when the per-patch gradients are spread over ranks:
     all-reduce(sum) of [sum of local [n_cat] vectors | local count]."""
@@ -86,8 +135,7 @@ def mean_psi_grad(local_dLdpsis, group=None):
         buf[:n_cat] = s
         buf[n_cat] = len(local_dLdpsis)
     if world > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else buf.device
-        buf = buf.to(dev)
+        buf = buf.to(_comm_device(group))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf = buf.cpu()
     return (buf[:n_cat] / buf[n_cat]).to(torch.float32)

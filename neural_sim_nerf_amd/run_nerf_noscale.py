@@ -220,34 +220,66 @@ def _scaled_hw(hwf, render_factor):
     return int(H), int(W), focal
 
 
-def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None,
-                object_id=2, render_factor=0):
-    """RN:213-255.  All poses are rendered by ONE persistent-kernel launch (the reference loops serially,
-    RN:229); PNGs land in savedir/<object_id>/{i:03d}.png exactly as before.  `categorical_prob` is unused
-    (as in the reference).  Returns (rgbs [K,H,W,3] float32, disps [K,H,W] float32) numpy arrays."""
+def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False):
     H, W, _ = _scaled_hw(hwf, render_factor)
     kw = dict(render_kwargs)
     near, far = kw.pop("near", 0.), kw.pop("far", 1.)
     if kw.pop("ndc", True):
-        raise NotImplementedError("render_path: ndc=True is not supported")
+        raise NotImplementedError("%s: ndc=True is not supported" % name)
     if not kw.pop("use_viewdirs", False):
-        raise NotImplementedError("render_path: use_viewdirs=False is not supported")
+        raise NotImplementedError("%s: use_viewdirs=False is not supported" % name)
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
+    if need_fine and n_imp != 128:
+        raise NotImplementedError("%s needs the coarse+fine configuration (N_importance=128)" % name)
     model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
+    return H, W, near, far, model
+
+
+def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None,
+                object_id=2, render_factor=0):
+    """RN:213-255.  All poses are rendered by ONE persistent-kernel launch (the reference loops serially,
+    RN:229); PNGs land in savedir/<object_id>/{i:03d}.png exactly as before.  `categorical_prob` is unused
+    (as in the reference).  Returns (rgbs [K,H,W,3] float32, disps [K,H,W] float32) numpy arrays.
+
+    Multi-GPU: when a torch.distributed process group with more than one rank is initialised (the
+    script runs under torchrun), pose i is rendered by rank i mod world, every rank writes the PNGs of its own
+    poses, the images are all-gathered (RCCL) and EVERY rank returns all K views in pose order -- the call site
+    NM:128 needs no change.  NSR_AUTO_SHARD=0 disables it."""
+    from . import dist as D
+    H, W, near, far, model = _path_setup("render_path", hwf, render_factor, render_kwargs)
     if savedir is not None:
         os.makedirs(os.path.join(savedir, str(object_id)), exist_ok=True)
-    poses = torch.as_tensor(render_poses, dtype=torch.float32)
+    poses = torch.as_tensor(render_poses, dtype=torch.float32).detach()
+
+    def render_fn(p):
+        if p.shape[0] == 0:
+            return (torch.zeros((0, H, W, 3), device=model.device), torch.zeros((0, H, W), device=model.device))
+        out = model.render_views(p[:, :3, :4].to(model.device), H, W, K, near, far)
+        return out["rgb_map"].reshape(-1, H, W, 3), out["disp_map"].reshape(-1, H, W)
+
     t = time.time()
     with torch.no_grad():
-        out = model.render_views(poses[:, :3, :4].to(model.device), H, W, K, near, far)
-        rgbs = out["rgb_map"].reshape(-1, H, W, 3).cpu().numpy()
-        disps = out["disp_map"].reshape(-1, H, W).cpu().numpy()
+        if D.auto_shard_enabled():
+            rgbs, disps = D.render_path_distributed(render_fn, poses, savedir=savedir, object_id=object_id)
+            print("rendered %d views on %d ranks in %.3f s" % (rgbs.shape[0], D.world_info()[0], time.time() - t))
+            return rgbs, disps
+        rgb, disp = render_fn(poses)
+        rgbs, disps = rgb.cpu().numpy(), disp.cpu().numpy()
     print("rendered %d views in %.3f s" % (rgbs.shape[0], time.time() - t))
     if savedir is not None:
         for i in range(rgbs.shape[0]):
             png.imwrite(os.path.join(savedir, str(object_id), "{:03d}.png".format(i)), to8b(rgbs[i]))
     return rgbs, disps
+
+
+def _pose_patch_grads(model, c2w, cot, H, W, K, near, far, N_rand):
+    """One pose of render_path_grad on the device: (rgb [H,W,3], dL/d c2w[3,4] per patch [n_patches,3,4])."""
+    with torch.no_grad():
+        ro, rd = model.get_rays(H, W, K, c2w[:3, :4].detach().to(model.device))
+        go, gd, out = model.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, cot, with_forward=True)
+        g_pose = model.pose_grad(go, gd, H, W, K, N_rand)
+    return out["rgb_map"].reshape(H, W, 3), g_pose
 
 
 def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, render_kwargs, gt_imgs=None,
@@ -258,48 +290,52 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
     The reference runs 313 forward+2 autograd calls per 400x400 image; here ONE forward+backward launch per pose
     returns dL/d(rays) for the whole image, a second tiny kernel contracts it per patch with d(rays)/d(c2w)
     (linear, RH:160-164) to [n_patches,3,4], and the 12x8 Jacobian d(c2w)/d(psi) of the caller's own pose graph
-    (sample_pose, LL:202-247) finishes the chain -- the same numbers as the per-patch autograd.grad of RN:177-181."""
-    H, W, _ = _scaled_hw(hwf, render_factor)
-    kw = dict(render_kwargs)
-    near, far = kw.pop("near", 0.), kw.pop("far", 1.)
-    if kw.pop("ndc", True):
-        raise NotImplementedError("render_path_grad: ndc=True is not supported")
-    if not kw.pop("use_viewdirs", False):
-        raise NotImplementedError("render_path_grad: use_viewdirs=False is not supported")
-    _check_kwargs(kw)
-    n_imp = kw.get("N_importance", 0)
-    if n_imp != 128:
-        raise NotImplementedError("render_path_grad needs the coarse+fine configuration (N_importance=128)")
-    model = _model_for(kw["network_fn"], kw.get("network_fine", None), n_imp, kw)
+    (sample_pose, LL:202-247) finishes the chain -- the same numbers as the per-patch autograd.grad of RN:177-181.
+
+    Multi-GPU: under an initialised process group pose i goes to rank i mod world; images and per-patch gradients
+    are all-gathered, so every rank returns the reference's full (rgbs, dLdpsis) in pose-major order and NM:184-191
+    run unchanged (the mean over the stacked list equals dist.mean_psi_grad's all-reduce)."""
+    from . import dist as D
+    H, W, near, far, model = _path_setup("render_path_grad", hwf, render_factor, render_kwargs, need_fine=True)
     n_rays = H * W
     N_rand = int(chunk)
     n_patches = (n_rays + N_rand - 1) // N_rand
-    rgbs, dLdpsis = [], []
-    for i_pose, c2w in enumerate(render_poses):
-        if i_pose >= len(grad_E):                          # RN:142
-            break
+    n_poses = min(len(render_poses), len(grad_E))              # RN:142
+    shard = D.auto_shard_enabled()
+    world, rank = D.world_info() if shard else (1, 0)
+    if shard:
+        D.check_same_poses(torch.stack([torch.as_tensor(p, dtype=torch.float32).detach() for p in render_poses[:n_poses]])
+                           if n_poses else torch.zeros(0, 4, 4))
+    mine = D.shard_indices(n_poses, world, rank)
+    rgb_l, grad_l = [], []
+    for i_pose in mine:
+        c2w = render_poses[i_pose]
         pose = c2w[:3, :4]
         g = grad_E[i_pose]["grad_E"][0]
         g = torch.as_tensor(g.detach().cpu().numpy().transpose(1, 2, 0) if isinstance(g, torch.Tensor)
                             else np.asarray(g).transpose(1, 2, 0), dtype=torch.float32)      # RN:154 CHW -> HWC
         cot = g.reshape(-1, 3).to(model.device).contiguous()
-        with torch.no_grad():
-            ro, rd = model.get_rays(H, W, K, pose.detach().to(model.device))
-            go, gd, out = model.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, cot,
-                                                with_forward=True)
-            g_pose = model.pose_grad(go, gd, H, W, K, N_rand)                                # [n_patches,3,4]
+        rgb, g_pose = _pose_patch_grads(model, pose, cot, H, W, K, near, far, N_rand)        # [n_patches,3,4]
         # d vec(c2w[:3,:4]) / d psi through the caller's graph: 12 rows, one batched autograd call
         basis = torch.eye(12, dtype=pose.dtype, device=pose.device).reshape(12, 3, 4)
         (J,) = torch.autograd.grad(pose, categorical_prob, grad_outputs=basis, retain_graph=True,
                                    is_grads_batched=True)                                    # [12, n_cat]
-        per_patch = g_pose.reshape(n_patches, 12).to(J.device, J.dtype) @ J                  # [n_patches, n_cat]
-        dLdpsis.extend(per_patch[p].cpu().detach() for p in range(n_patches))                # RN:190
-        rgbs.append(out["rgb_map"].reshape(H, W, 3).cpu().numpy())
+        grad_l.append((g_pose.reshape(n_patches, 12).to(J.device, J.dtype) @ J).detach().to(torch.float32).cpu())
+        rgb_l.append(rgb.cpu())
         if savedir is not None:
             d = os.path.join(savedir, str(object_id), "withgrad")
             os.makedirs(d, exist_ok=True)
-            png.imwrite(os.path.join(d, "{:03d}.png".format(i_pose)), to8b(rgbs[-1]))       # RN:200-206
-    return np.stack(rgbs, 0), dLdpsis
+            png.imwrite(os.path.join(d, "{:03d}.png".format(i_pose)), to8b(rgb_l[-1].numpy()))  # RN:200-206
+    n_cat = int(categorical_prob.numel())
+    rgbs = torch.stack(rgb_l) if rgb_l else torch.zeros((0, H, W, 3))
+    grads = torch.stack(grad_l) if grad_l else torch.zeros((0, n_patches, n_cat))
+    if shard:
+        rgbs = D.gather_views(rgbs, n_poses).cpu()
+        grads = D.gather_patch_grads(grads, n_poses).cpu()
+        if savedir is not None:
+            torch.distributed.barrier()
+    dLdpsis = [grads[i, p] for i in range(grads.shape[0]) for p in range(n_patches)]         # RN:190 order
+    return rgbs.numpy(), dLdpsis
 
 
 def create_nerf(args):
