@@ -1,28 +1,40 @@
 #!/usr/bin/env python
 """bench.py -- Mray-samples/s of the NeRF volumetric render path on MI355X (BASELINE.json metric).
 
-A "step" = one pass of the hot path over one batch of synthetic input = ONE 400x400 view rendered with 64 coarse
-+ 128 importance samples per ray through the 8x256 NeRF MLP pair (BASELINE.json configs[1]), fp32 end to end,
-rays generated in-kernel from the camera, outputs (rgb/disp/acc/rgb0/disp0/acc0/z_std) written to HBM.
-With N GPUs every rank renders its own views (view sharding, no data-path collective); the rendered images
-are all-gathered over RCCL once, at the outer-loop boundary, inside the timed region (BASELINE configs[2]).
+Default workload (`--workload view400`, the one the driver records): a "step" = one pass of the hot path over one
+batch of synthetic input = ONE 400x400 view rendered with 64 coarse + 128 importance samples per ray through the
+8x256 NeRF MLP pair (BASELINE.json configs[1]), fp32 end to end, rays generated in-kernel from the camera, outputs
+(rgb/disp/acc/rgb0/disp0/acc0/z_std) written to HBM.  With N GPUs every rank renders its own views (view sharding,
+no data-path collective); the rendered images are all-gathered over RCCL once, at the outer-loop boundary, inside
+the timed region (BASELINE configs[2]).
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+    python bench.py                                   # N=1, 3 steps, 1 warm-up
+    python bench.py --gpus N --steps K --warmup W     # self-launches N ranks (torch.distributed.run) when not already
+                                                      # under a launcher; under the driver's launcher it just runs
+    python bench.py --gpus 8 --workload sweep100 --steps 1      # BASELINE configs[2]: 100-view pose sweep
+    python bench.py --gpus 8 --workload models21 --steps 1      # BASELINE configs[4]: 21 models, one stream each
 
-Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     -- dominant kernel nsr::k_render16: algorithmic FLOP per launch / HIP-event kernel time, against
-                  the fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
-  cpu_baseline -- the oracle (CPU restatement of the reference path, "port") timed on this host's cores on a
-                  bounded sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
-  parity       -- PSNR / max-abs of the GPU render vs the oracle on that sample, and the exact-match rate of
-                  the resampling indices.
+Prints ONE JSON line on rank 0.  Objects beside the contract fields:
+  roofline       -- dominant kernel nsr::k_render16: algorithmic FLOP per launch / HIP-event kernel time, against the
+                    fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
+                    `traffic` comes from a rocprofv3 --pmc profile ONLY if that profile was collected from exactly
+                    the kernel sources in this tree (hash check), else null;
+  roofline_vjp   -- the same for nsr::k_render_vjp (render_path_grad's forward+input-gradient launch, config 4's render leg);
+  cpu_baseline   -- the oracle (CPU restatement of the reference path, "port") timed on this host's cores on a bounded
+                    sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
+  parity         -- PSNR / max-abs of the GPU render vs the oracle on that sample, exact-match rate of the indices;
+  extra_workloads.config1 -- BASELINE configs[0] (64x64, 64 coarse samples only): GPU throughput next to the oracle at
+                    chunk 512 (the reference's config) and 4096;
+  ranks_seen, kernel_ms_per_rank -- what RCCL actually saw (sum of ones over ranks; per-rank kernel time spread).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -32,23 +44,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from neural_sim_nerf_amd import synthetic as S          # noqa: E402
+from neural_sim_nerf_amd import dist as D               # noqa: E402
+from neural_sim_nerf_amd import _lib                    # noqa: E402
 from neural_sim_nerf_amd.engine import NsrModel         # noqa: E402
 
 H = W = 400
 SAMPLES_PER_RAY = 64 + 128                 # the metric's unit
 EVALS_PER_RAY = 64 + 192                   # network evaluations per ray (RN:477-483)
 FLOP_PER_RAY = EVALS_PER_RAY * S.FLOP_PER_POINT          # 303 824 896
-PEAK_F32_MFMA_TFLOPS = 157.3               # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+FLOP_PER_RAY_VJP = (EVALS_PER_RAY + 192) * S.FLOP_PER_POINT   # + 192 transposed evaluations of the fine net: 531.7 M
+PEAK_F32_MFMA_TFLOPS = 157.3               # v_mfma_f32_32x32x2_f32 / 16x16x4, dense (MI355X_MICROARCH.md)
+METRIC = "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP"
 
 
-def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
-    """Oracle on a bounded sample (64x64 view, 64+128) -- the checker, timed; never the thing shipped."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
-    run = lambda side: O.render(sd_c, sd_f, side, side, S.scaled_K(400.0 / side), c2w=c2w[:3, :4], near=S.YCBV_NEAR,
-                                far=S.YCBV_FAR, chunk=4096)
-    # Be fair to the CPU: calibrate the backend (MLP/encoding on torch-CPU ops like the reference, or numpy+OpenBLAS)
-    # and the thread count on a 32x32 view, then time the sample with the fastest setting.
+    return O
+
+
+def _fastest_cpu_setting(O, run):
+    """Be fair to the CPU: calibrate the backend (MLP/encoding on torch-CPU ops like the reference, or
+    numpy+OpenBLAS) and the thread count on a small case; returns (seconds, backend, threads)."""
     ncpu = os.cpu_count() or 1
     best = None
     for backend, threads in [("torch", t) for t in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)})] + [("numpy", 0)]:
@@ -61,7 +88,16 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
         t32 = time.perf_counter() - t0
         if best is None or t32 < best[0]:
             best = (t32, backend, threads)
-    t32, backend, threads = best
+    return best
+
+
+def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
+    """Oracle on a bounded sample (one smaller view, 64+128) -- the checker, timed; never the thing shipped."""
+    O = _oracle()
+    run = lambda side: O.render(sd_c, sd_f, side, side, S.scaled_K(400.0 / side), c2w=c2w[:3, :4], near=S.YCBV_NEAR,
+                                far=S.YCBV_FAR, chunk=4096)
+    ncpu = os.cpu_count() or 1
+    t32, backend, threads = _fastest_cpu_setting(O, run)
     O.set_backend(backend)
     if threads:
         torch.set_num_threads(threads)
@@ -89,7 +125,8 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
     # PSNR delta against a pseudo ground truth T = oracle + N(0, 0.01^2)
     T = ref["rgb_map"] + np.random.RandomState(0).normal(0, 0.01, ref["rgb_map"].shape).astype(np.float32)
     cpu = {"value": round(side * side * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
-           "kind": "port", "sample": "one %dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
+           "kind": "port", "cpu_model": cpu_model(), "host_logical_cpus": ncpu,
+           "sample": "one %dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
            "oracle/nerf_oracle.py, fastest of {torch-CPU ops x thread counts, numpy+OpenBLAS} on this host: %s backend, "
            "%d threads; %.1f s" % (side, side, side * side, backend, n_threads, dt)}
     par = {"psnr_vs_oracle_db": round(O.psnr(rgb, ref["rgb_map"]), 2),
@@ -101,7 +138,106 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
            "max_abs_z_std": maxabs("z_std", (side, side)),
            "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
            "sample": "%dx%d view; indices/samples: oracle sample_pdf on the kernel's own coarse weights" % (side, side)}
-    return cpu, par
+    return cpu, par, (backend, threads)
+
+
+def config1_workload(sd_c, c2w, device, cpu_setting):
+    """BASELINE configs[0]: 64x64 view, 64 coarse samples only.  GPU: 50 launches, HIP-event mean.
+    CPU: the oracle on the same view at the reference's chunk (512, CF:25) and at 4096."""
+    side, n_s = 64, 64
+    K = S.scaled_K(400.0 / side)
+    m1 = NsrModel(sd_c, None, device=device, n_importance=0)
+    pose = torch.as_tensor(c2w[:3, :4], device=m1.device)
+    for _ in range(3):
+        got = m1.render_views(pose, side, side, K, S.YCBV_NEAR, S.YCBV_FAR)
+    ms = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        got = m1.render_views(pose, side, side, K, S.YCBV_NEAR, S.YCBV_FAR)
+        ms.append(m1.last_kernel_ms())
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 50
+    k_ms = float(np.mean(ms))
+    rays = side * side
+    flop = rays * n_s * S.FLOP_PER_POINT
+    out = {"workload": "YCB-V object-2 camera, 64x64 view, N_samples=64 coarse only (BASELINE configs[0])",
+           "gpu": {"value": round(rays * n_s / wall / 1e6, 3), "unit": "Mray-samples/s", "ms_per_view_wall": round(wall * 1e3, 4),
+                   "kernel_ms": round(k_ms, 4), "kernel_TFLOPs": round(flop / (k_ms * 1e-3) / 1e12, 2),
+                   "note": "4096 rays = 8 rays per workgroup of the 512-workgroup grid: launch- and tail-bound, not "
+                           "MFMA-bound; the per-view wall time includes the host's call overhead"}}
+    if cpu_setting is not None:
+        O = _oracle()
+        backend, threads = cpu_setting
+        O.set_backend(backend)
+        if threads:
+            torch.set_num_threads(threads)
+        cpu = {}
+        ref = None
+        for chunk in (512, 4096):
+            O.render(sd_c, None, side, side, K, c2w=c2w[:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=chunk, n_importance=0)
+            t0 = time.perf_counter()
+            ref = O.render(sd_c, None, side, side, K, c2w=c2w[:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=chunk,
+                           n_importance=0)
+            dt = time.perf_counter() - t0
+            cpu["chunk_%d" % chunk] = {"value": round(rays * n_s / dt / 1e6, 4), "unit": "Mray-samples/s", "seconds": round(dt, 3)}
+        O.set_backend("numpy")
+        cpu.update(kind="port", cores=threads if threads else min(os.cpu_count() or 1, 64), backend=backend,
+                   cpu_model=cpu_model())
+        out["cpu_baseline"] = cpu
+        out["max_abs_rgb_vs_oracle"] = float(np.abs(got["rgb_map"].cpu().numpy().reshape(side, side, 3) - ref["rgb_map"]).max())
+    m1.close()
+    return out
+
+
+def vjp_roofline(model, c2w):
+    """nsr::k_render_vjp on one 400x400 image (render_path_grad's per-pose launch): HIP-event time of 2 launches."""
+    o, d = model.get_rays(H, W, S.YCBV_K, c2w)
+    cot = torch.randn(H * W, 3, device=model.device, generator=torch.Generator(device=model.device).manual_seed(0))
+    ms = []
+    for _ in range(3):
+        model.render_rays_vjp(o.reshape(-1, 3), d.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot)
+        ms.append(model.last_kernel_ms())
+    k_ms = float(np.mean(ms[1:]))
+    ach = H * W * FLOP_PER_RAY_VJP / (k_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "nsr::k_render_vjp",
+            "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
+            "flop_note": "per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
+                         "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP"}
+
+
+def pmc_traffic(pmc_file):
+    """HBM-side bytes per launch from a rocprofv3 --pmc profile (tools/collect_profiles.sh + summarize_pmc.py), used
+    ONLY when the profile was collected from exactly the kernel sources in this tree; otherwise null."""
+    if not os.path.exists(pmc_file):
+        return None, "no PMC profile at %s" % os.path.relpath(pmc_file, ROOT)
+    prof = json.load(open(pmc_file))
+    here = _lib.kernel_source_hash()
+    if prof.get("kernel_source_sha256") != here:
+        return None, ("PMC profile %s was collected from other kernel sources (%s..., this tree %s...): not reported"
+                      % (os.path.relpath(pmc_file, ROOT), str(prof.get("kernel_source_sha256"))[:12], here[:12]))
+    blob = hashlib.sha1(b"blob %d\0" % os.path.getsize(pmc_file) + open(pmc_file, "rb").read()).hexdigest()
+    t = prof["x16_default"]["derived"]["hbm_traffic_bytes_per_launch"]
+    return t, ("offline measurement: bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
+               "this command (%s, git blob %s, kernel sources sha256 %s... = this tree); FETCH_SIZE counts L2 misses that "
+               "Infinity Cache serves: re-streaming of the weight images (4.6 MiB of networks vs 4 MiB L2 per XCD), not HBM "
+               "reads; algorithmic HBM bytes are 7.0e6 per launch (DESIGN.md 4)" % (os.path.relpath(pmc_file, ROOT), blob[:12], here[:12]))
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, n_dev))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -109,95 +245,232 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("view400", "sweep100", "models21"), default="view400")
+    ap.add_argument("--views", type=int, default=100, help="sweep100: number of views in the sweep (config 3 uses 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip roofline_vjp and the config-1 workload")
+    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r02", "pmc_k_render.json"))
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if launched and args.gpus != world:
+        raise SystemExit("bench.py --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: local rank %d has no HIP device (%d visible)" % (local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dist = None
-    if world > 1 or "RANK" in os.environ:         # under torch.distributed.run, also for a single rank
+    if launched:                                  # under torch.distributed.run, also for a single rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"     # RCCL's version banner goes to stdout: keep stdout to the ONE JSON line
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    sd_c = S.synth_weights(0)
-    sd_f = S.synth_weights(1000, fine_of=sd_c)
-    model = NsrModel(sd_c, sd_f, device=local)
-    n_total = args.warmup + args.steps
-    poses = S.sweep_poses(n_total * world, seed=0)[rank::world]      # view i -> rank i mod world
-    poses_d = torch.as_tensor(poses[:, :3, :4], device=model.device)
+    dev = torch.device("cuda", local)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
-    if dist is not None:          # untimed: bring up the RCCL channels the timed all_gather will use (same shape)
-        dummy = torch.zeros((args.steps, H * W, 3), device=model.device)
-        dist.all_gather([torch.empty_like(dummy) for _ in range(world)], dummy)
-        del dummy
-    barrier()
-    kernel_ms = []
-    images = []
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_total):
-        out = model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
-        kernel_ms.append(model.last_kernel_ms())      # HIP events on the launch stream (syncs on the stop event)
-        images.append(out["rgb_map"])
-    if dist is not None:                                # outer-loop boundary: gather the rendered images
-        mine = torch.stack(images, 0)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=model.device, dtype=torch.float64)
+    def allmax(x):
+        if dist is None:
+            return float(x)
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return float(t.item())
+
+    def rank_stats(k_ms):
+        """ranks_seen = all-reduce(sum) of ones; per-rank mean kernel time gathered to every rank."""
+        if dist is None:
+            return 1, [float(k_ms)]
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        mine = torch.tensor([k_ms], device=dev, dtype=torch.float64)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        return int(ones.item()), [float(p.item()) for p in parts]
+
+    sd_c = S.synth_weights(0)
+    sd_f = S.synth_weights(1000, fine_of=sd_c)
+    line = {"metric": METRIC, "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+
+    # ------------------------------------------------------------------------------------------------------------
+    if args.workload == "view400":
+        model = NsrModel(sd_c, sd_f, device=local)
+        n_total = args.warmup + args.steps
+        poses = S.sweep_poses(n_total * world, seed=0)[rank::world]      # view i -> rank i mod world (SURVEY 8e)
+        poses_d = torch.as_tensor(poses[:, :3, :4], device=model.device)
+        for i in range(args.warmup):
+            model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+        if dist is not None:          # untimed: bring up the RCCL channels the timed all_gather will use (same shape)
+            dummy = torch.zeros((args.steps, H * W, 3), device=model.device)
+            dist.all_gather([torch.empty_like(dummy) for _ in range(world)], dummy)
+            del dummy
+        barrier()
+        kernel_ms, images = [], []
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_total):
+            out = model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+            kernel_ms.append(model.last_kernel_ms())      # HIP events on the launch stream (syncs on the stop event)
+            images.append(out["rgb_map"])
+        if dist is not None:                                # outer-loop boundary: gather the rendered images
+            mine = torch.stack(images, 0)
+            gathered = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+        barrier()
+        dt = allmax(time.perf_counter() - t0)
+        k_ms = float(np.mean(kernel_ms))
+        ranks_seen, per_rank = rank_stats(k_ms)
+        if rank == 0:
+            rays = args.steps * H * W * world
+            achieved = H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
+            traffic, traffic_note = pmc_traffic(args.pmc_file)
+            line.update({
+                "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
+                                       "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), fp32, fused "
+                                       "persistent kernel (x16: 2 workgroups per CU), rays generated in-kernel",
+                           "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
+                           "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
+                "rays_per_s": round(rays / dt, 1), "mlp_evals_per_s": round(rays * EVALS_PER_RAY / dt, 1),
+                "ranks_seen": ranks_seen,
+                "kernel_ms_per_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),
+                                       "mean": round(float(np.mean(per_rank)), 3)},
+                "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                             "traffic_note": traffic_note, "kernel": "nsr::k_render16", "kernel_ms": round(k_ms, 3),
+                             "flop_per_launch": H * W * FLOP_PER_RAY},
+            })
+            cpu_setting = None
+            if world == 1 and not args.no_cpu_baseline:
+                cpu, par, cpu_setting = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
+                line["cpu_baseline"] = cpu
+                line["parity"] = par
+            if world == 1 and not args.no_extras:
+                line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup])
+                line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting)}
+        model.close()
+
+    # ------------------------------------------------------------------------------------------------------------
+    elif args.workload == "sweep100":
+        # BASELINE configs[2]: 100-view pose sweep, view i -> rank i mod N (13/12 views per rank at N=8), each rank
+        # renders its views in ONE launch, converts to uint8 on the device (to8b, RH:14), writes its own PNGs; the
+        # images are all-gathered both as uint8 (what the detector consumes, 0.48 MB/view) and as fp32 (what
+        # render_path returns, 1.92 MB/view).  A step = one whole sweep.
+        from neural_sim_nerf_amd import png
+        n_views = args.views
+        model = NsrModel(sd_c, sd_f, device=local)
+        poses = S.sweep_poses(n_views, seed=0)
+        mine = D.shard_indices(n_views, world, rank)
+        poses_d = torch.as_tensor(poses[mine][:, :3, :4], device=model.device)
+        tmp = tempfile.mkdtemp(prefix="nsr_sweep_")
+        for _ in range(max(1, args.warmup)):
+            out = model.render_views(poses_d[:1], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+            D.gather_views(model.to8b(out["rgb_map"].reshape(1, H, W, 3)), world)     # RCCL channel bring-up
+        phases = {"render": 0.0, "gather_u8": 0.0, "gather_f32": 0.0, "png": 0.0}
+        kernel_ms = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            t = time.perf_counter()
+            out = model.render_views(poses_d, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+            rgb = out["rgb_map"].reshape(-1, H, W, 3)
+            u8 = model.to8b(rgb)
+            kernel_ms.append(model.last_kernel_ms())
+            torch.cuda.synchronize()
+            phases["render"] += time.perf_counter() - t
+            t = time.perf_counter()
+            all_u8 = D.gather_views(u8, n_views)
+            torch.cuda.synchronize()
+            phases["gather_u8"] += time.perf_counter() - t
+            t = time.perf_counter()
+            all_f32 = D.gather_views(rgb, n_views)
+            torch.cuda.synchronize()
+            phases["gather_f32"] += time.perf_counter() - t
+            t = time.perf_counter()
+            host = u8.cpu().numpy()
+            for k, i in enumerate(mine):                    # every rank writes its own views, named by pose index
+                png.imwrite(os.path.join(tmp, "%03d.png" % i), host[k])
+            phases["png"] += time.perf_counter() - t
+        barrier()
+        dt = allmax(time.perf_counter() - t0)
+        phases = {k: round(allmax(v) / args.steps, 4) for k, v in phases.items()}
+        ranks_seen, per_rank = rank_stats(float(np.mean(kernel_ms)))
+        assert tuple(all_u8.shape) == (n_views, H, W, 3) and tuple(all_f32.shape) == (n_views, H, W, 3)
+        if rank == 0:
+            rays = args.steps * n_views * H * W
+            k_max = (n_views + world - 1) // world
+            line.update({
+                "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "scaling": "strong",
+                "config": {"workload": "%d-view pose sweep (BASELINE configs[2]), 400x400, 64+128 samples/ray, view i -> "
+                                       "rank i mod N, one launch per rank, device to8b, uint8 + fp32 image all-gather, "
+                                       "PNG write per rank" % n_views, "views": n_views, "views_on_busiest_rank": k_max,
+                           "parallelism": "views sharded over %d GPU(s)" % world},
+                "views_per_s": round(args.steps * n_views / dt, 3),
+                "ideal_speedup_over_1_gpu": round(n_views / k_max, 3),
+                "seconds_per_sweep_by_phase_max_over_ranks": phases,
+                "ranks_seen": ranks_seen,
+                "kernel_ms_per_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),
+                                       "mean": round(float(np.mean(per_rank)), 3)},
+            })
+        model.close()
+
+    # ------------------------------------------------------------------------------------------------------------
+    else:
+        # BASELINE configs[4]: all 21 YCB-V NeRFs (synthetic weights, seeds 0..20), model m -> rank m mod N, one native
+        # handle + one HIP stream per model, one 400x400 view per model per step; no collective on the data path.
+        n_models = 21
+        mine = D.shard_models(n_models, world, rank)
+        models, streams = [], []
+        for m in mine:
+            c = S.synth_weights(m)
+            models.append(NsrModel(c, S.synth_weights(1000 + m, fine_of=c), device=local))
+            streams.append(torch.cuda.Stream(device=dev))
+        poses = torch.as_tensor(S.sweep_poses(n_models, seed=3)[:, :3, :4], device=dev)
+
+        def sweep():
+            outs = []
+            for i, (m, st) in enumerate(zip(models, streams)):
+                with torch.cuda.stream(st):
+                    outs.append(m.render_views(poses[mine[i]], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)["rgb_map"])
+            return outs
+        for _ in range(max(1, args.warmup)):
+            sweep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            outs = sweep()
+        barrier()
+        dt = allmax(time.perf_counter() - t0)
+        k_ms = float(np.mean([m.last_kernel_ms() for m in models])) if models else 0.0
+        ranks_seen, per_rank = rank_stats(k_ms)
+        if rank == 0:
+            rays = args.steps * n_models * H * W
+            k_max = (n_models + world - 1) // world
+            line.update({
+                "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "scaling": "strong",
+                "config": {"workload": "21 NeRF models (BASELINE configs[4]), one 400x400 64+128 view each per step, model m "
+                                       "-> rank m mod N, one handle + HIP stream per model", "models": n_models,
+                           "models_on_busiest_rank": k_max, "parallelism": "models sharded over %d GPU(s)" % world},
+                "views_per_s": round(args.steps * n_models / dt, 3),
+                "ideal_speedup_over_1_gpu": round(n_models / k_max, 3),
+                "ranks_seen": ranks_seen,
+                "kernel_ms_per_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),
+                                       "mean": round(float(np.mean(per_rank)), 3)},
+            })
+        for m in models:
+            m.close()
 
     if rank == 0:
-        rays = args.steps * H * W * world
-        value = rays * SAMPLES_PER_RAY / dt / 1e6
-        k_ms = float(np.mean(kernel_ms))
-        achieved = H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
-        traffic = None      # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
-        prof = os.path.join(ROOT, "profiles", "r01", "pmc_k_render.json")
-        if os.path.exists(prof):
-            traffic = json.load(open(prof))["x16_default"]["derived"]["hbm_traffic_bytes_per_launch"]
-        line = {
-            "metric": "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP",
-            "value": round(value, 3), "unit": "Mray-samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
-                                   "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), fp32, fused "
-                                   "persistent kernel (x16: 2 workgroups per CU), rays generated in-kernel",
-                       "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
-                       "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
-            "rays_per_s": round(rays / dt, 1), "mlp_evals_per_s": round(rays * EVALS_PER_RAY / dt, 1),
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_note": "bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc passes "
-                                         "(profiles/r01/pmc_k_render.json); L2 misses of the weight streams (4.6 MiB of "
-                                         "networks vs 4 MiB L2 per XCD), served by Infinity Cache at 0.28 TB/s, not by "
-                                         "HBM; a schedule with 2.9e9 exists and is 2.4 % slower (DESIGN.md, chunk queue); "
-                                         "algorithmic HBM bytes are 7.0e6 per launch",
-                         "kernel": "nsr::k_render16", "kernel_ms": round(k_ms, 3),
-                         "flop_per_launch": H * W * FLOP_PER_RAY},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            cpu, par = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
-            line["cpu_baseline"] = cpu
-            line["parity"] = par
         print(json.dumps(line))
-    model.close()
     if dist is not None:
         dist.destroy_process_group()
 

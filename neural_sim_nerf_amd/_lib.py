@@ -64,6 +64,19 @@ SIGNATURES = {
 
 _lib = None
 
+KERNEL_SOURCES = ("nsr_device.h", "nsr_kernels.hip", "nsr_handoff.hip", "nsr_api.hip")
+
+
+def kernel_source_hash():
+    """sha256 over the sources libnsr.so is built from: ties a committed rocprofv3 profile to the kernels it measured
+    (bench.py reports a PMC-derived figure only when this matches the hash recorded with the profile)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
 
 class NsrError(RuntimeError):
     pass

@@ -241,3 +241,17 @@ def test_create_nerf_loads_reference_checkpoints(tmp_path, synth_nets):
     for net, sd in zip((test["network_fn"], test["network_fine"]), synth_nets):
         got = net.state_dict()
         assert all(np.array_equal(got[k].cpu().numpy(), sd[k]) for k in sd)
+
+
+def test_bench_self_launch_fails_only_on_device_count():
+    """`python bench.py --gpus N` outside a launcher re-execs itself under torch.distributed.run; with fewer than N
+    devices the ONLY failure is the device count, stated as such (no 'use torchrun' error)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a node with fewer than 2 devices")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "--gpus 2: only %d HIP device(s) visible" % torch.cuda.device_count() in (r.stderr + r.stdout)

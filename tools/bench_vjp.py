@@ -10,7 +10,7 @@ K = S.scaled_K(400.0 / H)
 c2w = S.sweep_poses(1, 0)[0]
 o, d = m.get_rays(H, W, K, c2w)
 cot = torch.randn(H * W, 3, device=m.device)
-for _ in range(2):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
     m.render_rays_vjp(o.reshape(-1, 3), d.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot)
     ms = m.last_kernel_ms()
 flop = H * W * (64 + 192 + 192) * S.FLOP_PER_POINT

@@ -1,22 +1,34 @@
 #!/bin/bash
 # Collects what profiles/rNN holds, on the GPU box (run through gpurun from the repo root):
-#   bench line, rocprofv3 kernel stats of the same command, and separate --pmc passes (counters only + kernel trace)
-#   for the default forward kernel (bench.py) and the x32 kernel (tools/one_view.py 32).
-# Output under gpurun_out/prof/; tools/summarize_pmc.py turns the PMC CSVs into pmc_k_render.json.
+#   bench line, rocprofv3 kernel stats of the same command, separate --pmc passes (counters only + kernel trace) for
+#   the default forward kernel (bench.py), the x32 forward kernel (tools/one_view.py 32) and the VJP kernel
+#   (tools/bench_vjp.py), kernel stats of the VJP and of the hand-off kernels, and the sha256 of the kernel sources
+#   that were measured (bench.py only reports a PMC figure whose hash matches the tree it runs from).
+# Output under gpurun_out/prof/; tools/summarize_pmc.py rNN turns it into profiles/rNN/.
+# usage: collect_profiles.sh [quick]      (quick: kernel stats + FETCH/WRITE + MFMA-busy passes only)
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof
-mkdir -p $O
+rm -rf $O; mkdir -p $O
+cd $R && python -c "from neural_sim_nerf_amd import _lib; print(_lib.kernel_source_hash())" > $O/kernel_source_sha256.txt
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vjp -- python $R/tools/bench_vjp.py > $O/stats_vjp.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_handoff -- python $R/tools/bench_handoff.py > $O/stats_handoff.log 2>&1
+if [ "$1" = quick ]; then
+  SETS=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE")
+else
+  SETS=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
+        "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
+        "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
+        "SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES" \
+        "FETCH_SIZE" "WRITE_SIZE")
+fi
 i=0
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
-           "SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16_$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_x16_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16_$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_x16_$i.log 2>&1
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x32_$i -- python $R/tools/one_view.py 32 > $O/pmc_x32_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_vjp_$i -- python $R/tools/bench_vjp.py 400 1 > $O/pmc_vjp_$i.log 2>&1
 done
 ls $O

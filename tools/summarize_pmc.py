@@ -6,8 +6,9 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
 os.makedirs(dst, exist_ok=True)
 out = {}
-for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_render(")):
-    tot, disp, ns = {}, {}, None
+FLOP = {"x16": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568}
+for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp")):
+    tot, disp, ns, first_id = {}, {}, None, {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
         if not os.path.isdir(d):
             continue
@@ -15,11 +16,14 @@ for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_
         for f in newest("*_counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 if kname in r["Kernel_Name"]:
+                    first = first_id.setdefault(f, r["Dispatch_Id"])      # one launch per pass: the first dispatch of the kernel
+                    if r["Dispatch_Id"] != first:
+                        continue
                     tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                     disp = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size") if k in r}
         for f in newest("*_kernel_trace.csv"):
             for r in csv.DictReader(open(f)):
-                if kname in r["Kernel_Name"]:
+                if kname in r["Kernel_Name"] and ns is None:
                     ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     if not tot:
         continue
@@ -38,14 +42,24 @@ for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_
         der["lds_bank_conflict_frac_of_lds_active"] = tot.get("SQ_LDS_BANK_CONFLICT", 0) / tot["SQ_LDS_IDX_ACTIVE"]
     if "FETCH_SIZE" in tot:
         der["hbm_traffic_bytes_per_launch"] = (2 * tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0)) * 1024
+    if ns:
+        der["algorithmic_TFLOPs_under_pmc"] = FLOP[tag] / ns / 1e3
     der["note"] = ("one 400x400x(64+128) view per launch; separate rocprofv3 --pmc passes with --kernel-trace only "
                    "(tools/collect_profiles.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md; counters summed over the XCDs")
     out[key] = {"counters": tot, "dispatch": disp, "kernel_ns_under_pmc": ns, "derived": der}
+hf = os.path.join(src, "kernel_source_sha256.txt")
+out["kernel_source_sha256"] = open(hf).read().strip() if os.path.exists(hf) else None
 json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
-for f in sorted(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
-    shutil.copy(f, os.path.join(dst, "kernel_stats_bench_steps3.csv"))
+for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
+                  ("stats_handoff", "kernel_stats_handoff.csv")):
+    for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
+        rows = list(csv.reader(open(f)))          # keep our kernels + the top rows, drop torch's kilobyte-long template names
+        with open(os.path.join(dst, name), "w", newline="") as g:
+            w = csv.writer(g)
+            for r in rows[:1] + [r for r in rows[1:] if r and (r[0].startswith("nsr::") or len(r[0]) < 120)]:
+                w.writerow(r)
 if os.path.exists(os.path.join(src, "bench.json")):
     lines = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
     if lines:
         open(os.path.join(dst, "bench_final_kernel.json"), "w").write(lines[-1])
-print(json.dumps({k: v["derived"] for k, v in out.items()}, indent=1))
+print(json.dumps({k: v["derived"] for k, v in out.items() if isinstance(v, dict)}, indent=1))
