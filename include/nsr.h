@@ -185,6 +185,23 @@ int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int 
                   int32_t* d_count, uint8_t* d_mask, void* stream);
 int nsr_reserve_bbox(nsr_handle h, int H, int W);
 
+/* psi -> camera pose on the device (LL = optimization/utils/load_LINEMOD_noscale.py, GU = utils/gumble.py).
+ * The random draws stay where the reference makes them (numpy on the host, recorded in sample_log, LL:273-297); these
+ * are the deterministic maps (probabilities, recorded noise) -> poses, written straight into device memory.
+ * nsr_sample_pose = sample_pose LL:202-247 (GU:57-63, pose_spherical LL:62-71) in torch's fp32 arithmetic:
+ *   d_prob [n_cat] fp32; d_gumbel [K,n_cat], d_uniform [K], d_theta [K] fp64 (the python floats of sample_log);
+ *   outputs (each nullable): d_poses44 [K,4,4], d_c2w34 [K,3,4] (= what nsr_render_views reads), d_jac [K,12,n_cat] =
+ *   d c2w[:3,:4] / d prob (the chain RN:179-181 needs).  Bin centres are 45 j + 22.5 degrees (LL:217); n_cat <= 16.
+ * nsr_sample_pose_nograd = sample_pose_nograd LL:250-301 (GU:46-47, GU:64-70, pose_spherical_nograd LL:89-94) in numpy's
+ *   fp64 arithmetic: d_logits [n_cat] fp64 = np.log(probs) exactly as the caller's numpy computed it (NM:88 makes the
+ *   probabilities float16, so the log is a float16 value). */
+int nsr_sample_pose(nsr_handle h, const float* d_prob, const double* d_gumbel, const double* d_uniform,
+                    const double* d_theta, int K, int n_cat, double gumbel_T, double radius, float* d_poses44,
+                    float* d_c2w34, float* d_jac, void* stream);
+int nsr_sample_pose_nograd(nsr_handle h, const double* d_logits, const double* d_gumbel, const double* d_uniform,
+                           const double* d_theta, int K, int n_cat, double gumbel_T, double radius, float* d_poses44,
+                           float* d_c2w34, void* stream);
+
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
 

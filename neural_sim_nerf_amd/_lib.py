@@ -51,6 +51,10 @@ SIGNATURES = {
     "nsr_to8b": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsr_find_bbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
+    "nsr_sample_pose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsr_sample_pose_nograd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "nsr_run_network": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsr_raw2outputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
@@ -64,7 +68,7 @@ SIGNATURES = {
 
 _lib = None
 
-KERNEL_SOURCES = ("nsr_device.h", "nsr_kernels.hip", "nsr_handoff.hip", "nsr_api.hip")
+KERNEL_SOURCES = ("nsr_device.h", "nsr_kernels.hip", "nsr_handoff.hip", "nsr_pose.hip", "nsr_api.hip")
 
 
 def kernel_source_hash():

@@ -6,6 +6,7 @@
 // it, and they can be captured into a hipGraph.
 #include "nsr_kernels.hip"
 #include "nsr_handoff.hip"
+#include "nsr_pose.hip"
 
 #include <string>
 #include <vector>
@@ -458,6 +459,34 @@ int nsr_reserve_bbox(nsr_handle h, int H, int W) {
   h->d_box_scratch = nullptr; h->box_scratch_ints = 0;
   NSR_HIP(hipMalloc(&h->d_box_scratch, need * sizeof(int)));
   h->box_scratch_ints = need;
+  return 0;
+}
+
+int nsr_sample_pose(nsr_handle h, const float* d_prob, const double* d_gumbel, const double* d_uniform,
+                    const double* d_theta, int K, int n_cat, double gumbel_T, double radius, float* d_poses44,
+                    float* d_c2w34, float* d_jac, void* stream) {
+  if (h && K == 0) return 0;
+  if (!h || !d_prob || !d_gumbel || !d_uniform || !d_theta) return fail("nsr_sample_pose: null argument");
+  if (K < 0 || n_cat < 1 || n_cat > nsr::kMaxCat) return fail("nsr_sample_pose: K >= 0, n_cat in 1..16");
+  if (!(gumbel_T > 0.0)) return fail("nsr_sample_pose: gumbel_T must be positive");
+  NSR_DEVICE(h);
+  nsr::PoseArgs a{d_prob, nullptr, d_gumbel, d_uniform, d_theta, K, n_cat, gumbel_T, radius, d_poses44, d_c2w34, d_jac};
+  hipLaunchKernelGGL(nsr::k_sample_pose, dim3((K + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_sample_pose_nograd(nsr_handle h, const double* d_logits, const double* d_gumbel, const double* d_uniform,
+                           const double* d_theta, int K, int n_cat, double gumbel_T, double radius, float* d_poses44,
+                           float* d_c2w34, void* stream) {
+  if (h && K == 0) return 0;
+  if (!h || !d_logits || !d_gumbel || !d_uniform || !d_theta) return fail("nsr_sample_pose_nograd: null argument");
+  if (K < 0 || n_cat < 1 || n_cat > nsr::kMaxCat) return fail("nsr_sample_pose_nograd: K >= 0, n_cat in 1..16");
+  if (!(gumbel_T > 0.0)) return fail("nsr_sample_pose_nograd: gumbel_T must be positive");
+  NSR_DEVICE(h);
+  nsr::PoseArgs a{nullptr, d_logits, d_gumbel, d_uniform, d_theta, K, n_cat, gumbel_T, radius, d_poses44, d_c2w34, nullptr};
+  hipLaunchKernelGGL(nsr::k_sample_pose_nograd, dim3((K + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
+  NSR_HIP(hipGetLastError());
   return 0;
 }
 

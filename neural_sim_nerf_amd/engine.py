@@ -198,6 +198,34 @@ class NsrModel:
                                          _stream_ptr(self.device)))
         return o, d
 
+    def sample_pose(self, prob, gumbel, uniform, theta, gumbel_T, radius=1.01, want_jac=True):
+        """sample_pose (LL:202-247) on the device in torch's fp32 arithmetic: prob [n_cat] (fp32), recorded noise
+        (sample_log lists / arrays, fp64) -> (poses [K,4,4], jac [K,12,n_cat] = d c2w[:3,:4] / d prob or None)."""
+        prob = self._f32(prob).reshape(-1)
+        f64 = lambda x, shape: torch.as_tensor(np.asarray(x, dtype=np.float64), device=self.device).reshape(shape).contiguous()
+        n_cat = prob.numel()
+        th = f64(theta, (-1,))
+        K = th.numel()
+        g, u = f64(gumbel, (K, n_cat)), f64(uniform, (K,))
+        poses = self._new(K, 4, 4)
+        jac = self._new(K, 12, n_cat) if want_jac else None
+        _lib.check(self.lib.nsr_sample_pose(self.h, _dev(prob), _dev(g), _dev(u), _dev(th), K, n_cat, float(gumbel_T),
+                                            float(radius), _dev(poses), None, _dev(jac), _stream_ptr(self.device)))
+        return poses, jac
+
+    def sample_pose_nograd(self, logits64, gumbel, uniform, theta, gumbel_T, radius=1.01):
+        """sample_pose_nograd's deterministic part (LL:275-293) on the device in numpy's fp64 arithmetic."""
+        f64 = lambda x, shape: torch.as_tensor(np.asarray(x, dtype=np.float64), device=self.device).reshape(shape).contiguous()
+        lg = f64(logits64, (-1,))
+        th = f64(theta, (-1,))
+        K, n_cat = th.numel(), lg.numel()
+        g, u = f64(gumbel, (K, n_cat)), f64(uniform, (K,))
+        poses = self._new(K, 4, 4)
+        _lib.check(self.lib.nsr_sample_pose_nograd(self.h, _dev(lg), _dev(g), _dev(u), _dev(th), K, n_cat,
+                                                   float(gumbel_T), float(radius), _dev(poses), None,
+                                                   _stream_ptr(self.device)))
+        return poses
+
     def to8b(self, x):
         """to8b (RH:14) on device: float tensor -> uint8 tensor of the same shape."""
         x = self._f32(x)

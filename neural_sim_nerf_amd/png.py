@@ -37,23 +37,72 @@ def imwrite(path, img):
         f.write(_chunk(b"IEND", b""))
 
 
-def imread(path):
-    """Reads back what imwrite produced (filter type 0 only) -- used by the tests."""
+def _parse(path):
     with open(path, "rb") as f:
         data = f.read()
-    assert data[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat, w = 8, b"", None
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("%s is not a PNG file" % path)
+    pos, idat, hdr, plte = 8, [], None, None
     while pos < len(data):
         (n,), tag = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
         body = data[pos + 8:pos + 8 + n]
         if tag == b"IHDR":
-            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
-            assert depth == 8
-            ch = {0: 1, 2: 3, 6: 4}[ctype]
+            hdr = struct.unpack(">IIBBBBB", body[:13])
+        elif tag == b"PLTE":
+            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
         elif tag == b"IDAT":
-            idat += body
+            idat.append(body)
         pos += 12 + n
-    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch)
-    assert (rows[:, 0] == 0).all(), "only filter type 0 is supported"
-    img = rows[:, 1:].reshape(h, w, ch)
+    return hdr, plte, b"".join(idat)
+
+
+def imsize(path):
+    """(width, height) from the header, without decoding."""
+    hdr, _, _ = _parse(path)
+    return hdr[0], hdr[1]
+
+
+def imread(path):
+    """8-bit non-interlaced PNG -> uint8 [H,W] (grey), [H,W,2] (grey+alpha), [H,W,3] or [H,W,4], the array
+    imageio.imread returns for the dataset frames (LL:120).  All five scan-line filters are undone (None and Up are
+    vector operations, Sub a wrapped cumulative sum; Average and Paeth are sequential along the row by definition)."""
+    (w, h, depth, ctype, _comp, _filt, interlace), plte, idat = _parse(path)
+    if depth != 8 or interlace != 0 or ctype not in (0, 2, 3, 4, 6):
+        raise NotImplementedError("png.imread: only 8-bit non-interlaced PNGs (got depth %d, colour type %d, interlace %d)"
+                                  % (depth, ctype, interlace))
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    stride = w * ch
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + stride)
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.uint8)
+    for y in range(h):
+        ft, line = int(rows[y, 0]), rows[y, 1:]
+        if ft == 0:
+            cur = line.copy()
+        elif ft == 2:
+            cur = line + prev                                        # uint8 arithmetic wraps mod 256
+        elif ft == 1:
+            cur = np.cumsum(line.reshape(w, ch), axis=0, dtype=np.uint8).reshape(-1)
+        elif ft in (3, 4):
+            cur = np.zeros(stride, np.uint8)
+            ln, pv, cu = line.tolist(), prev.tolist(), [0] * stride
+            for i in range(stride):
+                a = cu[i - ch] if i >= ch else 0
+                b = pv[i]
+                if ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    c = pv[i - ch] if i >= ch else 0
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cu[i] = (ln[i] + pred) & 255
+            cur = np.array(cu, np.uint8)
+        else:
+            raise ValueError("png.imread: bad filter type %d" % ft)
+        out[y] = cur
+        prev = cur
+    img = out.reshape(h, w, ch)
+    if ctype == 3:
+        return plte[img[..., 0]]
     return img[..., 0] if ch == 1 else img

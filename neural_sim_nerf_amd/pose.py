@@ -6,8 +6,14 @@ whole psi -> image -> d/dpsi chain can be driven from this package (and pinned e
     pose_spherical         LL:62-71     sample_pose         LL:202-247 (torch fp32, differentiable w.r.t. the
                                                                         categorical probabilities, replays the noise)
 
-Host-side torch/numpy: O(K) scalar work per outer epoch, not on the render path.  The only deliberate difference:
-`sample_pose_nograd` takes an explicit `seed` instead of seeding numpy with datetime.now().second (LL:273)."""
+Two implementations of the same maps:
+  * host (`sample_pose`, `sample_pose_nograd`): torch/numpy, bit-equal to the reference on its own host arithmetic;
+  * device (`sample_pose_device`, `sample_pose_nograd_device`): csrc/nsr_pose.hip through the C ABI -- the poses are
+    written into device memory where nsr_render_views reads them, and the d(pose)/d(psi) Jacobian comes out of the same
+    kernel, so render_path_grad needs no host autograd graph.  The RANDOM DRAWS stay on the host in both (numpy's
+    Mersenne Twister, as the reference; O(K) numbers), recorded in `sample_log` and uploaded.
+The only deliberate difference from the reference: `sample_pose_nograd*` take an explicit `seed` instead of seeding
+numpy with datetime.now().second (LL:273)."""
 import numpy as np
 import torch
 
@@ -76,3 +82,86 @@ def sample_pose(categorical_prob, num_K, gumble_T, sample_log):
         theta = torch.tensor([sample_log["thetas"][n]], dtype=torch.float32)
         poses.append(pose_spherical(theta, phi - 180, RADIUS))
     return torch.stack(poses, 0)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# device versions (csrc/nsr_pose.hip)
+# ----------------------------------------------------------------------------------------------------------
+def _util(device=None):
+    from .run_nerf_noscale import _util_model
+    return _util_model(device)
+
+
+def draw_noise(categorical_prob, num_K, seed=0):
+    """The reference's random draws (LL:273-292) in its order: K Gumbel vectors, then K uniforms, then K thetas."""
+    n_cat = len(categorical_prob)
+    rng = np.random.RandomState(seed)
+    gumbels = [rng.gumbel(size=n_cat).tolist() for _ in range(num_K)]
+    uniforms = [rng.uniform(0, 1) for _ in range(num_K)]
+    thetas = [rng.uniform(85, 95) for _ in range(num_K)]
+    return {"gumbel_noises": gumbels, "uniform_noises": uniforms, "thetas": thetas}
+
+
+def sample_pose_nograd_device(categorical_prob, num_K, gumble_T, seed=0, device=None):
+    """LL:250-301 with the deterministic part on the device: returns (poses [K,4,4] fp32 DEVICE tensor, sample_log).
+    `categorical_prob` is what NM:88 passes: a numpy array (float16 there); np.log keeps its dtype as in LL:268."""
+    log = draw_noise(categorical_prob, num_K, seed)
+    logits = np.log(np.asarray(categorical_prob)).astype(np.float64)
+    poses = _util(device).sample_pose_nograd(logits, log["gumbel_noises"], log["uniform_noises"], log["thetas"], gumble_T,
+                                             RADIUS)
+    return poses, log
+
+
+class _SamplePose(torch.autograd.Function):
+    """poses = f(categorical_prob) with the kernel's own Jacobian as the backward (rank one per pose: only the azimuth
+    depends on psi).  vmap-able, so torch.autograd.grad(..., is_grads_batched=True) (render_path_grad) works on it."""
+    generate_vmap_rule = True
+
+    @staticmethod
+    def forward(prob, jac, poses):
+        return poses.clone()
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.save_for_backward(inputs[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (jac,) = ctx.saved_tensors                             # [K,12,n_cat]
+        g12 = g[:, :3, :4].reshape(g.shape[0], 12, 1).to(jac.dtype)
+        return (g12 * jac).sum((0, 1)), None, None
+
+
+def sample_pose_device(categorical_prob, num_K, gumble_T, sample_log, device=None):
+    """LL:202-247 on the device: poses [K,4,4] fp32 DEVICE tensor, differentiable w.r.t. `categorical_prob` (a CPU or
+    device fp32 tensor); the gradient reaches it on its own device.  The Jacobian is also attached as `poses.nsr_jac`
+    ([K,12,n_cat], device) for callers that want it without autograd."""
+    m = _util(device)
+    prob = categorical_prob.detach()
+    poses, jac = m.sample_pose(prob, sample_log["gumbel_noises"][:num_K], sample_log["uniform_noises"][:num_K],
+                               sample_log["thetas"][:num_K], gumble_T, RADIUS)
+    if categorical_prob.requires_grad:
+        jac_p = jac if categorical_prob.is_cuda else jac.cpu()
+        out = _SamplePose.apply(categorical_prob, jac_p, poses if categorical_prob.is_cuda else poses.cpu())
+        out = out if categorical_prob.is_cuda else _ToDevice.apply(out, m.device)
+    else:
+        out = poses
+    out.nsr_jac = jac
+    return out
+
+
+class _ToDevice(torch.autograd.Function):
+    """Identity that moves the pose tensor to the render device and its gradient back (psi may live on the host)."""
+    generate_vmap_rule = True
+
+    @staticmethod
+    def forward(x, device):
+        return x.to(device)
+
+    @staticmethod
+    def setup_context(ctx, inputs, output):
+        ctx.src = inputs[0].device
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.src), None

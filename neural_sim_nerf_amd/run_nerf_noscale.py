@@ -307,6 +307,7 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
         D.check_same_poses(torch.stack([torch.as_tensor(p, dtype=torch.float32).detach() for p in render_poses[:n_poses]])
                            if n_poses else torch.zeros(0, 4, 4))
     mine = D.shard_indices(n_poses, world, rank)
+    jac_all = getattr(render_poses, "nsr_jac", None)           # [K,12,n_cat] when the poses come from the device sampler
     rgb_l, grad_l = [], []
     for i_pose in mine:
         c2w = render_poses[i_pose]
@@ -316,10 +317,13 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
                             else np.asarray(g).transpose(1, 2, 0), dtype=torch.float32)      # RN:154 CHW -> HWC
         cot = g.reshape(-1, 3).to(model.device).contiguous()
         rgb, g_pose = _pose_patch_grads(model, pose, cot, H, W, K, near, far, N_rand)        # [n_patches,3,4]
-        # d vec(c2w[:3,:4]) / d psi through the caller's graph: 12 rows, one batched autograd call
-        basis = torch.eye(12, dtype=pose.dtype, device=pose.device).reshape(12, 3, 4)
-        (J,) = torch.autograd.grad(pose, categorical_prob, grad_outputs=basis, retain_graph=True,
-                                   is_grads_batched=True)                                    # [12, n_cat]
+        if jac_all is not None:
+            J = jac_all[i_pose]                    # the device sampler's own Jacobian (pose.sample_pose_device): no autograd
+        else:
+            # d vec(c2w[:3,:4]) / d psi through the caller's graph: 12 rows, one batched autograd call
+            basis = torch.eye(12, dtype=pose.dtype, device=pose.device).reshape(12, 3, 4)
+            (J,) = torch.autograd.grad(pose, categorical_prob, grad_outputs=basis, retain_graph=True,
+                                       is_grads_batched=True)                                # [12, n_cat]
         grad_l.append((g_pose.reshape(n_patches, 12).to(J.device, J.dtype) @ J).detach().to(torch.float32).cpu())
         rgb_l.append(rgb.cpu())
         if savedir is not None:

@@ -518,6 +518,66 @@ def test_bilevel_gradient_end_to_end_vs_reference(synth_nets, oracle, tmp_path):
     assert np.abs(got.mean(0) - g["dLdpsis"].mean(0)).max() < 1e-2 * scale
 
 
+def test_device_pose_pipeline_vs_reference(synth_nets, oracle, tmp_path):
+    """f-2: psi -> poses on the device (csrc/nsr_pose.hip) against what the REFERENCE's sample_pose /
+    sample_pose_nograd returned for the same psi and recorded noise (g10).  Tolerance 1e-6 absolute per pose entry
+    (entries <= 1.01): the azimuth is an fp32 number of DEGREES up to 360, one ulp of which is 3e-5 deg = 5e-7 rad, and
+    torch's vectorised 8-element softmax / sum associate differently from a sequential loop; everything after the
+    angles is exact (one product per matrix entry).  The Jacobian is checked against autograd through the host
+    restatement (pose.sample_pose, itself bit-equal to the reference), and the bilevel gradient end to end."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd import pose as P
+    g = load_golden("g10_path_grad")
+    log = {"gumbel_noises": g["gumbel"].tolist(), "uniform_noises": g["uniform"].tolist(), "thetas": g["thetas"].tolist()}
+    prob = torch.softmax(torch.tensor(g["psi"]) / 0.25, 0).requires_grad_()
+    poses = P.sample_pose_device(prob, 2, 0.1, log)
+    assert poses.is_cuda and tuple(poses.shape) == (2, 4, 4)
+    assert np.abs(cpu(poses) - g["poses_grad"]).max() < 1e-6, np.abs(cpu(poses) - g["poses_grad"]).max()
+    # nograd path: the deterministic part of LL:250-301 in fp64 (NM:88: float16 probabilities)
+    m = R._util_model(None)
+    png_ = m.sample_pose_nograd(np.log(g["prob16"]).astype(np.float64), log["gumbel_noises"], log["uniform_noises"],
+                                log["thetas"], 0.1)
+    assert np.abs(cpu(png_) - g["poses_nograd"]).max() < 1e-6, np.abs(cpu(png_) - g["poses_nograd"]).max()
+    # same draws as the host sampler for the same seed
+    p_dev, log_dev = P.sample_pose_nograd_device(g["prob16"], 3, 0.1, seed=5)
+    p_host, log_host = P.sample_pose_nograd(g["prob16"], 3, 0.1, seed=5)
+    assert log_dev == log_host and np.abs(cpu(p_dev) - p_host.numpy()).max() < 1e-6
+    # Jacobian: kernel vs autograd through the host restatement
+    prob_h = prob.detach().clone().requires_grad_()
+    poses_h = P.sample_pose(prob_h, 2, 0.1, log)
+    basis = torch.eye(12).reshape(12, 3, 4)
+    for i in range(2):
+        (J,) = torch.autograd.grad(poses_h[i, :3, :4], prob_h, grad_outputs=basis, retain_graph=True, is_grads_batched=True)
+        Jd = cpu(poses.nsr_jac[i])
+        assert np.abs(Jd - J.numpy()).max() < 2e-4 * np.abs(J.numpy()).max(), (i, np.abs(Jd - J.numpy()).max())
+        # ... and through the device tensor's own autograd node (what an unchanged caller would do)
+        (Ja,) = torch.autograd.grad(poses[i, :3, :4], prob, grad_outputs=basis.to(poses.device), retain_graph=True,
+                                    is_grads_batched=True)
+        assert np.allclose(Ja.numpy(), Jd, rtol=1e-6, atol=1e-9)
+    # the bilevel gradient with device poses: same bound as with host poses
+    nets = []
+    for sd in synth_nets:
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=oracle.YCBV_NEAR, far=oracle.YCBV_FAR)
+    grad_E = [{"grad_E": [torch.from_numpy(x)]} for x in g["grad_E"]]
+    K = g["K"].tolist()
+    scale = np.abs(g["dLdpsis"]).max()
+    for variant in ("attribute", "autograd"):
+        pp = poses if variant == "attribute" else poses.detach().clone().requires_grad_(False)
+        if variant == "autograd":
+            pp = P.sample_pose_device(prob, 2, 0.1, log)
+            del pp.nsr_jac                                                 # force the generic autograd route
+        rgbs, dl = R.render_path_grad(prob, pp, [8, 8, K[0][0]], K, 16, grad_E, kw, savedir=None)
+        got = np.stack([d.numpy() for d in dl])
+        assert oracle.psnr(rgbs, g["rgbs"]) > 50.0
+        assert np.abs(got - g["dLdpsis"]).max() < 2e-2 * scale, (variant, np.abs(got - g["dLdpsis"]).max() / scale)
+
+
 def test_render_path_api_and_png_side_effects(oracle, synth_nets, tmp_path):
     """render_path (RN:213-255) through the reference-shaped API built by create_nerf from a checkpoint file:
     shapes, numpy returns, savedir/<object_id>/%03d.png written with to8b truncation, one launch for all poses
