@@ -26,6 +26,15 @@
 
 namespace nsr {
 
+// Opaque copies: the per-item phases of the persistent kernels index LDS and the argument block with expressions that
+// are invariant across the main loop (tid-derived LDS addresses, argument-block fields).  Left alone, LICM hoists ~80
+// of them above the loop, where they stay live across the MFMA passes -- which have no registers to spare -- and get
+// spilled to scratch (34 VGPRs + 258 SGPRs in k_render16).  Re-deriving them from an opaque copy inside the loop body
+// costs one or two VALU/SALU instructions per use and keeps the passes free of spill code.
+__device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); return x; }
+template <typename T>
+__device__ __forceinline__ const T* opaque_s(const T* p) { asm volatile("" : "+s"(p)); return p; }
+
 // ------------------------------------------------------------------------------------------------------
 // ring (LDS weight stream)
 // ------------------------------------------------------------------------------------------------------
@@ -221,14 +230,19 @@ struct BViews {    // cat([feature, input_views]) (RH:111): 128 k-steps of regis
   __device__ __forceinline__ float operator()(int t) const { return t < 128 ? v[(t & 127) >> 4][t & 15] : ed[t & 15]; }
 };
 
+// 4 * (lane half) as an opaque value: every aux-block access of a pass is then ONE per-lane base register plus an
+// immediate offset.  (With the plain expression the compiler folds the half into ~70 distinct per-lane addresses,
+// hoists them out of the main loop and spills them across the MFMA passes.)
+__device__ __forceinline__ int aux_half(int lane) { return opaque_v((lane >> 5) * 4); }
+
 // accumulator init = bias in C-fragment order (aux layout: [(mo*4+rq)*2+h] float4)
 template <int NMO>
-__device__ __forceinline__ void load_bias(const float* bias, int h, f32x16 (&acc)[NMO]) {
+__device__ __forceinline__ void load_bias(const float* bias, int h4 /* 4 * lane half, see aux_half() */, f32x16 (&acc)[NMO]) {
 #pragma unroll
   for (int mo = 0; mo < NMO; ++mo)
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
-      f32x4 v = *(const f32x4*)(bias + ((mo * 4 + rq) * 2 + h) * 4);
+      f32x4 v = *(const f32x4*)(bias + (mo * 4 + rq) * 8 + h4);
       acc[mo][rq * 4 + 0] = v[0];
       acc[mo][rq * 4 + 1] = v[1];
       acc[mo][rq * 4 + 2] = v[2];
@@ -302,8 +316,9 @@ __device__ __forceinline__ float enc_poison(float px, float py, float pz, float 
 template <bool CAPTURE>
 __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                          float px, float py, float pz, float vx, float vy, float vz,
-                                         float (&raw)[4], uint4* mask_dst = nullptr) {
+                                         float (&raw)[4], uint4* mask_dst = nullptr /* uniform */, int mask_tid = 0) {
   const int h = lane >> 5;
+  const int h4 = aux_half(lane);
   const float poison = enc_poison(px, py, pz, vx, vy, vz);
   float e[32];   // position encoding, k-step t: h=0 -> sin(2^L p_ax), h=1 -> cos(2^L p_ax), t = 3L+ax
   float ed[16];  // direction encoding, same scheme with L < 4
@@ -329,9 +344,9 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   f32x16 acc[8];
   f32x16 in[8];
   // layer 0
-  load_bias<8>(aux + kAuxBias, h, acc);
+  load_bias<8>(aux + kAuxBias, h4, acc);
   seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
-  if (CAPTURE) mask_dst[0] = relu_mask<8>(acc);
+  if (CAPTURE) mask_dst[mask_tid] = relu_mask<8>(acc);
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
 
@@ -339,21 +354,21 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   // layers 1..7 (ReLU) and 8 = feature_linear (no activation)
 #pragma unroll 1
   for (int L = 1; L <= 8; ++L) {
-    load_bias<8>(aux + kAuxBias + L * 256, h, acc);
+    load_bias<8>(aux + kAuxBias + L * 256, h4, acc);
     if (L == 5) seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);  // skip: cat([input_pts, h]) -> input columns first (RH:105)
     if (L == 8) {
       // alpha_linear on h7 (RH:109): VALU dot product over this lane's 128 features, halves summed below
       const float* wa = aux + kAuxWAlpha;
 #pragma unroll
       for (int tq = 0; tq < 32; ++tq) {
-        f32x4 w = *(const f32x4*)(wa + (tq * 2 + h) * 4);
+        f32x4 w = *(const f32x4*)(wa + tq * 8 + h4);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
           alpha_part = __builtin_fmaf(w[kk], in[(4 * tq + kk) >> 4][(4 * tq + kk) & 15], alpha_part);
       }
     }
     seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
-    if (CAPTURE && L < 8) mask_dst[L * 256] = relu_mask<8>(acc);
+    if (CAPTURE && L < 8) mask_dst[L * 256 + mask_tid] = relu_mask<8>(acc);
     const int thr = (L == 8) ? (int)0x80000000 : 0;      // feature_linear has no activation
 #pragma unroll
     for (int mo = 0; mo < 8; ++mo) in[mo] = clamp_bits16(acc[mo], thr);
@@ -361,9 +376,9 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 
   // views_linears.0 (RH:111-115): cat([feature, input_views]) -> 128, ReLU
   f32x16 av[4];
-  load_bias<4>(aux + kAuxBiasV, h, av);
+  load_bias<4>(aux + kAuxBiasV, h4, av);
   seg<4, 36>(rg, A0, A1, BViews{in, ed}, av, lane);
-  if (CAPTURE) mask_dst[8 * 256] = relu_mask<4>(av);
+  if (CAPTURE) mask_dst[8 * 256 + mask_tid] = relu_mask<4>(av);
 
   // rgb_linear (RH:117) on relu(av): VALU
   float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};
@@ -374,7 +389,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
     for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        f32x4 w = *(const f32x4*)(wr + ((mo * 4 + rq) * 2 + h) * 4);
+        f32x4 w = *(const f32x4*)(wr + (mo * 4 + rq) * 8 + h4);
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri)
           part[c] = __builtin_fmaf(w[ri], fmaxf(av[mo][rq * 4 + ri], 0.0f), part[c]);
@@ -707,38 +722,38 @@ __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; *a.w
 
 __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const RenderArgs& a = *ap;
+  const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = clock64();
 #endif
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int j = lane & 31;
   ItemState& st = *(ItemState*)(smem + kLdsState);
 
-  const long long n_rays = a.n_rays;
+  const long long n_rays = a_setup.n_rays;
   const long long n_items = (n_rays + 1) >> 1;
   if ((long long)blockIdx.x >= n_items) return;
-  const int fine = a.fine;
+  const int fine = a_setup.fine;
 
   Ring rg;
-  ring_init(rg, smem, a.nets, a.net_stride, fine ? 4 : 1, wave, lane);
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 4 : 1, wave, lane);
 
   f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
 
-  load_aux(smem, a, tid);
-  if (tid < 64) st.tcoarse[tid] = a.tcoarse[tid];
-  if (tid < 128) st.ufine[tid] = a.ufine[tid];
+  load_aux(smem, a_setup, tid0);
+  if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
+  if (tid0 < 128) st.ufine[tid0] = a_setup.ufine[tid0];
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
 
   // items come from a global counter: nothing forces the workgroups to progress at the same rate
   long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
   auto next_item = [&]() -> long long {
-    if (tid == 0) *item_slot = (long long)atomicAdd(a.work_counter, 1ull);
+    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
     __syncthreads();
     const long long v = *item_slot;
     __syncthreads();
@@ -752,6 +767,8 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
     const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
     if (pass == 0) {
       // ---- stage the two rays --------------------------------------------------------------------
+      const RenderArgs& a = *opaque_s(ap);                // see opaque_v / opaque_s
+      const int tid = opaque_v(tid0);
       const float near_ = a.near_, far_ = a.far_;
       if (tid < 2) {
         const long long rr = ray0 + (tid < valid ? tid : 0);
@@ -804,6 +821,8 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
     }
     NSR_T(1);
 
+    const RenderArgs& a = *opaque_s(ap);                  // nothing below may be hoisted above the network pass
+    const int tid = opaque_v(tid0);
     if (pass == 0) {
       __syncthreads();
       if (a.dbg_raw0) {
@@ -874,8 +893,8 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 #ifdef NSR_PHASE_TIMING
-  if (tid == 0 && a.dbg_raw == nullptr && a.dbg_inds)      // diagnostic hijack: dbg_inds receives [grid][8] cycle totals
-    for (int i = 0; i < 8; ++i) a.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
+  if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)      // diagnostic hijack: dbg_inds receives [grid][8] cycle totals
+    for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
 #endif
 }
 
@@ -913,22 +932,24 @@ __device__ __forceinline__ void embed_bwd(const float (&x)[3], const float* G /*
 }
 
 __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
-                                             const uint4* mask_src, float g0, float g1, float g2, float gs,
+                                             const uint4* mask_src /* uniform */, int mask_tid, float g0, float g1,
+                                             float g2, float gs,
                                              float px, float py, float pz, float vx, float vy, float vz,
                                              float (&dp)[3], float (&dv)[3]) {
   const int h = lane >> 5;
+  const int h4 = aux_half(lane);
   // rgb_linear^T (VALU) masked by the views layer's relu pattern
   f32x16 gv[4];
   {
-    const uint4 mk = mask_src[8 * 256];
+    const uint4 mk = mask_src[8 * 256 + mask_tid];
     const unsigned mw[2] = {mk.x, mk.y};
 #pragma unroll
     for (int mo = 0; mo < 4; ++mo)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
-        const f32x4 w0 = *(const f32x4*)(aux + kAuxWRgb + 0 * 128 + ((mo * 4 + rq) * 2 + h) * 4);
-        const f32x4 w1 = *(const f32x4*)(aux + kAuxWRgb + 1 * 128 + ((mo * 4 + rq) * 2 + h) * 4);
-        const f32x4 w2 = *(const f32x4*)(aux + kAuxWRgb + 2 * 128 + ((mo * 4 + rq) * 2 + h) * 4);
+        const f32x4 w0 = *(const f32x4*)(aux + kAuxWRgb + 0 * 128 + (mo * 4 + rq) * 8 + h4);
+        const f32x4 w1 = *(const f32x4*)(aux + kAuxWRgb + 1 * 128 + (mo * 4 + rq) * 8 + h4);
+        const f32x4 w2 = *(const f32x4*)(aux + kAuxWRgb + 2 * 128 + (mo * 4 + rq) * 8 + h4);
 #pragma unroll
         for (int ri = 0; ri < 4; ++ri) {
           const float v = __builtin_fmaf(w2[ri], g2, __builtin_fmaf(w1[ri], g1, w0[ri] * g0));
@@ -958,14 +979,14 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
   // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (10 blocks: first use of acc[8..9]), 4..7 L4^T..L1^T
 #pragma unroll 1
   for (int idx = 0; idx < 8; ++idx) {
-    const uint4 mk = mask_src[(7 - idx) * 256];              // relu pattern of the layer this GEMM feeds back to
+    const uint4 mk = mask_src[(7 - idx) * 256 + mask_tid];   // relu pattern of the layer this GEMM feeds back to
     if (idx == 3) seg<10, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
     else seg<8, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
     if (idx == 0) {
       const float* wa = aux + kAuxWAlpha;                    // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
 #pragma unroll
       for (int tq = 0; tq < 32; ++tq) {
-        const f32x4 w = *(const f32x4*)(wa + (tq * 2 + h) * 4);
+        const f32x4 w = *(const f32x4*)(wa + tq * 8 + h4);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
           acc[(4 * tq + kk) >> 4][(4 * tq + kk) & 15] =
@@ -1070,35 +1091,37 @@ __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; *a.r.w
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict__ vp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const VjpArgs& va = *vp;
-  const RenderArgs& a = va.r;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const VjpArgs& va_setup = *vp;
+  const RenderArgs& a_setup = va_setup.r;
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int j = lane & 31;
   ItemState& st = *(ItemState*)(smem + kLdsState);
 
-  const long long n_rays = a.n_rays;
+  const long long n_rays = a_setup.n_rays;
   const long long n_items = (n_rays + 1) >> 1;
   if ((long long)blockIdx.x >= n_items) return;
 
   Ring rg;
-  ring_init(rg, smem, a.nets, a.net_stride, 7, wave, lane);
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);
 
   f32x4 A0[4], A1[4];
   ring_start(rg, A0, lane);
-  load_aux(smem, a, tid);
-  if (tid < 64) st.tcoarse[tid] = a.tcoarse[tid];
-  if (tid < 128) st.ufine[tid] = a.ufine[tid];
+  load_aux(smem, a_setup, tid0);
+  if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
+  if (tid0 < 128) st.ufine[tid0] = a_setup.ufine[tid0];
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
   const float* aux_f = aux_c + kAuxFloats;
-  uint4* my_masks = va.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256) + tid;
+  // relu-pattern scratch of this workgroup: a UNIFORM base (scalar registers) + the thread index at each access, so
+  // that no per-lane 64-bit address is kept alive across the passes
+  uint4* my_masks = va_setup.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256);
   float* grgb = &st.res[0][0];   // [2][3] cotangent staged here during the backward half (res is free then)
 
   long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
   auto next_item = [&]() -> long long {
-    if (tid == 0) *item_slot = (long long)atomicAdd(a.work_counter, 1ull);
+    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
     __syncthreads();
     const long long v = *item_slot;
     __syncthreads();
@@ -1111,6 +1134,8 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
     const long long ray0 = item * 2;
     const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
     if (pass == 0) {
+      const RenderArgs& a = opaque_s(vp)->r;              // see opaque_v / opaque_s
+      const int tid = opaque_v(tid0);
       const float near_ = a.near_, far_ = a.far_;
       if (tid < 2) {
         const long long rr = ray0 + (tid < valid ? tid : 0);
@@ -1148,7 +1173,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const float* ry = st.ray[r];
       float raw[4];
       mlp_pass<true>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
-                     ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256));
+                     ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), tid0);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     } else {
       // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
@@ -1158,7 +1183,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const float* ry = st.ray[r];
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
-      mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), g[0], g[1], g[2], g[3],
+      mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), tid0, g[0], g[1], g[2], g[3],
                    ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
       // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
       float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
@@ -1171,6 +1196,9 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
         for (int c = 0; c < 9; ++c) st.psum[r][slot][c] = red[c];
     }
 
+    const VjpArgs& va = *opaque_s(vp);                    // nothing below may be hoisted above the network passes
+    const RenderArgs& a = va.r;
+    const int tid = opaque_v(tid0);
     if (pass == 0) {
       __syncthreads();
       composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
@@ -1408,26 +1436,26 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
 // time: 2.3 MiB against the 4 MiB L2 of an XCD, instead of both networks (4.6 MiB) thrashing it.
 __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const RenderArgs& a = *ap;
+  const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long tlast = clock64();
 #endif
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int j = lane & 15;
   ItemState16& st = *(ItemState16*)(smem + kLds16State);
 
-  const long long n_items = a.n_rays;
-  const int fine = a.fine;
-  const int K = a.chunk;
+  const long long n_items = a_setup.n_rays;
+  const int fine = a_setup.fine;
+  const int K = a_setup.chunk;
   const long long n_chunks = (n_items + K - 1) / K;
-  float* zscr = a.zf_scratch + (size_t)blockIdx.x * K * 192;
+  float* zscr = a_setup.zf_scratch + (size_t)blockIdx.x * K * 192;
   long long* chunk_slot = (long long*)&st.res[0][6];       // 8-byte LDS slot that broadcasts the chunk id
 
   Ring rg;
-  ring_init(rg, smem, a.nets, a.net_stride, 1, wave, lane);
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1, wave, lane);
   rg.pn0 = fine ? K : 0x7fffffff;                          // K coarse passes, then 3K fine passes, repeating
   rg.pn1 = fine ? 4 * K : 0x7fffffff;
   rg.ppi = fine ? 4 * K : 1;
@@ -1435,9 +1463,9 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   ring_start<kRing16>(rg, A0, lane);
   {
     float* dst = (float*)(smem + kLds16Aux);
-    for (int i = tid; i < kAux16Floats; i += 256) {
-      dst[i] = a.aux[0][i];
-      dst[kAux16Floats + i] = a.aux[1][i];
+    for (int i = tid0; i < kAux16Floats; i += 256) {
+      dst[i] = a_setup.aux[0][i];
+      dst[kAux16Floats + i] = a_setup.aux[1][i];
     }
   }
   __syncthreads();
@@ -1447,7 +1475,7 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   int jr = 0;                                              // ray within the chunk
   int pass = 0;                                            // 0 = coarse pass (phase A), 1..3 = fine passes (phase B)
   auto next_chunk = [&]() -> bool {
-    if (tid == 0) *chunk_slot = (long long)atomicAdd(a.work_counter, 1ull);
+    if (opaque_v(tid0) == 0) *chunk_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
     __syncthreads();
     const long long c = *chunk_slot;
     __syncthreads();
@@ -1459,7 +1487,9 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   while (more) {
     // a short last chunk is padded with repeats of the last ray (recomputed and rewritten with identical values)
     const long long rr = (c0 + jr) < n_items ? (c0 + jr) : n_items - 1;
-    if (pass == 0 || (pass == 1 && K > 1)) {               // a new ray enters the workgroup state (with one ray
+    if (pass == 0 || (pass == 1 && K > 1)) {
+      const RenderArgs& a = *opaque_s(ap);
+      const int tid = opaque_v(tid0);               // a new ray enters the workgroup state (with one ray
                                                            // per chunk phase B simply continues in LDS)
       const float near_ = a.near_, far_ = a.far_;
       if (tid == 0) {
@@ -1504,6 +1534,8 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
     }
     NSR_T(1);
 
+    const RenderArgs& a = *opaque_s(ap);                  // see opaque_v / opaque_s: nothing below may be hoisted
+    const int tid = opaque_v(tid0);                       // above the network pass
     if (pass == 0) {
       __syncthreads();
       if (a.dbg_raw0) {
@@ -1583,8 +1615,8 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 #ifdef NSR_PHASE_TIMING
-  if (tid == 0 && a.dbg_raw == nullptr && a.dbg_inds)
-    for (int i = 0; i < 8; ++i) a.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
+  if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)
+    for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
 #endif
 }
 
