@@ -57,8 +57,9 @@ typedef struct NsrConfig {
   int32_t n_samples;       /* must be 64                                                           */
   int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1)               */
   int32_t max_workgroups;  /* 0 = fill the chip (one workgroup per CU for x32, two for x16)        */
-  int32_t variant;         /* forward kernel: 0 = library default (= 16), 16 = 16 points/wave, two workgroups
-                              per CU (needs nsr_upload_weights16), 32 = 32 points/wave, one workgroup/CU  */
+  int32_t variant;         /* render AND input-gradient kernels: 0 = library default (= 16); 16 = 16 points/wave, two
+                              workgroups per CU (needs nsr_upload_weights16 / _bwd16); 32 = 32 points/wave, one
+                              workgroup per CU (nsr_upload_weights / _bwd)                                   */
   int32_t flags;           /* NSR_FLAG_* render options (0 = the YCB-V configuration)                */
   int32_t chunk;           /* x16 kernel: rays per chunk of the work queue; 0 = default (1).  Larger chunks trade
                               load balance for L2 locality of the weight streams ("Chunk queue")  */
@@ -104,6 +105,10 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
 /* Transposed stream of the FINE network for the input-gradient kernel (pack.py: pack_network_backward);
  * host buffer of NSR_STREAM_SLABS*NSR_SLAB_FLOATS floats.  Needed only by nsr_render_rays_vjp. */
 int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats);
+
+/* The same transposed stream in the x16 layout (pack.py: pack_network_backward16), for the x16 forward+input-gradient
+ * kernel k_render_vjp16 that variant 0 / 16 handles use (two workgroups per CU, one ray per work item). */
+int nsr_upload_weights_bwd16(nsr_handle h, const float* stream, size_t n_floats);
 
 /* The two linspace tables the reference builds on the host and moves to the device
  * (RN:439 t_vals[64], RH:208 u[128]); host buffers. */

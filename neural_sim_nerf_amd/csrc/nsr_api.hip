@@ -50,6 +50,7 @@ struct DeviceGuard {
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
 constexpr size_t kRender16Lds = nsr::kLds16State + sizeof(nsr::ItemState16);
+constexpr size_t kVjp16Lds = nsr::kLds16State + sizeof(nsr::ItemStateV16);
 constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
 
 }  // namespace
@@ -61,15 +62,15 @@ struct nsr_handle_s {
   float* d_nets = nullptr;
   float* d_packed[3] = {nullptr, nullptr, nullptr};   // views into d_nets: coarse, fine, fine transposed
   bool have_net[3] = {false, false, false};
-  float* d_nets16 = nullptr;                            // coarse | fine in the x16 layout
-  bool have_net16[2] = {false, false};
+  float* d_nets16 = nullptr;                            // coarse | fine | fine transposed in the x16 layout
+  bool have_net16[3] = {false, false, false};
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
   nsr::RenderArgs* d_args = nullptr;  // kernel argument block (device), written stream-ordered by k_set_args
   nsr::VjpArgs* d_vjp_args = nullptr;
-  uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes, [n_cu][3][9][256] (nsr_upload_weights_bwd)
-  int mask_grid = 0;
+  uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes: x32 [n_cu][3][9][256] uint4 = x16
+  int mask_grid = 0;                  // [2 n_cu][3][9][256] uint2 (same bytes); allocated by nsr_upload_weights_bwd*
   unsigned long long* d_work_counter = nullptr;  // work-queue head
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
   int zf_grid = 0;
@@ -135,7 +136,8 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
   NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
   for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
-  NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 2 * NSR_PACKED_FLOATS));
+  NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
@@ -197,16 +199,30 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
   return 0;
 }
 
+static int alloc_mask_scratch(nsr_handle h) {
+  if (h->d_mask_scratch) return 0;   // setup call: the VJP kernels' relu-pattern scratch, one block per workgroup
+  h->mask_grid = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : h->n_cu;     // in x32 workgroups (16 B entries)
+  NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)h->mask_grid * 3 * 9 * 256));
+  return 0;
+}
+
 int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats) {
   if (!h || !stream) return fail("nsr_upload_weights_bwd: null argument");
   if (n_floats != (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd: wrong stream size");
   NSR_DEVICE(h);
   NSR_HIP(hipMemcpy(h->d_packed[2], stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
-  if (!h->d_mask_scratch) {          // setup call: the VJP kernel's relu-pattern scratch, one block per workgroup
-    h->mask_grid = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : h->n_cu;
-    NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)h->mask_grid * 3 * 9 * 256));
-  }
+  if (int e = alloc_mask_scratch(h)) return e;
   h->have_net[2] = true;
+  return 0;
+}
+
+int nsr_upload_weights_bwd16(nsr_handle h, const float* stream, size_t n_floats) {
+  if (!h || !stream) return fail("nsr_upload_weights_bwd16: null argument");
+  if (n_floats != (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd16: wrong stream size");
+  NSR_DEVICE(h);
+  NSR_HIP(hipMemcpy(h->d_nets16 + (size_t)2 * NSR_PACKED_FLOATS, stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  if (int e = alloc_mask_scratch(h)) return e;
+  h->have_net16[2] = true;
   return 0;
 }
 
@@ -333,7 +349,10 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   if (!h) return fail("nsr_render_rays_vjp: null handle");
   if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
   if (int e = check_ready(h, true)) return e;
-  if (!h->have_net[2]) return fail("nsr_render_rays_vjp: backward stream not uploaded (nsr_upload_weights_bwd)");
+  const bool x16 = use_x16(h);
+  if (x16 && !(h->have_net16[0] && h->have_net16[1] && h->have_net16[2]))
+    return fail("nsr_render_rays_vjp: variant 16 needs nsr_upload_weights16 (both networks) and nsr_upload_weights_bwd16");
+  if (!x16 && !h->have_net[2]) return fail("nsr_render_rays_vjp: backward stream not uploaded (nsr_upload_weights_bwd)");
   if (!d_rays_o || !d_rays_d || !d_grad_rgb || !d_grad_o || !d_grad_d) return fail("nsr_render_rays_vjp: null argument");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_render_rays_vjp: negative ray count");
   NSR_DEVICE(h);
@@ -341,17 +360,24 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   bool capturing = false;
   if (int e = stream_capturing(s, &capturing)) return e;
   if (int e = claim_stream(h, s, capturing)) return e;
-  const long long n_items = (n_rays + 1) / 2;
-  int grid = grid_for(h, n_items);
-  if (grid > h->mask_grid) grid = h->mask_grid;          // the relu-pattern scratch was sized at upload time
+  long long grid;
+  if (x16) {                                               // one ray per item, two workgroups per CU
+    grid = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;
+    if (grid > 2LL * h->mask_grid) grid = 2LL * h->mask_grid;   // scratch entries are half the size (uint2)
+    if (grid > n_rays) grid = n_rays;
+  } else {
+    grid = grid_for(h, (n_rays + 1) / 2);
+    if (grid > h->mask_grid) grid = h->mask_grid;          // the relu-pattern scratch was sized at upload time
+  }
   nsr::VjpArgs v;
   memset(&v, 0, sizeof(v));
   nsr::RenderArgs& a = v.r;
   a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.n_rays = n_rays; a.near_ = near_; a.far_ = far_; a.camera = 0;
-  a.nets = h->d_nets;
+  float* nets = x16 ? h->d_nets16 : h->d_nets;
+  a.nets = nets;
   a.net_stride = (long long)sizeof(float) * NSR_PACKED_FLOATS;
-  a.aux[0] = h->d_packed[0] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
-  a.aux[1] = h->d_packed[1] + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.aux[0] = nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.aux[1] = nets + (size_t)NSR_PACKED_FLOATS + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = 1;
@@ -363,7 +389,10 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   v.z_fine = d_z_fine;
   hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);   // also zeroes the work counter
   if (!capturing) NSR_HIP(hipEventRecord(h->ev0, s));
-  hipLaunchKernelGGL(nsr::k_render_vjp, dim3(grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  if (x16)
+    hipLaunchKernelGGL(nsr::k_render_vjp16, dim3((int)grid), dim3(256), kVjp16Lds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  else
+    hipLaunchKernelGGL(nsr::k_render_vjp, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   NSR_HIP(hipGetLastError());
   if (!capturing) {
     NSR_HIP(hipEventRecord(h->ev1, s));

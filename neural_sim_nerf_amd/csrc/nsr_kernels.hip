@@ -1173,7 +1173,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const float* ry = st.ray[r];
       float raw[4];
       mlp_pass<true>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
-                     ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), tid0);
+                     ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     } else {
       // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
@@ -1183,7 +1183,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const float* ry = st.ray[r];
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
-      mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), tid0, g[0], g[1], g[2], g[3],
+      mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
                    ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
       // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
       float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
@@ -1349,10 +1349,39 @@ __device__ __forceinline__ f32x4 clamp_bits4(f32x4 x, int thr) {
 
 // One network pass for this lane's point: lane (j = lane&15, g = lane>>4), the four lanes of a point hold
 // complementary quarters of every feature vector.  Embedder RH:18-48, NeRF.forward RH:99-122.
+// relu pattern of one x16 layer output (lane-private C fragment): element e = 4 (mo & 7) + r of word mo >> 3 ends up at
+// bit 31 - e, SET when the unit is ON (x > +0, torch's relu').  0 - max(int(x), 0) is negative exactly then; one
+// v_alignbit per element shifts that sign into the word.
+template <int NMO>
+__device__ __forceinline__ uint2 relu_mask4(const f32x4 (&acc)[NMO]) {
+  unsigned w[2] = {0u, 0u};
+#pragma unroll
+  for (int mo = 0; mo < NMO; ++mo)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int on = 0 - max(__float_as_int(acc[mo][r]), 0);
+      w[mo >> 3] = __builtin_amdgcn_alignbit(w[mo >> 3], (unsigned)on, 31);
+    }
+  return make_uint2(w[0], w[1]);
+}
+
+// x where the unit was on, +0 where it was off: one v_bfe_i32 (bit -> 0 / -1) and one v_and per element
+__device__ __forceinline__ f32x4 apply_mask4(f32x4 x, unsigned word, int shift) {
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = __int_as_float(__float_as_int(x[i]) & __builtin_amdgcn_sbfe((int)word, 31 - (shift + i), 1));
+  return r;
+}
+
+// LOCAL_G: derive the per-group encoding constants (frequency, sin/cos, axis of column 15 g + t) from an opaque copy of
+// the lane group inside the pass instead of letting them be hoisted out of the kernel's main loop -- for kernels whose
+// other passes need the registers (k_render_vjp16); k_render16 keeps them resident (as lane masks in SGPRs).
+template <bool CAPTURE = false, bool LOCAL_G = false>
 __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                            float px, float py, float pz, float vx, float vy, float vz,
-                                           float (&raw)[4]) {
-  const int g = lane >> 4;
+                                           float (&raw)[4], uint2* mask_dst = nullptr /* uniform */, int mask_tid = 0) {
+  const int g = LOCAL_G ? opaque_v(lane >> 4) : (lane >> 4);
   const float poison = enc_poison(px, py, pz, vx, vy, vz);
   float e[16];   // 60 sin/cos columns dealt 15 per lane group (reference order), then the identity column g
   float ed[8];   // directions: group g holds frequency 2^g (sin xyz, cos xyz), then the identity column g
@@ -1380,6 +1409,7 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
   };
   load_bias16(bias_g);
   seg<16, 4, kRing16>(rg, A0, A1, BArr<16>{e}, acc, lane);
+  if (CAPTURE) mask_dst[mask_tid] = relu_mask4<16>(acc);
 #pragma unroll
   for (int mo = 0; mo < 16; ++mo) in[mo] = clamp_bits4(acc[mo], 0);
 
@@ -1398,6 +1428,7 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
       }
     }
     seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
+    if (CAPTURE && L < 8) mask_dst[L * 256 + mask_tid] = relu_mask4<16>(acc);
     const int thr = (L == 8) ? (int)0x80000000 : 0;                         // feature_linear has no activation
 #pragma unroll
     for (int mo = 0; mo < 16; ++mo) in[mo] = clamp_bits4(acc[mo], thr);
@@ -1407,6 +1438,7 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) av[mo] = *(const f32x4*)(aux + kAuxBiasV + 4 * g + 16 * mo);
   seg<8, 18, kRing16>(rg, A0, A1, BViews4{in, ed}, av, lane);
+  if (CAPTURE) mask_dst[8 * 256 + mask_tid] = relu_mask4<8>(av);
 
   float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};                           // rgb_linear (RH:117)
 #pragma unroll
@@ -1618,6 +1650,342 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)
     for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------
+// x16 variant of the forward + input-gradient kernel (k_render_vjp16): the scheme of k_render16 (16 points per wave,
+// <= 256 registers, 80 KB of LDS, TWO workgroups per CU) applied to the seven passes of an item.  A work item is ONE
+// ray: coarse forward (64 points), three fine forward passes with the relu patterns captured, compositing forward +
+// backward, three backward passes through the transposed fine network (pack_network_backward16), per-ray reduction.
+// ------------------------------------------------------------------------------------------------------
+// d(encoding)/d(x) for the x16 encoding registers: lane group g holds G[t] = dL/d e[t] of ITS registers
+// (t < PER: column q = PER g + t -> frequency q / 6, sin or cos, axis q % 3; t = PER: identity column g).
+// Returns this group's contribution; the caller adds the four groups.
+template <int NFREQ>
+__device__ __forceinline__ void embed_bwd16(const float (&x)[3], const float* G, int g, float (&out)[3]) {
+  constexpr int PER = 6 * NFREQ / 4;
+  const float xd[3] = {enc_domain(x[0], NFREQ), enc_domain(x[1], NFREQ), enc_domain(x[2], NFREQ)};
+  out[0] = g == 0 ? G[PER] : 0.0f;
+  out[1] = g == 1 ? G[PER] : 0.0f;
+  out[2] = g == 2 ? G[PER] : 0.0f;
+#pragma unroll
+  for (int t = 0; t < PER; ++t) {
+    if (NFREQ == 4) {                      // PER = 6: group g holds frequency 2^g, t = 3 sc + ax
+      const int sc = t / 3, ax = t % 3;
+      const float f = ldexpf(1.0f, g);
+      out[ax] = __builtin_fmaf(f * G[t], enc_trig(xd[ax] * f, 1 + sc), out[ax]);   // d sin = f cos, d cos = -f sin
+    } else {
+      const int q = PER * g + t, L = q / 6, sc = (q % 6) / 3, ax = q % 3;
+      const float xa = ax == 0 ? xd[0] : (ax == 1 ? xd[1] : xd[2]);
+      const float f = ldexpf(1.0f, L);
+      const float c = (f * G[t]) * enc_trig(xa * f, 1 + sc);
+      out[0] += ax == 0 ? c : 0.0f;
+      out[1] += ax == 1 ? c : 0.0f;
+      out[2] += ax == 2 ? c : 0.0f;
+    }
+  }
+}
+
+// Backward (input-side VJP) of one x16 network pass, stream order as mlp_bwd_pass:
+//   views^T 9 slabs (16 feature blocks + 2 direction-encoding blocks, K = 128) | feature^T 16 | L7^T 16 | L6^T 16 |
+//   L5^T 20 (16 blocks h4 + 4 blocks encoding) | L4^T..L1^T 64 | L0^T 4 (4 encoding blocks) = 145 slabs.
+// The gradient fragment of layer l (C layout: register (mo, r) of group g = feature 16 mo + 4 g + r) is masked with the
+// relu pattern captured in the forward pass and is, register for register, the B operand of layer l-1's transposed GEMM.
+__device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
+                                               const uint2* mask_src /* uniform */, int mask_tid, float g0, float g1,
+                                               float g2, float gs, float px, float py, float pz, float vx, float vy,
+                                               float vz, float (&dp)[3], float (&dv)[3]) {
+  const int g = lane >> 4;
+  const int g4 = opaque_v(4 * g);                            // one per-lane base register for every aux access
+  f32x4 gin[16];
+  f32x4 acc[20];   // 0-15: gradient w.r.t. the 256 hidden features; 16-19: gradient w.r.t. the 64 encoding registers
+  {
+    // rgb_linear^T (VALU) masked by the views layer's relu pattern -> dL/d(views pre-activation), 128 features
+    f32x4 gv[8];
+    const unsigned mk = mask_src[8 * 256 + mask_tid].x;
+#pragma unroll
+    for (int mo = 0; mo < 8; ++mo) {
+      const f32x4 w0 = *(const f32x4*)(aux + kAuxWRgb + 0 * 128 + 16 * mo + g4);
+      const f32x4 w1 = *(const f32x4*)(aux + kAuxWRgb + 1 * 128 + 16 * mo + g4);
+      const f32x4 w2 = *(const f32x4*)(aux + kAuxWRgb + 2 * 128 + 16 * mo + g4);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(w2[r], g2, __builtin_fmaf(w1[r], g1, w0[r] * g0));
+      gv[mo] = apply_mask4(v, mk, 4 * mo);
+    }
+    // views^T: 256 feature rows (blocks 0-15) + 32 direction-encoding rows (blocks 16-17), K = 128
+    seg<18, 8, kRing16, true>(rg, A0, A1, BRegs4<8>{gv}, acc, lane);
+  }
+  {
+    float Gd[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) Gd[t] = acc[16 + (t >> 2)][t & 3];
+    const float v[3] = {vx, vy, vz};
+    float part[3];
+    embed_bwd16<kMultiresViews>(v, Gd, opaque_v(g), part);   // opaque: keep the per-group constants out of the main loop's live set
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      float x = part[ax];
+      x = x + __shfl_xor(x, 16);
+      dv[ax] = x + __shfl_xor(x, 32);
+    }
+  }
+#pragma unroll
+  for (int mo = 0; mo < 16; ++mo) gin[mo] = acc[mo];        // feature_linear has no activation
+  // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (20 blocks: first use of acc[16..19]), 4..7 L4^T..L1^T
+#pragma unroll 1
+  for (int idx = 0; idx < 8; ++idx) {
+    const uint2 mk = mask_src[(7 - idx) * 256 + mask_tid];   // relu pattern of the layer this GEMM feeds back to
+    if (idx == 3) seg<20, 16, kRing16, true>(rg, A0, A1, BRegs4<16>{gin}, acc, lane);
+    else seg<16, 16, kRing16, true>(rg, A0, A1, BRegs4<16>{gin}, acc, lane);
+    if (idx == 0) {                                          // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
+#pragma unroll
+      for (int mo = 0; mo < 16; ++mo) {
+        const f32x4 w = *(const f32x4*)(aux + kAuxWAlpha + 16 * mo + g4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mo][r] = __builtin_fmaf(w[r], gs, acc[mo][r]);
+      }
+    }
+#pragma unroll
+    for (int mo = 0; mo < 16; ++mo) gin[mo] = apply_mask4(acc[mo], mo < 8 ? mk.x : mk.y, 4 * (mo & 7));
+  }
+  // L0^T: the remaining contribution to the 64 encoding rows (accumulates onto L5^T's)
+  seg<4, 16, kRing16>(rg, A0, A1, BRegs4<16>{gin}, *(f32x4(*)[4]) & acc[16], lane);
+  {
+    float Ge[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) Ge[t] = acc[16 + (t >> 2)][t & 3];
+    const float p[3] = {px, py, pz};
+    float part[3];
+    embed_bwd16<kMultires>(p, Ge, opaque_v(g), part);
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      float x = part[ax];
+      x = x + __shfl_xor(x, 16);
+      dp[ax] = x + __shfl_xor(x, 32);
+    }
+  }
+}
+
+struct ItemStateV16 {           // one ray; the coarse-phase arrays are dead once the samples are sorted and are reused
+  float ray[1][16];
+  union {
+    struct { float zc[1][64]; float w0[1][64]; float cdf[1][64]; float zs[1][128]; };     // pass 0
+    struct { float at[192]; float psum[12][9]; float gnorm[1]; float grgb[3]; };           // backward half
+  };
+  float zf[1][192];
+  float rawf[1][192][4];        // coarse raw (first 64), fine raw -> sigmoid(rgb), sigma -> dL/d raw
+  float alpha[1][192];
+  union { float om[1][192]; float wf[1][192]; };   // 1 - alpha + 1e-10 during the scan, then the fine weights
+  union { float tf[1][192]; float aw[192]; };      // T_i, then A_i w_i and its exclusive suffix sums
+  float res[1][8];
+};
+static_assert(kLds16State + sizeof(ItemStateV16) <= 81920, "two workgroups must fit in the 160 KiB LDS of a CU");
+
+// Backward of raw2outputs (RN:343-387) for the ray of an x16 item, as composite_bwd: dL/d raw written over st.rawf,
+// dL/d|rays_d| in st.gnorm.  st.rawf holds sigmoid(rgb) and the raw sigma, st.alpha / st.wf / st.tf the forward
+// alpha, weights, T; A_i T_i goes to st.at, A_i w_i (then its suffix sums) replaces T_i in place.
+__device__ __forceinline__ void composite_bwd_ray(ItemStateV16& st, int tid) {
+  constexpr int S = 192;
+  const float g0 = st.grgb[0], g1 = st.grgb[1], g2 = st.grgb[2];
+  if (tid < S) {
+    const float* q = st.rawf[0][tid];
+    float a_i = (g0 * q[0] + g1 * q[1]) + g2 * q[2];
+    if (st.ray[0][12] != 0.0f) a_i = a_i - ((g0 + g1) + g2);       // white_bkgd: d(1 - acc)/dw
+    const float T = st.tf[0][tid];
+    st.at[tid] = a_i * T;
+    st.aw[tid] = a_i * st.wf[0][tid];                              // same thread, same slot as T: read above
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float suffix = 0.0f;
+#pragma unroll 1
+    for (int i0 = S - 8; i0 >= 0; i0 -= 8) {
+      float f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = st.aw[i0 + k];
+#pragma unroll
+      for (int k = 7; k >= 0; --k) { st.aw[i0 + k] = suffix; suffix = suffix + f[k]; }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const float nrm = st.ray[0][11];
+    float dn = 0.0f;
+#pragma unroll
+    for (int i = tid; i < S; i += 64) {
+      float* q = st.rawf[0][i];
+      const float a = st.alpha[0][i], w = st.wf[0][i];
+      const float c0 = q[0], c1 = q[1], c2 = q[2], sigma = q[3];
+      const float om = (1.0f - a) + 1e-10f;
+      const float d_alpha = st.at[i] - st.aw[i] / om;                    // T_k (k>i) carries the factor om_i
+      const float dz = (i < S - 1) ? (st.zf[0][i + 1] - st.zf[0][i]) : 1e10f;
+      const float e = 1.0f - a;                                           // exp(-relu(sigma) * delta)
+      const float d_sigma = (sigma > 0.0f) ? d_alpha * (dz * nrm) * e : 0.0f;
+      dn = dn + (d_alpha * fmaxf(sigma, 0.0f) * e) * dz;                  // d delta / d|d| = dz
+      q[0] = w * g0 * c0 * (1.0f - c0);
+      q[1] = w * g1 * c1 * (1.0f - c1);
+      q[2] = w * g2 * c2 * (1.0f - c2);
+      q[3] = d_sigma;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dn += __shfl_xor(dn, m);
+    if (tid == 0) st.gnorm[0] = dn;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const VjpArgs& va_setup = *vp;
+  const RenderArgs& a_setup = va_setup.r;
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int j = lane & 15;
+  ItemStateV16& st = *(ItemStateV16*)(smem + kLds16State);
+  const long long n_items = a_setup.n_rays;                  // a work item is one ray
+
+  Ring rg;
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);   // coarse | 3 x fine | 3 x fine^T per item
+  f32x4 A0[4], A1[4];
+  ring_start<kRing16>(rg, A0, lane);
+  {
+    float* dst = (float*)(smem + kLds16Aux);
+    for (int i = tid0; i < kAux16Floats; i += 256) {
+      dst[i] = a_setup.aux[0][i];
+      dst[kAux16Floats + i] = a_setup.aux[1][i];
+    }
+  }
+  __syncthreads();
+  const float* aux_c = (const float*)(smem + kLds16Aux);
+  const float* aux_f = aux_c + kAux16Floats;
+  // relu-pattern scratch of this workgroup: uniform base + thread index at each access
+  uint2* my_masks = (uint2*)va_setup.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256);
+  long long* item_slot = (long long*)&st.res[0][6];
+  auto next_item = [&]() -> long long {
+    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
+    __syncthreads();
+    const long long v = *item_slot;
+    __syncthreads();
+    return v;
+  };
+  long long item = next_item();
+  int pass = 0;
+#pragma unroll 1
+  while (item < n_items) {
+    const long long rr = item;
+    if (pass == 0) {
+      const RenderArgs& a = opaque_s(vp)->r;               // see opaque_v / opaque_s
+      const int tid = opaque_v(tid0);
+      const float near_ = a.near_, far_ = a.far_;
+      if (tid == 0) {
+        float o[3], d[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
+        const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));   // torch.norm RN:97, RN:361
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { st.ray[0][c] = o[c]; st.ray[0][3 + c] = d[c]; st.ray[0][6 + c] = d[c] / nrm; }
+        st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
+        st.ray[0][12] = a.white_bkgd ? 1.0f : 0.0f;
+      }
+      if (tid < 64) st.zc[0][tid] = coarse_z(near_, far_, a.tcoarse[tid], a.lindisp);
+      __syncthreads();
+    }
+
+    if (pass <= 3) {
+      // forward passes: 64 points; coarse: sample 16w + j; fine p: sample 64(p-1) + 16w + j
+      const int i = (pass == 0 ? 0 : 64 * (pass - 1)) + 16 * wave + j;
+      const float z = (pass == 0) ? st.zc[0][i] : st.zf[0][i];
+      const float* ry = st.ray[0];
+      float raw[4];
+      if (pass == 0)
+        mlp_pass16<false, true>(rg, aux_c, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7],
+                          ry[8], raw);
+      else
+        mlp_pass16<true, true>(rg, aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7],
+                         ry[8], raw, my_masks + (pass - 1) * (9 * 256), opaque_v(tid0));
+      if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    } else {
+      // backward passes: same point mapping as the fine forward pass p = pass - 4
+      const int i = 64 * (pass - 4) + 16 * wave + j;
+      const float z = st.zf[0][i];
+      const float* ry = st.ray[0];
+      const f32x4 g = *(const f32x4*)st.rawf[0][i];
+      float dp[3], dv[3];
+      mlp_bwd_pass16(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
+                     ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
+      // reduce the 16 points of this wave: sum dp, sum z*dp, sum dv (every lane group holds the same totals)
+      float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) red[c] += __shfl_xor(red[c], m);
+      if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 9; ++c) st.psum[(pass - 4) * 4 + wave][c] = red[c];
+    }
+
+    const VjpArgs& va = *opaque_s(vp);                      // nothing below may be hoisted above the network passes
+    const RenderArgs& a = va.r;
+    const int tid = opaque_v(tid0);
+    if (pass == 0) {
+      __syncthreads();
+      composite<64, 1>(st, &st.zc[0][0], &st.rawf[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
+      int64_t* none = nullptr;
+      sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
+                         [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, 1);
+      merge_sort_item<1>(st, tid);
+      if (va.z_fine) {                                       // caller-supplied depths replace the resampled ones
+        if (tid < 192) st.zf[0][tid] = va.z_fine[rr * 192 + tid];
+        __syncthreads();
+      }
+      pass = 1;
+    } else if (pass < 3) {
+      ++pass;
+    } else if (pass == 3) {
+      __syncthreads();
+      composite<192, 1>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid);
+      if (tid < 8) {
+        const int c = tid;
+        const float v = st.res[0][c];
+        if (c < 3) { if (a.rgb) a.rgb[rr * 3 + c] = v; }
+        else if (c == 3) { if (a.disp) a.disp[rr] = v; }
+        else if (c == 4) { if (a.acc) a.acc[rr] = v; }
+      }
+      if (tid < 3) st.grgb[tid] = va.grad_rgb[rr * 3 + tid];   // the coarse-phase arrays are dead: backward half
+      __syncthreads();
+      composite_bwd_ray(st, tid);
+      pass = 4;
+    } else if (pass < 6) {
+      ++pass;
+    } else {
+      __syncthreads();
+      if (tid == 0) {
+        float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
+        for (int s = 0; s < 12; ++s)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            so[c] += st.psum[s][c];
+            sd[c] += st.psum[s][3 + c];
+            sv[c] += st.psum[s][6 + c];
+          }
+        const float* ry = st.ray[0];
+        const float nrm = ry[11];
+        const float vdot = (sv[0] * ry[6] + sv[1] * ry[7]) + sv[2] * ry[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = ry[6 + c];
+          va.grad_o[rr * 3 + c] = so[c];
+          va.grad_d[rr * 3 + c] = sd[c] + (sv[c] - v * vdot) / nrm + st.gnorm[0] * v;   // RN:97, RN:361
+        }
+      }
+      __syncthreads();
+      pass = 0;
+      item = next_item();
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
 // ------------------------------------------------------------------------------------------------------

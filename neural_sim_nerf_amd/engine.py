@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .pack import pack_network, pack_network16, pack_network_backward, PACKED_FLOATS
+from .pack import pack_network, pack_network16, pack_network_backward, pack_network_backward16, PACKED_FLOATS
 
 N_SAMPLES = 64
 N_IMPORTANCE = 128
@@ -160,8 +160,12 @@ class NsrModel:
         if self.n_importance == 0:
             raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
         if not self._bwd_ready:                      # the transposed stream is packed on first use only
-            b = pack_network_backward(self._sd_fine_np)
-            _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
+            if self.variant == 32:
+                b = pack_network_backward(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
+            else:                                    # 0 = library default = x16
+                b = pack_network_backward16(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights_bwd16(self.h, _fptr(b), b.size))
             self._bwd_ready = True
         rays_o = self._f32(rays_o, (-1, 3))
         rays_d = self._f32(rays_d, (-1, 3))

@@ -263,3 +263,43 @@ def pack_network16(sd):
     aux[AUX_B_ALPHA] = g("alpha_linear.bias")[0]
     aux[AUX_B_RGB:AUX_B_RGB + 3] = g("rgb_linear.bias")
     return np.concatenate([stream, aux]).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# x16 backward (input-gradient) stream for k_render_vjp16: the x16 machinery with W^T as the A operand
+# ----------------------------------------------------------------------------------------------------------
+def _enc_rows16(W_cols, n_freq, n_blocks):
+    """Rows of a transposed matrix that produce d/d(encoding register): output block b, register r of lane group g is
+    row 16b + 4g + r and must be the gradient w.r.t. encoding register t = 4b + r of that group, i.e. reference column
+    eps16(t, g).  W_cols [K_out, n_in] (reference column order) -> [16 * n_blocks, K_out]."""
+    rows = np.zeros((16 * n_blocks, W_cols.shape[0]), np.float32)
+    for b in range(n_blocks):
+        for gg in range(4):
+            for r in range(4):
+                col = eps16(4 * b + r, gg, n_freq)
+                if col >= 0:
+                    rows[16 * b + 4 * gg + r] = W_cols[:, col]
+    return rows
+
+
+def pack_network_backward16(sd):
+    """Transposed stream of one network in the x16 layout.  Order and slab counts as pack_network_backward:
+    views^T (18 blocks x 8 quads = 9 slabs) | feature^T 16 | L7^T 16 | L6^T 16 | L5^T (20 blocks: 16 hidden + 4
+    encoding) 20 | L4^T..L1^T 64 | L0^T (4 encoding blocks) 4 = 145 slabs.  k-step t of lane group g contracts
+    over output feature kappa16(t, g) of the forward layer.  Returns float32 [STREAM_SLABS * SLAB_FLOATS]."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    cols = lambda n_k: np.stack([kappa16(np.arange(n_k), gg) for gg in range(4)], 1)
+    segs = []
+    Wv = g("views_linears.0.weight")                                     # [128, 256 + 27]
+    segs.append(_pack16(np.concatenate([Wv[:, :256].T, _enc_rows16(Wv[:, 256:], 4, 2)], 0), cols(32), 18))
+    segs.append(_pack16(g("feature_linear.weight").T, cols(64), 16))
+    for l in (7, 6):
+        segs.append(_pack16(g("pts_linears.%d.weight" % l).T, cols(64), 16))
+    W5 = g("pts_linears.5.weight")                                       # [256, 63 + 256], input columns first
+    segs.append(_pack16(np.concatenate([W5[:, 63:].T, _enc_rows16(W5[:, :63], 10, 4)], 0), cols(64), 20))
+    for l in (4, 3, 2, 1):
+        segs.append(_pack16(g("pts_linears.%d.weight" % l).T, cols(64), 16))
+    segs.append(_pack16(_enc_rows16(g("pts_linears.0.weight"), 10, 4), cols(64), 4))
+    stream = np.concatenate([x.reshape(-1) for x in segs]).astype(np.float32)
+    assert stream.size == STREAM_SLABS * SLAB_FLOATS
+    return stream

@@ -207,8 +207,9 @@ def _encode16(X, nfreq, n):
     return e
 
 
-def mlp_pass16(packed16, pts, dirs):
-    """pts, dirs [16,3] -> raw [16,4]; lanes j, j+16, j+32, j+48 all own point j."""
+def mlp_pass16(packed16, pts, dirs, masks=None):
+    """pts, dirs [16,3] -> raw [16,4]; lanes j, j+16, j+32, j+48 all own point j.
+    `masks`: optional dict filled with the relu patterns ([nmo,64,4] bool per layer), like mask capture."""
     from neural_sim_nerf_amd import pack as PK
     st = Stream16(packed16[:PK.STREAM_SLABS * PK.SLAB_FLOATS])
     aux = packed16[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
@@ -226,6 +227,8 @@ def mlp_pass16(packed16, pts, dirs):
         return acc
     acc = bias(PK.AUX_BIAS, 16)
     st.seg(16, 4, lambda t: e[t], acc)
+    if masks is not None:
+        masks[0] = acc > 0
     inp = np.maximum(acc, 0)
     alpha_part = np.zeros(64, np.float32)
     for L in range(1, 9):
@@ -236,9 +239,13 @@ def mlp_pass16(packed16, pts, dirs):
             for t in range(64):
                 alpha_part = alpha_part + aux[PK.AUX_W_ALPHA + 16 * (t >> 2) + 4 * g + (t & 3)] * inp[t >> 2][:, t & 3]
         st.seg(16, 16, regs(inp), acc)
+        if masks is not None and L < 8:
+            masks[L] = acc > 0
         inp = np.maximum(acc, 0) if L < 8 else acc.copy()
     av = bias(PK.AUX_BIAS_V, 8)
     st.seg(8, 18, lambda t: inp[t >> 2][:, t & 3] if t < 64 else ed[t - 64], av)
+    if masks is not None:
+        masks[8] = av > 0
     assert st.pos == 145 * 16
     part = np.zeros((4, 64), np.float32)
     part[3] = alpha_part
@@ -251,3 +258,58 @@ def mlp_pass16(packed16, pts, dirs):
         b = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
         raw[:, c] = part[c].reshape(4, 16).sum(0) + b
     return raw
+
+
+def _embed_bwd16(X, G, nfreq):
+    """csrc embed_bwd16: lane group g holds the gradients G[t] of its own encoding registers (t < 6 nfreq / 4: column
+    q = per*g + t -> frequency q // 6, sin/cos, axis; t = per: identity column g); the four groups are added."""
+    g = LANE >> 4
+    per = 6 * nfreq // 4
+    out = np.zeros((3, 64), np.float64)
+    for ax in range(3):
+        out[ax] = np.where(g == ax, G[per], 0.0)
+    for t in range(per):
+        q = per * g + t
+        L, sc, ax = q // 6, (q % 6) // 3, q % 3
+        f = np.exp2(L).astype(np.float32)
+        arg = (X[LANE, ax] * f).astype(np.float32)
+        c = f * G[t] * np.where(sc == 1, -np.sin(arg), np.cos(arg))
+        for a in range(3):
+            out[a] += np.where(ax == a, c, 0.0)
+    return out.reshape(3, 4, 16).sum(1).T          # [16,3]
+
+
+def mlp_bwd_pass16(packed16_fwd, stream_bwd16, masks, pts, dirs, g_raw):
+    """Emulates csrc mlp_bwd_pass16 for one wave: g_raw [16,4] -> (dL/dpts [16,3], dL/ddirs [16,3])."""
+    from neural_sim_nerf_amd import pack as PK
+    st = Stream16(stream_bwd16)
+    aux = packed16_fwd[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
+    g = LANE >> 4
+    P = np.tile(pts, (4, 1)).astype(np.float32)
+    V = np.tile(dirs, (4, 1)).astype(np.float32)
+    G = np.tile(g_raw, (4, 1)).astype(np.float32)      # per lane
+    regs = lambda arr: (lambda t: arr[t >> 2][:, t & 3])
+    gv = np.zeros((8, 64, 4), np.float32)
+    for mo in range(8):
+        for r in range(4):
+            f = 16 * mo + 4 * g + r
+            v = (aux[PK.AUX_W_RGB + f] * G[:, 0] + aux[PK.AUX_W_RGB + 128 + f] * G[:, 1] + aux[PK.AUX_W_RGB + 256 + f] * G[:, 2])
+            gv[mo][:, r] = np.where(masks[8][mo][:, r], v, 0)
+    accv = np.zeros((18, 64, 4), np.float32)
+    st.seg(18, 8, regs(gv), accv)
+    dv = _embed_bwd16(V, [accv[16 + (t >> 2)][:, t & 3] for t in range(8)], 4)
+    gin = accv[:16].copy()
+    acc = np.zeros((20, 64, 4), np.float32)
+    for idx in range(8):
+        acc[:16] = 0
+        st.seg(20 if idx == 3 else 16, 16, regs(gin), acc)
+        if idx == 0:
+            for mo in range(16):
+                for r in range(4):
+                    acc[mo][:, r] += aux[PK.AUX_W_ALPHA + 16 * mo + 4 * g + r] * G[:, 3]
+        gin = np.where(masks[7 - idx], acc[:16], 0).astype(np.float32)
+    genc = acc[16:]
+    st.seg(4, 16, regs(gin), genc)
+    assert st.pos == 145 * 16
+    dp = _embed_bwd16(P, [genc[t >> 2][:, t & 3] for t in range(16)], 10)
+    return dp, dv

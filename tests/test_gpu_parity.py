@@ -26,6 +26,15 @@ def model(synth_nets):
     m.close()
 
 
+@pytest.fixture(scope="module", params=[16, 32])
+def vjp_model(request, synth_nets):
+    """Both input-gradient kernels: k_render_vjp16 (variant 16 = the default) and k_render_vjp (variant 32)."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1], variant=request.param)
+    yield m
+    m.close()
+
+
 def cpu(t):
     return t.detach().cpu().numpy()
 
@@ -205,8 +214,8 @@ def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
     outs = m.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd)
     want = oracle.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd, white_bkgd=True)
     assert_close(cpu(outs[0]), want[0], atol=3e-6, what="raw2outputs stage, white_bkgd")
-    # VJP (an x32 kernel: compared on the x32 forward's own sample positions)
-    if variant == 32:
+    # VJP (compared on the same handle's forward's own sample positions)
+    if True:
         n = g["cot"].shape[0]
         fwd = m.render_rays(ro[:n], rd[:n], near, far, debug=True)
         go, gd, f2 = m.render_rays_vjp(ro[:n], rd[:n], near, far, g["cot"], with_forward=True)
@@ -340,7 +349,8 @@ def _relfro(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
 
 
-def test_render_rays_vjp(model, oracle, synth_nets):
+def test_render_rays_vjp(vjp_model, oracle, synth_nets):
+    model = vjp_model
     """Tolerance: relative Frobenius error 2e-4 against the oracle's float64 backprop evaluated on the kernel's
     OWN sample positions (fp32 MFMA chains forward and backward); against the reference's autograd output 1e-4
     when the kernel is handed the reference's own sample depths (nsr_render_rays_vjp d_z_fine), 3e-2 end to end
@@ -372,7 +382,8 @@ def test_render_rays_vjp(model, oracle, synth_nets):
     assert_close(cpu(f3["rgb_map"]), g["rgb"], atol=2e-5, what="VJP-launch forward vs reference at its depths")
 
 
-def test_vjp_odd_ray_count_and_linearity(model, oracle):
+def test_vjp_odd_ray_count_and_linearity(vjp_model, oracle):
+    model = vjp_model
     g = load_golden("g8_backward")
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     ro, rd, cot = g["rays"][0][:5], g["rays"][1][:5], g["cot"][:5]
@@ -401,9 +412,11 @@ def test_pose_grad_kernel(model, oracle):
         assert np.allclose(got[p], want, rtol=1e-5, atol=1e-5)
 
 
-def test_render_api_autograd_and_render_path_grad(model, oracle, synth_nets, tmp_path):
+def test_render_api_autograd_and_render_path_grad(model16, oracle, synth_nets, tmp_path):
     """The reference-shaped API: render(rays=...) differentiable w.r.t. rays (RN:177), and render_path_grad's
-    per-patch dL/d psi (RN:179-190) against the same chain assembled from the oracle."""
+    per-patch dL/d psi (RN:179-190) against the same chain assembled from the oracle.  The API uses the library
+    default kernels (x16 forward and VJP), so the direct engine calls it is compared with do too."""
+    model = model16
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
     nets = []

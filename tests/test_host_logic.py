@@ -44,6 +44,29 @@ def test_no_gpu_means_loud_failure(synth_nets):
         NsrModel(synth_nets[0], synth_nets[1])
 
 
+def test_packer16_backward_through_kernel_emulation(oracle, synth_nets):
+    """The x16 forward stream with relu capture and the x16 transposed stream (pack_network_backward16), one wave of 16
+    points emulated lane by lane, against the oracle's network and its input-side VJP."""
+    from neural_sim_nerf_amd import pack
+    import kernel_emulator as E
+    sd = synth_nets[1]
+    p16, b16 = pack.pack_network16(sd), pack.pack_network_backward16(sd)
+    assert b16.shape == (pack.STREAM_SLABS * pack.SLAB_FLOATS,)
+    rng = np.random.RandomState(1)
+    pts = rng.uniform(-1.5, 1.5, (16, 3)).astype(np.float32)
+    d = rng.standard_normal((16, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    masks = {}
+    raw = E.mlp_pass16(p16, pts, d, masks)
+    want = oracle.mlp(sd, np.concatenate([oracle.embed(pts, 10), oracle.embed(d, 4)], -1))
+    assert np.abs(raw - want).max() < 2e-5
+    g = rng.standard_normal((16, 4)).astype(np.float32)
+    dp, dv = E.mlp_bwd_pass16(p16, b16, masks, pts, d, g)
+    rp, rv = oracle.network_vjp(sd, pts, d, g)
+    assert np.abs(dp - rp).max() < 1e-5 * np.abs(rp).max(), np.abs(dp - rp).max() / np.abs(rp).max()
+    assert np.abs(dv - rv).max() < 1e-5 * np.abs(rv).max(), np.abs(dv - rv).max() / np.abs(rv).max()
+
+
 def test_kappa_is_a_permutation():
     from neural_sim_nerf_amd.pack import kappa, eps
     t = np.arange(128)
