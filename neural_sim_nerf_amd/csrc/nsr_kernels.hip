@@ -612,7 +612,15 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
     if (k < 63) bad |= !(st.zc[r][k] <= st.zc[r][k + 1]);
     else if (k >= 64 && k < 191) bad |= !(st.zs[r][k - 64] <= st.zs[r][k - 63]);
   }
-  if (!__syncthreads_or(bad)) {
+  // workgroup-wide OR through four LDS words (st.res is free here).  Not __syncthreads_or: its library implementation
+  // rebuilds the flat thread id from threadIdx.y/z, which keeps two more VGPRs alive through the whole kernel.
+  int* orw = (int*)&st.res[0][0];
+  const bool wave_bad = __builtin_amdgcn_ballot_w64(bad != 0) != 0;
+  if ((tid & 63) == 0) orw[tid >> 6] = wave_bad ? 1 : 0;
+  __syncthreads();
+  const int any_bad = (orw[0] | orw[1]) | (orw[2] | orw[3]);
+  __syncthreads();
+  if (!any_bad) {
     for (int e = tid; e < 192 * R; e += 256) {
       const int r = e / 192, k = e - r * 192;
       int rank;
@@ -1380,7 +1388,7 @@ __device__ __forceinline__ f32x4 apply_mask4(f32x4 x, unsigned word, int shift) 
 template <bool CAPTURE = false, bool LOCAL_G = false>
 __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                            float px, float py, float pz, float vx, float vy, float vz,
-                                           float (&raw)[4], uint2* mask_dst = nullptr /* uniform */, int mask_tid = 0) {
+                                           float (&raw)[4], uint2* mask_dst = nullptr /* uniform */, unsigned mask_tid = 0u) {
   const int g = LOCAL_G ? opaque_v(lane >> 4) : (lane >> 4);
   const float poison = enc_poison(px, py, pz, vx, vy, vz);
   float e[16];   // 60 sin/cos columns dealt 15 per lane group (reference order), then the identity column g
@@ -1409,7 +1417,7 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
   };
   load_bias16(bias_g);
   seg<16, 4, kRing16>(rg, A0, A1, BArr<16>{e}, acc, lane);
-  if (CAPTURE) mask_dst[mask_tid] = relu_mask4<16>(acc);
+  if (CAPTURE) mask_dst[mask_tid] = relu_mask4<16>(acc);     // uniform base + 32-bit lane offset (saddr form)
 #pragma unroll
   for (int mo = 0; mo < 16; ++mo) in[mo] = clamp_bits4(acc[mo], 0);
 
@@ -1428,7 +1436,7 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
       }
     }
     seg<16, 16, kRing16>(rg, A0, A1, BRegs4<16>{in}, acc, lane);
-    if (CAPTURE && L < 8) mask_dst[L * 256 + mask_tid] = relu_mask4<16>(acc);
+    if (CAPTURE && L < 8) mask_dst[(unsigned)L * 256u + mask_tid] = relu_mask4<16>(acc);
     const int thr = (L == 8) ? (int)0x80000000 : 0;                         // feature_linear has no activation
 #pragma unroll
     for (int mo = 0; mo < 16; ++mo) in[mo] = clamp_bits4(acc[mo], thr);
@@ -1438,7 +1446,7 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) av[mo] = *(const f32x4*)(aux + kAuxBiasV + 4 * g + 16 * mo);
   seg<8, 18, kRing16>(rg, A0, A1, BViews4{in, ed}, av, lane);
-  if (CAPTURE) mask_dst[8 * 256 + mask_tid] = relu_mask4<8>(av);
+  if (CAPTURE) mask_dst[8u * 256u + mask_tid] = relu_mask4<8>(av);
 
   float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};                           // rgb_linear (RH:117)
 #pragma unroll
@@ -1692,7 +1700,7 @@ __device__ __forceinline__ void embed_bwd16(const float (&x)[3], const float* G,
 // The gradient fragment of layer l (C layout: register (mo, r) of group g = feature 16 mo + 4 g + r) is masked with the
 // relu pattern captured in the forward pass and is, register for register, the B operand of layer l-1's transposed GEMM.
 __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
-                                               const uint2* mask_src /* uniform */, int mask_tid, float g0, float g1,
+                                               const uint2* mask_src /* uniform */, unsigned mask_tid, float g0, float g1,
                                                float g2, float gs, float px, float py, float pz, float vx, float vy,
                                                float vz, float (&dp)[3], float (&dv)[3]) {
   const int g = lane >> 4;
@@ -1702,7 +1710,7 @@ __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4
   {
     // rgb_linear^T (VALU) masked by the views layer's relu pattern -> dL/d(views pre-activation), 128 features
     f32x4 gv[8];
-    const unsigned mk = mask_src[8 * 256 + mask_tid].x;
+    const unsigned mk = mask_src[8u * 256u + mask_tid].x;
 #pragma unroll
     for (int mo = 0; mo < 8; ++mo) {
       const f32x4 w0 = *(const f32x4*)(aux + kAuxWRgb + 0 * 128 + 16 * mo + g4);
@@ -1735,7 +1743,7 @@ __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4
   // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (20 blocks: first use of acc[16..19]), 4..7 L4^T..L1^T
 #pragma unroll 1
   for (int idx = 0; idx < 8; ++idx) {
-    const uint2 mk = mask_src[(7 - idx) * 256 + mask_tid];   // relu pattern of the layer this GEMM feeds back to
+    const uint2 mk = mask_src[(unsigned)(7 - idx) * 256u + mask_tid];   // relu pattern of the layer this GEMM feeds back to
     if (idx == 3) seg<20, 16, kRing16, true>(rg, A0, A1, BRegs4<16>{gin}, acc, lane);
     else seg<16, 16, kRing16, true>(rg, A0, A1, BRegs4<16>{gin}, acc, lane);
     if (idx == 0) {                                          // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
@@ -1860,8 +1868,9 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLds16Aux);
   const float* aux_f = aux_c + kAux16Floats;
-  // relu-pattern scratch of this workgroup: uniform base + thread index at each access
-  uint2* my_masks = (uint2*)va_setup.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256);
+  // relu-pattern scratch of this workgroup: uniform base (re-read from the argument block where it is used, so that
+  // it lives in scalar registers only around the pass) + thread index at each access
+  auto my_masks = [&]() { return (uint2*)opaque_s(vp)->mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256); };
   long long* item_slot = (long long*)&st.res[0][6];
   auto next_item = [&]() -> long long {
     if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
@@ -1904,8 +1913,9 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
                           ry[8], raw);
       else
         mlp_pass16<true, true>(rg, aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7],
-                         ry[8], raw, my_masks + (pass - 1) * (9 * 256), opaque_v(tid0));
-      if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
+                         ry[8], raw, my_masks() + (pass - 1) * (9 * 256), (unsigned)opaque_v(tid0));
+      const int lo = opaque_v(lane);
+      if (lo < 16) *(f32x4*)st.rawf[0][(pass == 0 ? 0 : 64 * (pass - 1)) + 16 * wave + lo] = f32x4{raw[0], raw[1], raw[2], raw[3]};
     } else {
       // backward passes: same point mapping as the fine forward pass p = pass - 4
       const int i = 64 * (pass - 4) + 16 * wave + j;
@@ -1913,10 +1923,12 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
       const float* ry = st.ray[0];
       const f32x4 g = *(const f32x4*)st.rawf[0][i];
       float dp[3], dv[3];
-      mlp_bwd_pass16(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
+      mlp_bwd_pass16(rg, aux_f, A0, A1, lane, my_masks() + (pass - 4) * (9 * 256), (unsigned)opaque_v(tid0), g[0], g[1], g[2], g[3],
                      ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
-      // reduce the 16 points of this wave: sum dp, sum z*dp, sum dv (every lane group holds the same totals)
-      float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
+      // reduce the 16 points of this wave: sum dp, sum z*dp, sum dv (every lane group holds the same totals); z is
+      // re-read rather than kept alive across the pass
+      const float zz = st.zf[0][64 * (pass - 4) + 16 * wave + (opaque_v(lane) & 15)];
+      float red[9] = {dp[0], dp[1], dp[2], zz * dp[0], zz * dp[1], zz * dp[2], dv[0], dv[1], dv[2]};
 #pragma unroll
       for (int m = 8; m >= 1; m >>= 1)
 #pragma unroll
