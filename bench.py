@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0.  Objects beside the contract fields:
                     fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
                     `traffic` comes from a rocprofv3 --pmc profile ONLY if that profile was collected from exactly
                     the kernel sources in this tree (hash check), else null;
-  roofline_vjp   -- the same for nsr::k_render_vjp (render_path_grad's forward+input-gradient launch, config 4's render leg);
+  roofline_vjp   -- the same for nsr::k_render_vjp16 (render_path_grad's forward+input-gradient launch, config 4's render leg);
   cpu_baseline   -- the oracle (CPU restatement of the reference path, "port") timed on this host's cores on a bounded
                     sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
   parity         -- PSNR / max-abs of the GPU render vs the oracle on that sample, exact-match rate of the indices;
@@ -191,7 +191,8 @@ def config1_workload(sd_c, c2w, device, cpu_setting):
 
 
 def vjp_roofline(model, c2w):
-    """nsr::k_render_vjp on one 400x400 image (render_path_grad's per-pose launch): HIP-event time of 2 launches."""
+    """The input-gradient kernel (nsr::k_render_vjp16 by default) on one 400x400 image = render_path_grad's per-pose
+    launch: mean HIP-event time of 2 launches after one warm-up."""
     o, d = model.get_rays(H, W, S.YCBV_K, c2w)
     cot = torch.randn(H * W, 3, device=model.device, generator=torch.Generator(device=model.device).manual_seed(0))
     ms = []
@@ -201,7 +202,8 @@ def vjp_roofline(model, c2w):
     k_ms = float(np.mean(ms[1:]))
     ach = H * W * FLOP_PER_RAY_VJP / (k_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": "nsr::k_render_vjp",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "nsr::k_render_vjp" if model.variant == 32 else "nsr::k_render_vjp16",
             "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
             "flop_note": "per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
                          "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP"}

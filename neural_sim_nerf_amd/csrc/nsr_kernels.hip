@@ -941,8 +941,8 @@ __device__ __forceinline__ void embed_bwd(const float (&x)[3], const float* G /*
 
 __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                              const uint4* mask_src /* uniform */, int mask_tid, float g0, float g1,
-                                             float g2, float gs,
-                                             float px, float py, float pz, float vx, float vy, float vz,
+                                             float g2, float gs, const float* ry /* LDS: the ray block */,
+                                             const float* zrow /* LDS: z of this wave's 32 points */,
                                              float (&dp)[3], float (&dv)[3]) {
   const int h = lane >> 5;
   const int h4 = aux_half(lane);
@@ -973,7 +973,7 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
     float Gd[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) Gd[t] = accv[8][t];
-    const float v[3] = {vx, vy, vz};
+    const float v[3] = {ry[6], ry[7], ry[8]};              // re-read where needed: not kept alive across the GEMMs
     float part[3];
     embed_bwd<kMultiresViews>(v, Gd, h, part);
 #pragma unroll
@@ -1011,7 +1011,8 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
     float Ge[32];
 #pragma unroll
     for (int t = 0; t < 32; ++t) Ge[t] = acc[8 + (t >> 4)][t & 15];
-    const float p[3] = {px, py, pz};
+    const float z = zrow[opaque_v(lane) & 31];
+    const float p[3] = {ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z};
     float part[3];
     embed_bwd<kMultires>(p, Ge, h, part);
 #pragma unroll
@@ -1192,7 +1193,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
       mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
-                   ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
+                   ry, &st.zf[r][i - j], dp, dv);
       // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
       float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
 #pragma unroll
@@ -1701,8 +1702,9 @@ __device__ __forceinline__ void embed_bwd16(const float (&x)[3], const float* G,
 // relu pattern captured in the forward pass and is, register for register, the B operand of layer l-1's transposed GEMM.
 __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                                const uint2* mask_src /* uniform */, unsigned mask_tid, float g0, float g1,
-                                               float g2, float gs, float px, float py, float pz, float vx, float vy,
-                                               float vz, float (&dp)[3], float (&dv)[3]) {
+                                               float g2, float gs, const float* ry /* LDS: the ray block */,
+                                               const float* zrow /* LDS: z of this wave's 16 points */, float (&dp)[3],
+                                               float (&dv)[3]) {
   const int g = lane >> 4;
   const int g4 = opaque_v(4 * g);                            // one per-lane base register for every aux access
   f32x4 gin[16];
@@ -1728,7 +1730,7 @@ __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4
     float Gd[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) Gd[t] = acc[16 + (t >> 2)][t & 3];
-    const float v[3] = {vx, vy, vz};
+    const float v[3] = {ry[6], ry[7], ry[8]};              // re-read where needed: not kept alive across the GEMMs
     float part[3];
     embed_bwd16<kMultiresViews>(v, Gd, opaque_v(g), part);   // opaque: keep the per-group constants out of the main loop's live set
 #pragma unroll
@@ -1763,7 +1765,8 @@ __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4
     float Ge[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) Ge[t] = acc[16 + (t >> 2)][t & 3];
-    const float p[3] = {px, py, pz};
+    const float z = zrow[opaque_v(lane) & 15];
+    const float p[3] = {ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z};
     float part[3];
     embed_bwd16<kMultires>(p, Ge, opaque_v(g), part);
 #pragma unroll
@@ -1919,12 +1922,10 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
     } else {
       // backward passes: same point mapping as the fine forward pass p = pass - 4
       const int i = 64 * (pass - 4) + 16 * wave + j;
-      const float z = st.zf[0][i];
-      const float* ry = st.ray[0];
       const f32x4 g = *(const f32x4*)st.rawf[0][i];
       float dp[3], dv[3];
       mlp_bwd_pass16(rg, aux_f, A0, A1, lane, my_masks() + (pass - 4) * (9 * 256), (unsigned)opaque_v(tid0), g[0], g[1], g[2], g[3],
-                     ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], dp, dv);
+                     st.ray[0], &st.zf[0][64 * (pass - 4) + 16 * wave], dp, dv);
       // reduce the 16 points of this wave: sum dp, sum z*dp, sum dv (every lane group holds the same totals); z is
       // re-read rather than kept alive across the pass
       const float zz = st.zf[0][64 * (pass - 4) + 16 * wave + (opaque_v(lane) & 15)];
