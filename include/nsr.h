@@ -67,6 +67,9 @@ typedef struct NsrConfig {
 
 #define NSR_FLAG_WHITE_BKGD 1   /* white_bkgd (RN:384-385): rgb_map += 1 - acc_map, coarse and fine; also in the VJP */
 #define NSR_FLAG_LINDISP    2   /* lindisp (RN:443): coarse samples linear in inverse depth                          */
+#define NSR_FLAG_SCHED_PHASES 4 /* x16 forward kernel: "global phases" work schedule (k_render16p) -- bit-identical
+                                   results; every workgroup streams the same network most of the time, which cuts the
+                                   L2-miss (fabric) traffic of the weight streams; see DESIGN.md 4 for speed vs traffic */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {

@@ -48,6 +48,8 @@ struct DeviceGuard {
 };
 #define NSR_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSR_HIP(guard_.err)
 
+constexpr int kSuperLg = 12;           // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
+
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
 constexpr size_t kRender16Lds = nsr::kLds16State + sizeof(nsr::ItemState16);
 constexpr size_t kVjp16Lds = nsr::kLds16State + sizeof(nsr::ItemStateV16);
@@ -74,6 +76,8 @@ struct nsr_handle_s {
   unsigned long long* d_work_counter = nullptr;  // work-queue head
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
   int zf_grid = 0;
+  unsigned* d_sched_flags = nullptr;  // k_render16p: ready / taken generations of the 3 * 2^kSuperLg hand-off slots
+  unsigned* d_status = nullptr;       // k_render16p: non-zero after a hand-off wait timed out
   int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images (nsr_reserve_bbox)
   size_t box_scratch_ints = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel timing (eager launches only)
@@ -115,7 +119,9 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
   if (cfg->n_samples != NSR_N_SAMPLES)
     return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
-  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP)) return fail("nsr_create: unknown bits in flags");
+  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP | NSR_FLAG_SCHED_PHASES)) return fail("nsr_create: unknown bits in flags");
+  if ((cfg->flags & NSR_FLAG_SCHED_PHASES) && (cfg->variant == 32 || cfg->n_importance == 0))
+    return fail("nsr_create: NSR_FLAG_SCHED_PHASES applies to the x16 coarse+fine forward kernel only");
   if (cfg->chunk < 0 || cfg->chunk > 256) return fail("nsr_create: chunk must be 0 (default) or 1..256");
   if (cfg->variant != 0 && cfg->variant != 16 && cfg->variant != 32)
     return fail("nsr_create: variant must be 0 (default), 16 or 32");
@@ -145,7 +151,15 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   NSR_HIP(hipMalloc(&h->d_work_counter, sizeof(unsigned long long)));
   // k_render16's inter-phase scratch: bounded by the grid (2 workgroups per CU, or max_workgroups) x chunk
   h->zf_grid = cfg->max_workgroups > 0 ? cfg->max_workgroups : 2 * h->n_cu;
-  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * (size_t)h->zf_grid * h->chunk));
+  size_t zf_rays = (size_t)h->zf_grid * h->chunk;
+  if (cfg->flags & NSR_FLAG_SCHED_PHASES) {                // the z hand-off ring of the global-phases schedule
+    zf_rays = (size_t)3 << kSuperLg;
+    NSR_HIP(hipMalloc(&h->d_sched_flags, sizeof(unsigned) * 2 * zf_rays));
+    NSR_HIP(hipMalloc(&h->d_status, sizeof(unsigned)));
+    NSR_HIP(hipMemset(h->d_status, 0, sizeof(unsigned)));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
+  }
+  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * zf_rays));
   NSR_HIP(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
   NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
@@ -171,6 +185,8 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_box_scratch);
   hipFree(h->d_zf_scratch);
   hipFree(h->d_work_counter);
+  hipFree(h->d_sched_flags);
+  hipFree(h->d_status);
   hipEventDestroy(h->ev0);
   hipEventDestroy(h->ev1);
   hipEventDestroy(h->ev_busy);
@@ -286,7 +302,17 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   if (int e = stream_capturing(s, &capturing)) return e;
   if (int e = claim_stream(h, s, capturing)) return e;
   long long g = 0;
-  if (x16) {
+  const bool phases = x16 && fine && (h->cfg.flags & NSR_FLAG_SCHED_PHASES);
+  if (phases) {                                            // global-phases schedule: k_render16p
+    g = h->zf_grid;
+    if (g > 2 * a.n_rays) g = 2 * a.n_rays;
+    a.zf_scratch = h->d_zf_scratch;
+    a.sched_flags = h->d_sched_flags;
+    a.status = h->d_status;
+    a.super_lg = kSuperLg;
+    a.chunk = 1;
+    NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
+  } else if (x16) {
     g = h->zf_grid;                                        // two workgroups per CU (or max_workgroups)
     // rays per chunk (see k_render16).  Larger chunks keep one network per L2 for longer (less fabric traffic), but
     // the chunk is also the granularity of the dynamic load balance between the unevenly progressing workgroups:
@@ -304,7 +330,9 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   a.work_counter = h->d_work_counter;
   hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);     // also zeroes the work counter
   if (!capturing) NSR_HIP(hipEventRecord(h->ev0, s));
-  if (x16)
+  if (phases)
+    hipLaunchKernelGGL(nsr::k_render16p, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
+  else if (x16)
     hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   else
     hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
@@ -630,6 +658,11 @@ int nsr_last_kernel_ms(nsr_handle h, float* ms) {
   NSR_DEVICE(h);
   NSR_HIP(hipEventSynchronize(h->ev1));
   NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  if (h->d_status) {                                       // global-phases schedule: did any hand-off wait time out?
+    unsigned st = 0;
+    NSR_HIP(hipMemcpy(&st, h->d_status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0) return fail("k_render16p: a z hand-off wait timed out (results of that launch are invalid)");
+  }
   return 0;
 }
 

@@ -53,6 +53,8 @@ struct Ring {
   int cslot;             // consumer: slot of the slab being consumed
   int pnet_off;          // producer: byte offset of the current net within `base` (buffer-descriptor form)
   int pn0, pn1;          // producer: passes [0,pn0) of a cycle stream net 0, [pn0,pn1) net 1, the rest net 2
+  int dd;                // 1: data-driven sequence -- the consumer names the network of the FOLLOWING pass in pnet_next
+  int pnet_next;         //    at the start of every pass (k_render16p: the pass sequence depends on the task queue)
   __amdgpu_buffer_rsrc_t rsrc;
 };
 
@@ -66,6 +68,7 @@ __device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base
   rg.pslab = 0; rg.pslot = 0; rg.pphase = 0; rg.cslot = 0; rg.pnet_off = 0;
   rg.ppi = ppi;
   rg.pn0 = 1; rg.pn1 = 4;            // coarse pass, 3 fine passes, then (ppi = 7) 3 backward passes
+  rg.dd = 0; rg.pnet_next = 0;
   rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
 
@@ -93,7 +96,8 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   rg.pphase = wrap ? nphase : rg.pphase;
   // arithmetic, not a pointer table: keeps Ring in SGPRs
   const int net = rg.pphase < rg.pn0 ? 0 : (rg.pphase < rg.pn1 ? 1 : 2);
-  rg.pnet_off = net * (int)rg.stride;
+  const int named = wrap ? rg.pnet_next : rg.pnet_off;     // data-driven form (dd is a compile-time 0 elsewhere)
+  rg.pnet_off = rg.dd ? named : net * (int)rg.stride;
 }
 
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
@@ -702,6 +706,9 @@ struct RenderArgs {
   long long* dbg_inds;
   float* zf_scratch;        // k_render16: [grid][chunk][192] sorted fine z values between the two phases of a chunk
   int chunk;                // k_render16: rays per workgroup per phase
+  unsigned* sched_flags;    // k_render16p: [2][3 * super_rays] ready / taken generations of the z hand-off slots (zeroed per launch)
+  unsigned* status;         // k_render16p: set non-zero if a hand-off wait timed out (never expected; bounds every spin)
+  int super_lg;             // k_render16p: log2 of the rays per super-chunk
   unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays
 };
 
@@ -1659,6 +1666,224 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)
     for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_render16p: k_render16 with the "global phases" schedule (NSR_FLAG_SCHED_PHASES).  Same arithmetic, same results;
+// what changes is WHEN each workgroup streams which network.  With the default queue every workgroup alternates
+// coarse net / fine net per ray, so the 64 workgroups of an XCD keep both weight images (4.6 MiB) cycling through its
+// 4 MiB L2 and 3-5 % of the weight traffic misses to the fabric.  Here the rays are cut into super-chunks of S = 2^lg
+// rays and ONE global queue hands out, per super-chunk, first its S coarse tasks (1 pass each) and then its S fine tasks
+// (3 passes each): all workgroups work on the same network most of the time whatever their individual speed, and any
+// workgroup may run the fine task of a ray whose coarse task another workgroup ran.
+//   * hand-off: the coarse task leaves the ray's 192 sorted z values in slot (ray mod 3S) of a global ring, written with
+//     agent-scope (sc1, write-through) stores, drained (vmcnt(0)) before lane 0 publishes ready[slot] = k + 1 (k = super-
+//     chunk); the fine task polls ready (one lane, relaxed agent loads, s_sleep), reads with agent-scope loads and then
+//     publishes taken[slot] = k + 1; the coarse task of super-chunk k + 3 waits for that before it reuses the slot.
+//     Every wait points at a task with a smaller queue index and waits happen only at task start, so the dependency
+//     graph is acyclic and all workgroups are resident (grid <= 2 per CU): no deadlock.  Every spin is bounded anyway;
+//     a timeout raises *status and disables further waiting.
+//   * the LDS-DMA producer runs two slabs ahead of the consumer, across pass boundaries, so the network of the pass
+//     AFTER the current one must be known when a pass starts: each workgroup holds its current AND its next task
+//     (the queue is pulled one task ahead) and names the following network in rg.pnet_next (Ring::dd).
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void spin_until(const unsigned* flag, unsigned want, unsigned* status) {
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+#pragma unroll 1
+  for (int it = 0; it < (1 << 18); ++it) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const RenderArgs& a_setup = *ap;
+  const int tid0 = threadIdx.x;
+  const int lane = tid0 & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int j = lane & 15;
+  ItemState16& st = *(ItemState16*)(smem + kLds16State);
+
+  const long long n_rays = a_setup.n_rays;
+  const long long total = 2 * n_rays;                      // tasks: one coarse + one fine per ray
+  const int lg = a_setup.super_lg;
+  const long long S = 1ll << lg;
+  long long* task_slot = (long long*)&st.res[0][6];        // 8-byte LDS slot that broadcasts a task id
+  auto pull = [&]() -> long long {
+    if (opaque_v(tid0) == 0) *task_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
+    __syncthreads();
+    const long long t = *task_slot;
+    __syncthreads();
+    return t;
+  };
+  // task t -> (super-chunk k, fine?, ray): super-chunk k owns ids [2kS, 2kS + 2 S_k), coarse tasks first
+  auto decode = [&](long long t, long long& k, bool& is_fine, long long& ray) {
+    k = t >> (lg + 1);
+    const long long off = t & (2 * S - 1);
+    const long long left = n_rays - (k << lg);
+    const long long Sk = left < S ? left : S;
+    is_fine = off >= Sk;
+    ray = (k << lg) + off - (is_fine ? Sk : 0);
+  };
+  long long cur = pull();
+  if (cur >= total) return;
+  long long nxt = pull();
+  long long k, rr;
+  bool cur_fine;
+  decode(cur, k, cur_fine, rr);
+
+  Ring rg;
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1, wave, lane);
+  rg.dd = 1;
+  rg.ppi = 0x7fffffff;
+  const int fine_off = (int)a_setup.net_stride;
+  rg.pnet_off = cur_fine ? fine_off : 0;
+  rg.pnet_next = rg.pnet_off;
+  f32x4 A0[4], A1[4];
+  ring_start<kRing16>(rg, A0, lane);
+  {
+    float* dst = (float*)(smem + kLds16Aux);
+    for (int i = tid0; i < kAux16Floats; i += 256) {
+      dst[i] = a_setup.aux[0][i];
+      dst[kAux16Floats + i] = a_setup.aux[1][i];
+    }
+  }
+  __syncthreads();
+  const float* aux_c = (const float*)(smem + kLds16Aux);
+
+  int pass = cur_fine ? 1 : 0;                             // 0 = the coarse task's pass, 1..3 = the fine task's passes
+#pragma unroll 1
+  while (true) {
+    const long long slots = 3 * S;
+    const long long slot = rr % slots;
+    if (pass <= 1) {                                       // a task starts
+      const RenderArgs& a = *opaque_s(ap);
+      const int tid = opaque_v(tid0);
+      unsigned* ready = a.sched_flags;
+      unsigned* taken = a.sched_flags + slots;
+      if (tid == 0) {
+        if (pass == 1) spin_until(ready + slot, (unsigned)(k + 1), a.status);            // the coarse task's results
+        else if (k >= 3) spin_until(taken + slot, (unsigned)(k - 2), a.status);          // the slot's previous reader
+        const float near_ = a.near_, far_ = a.far_;
+        float o[3], d[3];
+        if (a.camera) {
+          const long long hw = (long long)a.H * a.W;
+          const long long v = rr / hw;
+          const int pix = (int)(rr - v * hw);
+          gen_ray(a.c2w + v * 12, a.fx, a.fy, a.cx, a.cy, pix / a.W, pix % a.W, o, d);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
+        }
+        const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));   // torch.norm RN:97, RN:361
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { st.ray[0][c] = o[c]; st.ray[0][3 + c] = d[c]; st.ray[0][6 + c] = d[c] / nrm; }
+        st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
+        st.ray[0][12] = a.white_bkgd ? 1.0f : 0.0f;
+      }
+      __syncthreads();                                     // the wait is over for the whole workgroup
+      if (pass == 0) {
+        if (tid < 64) st.zc[0][tid] = coarse_z(a.near_, a.far_, a.tcoarse[tid], a.lindisp);
+        __syncthreads();
+      } else {
+        if (tid < 192)
+          st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)a.zf_scratch + slot * 192 + tid,
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();                                   // every lane's value has arrived (it was written to LDS)
+        if (tid == 0) __hip_atomic_store(taken + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    {
+      // the network of the pass AFTER this one: the fine net inside a fine task, else the first pass of the next task
+      bool nf = true;
+      if (pass == 0 || pass == 3) {
+        long long k2, r2;
+        nf = cur_fine;
+        if (nxt < total) decode(nxt, k2, nf, r2);
+      }
+      rg.pnet_next = nf ? fine_off : 0;
+    }
+
+    // one network pass: 64 points; coarse: sample 16w + j; fine p: sample 64(p-1) + 16w + j
+    {
+      const int i = (pass == 0 ? 0 : 64 * (pass - 1)) + 16 * wave + j;
+      const float z = (pass == 0) ? st.zc[0][i] : st.zf[0][i];
+      const float* ry = st.ray[0];
+      float raw[4];
+      mlp_pass16(rg, aux_c + (pass == 0 ? 0 : kAux16Floats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+                 ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
+      if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
+    }
+
+    const RenderArgs& a = *opaque_s(ap);                  // nothing below may be hoisted above the network pass
+    const int tid = opaque_v(tid0);
+    bool task_done = false;
+    if (pass == 0) {
+      __syncthreads();
+      if (a.dbg_raw0) {
+        if (tid < 256) a.dbg_raw0[rr * 256 + tid] = (&st.rawf[0][0][0])[tid];
+        __syncthreads();
+      }
+      composite<64, 1>(st, &st.zc[0][0], &st.rawf[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
+      if (tid < 8) {
+        const int c = tid;
+        const float v = st.res[0][c];
+        if (c < 3) { if (a.rgb0) a.rgb0[rr * 3 + c] = v; }
+        else if (c == 3) { if (a.disp0) a.disp0[rr] = v; }
+        else if (c == 4) { if (a.acc0) a.acc0[rr] = v; }
+      }
+      if (a.dbg_w0 && tid < 64) a.dbg_w0[rr * 64 + tid] = st.w0[0][tid];
+      int64_t* inds = (int64_t*)a.dbg_inds;
+      sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
+                         [&](int r, int kk) { return 0.5f * (st.zc[r][kk + 1] + st.zc[r][kk]); },   // RN:473
+                         inds ? inds + rr * 128 : nullptr, 128, tid, 1);
+      if (wave == 0) {
+        const float sd = zstd_wave(st, 0, lane);
+        if (lane == 0 && a.z_std) a.z_std[rr] = sd;
+      }
+      if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
+      merge_sort_item<1>(st, tid);
+      if (tid < 192) {
+        const float zv = st.zf[0][tid];
+        __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(zv), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        if (a.dbg_zf) a.dbg_zf[rr * 192 + tid] = zv;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have left (write-through) before the flag is raised
+      __syncthreads();
+      if (tid == 0)
+        __hip_atomic_store(a.sched_flags + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      task_done = true;
+    } else if (pass < 3) {
+      ++pass;
+    } else {
+      __syncthreads();
+      if (a.dbg_raw) {
+        for (int idx = tid; idx < 768; idx += 256) a.dbg_raw[rr * 768 + idx] = (&st.rawf[0][0][0])[idx];
+        __syncthreads();
+      }
+      composite<192, 1>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.alpha[0][0], &st.tf[0][0], tid);
+      if (tid < 8) {
+        const int c = tid;
+        const float v = st.res[0][c];
+        if (c < 3) { if (a.rgb) a.rgb[rr * 3 + c] = v; }
+        else if (c == 3) { if (a.disp) a.disp[rr] = v; }
+        else if (c == 4) { if (a.acc) a.acc[rr] = v; }
+      }
+      __syncthreads();
+      task_done = true;
+    }
+    if (task_done) {
+      cur = nxt;
+      if (cur >= total) break;
+      nxt = pull();
+      decode(cur, k, cur_fine, rr);
+      pass = cur_fine ? 1 : 0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
 }
 
 // ------------------------------------------------------------------------------------------------------

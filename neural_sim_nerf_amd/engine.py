@@ -14,6 +14,7 @@ from .pack import pack_network, pack_network16, pack_network_backward, pack_netw
 
 N_SAMPLES = 64
 N_IMPORTANCE = 128
+DEFAULT_SCHEDULE = "queue"          # work schedule of the x16 forward kernel, see NSR_FLAG_SCHED_PHASES (include/nsr.h)
 
 
 def _host_tables():
@@ -37,10 +38,12 @@ def _stream_ptr(device):
 
 class NsrModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0,
-                 white_bkgd=False, lindisp=False, chunk=None):
+                 white_bkgd=False, lindisp=False, chunk=None, schedule=None):
         """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu).
         white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration).
-        chunk: rays per work-queue chunk of the x16 kernel (None: $NSR_CHUNK, read HERE once, else the library default)."""
+        chunk: rays per work-queue chunk of the x16 kernel (None: $NSR_CHUNK, read HERE once, else the library default).
+        schedule: "queue" (per-ray queue) or "phases" (global phases, NSR_FLAG_SCHED_PHASES); None: $NSR_SCHEDULE, else
+        the library default.  Both give bit-identical results."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
@@ -51,6 +54,12 @@ class NsrModel:
             chunk = int(os.environ.get("NSR_CHUNK", "0") or 0)
         if not 0 <= int(chunk) <= 256:
             raise ValueError("chunk must be in 0..256")
+        if schedule is None:
+            schedule = os.environ.get("NSR_SCHEDULE", DEFAULT_SCHEDULE)
+        if schedule not in ("queue", "phases"):
+            raise ValueError("schedule must be 'queue' or 'phases'")
+        phases = schedule == "phases" and variant != 32 and n_importance > 0      # the x16 coarse+fine kernel only
+        self.schedule = "phases" if phases else "queue"
         if n_importance not in (0, N_IMPORTANCE):
             raise NotImplementedError("N_importance must be 128 (or 0 for coarse-only); got %r" % (n_importance,))
         if n_importance > 0 and sd_fine is None:
@@ -61,7 +70,7 @@ class NsrModel:
         self.variant = variant
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant,
-                             (1 if white_bkgd else 0) | (2 if lindisp else 0), int(chunk))
+                             (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0), int(chunk))
         self._bbox_reserved = (0, 0)
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))

@@ -710,6 +710,36 @@ def test_x16_chunked_schedule_is_result_invariant(model16, synth_nets, monkeypat
         m.close()
 
 
+def test_phases_schedule_is_result_invariant(model16, synth_nets, oracle):
+    """NSR_FLAG_SCHED_PHASES (k_render16p, global phases: coarse and fine tasks of a ray may run on different
+    workgroups, z values handed over through a global ring with ready/taken flags) gives bit-identical results to the
+    default per-ray queue: a batch smaller than one super-chunk (4096 rays), and 3 views of 110x110 = 36 300 rays = 9
+    super-chunks, so that every hand-off slot is reused (slot = ray mod 12 288) and the taken-flag wait is exercised;
+    no hand-off wait may time out (last_kernel_ms raises if one did)."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    mp = NsrModel(synth_nets[0], synth_nets[1], schedule="phases")
+    assert mp.schedule == "phases" and model16.schedule == "queue"
+    ro = np.tile(g["rays_o"], (8, 1))[:1500 + 7]
+    rd = np.tile(g["rays_d"], (8, 1))[:1500 + 7]
+    want = model16.render_rays(ro, rd, near, far, debug=True)
+    got = mp.render_rays(ro, rd, near, far, debug=True)
+    mp.last_kernel_ms()
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std", "z_fine", "inds", "raw", "raw0", "weights0"):
+        assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), k
+    poses = np.asarray(oracle.sweep_poses(3, seed=4))
+    K = oracle.scaled_K(400.0 / 110)
+    for rep in range(2):                                   # twice: the flags are reset by every launch
+        want = model16.render_views(poses, 110, 110, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)
+        got = mp.render_views(poses, 110, 110, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)
+        mp.last_kernel_ms()
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
+            assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), (rep, k)
+    mp.close()
+
+
 def test_launch_is_graph_capturable_and_replays_bit_identically(synth_nets, oracle):
     """include/nsr.h: launch calls only enqueue kernels (no allocation, synchronisation or environment reads), so
     nsr_render_views and nsr_render_rays_vjp can be captured into a hipGraph; replays equal the eager launch bit

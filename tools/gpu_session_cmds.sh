@@ -1,3 +1,3 @@
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout 100 python tools/bench_vjp.py 400 3
-bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -3 $O/collect.log
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "phases" 2>&1 | tail -15
+timeout 120 python tools/one_view.py 16 0 phases 3
+timeout 120 python tools/one_view.py 16 0 queue 3

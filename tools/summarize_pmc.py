@@ -6,8 +6,9 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
 os.makedirs(dst, exist_ok=True)
 out = {}
-FLOP = {"x16": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568}
-for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp")):
+FLOP = {"x16": 160000 * 303824896, "x16p": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568}
+for tag, key, kname in (("x16", "x16_default", "k_render16("), ("x16p", "x16_phases_schedule", "k_render16p"),
+                        ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp")):
     tot, disp, ns, first_id = {}, {}, None, {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
         if not os.path.isdir(d):
@@ -49,6 +50,15 @@ for tag, key, kname in (("x16", "x16_default", "k_render16"), ("x32", "x32", "k_
     out[key] = {"counters": tot, "dispatch": disp, "kernel_ns_under_pmc": ns, "derived": der}
 hf = os.path.join(src, "kernel_source_sha256.txt")
 out["kernel_source_sha256"] = open(hf).read().strip() if os.path.exists(hf) else None
+sched = {}
+for name in ("queue", "phases"):
+    f = os.path.join(src, "schedule_%s.log" % name)
+    if os.path.exists(f):
+        ms = [float(l.split()[-1]) for l in open(f) if l.startswith("variant")]
+        if len(ms) > 1:
+            sched[name] = {"kernel_ms_after_warmup": ms[1:], "mean_ms": sum(ms[1:]) / len(ms[1:])}
+if sched:
+    out["schedule_timing_unprofiled"] = sched
 json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
 for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
                   ("stats_handoff", "kernel_stats_handoff.csv")):
