@@ -48,7 +48,7 @@ struct DeviceGuard {
 };
 #define NSR_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSR_HIP(guard_.err)
 
-constexpr int kSuperLg = 12;           // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
+static int kSuperLg = 12;              // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
 constexpr size_t kRender16Lds = nsr::kLds16State + sizeof(nsr::ItemState16);
@@ -153,6 +153,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   h->zf_grid = cfg->max_workgroups > 0 ? cfg->max_workgroups : 2 * h->n_cu;
   size_t zf_rays = (size_t)h->zf_grid * h->chunk;
   if (cfg->flags & NSR_FLAG_SCHED_PHASES) {                // the z hand-off ring of the global-phases schedule
+    if (const char* e = getenv("NSR_EXP_SUPER_LG")) kSuperLg = atoi(e);      // experiment knob, read at setup only
     zf_rays = (size_t)3 << kSuperLg;
     NSR_HIP(hipMalloc(&h->d_sched_flags, sizeof(unsigned) * 2 * zf_rays));
     NSR_HIP(hipMalloc(&h->d_status, sizeof(unsigned)));

@@ -35,6 +35,15 @@ __device__ __forceinline__ int opaque_v(int x) { asm volatile("" : "+v"(x)); ret
 template <typename T>
 __device__ __forceinline__ const T* opaque_s(const T* p) { asm volatile("" : "+s"(p)); return p; }
 
+// A 64-bit value that is wave-uniform by construction (read back from an LDS broadcast slot): say so.  Everything
+// derived from it (ray index, camera / ray addresses) then lives in scalar registers, and the ray staging loads become
+// scalar-cache loads instead of queueing behind the LDS-DMA weight stream in the vector memory pipeline.
+__device__ __forceinline__ long long uniform64(long long v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // ring (LDS weight stream)
 // ------------------------------------------------------------------------------------------------------
@@ -730,7 +739,7 @@ __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int ti
 __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; *a.work_counter = 0ull; }
 
 #ifdef NSR_PHASE_TIMING      // diagnostic build: per-workgroup cycle totals of the item phases (thread 0), see tools
-#define NSR_T(i) do { if (tid == 0) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#define NSR_T(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define NSR_T(i) do { } while (0)
 #endif
@@ -770,7 +779,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   auto next_item = [&]() -> long long {
     if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
     __syncthreads();
-    const long long v = *item_slot;
+    const long long v = uniform64(*item_slot);
     __syncthreads();
     return v;
   };
@@ -1139,7 +1148,7 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
   auto next_item = [&]() -> long long {
     if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
     __syncthreads();
-    const long long v = *item_slot;
+    const long long v = uniform64(*item_slot);
     __syncthreads();
     return v;
   };
@@ -1525,7 +1534,7 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
   auto next_chunk = [&]() -> bool {
     if (opaque_v(tid0) == 0) *chunk_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
     __syncthreads();
-    const long long c = *chunk_slot;
+    const long long c = uniform64(*chunk_slot);
     __syncthreads();
     c0 = c * K;
     return c < n_chunks;
@@ -1688,6 +1697,9 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
 //     (the queue is pulled one task ahead) and names the following network in rg.pnet_next (Ring::dd).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned want, unsigned* status) {
+#ifdef NSR_EXP_NOSPIN        // timing experiment only (unsafe)
+  return;
+#endif
   if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
 #pragma unroll 1
   for (int it = 0; it < (1 << 18); ++it) {
@@ -1700,6 +1712,10 @@ __device__ __forceinline__ void spin_until(const unsigned* flag, unsigned want, 
 __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const RenderArgs& a_setup = *ap;
+#ifdef NSR_PHASE_TIMING
+  long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tlast = clock64();
+#endif
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -1710,13 +1726,15 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
   const long long total = 2 * n_rays;                      // tasks: one coarse + one fine per ray
   const int lg = a_setup.super_lg;
   const long long S = 1ll << lg;
+  Ring rg;                                                 // (before any control flow: the descriptor stays in SGPRs)
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1, wave, lane);
   long long* task_slot = (long long*)&st.res[0][6];        // 8-byte LDS slot that broadcasts a task id
   auto pull = [&]() -> long long {
     if (opaque_v(tid0) == 0) *task_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
     __syncthreads();
-    const long long t = *task_slot;
+    const long long tv = uniform64(*task_slot);
     __syncthreads();
-    return t;
+    return tv;
   };
   // task t -> (super-chunk k, fine?, ray): super-chunk k owns ids [2kS, 2kS + 2 S_k), coarse tasks first
   auto decode = [&](long long t, long long& k, bool& is_fine, long long& ray) {
@@ -1734,8 +1752,6 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
   bool cur_fine;
   decode(cur, k, cur_fine, rr);
 
-  Ring rg;
-  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1, wave, lane);
   rg.dd = 1;
   rg.ppi = 0x7fffffff;
   const int fine_off = (int)a_setup.net_stride;
@@ -1795,6 +1811,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         if (tid == 0) __hip_atomic_store(taken + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+    NSR_T(0);
     {
       // the network of the pass AFTER this one: the fine net inside a fine task, else the first pass of the next task
       bool nf = true;
@@ -1817,6 +1834,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
 
+    NSR_T(1);
     const RenderArgs& a = *opaque_s(ap);                  // nothing below may be hoisted above the network pass
     const int tid = opaque_v(tid0);
     bool task_done = false;
@@ -1835,7 +1853,11 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         else if (c == 4) { if (a.acc0) a.acc0[rr] = v; }
       }
       if (a.dbg_w0 && tid < 64) a.dbg_w0[rr * 64 + tid] = st.w0[0][tid];
+#ifdef NSR_PHASE_TIMING
+      int64_t* inds = nullptr;                 // dbg_inds carries the cycle totals in this build
+#else
       int64_t* inds = (int64_t*)a.dbg_inds;
+#endif
       sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
                          [&](int r, int kk) { return 0.5f * (st.zc[r][kk + 1] + st.zc[r][kk]); },   // RN:473
                          inds ? inds + rr * 128 : nullptr, 128, tid, 1);
@@ -1845,16 +1867,20 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       }
       if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
       merge_sort_item<1>(st, tid);
+      NSR_T(2);
       if (tid < 192) {
         const float zv = st.zf[0][tid];
         __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(zv), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         if (a.dbg_zf) a.dbg_zf[rr * 192 + tid] = zv;
       }
+#ifndef NSR_EXP_NODRAIN      // timing experiment only (unsafe)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have left (write-through) before the flag is raised
+#endif
       __syncthreads();
       if (tid == 0)
         __hip_atomic_store(a.sched_flags + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      NSR_T(3);
       task_done = true;
     } else if (pass < 3) {
       ++pass;
@@ -1873,6 +1899,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         else if (c == 4) { if (a.acc) a.acc[rr] = v; }
       }
       __syncthreads();
+      NSR_T(4);
       task_done = true;
     }
     if (task_done) {
@@ -1881,9 +1908,14 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       nxt = pull();
       decode(cur, k, cur_fine, rr);
       pass = cur_fine ? 1 : 0;
+      NSR_T(5);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+#ifdef NSR_PHASE_TIMING
+  if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)
+    for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2103,7 +2135,7 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
   auto next_item = [&]() -> long long {
     if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
     __syncthreads();
-    const long long v = *item_slot;
+    const long long v = uniform64(*item_slot);
     __syncthreads();
     return v;
   };

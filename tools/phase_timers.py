@@ -21,6 +21,8 @@ tt = t.cpu().numpy().reshape(512, 8).astype(np.float64)
 tt = tt[tt.sum(1) > 0]
 print('variant', V, 'workgroups', len(tt))
 names = ["stage rays", "network passes", "coarse composite+out", "sample_pdf", "z_std+dbg", "merge sort", "fine composite+out", "-"]
+if m.schedule == "phases":
+    names = ["task start (wait, ray, z load)", "network passes", "coarse post-phase", "z publish", "fine post-phase", "queue pull", "-", "-"]
 tot = tt.sum(1).mean()
 print("kernel ms %.2f  total cycles/WG %.3e (100 MHz counter? ratio to ms: %.1f MHz)" % (ms, tot, tot / ms / 1e3))
 for i, nm in enumerate(names):
