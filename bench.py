@@ -15,7 +15,7 @@ the timed region (BASELINE configs[2]).
     python bench.py --gpus 8 --workload models21 --steps 1      # BASELINE configs[4]: 21 models, one stream each
 
 Prints ONE JSON line on rank 0.  Objects beside the contract fields:
-  roofline       -- dominant kernel nsr::k_render16: algorithmic FLOP per launch / HIP-event kernel time, against the
+  roofline       -- dominant kernel nsr::k_render16p (k_render16 with the global-phases schedule): algorithmic FLOP per launch / HIP-event kernel time, against the
                     fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
                     `traffic` comes from a rocprofv3 --pmc profile ONLY if that profile was collected from exactly
                     the kernel sources in this tree (hash check), else null;
@@ -209,7 +209,7 @@ def vjp_roofline(model, c2w):
                          "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP"}
 
 
-def pmc_traffic(pmc_file):
+def pmc_traffic(pmc_file, schedule="phases"):
     """HBM-side bytes per launch from a rocprofv3 --pmc profile (tools/collect_profiles.sh + summarize_pmc.py), used
     ONLY when the profile was collected from exactly the kernel sources in this tree; otherwise null."""
     if not os.path.exists(pmc_file):
@@ -220,11 +220,15 @@ def pmc_traffic(pmc_file):
         return None, ("PMC profile %s was collected from other kernel sources (%s..., this tree %s...): not reported"
                       % (os.path.relpath(pmc_file, ROOT), str(prof.get("kernel_source_sha256"))[:12], here[:12]))
     blob = hashlib.sha1(b"blob %d\0" % os.path.getsize(pmc_file) + open(pmc_file, "rb").read()).hexdigest()
-    t = prof["x16_default"]["derived"]["hbm_traffic_bytes_per_launch"]
+    key = "x16_phases_schedule" if schedule == "phases" else "x16_default"
+    if key not in prof:
+        return None, "PMC profile %s has no passes for the %s schedule" % (os.path.relpath(pmc_file, ROOT), schedule)
+    t = prof[key]["derived"]["hbm_traffic_bytes_per_launch"]
     return t, ("offline measurement: bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
-               "this command (%s, git blob %s, kernel sources sha256 %s... = this tree); FETCH_SIZE counts L2 misses that "
-               "Infinity Cache serves: re-streaming of the weight images (4.6 MiB of networks vs 4 MiB L2 per XCD), not HBM "
-               "reads; algorithmic HBM bytes are 7.0e6 per launch (DESIGN.md 4)" % (os.path.relpath(pmc_file, ROOT), blob[:12], here[:12]))
+               "this kernel and schedule (%s [%s], git blob %s, kernel sources sha256 %s... = this tree); FETCH_SIZE counts "
+               "L2 misses that Infinity Cache serves: re-streaming of the weight images (4.6 MiB of networks vs 4 MiB L2 per "
+               "XCD), not HBM reads; algorithmic HBM bytes are 7.0e6 per launch; the per-ray-queue schedule measures 5.3e10 "
+               "and is 0.3 %% faster (DESIGN.md 4)" % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
 
 
 def self_launch(args):
@@ -332,12 +336,13 @@ def main():
         if rank == 0:
             rays = args.steps * H * W * world
             achieved = H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
-            traffic, traffic_note = pmc_traffic(args.pmc_file)
+            traffic, traffic_note = pmc_traffic(args.pmc_file, model.schedule)
             line.update({
                 "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
                                        "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), fp32, fused "
-                                       "persistent kernel (x16: 2 workgroups per CU), rays generated in-kernel",
+                                       "persistent kernel (x16: 2 workgroups per CU, %s schedule), rays generated "
+                                       "in-kernel" % model.schedule,
                            "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
                            "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
                 "rays_per_s": round(rays / dt, 1), "mlp_evals_per_s": round(rays * EVALS_PER_RAY / dt, 1),
@@ -346,7 +351,9 @@ def main():
                                        "mean": round(float(np.mean(per_rank)), 3)},
                 "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                             "traffic_note": traffic_note, "kernel": "nsr::k_render16", "kernel_ms": round(k_ms, 3),
+                             "traffic_note": traffic_note,
+                             "kernel": "nsr::k_render16p" if model.schedule == "phases" else "nsr::k_render16",
+                             "kernel_ms": round(k_ms, 3),
                              "flop_per_launch": H * W * FLOP_PER_RAY},
             })
             cpu_setting = None

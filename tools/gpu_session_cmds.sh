@@ -1,3 +1,5 @@
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "phases" 2>&1 | tail -3
-timeout 120 python tools/one_view.py 16 0 phases 4 2>&1 | grep -v amdgpu.ids
-timeout 120 python tools/one_view.py 16 0 queue 4 2>&1 | grep -v amdgpu.ids
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 300 python bench.py 2>/dev/null | python -c "
+import sys, json
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('fwd', d['value'], d['roofline'], 'vjp', d['roofline_vjp']['kernel_ms'], d['roofline_vjp']['frac'], d['parity'])"
