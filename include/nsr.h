@@ -213,6 +213,12 @@ int nsr_sample_pose_nograd(nsr_handle h, const double* d_logits, const double* d
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
 
+/* Debug build (`make -C neural_sim_nerf_amd/csrc debug` -> libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent
+ * LDS / scratch index of the kernels (searchsorted results, merge ranks, hand-off slots) is range-checked; a violation
+ * is clamped and its source line recorded.  *built_with_checks = 0 for the release library (then *first_bad_line = 0).
+ * Synchronises the device. */
+int nsr_debug_bounds_status(nsr_handle h, int* built_with_checks, unsigned* first_bad_line);
+
 /* Timing helper for bench.py: HIP-event time in ms of the last EAGER nsr_render_* launch on this handle
  * (events recorded on the launch stream; this call synchronises on the stop event).  Launches made while the
  * stream is being captured into a graph are not timed. */

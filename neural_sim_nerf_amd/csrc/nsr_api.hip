@@ -653,6 +653,20 @@ int nsr_selftest(nsr_handle h, void* stream) {
   return 0;
 }
 
+int nsr_debug_bounds_status(nsr_handle h, int* built_with_checks, unsigned* first_bad_line) {
+  if (!h || !built_with_checks || !first_bad_line) return fail("nsr_debug_bounds_status: null argument");
+  *first_bad_line = 0u;
+#ifdef NSR_DEBUG_BOUNDS
+  NSR_DEVICE(h);
+  *built_with_checks = 1;
+  NSR_HIP(hipDeviceSynchronize());
+  NSR_HIP(hipMemcpyFromSymbol(first_bad_line, HIP_SYMBOL(nsr::g_bounds_violation), sizeof(unsigned)));
+#else
+  *built_with_checks = 0;
+#endif
+  return 0;
+}
+
 int nsr_last_kernel_ms(nsr_handle h, float* ms) {
   if (!h || !ms) return fail("nsr_last_kernel_ms: null argument");
   if (!h->timed) return fail("nsr_last_kernel_ms: no timed render launch yet (launches captured into a graph are not timed)");

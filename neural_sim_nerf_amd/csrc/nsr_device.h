@@ -44,6 +44,26 @@ __device__ __forceinline__ f32x16 clamp_bits16(f32x16 x, int thr) {
 }
 __device__ __forceinline__ f32x16 relu16(f32x16 x) { return clamp_bits16(x, 0); }
 
+// Bounds-checked indexing for the data-dependent LDS / scratch indices (searchsorted results, merge ranks, hand-off
+// slots).  Release build: the index itself.  `make debug` (-DNSR_DEBUG_BOUNDS, libnsr_debug.so): an out-of-range index
+// is clamped -- no wild LDS write, the kernel finishes -- and its source line is recorded in a device word that
+// nsr_debug_bounds_status() reads back.  (A trap would take the whole HSA queue down; this keeps the evidence.)
+#ifdef NSR_DEBUG_BOUNDS
+__device__ unsigned g_bounds_violation = 0u;      // first (highest) offending source line, 0 = clean
+__device__ __forceinline__ long long checked_index(long long i, long long n, unsigned line) {
+  if (i < 0 || i >= n) {
+    atomicMax(&g_bounds_violation, line);
+    return i < 0 ? 0 : n - 1;
+  }
+  return i;
+}
+#define NSR_IDX(i, n) ((int)nsr::checked_index((long long)(i), (long long)(n), __LINE__))
+#define NSR_IDX64(i, n) (nsr::checked_index((long long)(i), (long long)(n), __LINE__))
+#else
+#define NSR_IDX(i, n) (i)
+#define NSR_IDX64(i, n) (i)
+#endif
+
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __shfl_xor(lo, mask);

@@ -580,13 +580,13 @@ __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[12
     int lo = 0, hi = 63;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+      if (cdf[NSR_IDX(mid, 63)] <= u) lo = mid + 1; else hi = mid;
     }
     const int ind = lo;
     const int below = max(ind - 1, 0);
     const int above = min(ind, 62);
-    const float c0 = cdf[below], c1 = cdf[above];
-    const float b0 = bins(r, below), b1 = bins(r, above);
+    const float c0 = cdf[NSR_IDX(below, 63)], c1 = cdf[NSR_IDX(above, 63)];
+    const float b0 = bins(r, NSR_IDX(below, 63)), b1 = bins(r, NSR_IDX(above, 63));
     float denom = c1 - c0;
     if (denom < 1e-5f) denom = 1.0f;                            // RH:238-239
     const float t = (u - c0) / denom;
@@ -653,7 +653,7 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
         ub += (st.zc[r][ub] <= x) ? 1 : 0;
         rank = (k - 64) + ub;
       }
-      st.zf[r][rank] = x;
+      st.zf[r][NSR_IDX(rank, 192)] = x;
     }
   } else {
     for (int e = tid; e < 192 * R; e += 256) {
@@ -668,7 +668,7 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
         const float y = st.zs[r][j];
         rank += (y < x) || (y == x && (j + 64) < k);
       }
-      st.zf[r][rank] = x;
+      st.zf[r][NSR_IDX(rank, 192)] = x;
     }
   }
   __syncthreads();
@@ -1773,7 +1773,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
 #pragma unroll 1
   while (true) {
     const long long slots = 3 * S;
-    const long long slot = rr % slots;
+    const long long slot = NSR_IDX64(rr % slots, slots);
     if (pass <= 1) {                                       // a task starts
       const RenderArgs& a = *opaque_s(ap);
       const int tid = opaque_v(tid0);

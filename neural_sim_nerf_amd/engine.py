@@ -320,6 +320,12 @@ class NsrModel:
     def selftest(self):
         _lib.check(self.lib.nsr_selftest(self.h, _stream_ptr(self.device)))
 
+    def debug_bounds_status(self):
+        """(built_with_checks, first_bad_source_line): see nsr_debug_bounds_status / `make debug`."""
+        built, line = C.c_int(), C.c_uint()
+        _lib.check(self.lib.nsr_debug_bounds_status(self.h, C.byref(built), C.byref(line)))
+        return bool(built.value), int(line.value)
+
     def last_kernel_ms(self):
         ms = C.c_float()
         _lib.check(self.lib.nsr_last_kernel_ms(self.h, C.byref(ms)))

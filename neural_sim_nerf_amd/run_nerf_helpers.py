@@ -93,7 +93,9 @@ class NeRF(nn.Module):
         self._native = None
         self._native_key = None
 
-    def forward(self, x):
+    def _native_handle(self):
+        """The native (coarse-only) handle of THIS network for stand-alone evaluation; shared with render()'s cache
+        machinery: repacked when the weights change, dropped by invalidate()."""
         from .engine import NsrModel
         key = self.weights_version()
         if self._native is None or self._native_key != key:
@@ -101,8 +103,18 @@ class NeRF(nn.Module):
                 self._native.close()
             self._native = NsrModel(self.state_dict(), None, n_importance=0)
             self._native_key = key
+        return self._native
+
+    def evaluate(self, pts, viewdirs):
+        """run_network's arithmetic (RN:26-40 = Embedder RH:18-48 + the MLP RH:99-122) on raw points [P,3] and unit
+        directions [P,3] -> [P,4]; the encodings are fused into the kernel, nothing is materialised."""
+        return self._native_handle().run_network(pts, viewdirs, 0)
+
+    def forward(self, x):
+        """The reference's signature: x = cat([embedded points (63), embedded directions (27)]) [P,90].  Only the raw
+        coordinates (columns 0:3 and 63:66, the include_input part of each encoding) are read."""
         x = x.reshape(-1, x.shape[-1])
-        return self._native.run_network(x[:, :3], x[:, self.input_ch:self.input_ch + 3], 0)
+        return self.evaluate(x[:, :3], x[:, self.input_ch:self.input_ch + 3])
 
 
 def get_rays(H, W, K, c2w):

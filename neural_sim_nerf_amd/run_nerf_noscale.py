@@ -140,10 +140,13 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
         raise NotImplementedError("use_viewdirs=False is not supported")
     flat = inputs.reshape(-1, 3)
     dirs = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
-    x = torch.zeros(flat.shape[0], 90, dtype=torch.float32, device=flat.device)
-    x[:, :3] = flat
-    x[:, 63:66] = dirs
-    out = fn(x)
+    if isinstance(fn, NeRF):
+        out = fn.evaluate(flat, dirs)                       # straight to the native kernel: no [P,90] staging tensor
+    else:                                                   # any other callable gets the reference's [P,90] layout
+        x = torch.zeros(flat.shape[0], 90, dtype=torch.float32, device=flat.device)
+        x[:, :3] = flat
+        x[:, 63:66] = dirs
+        out = fn(x)
     return out.reshape(list(inputs.shape[:-1]) + [out.shape[-1]])
 
 

@@ -7,11 +7,14 @@ Tolerances (fp32, stated per test):
   * compositing given identical raw/z: 2e-6 (expf / sigmoid 1-2 ulp, sequential vs cascade sums);
   * end to end: coarse 1e-5; fine PSNR > 55 dB and mean abs < 2e-4 (the path is ill-conditioned where the pdf
     is flat, see tests/test_oracle_golden.py::test_render_rays_end_to_end)."""
+import os
+
 import numpy as np
 import pytest
 
 from conftest import assert_close, load_golden
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -598,6 +601,31 @@ def test_device_pose_pipeline_vs_reference(synth_nets, oracle, tmp_path):
     assert np.abs(res["attribute"].mean(0) - g["dLdpsis"].mean(0)).max() < 2e-2 * scale
 
 
+def test_network_query_fn_and_module_forward(oracle, synth_nets):
+    """run_network (RN:26-40) through the reference-shaped entry points: network_query_fn(inputs [N,S,3], viewdirs
+    [N,3], network_fn) goes straight to the native kernel (no [P,90] staging tensor), NeRF.forward keeps the reference's
+    [P,90] signature; both equal the oracle's network on the same points."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    net = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_nets[0].items()})
+    net = net.to(R.device)
+    rng = np.random.RandomState(5)
+    pts = rng.uniform(-1.2, 1.2, (7, 9, 3)).astype(np.float32)
+    dirs = rng.standard_normal((7, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    want = oracle.run_network(synth_nets[0], pts, dirs)
+    got = R.run_network(torch.tensor(pts, device=R.device), torch.tensor(dirs, device=R.device), net)
+    assert tuple(got.shape) == (7, 9, 4)
+    assert_close(cpu(got), want, atol=3e-5, rtol=2e-5, what="network_query_fn")
+    x = torch.zeros(63, 90, device=R.device)
+    x[:, :3] = torch.tensor(pts.reshape(-1, 3), device=R.device)
+    x[:, 63:66] = torch.tensor(np.repeat(dirs, 9, 0), device=R.device)
+    assert np.array_equal(cpu(net(x)), cpu(got).reshape(-1, 4))            # same kernel, same points
+    net.invalidate()
+    assert net._native is None
+
+
 def test_render_path_api_and_png_side_effects(oracle, synth_nets, tmp_path):
     """render_path (RN:213-255) through the reference-shaped API built by create_nerf from a checkpoint file:
     shapes, numpy returns, savedir/<object_id>/%03d.png written with to8b truncation, one launch for all poses
@@ -738,6 +766,51 @@ def test_phases_schedule_is_result_invariant(model16, synth_nets, oracle):
         for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
             assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), (rep, k)
     mp.close()
+
+
+def test_debug_bounds_build_is_clean(tmp_path):
+    """`make debug` (libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent LDS / scratch index is range-checked.
+    A fresh process renders ordinary and degenerate rays (NaN, inf, zero directions, far-away origins), both forward
+    schedules and both VJP kernels with it; no violation may be recorded and the images must equal the release build's."""
+    import subprocess
+    import sys
+    dbg = os.path.join(ROOT, "neural_sim_nerf_amd", "csrc", "libnsr_debug.so")
+    if not os.path.exists(dbg):
+        pytest.skip("libnsr_debug.so not built (make -C neural_sim_nerf_amd/csrc debug)")
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import nerf_oracle as O
+from neural_sim_nerf_amd.engine import NsrModel
+sd_c = O.synth_weights(0); sd_f = O.synth_weights(1000, fine_of=sd_c)
+g = np.load(%r)
+ro, rd = g["rays_o"].copy(), g["rays_d"].copy()
+ro[3] = np.nan; rd[5] = 0.0; rd[7] = np.inf; ro[9] = 1e30; rd[11] *= 1e-30
+out = {}
+for variant, schedule in ((16, "queue"), (16, "phases"), (32, "queue")):
+    m = NsrModel(sd_c, sd_f, variant=variant, schedule=schedule)
+    built, line = m.debug_bounds_status()
+    r = m.render_rays(ro, rd, O.YCBV_NEAR, O.YCBV_FAR, debug=True)
+    v = m.render_views(np.asarray(O.sweep_poses(2, seed=1)), 75, 75, O.scaled_K(400.0 / 75), O.YCBV_NEAR, O.YCBV_FAR)
+    go, gd = m.render_rays_vjp(ro, rd, O.YCBV_NEAR, O.YCBV_FAR, np.ones((ro.shape[0], 3), np.float32))
+    m.last_kernel_ms()
+    out["%%d_%%s" %% (variant, schedule)] = (built, m.debug_bounds_status()[1])
+    np.save(sys.argv[1] + "/rgb_%%d_%%s.npy" %% (variant, schedule), v["rgb_map"].cpu().numpy())
+    m.close()
+print(out)
+''' % (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests", "golden", "g6_render_rays.npz"))
+    res = {}
+    for name, lib in (("debug", dbg), ("release", os.path.join(ROOT, "neural_sim_nerf_amd", "csrc", "libnsr.so"))):
+        d = tmp_path / name
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", code, str(d)], env=dict(os.environ, NSR_LIB_PATH=lib),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = eval(r.stdout.strip().splitlines()[-1])
+    assert all(v == (True, 0) for v in res["debug"].values()), res["debug"]        # checks compiled in, none tripped
+    assert all(v == (False, 0) for v in res["release"].values()), res["release"]
+    for f in os.listdir(tmp_path / "debug"):
+        assert np.array_equal(np.load(tmp_path / "debug" / f), np.load(tmp_path / "release" / f), equal_nan=True), f
 
 
 def test_launch_is_graph_capturable_and_replays_bit_identically(synth_nets, oracle):
