@@ -768,6 +768,56 @@ def test_phases_schedule_is_result_invariant(model16, synth_nets, oracle):
     mp.close()
 
 
+def test_full_size_view_properties(synth_nets, oracle):
+    """BASELINE configs[1] at FULL size (400x400, 64+128) through size-independent properties: determinism; schedule
+    invariance (39 super-chunks, every hand-off slot reused 13 times); ray independence (a random subset of the rays
+    rendered alone is bit-equal to those pixels of the full view, forward and VJP); multi-view launch == single views;
+    range invariants (0 <= acc <= 1, rgb in [0,1], z_std >= 0, sorted depths); and the oracle on 384 random rays of it."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.YCBV_K
+    poses = np.asarray(oracle.sweep_poses(3, seed=21))
+    mp = NsrModel(synth_nets[0], synth_nets[1], schedule="phases")
+    mq = NsrModel(synth_nets[0], synth_nets[1], schedule="queue")
+    full = mp.render_views(poses[0], 400, 400, K, near, far)
+    again = mp.render_views(poses[0], 400, 400, K, near, far)
+    fq = mq.render_views(poses[0], 400, 400, K, near, far)
+    mp.last_kernel_ms()
+    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+    for k in keys:
+        assert np.array_equal(cpu(full[k]), cpu(again[k]), equal_nan=True), k          # deterministic
+        assert np.array_equal(cpu(full[k]), cpu(fq[k]), equal_nan=True), k             # schedule-invariant at full size
+    rgb, acc = cpu(full["rgb_map"]), cpu(full["acc_map"])
+    assert np.isfinite(rgb).all() and rgb.min() >= 0.0 and rgb.max() <= 1.0 + 1e-5
+    assert acc.min() >= 0.0 and acc.max() <= 1.0 + 1e-5 and (cpu(full["z_std"]) >= 0).all()
+    # three views in one launch == three launches
+    three = mp.render_views(poses, 400, 400, K, near, far)
+    assert np.array_equal(cpu(three["rgb_map"])[:160000], rgb)
+    one = mp.render_views(poses[2], 400, 400, K, near, far)
+    assert np.array_equal(cpu(three["rgb_map"])[320000:], cpu(one["rgb_map"]))
+    # ray independence + oracle on a random subset
+    ro, rd = mp.get_rays(400, 400, K, poses[0])
+    ro, rd = cpu(ro).reshape(-1, 3), cpu(rd).reshape(-1, 3)
+    sel = np.random.RandomState(0).choice(160000, 20000, replace=False)
+    sub = mp.render_rays(ro[sel], rd[sel], near, far, debug=True)
+    for k in keys:
+        assert np.array_equal(cpu(sub[k]), cpu(full[k])[sel], equal_nan=True), k
+    zf = cpu(sub["z_fine"])
+    assert (np.diff(zf, axis=1) >= 0).all() and zf.min() >= near * (1 - 1e-6) and zf.max() <= far * (1 + 1e-6)
+    sm = sel[:384]
+    ref = oracle.render(synth_nets[0], synth_nets[1], 400, 400, K, rays=(ro[sm], rd[sm]), near=near, far=far)
+    assert_close(cpu(full["rgb0"])[sm], ref["rgb0"], atol=1e-5, what="coarse rgb vs oracle at full size")
+    assert oracle.psnr(rgb[sm], ref["rgb_map"]) > 55.0
+    # the input-gradient kernel at full size: subset == full (bit-exact), linear in the cotangent
+    cot = np.random.RandomState(1).standard_normal((160000, 3)).astype(np.float32)
+    go, gd = mp.render_rays_vjp(ro, rd, near, far, cot)
+    so, sd = mp.render_rays_vjp(ro[sel[:4001]], rd[sel[:4001]], near, far, cot[sel[:4001]])
+    assert np.array_equal(cpu(so), cpu(go)[sel[:4001]]) and np.array_equal(cpu(sd), cpu(gd)[sel[:4001]])
+    assert np.isfinite(cpu(go)).all() and np.isfinite(cpu(gd)).all()
+    mp.close(); mq.close()
+
+
 def test_debug_bounds_build_is_clean(tmp_path):
     """`make debug` (libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent LDS / scratch index is range-checked.
     A fresh process renders ordinary and degenerate rays (NaN, inf, zero directions, far-away origins), both forward
