@@ -234,7 +234,7 @@ def pmc_traffic(pmc_file, schedule="phases"):
 def self_launch(args):
     """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not (args.share_gpu and n_dev > 0):
         raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, n_dev))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -255,6 +255,11 @@ def main():
     ap.add_argument("--views", type=int, default=100, help="sweep100: number of views in the sweep (config 3 uses 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_vjp and the config-1 workload")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo stages collectives through the host")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="validation only: ranks share the visible GPUs round-robin (e.g. --gpus 2 --backend gloo on a "
+                         "1-GPU box exercises the N>1 code path end to end; the number is not a scaling result)")
     ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r02", "pmc_k_render.json"))
     args = ap.parse_args()
 
@@ -266,8 +271,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if launched and args.gpus != world:
         raise SystemExit("bench.py --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.share_gpu and torch.cuda.device_count() > 0:
+        local = local % torch.cuda.device_count()
     if local >= torch.cuda.device_count():
         raise SystemExit("bench.py: local rank %d has no HIP device (%d visible)" % (local, torch.cuda.device_count()))
+    if args.share_gpu and args.backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py --share-gpu: RCCL cannot put two ranks on one device; use --backend gloo")
     torch.cuda.set_device(local)
     dist = None
     if launched:                                  # under torch.distributed.run, also for a single rank
@@ -275,8 +284,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"     # RCCL's version banner goes to stdout: keep stdout to the ONE JSON line
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
     dev = torch.device("cuda", local)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")       # where collective buffers live
 
     def barrier():
         if dist is not None:
@@ -286,7 +299,7 @@ def main():
     def allmax(x):
         if dist is None:
             return float(x)
-        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        t = torch.tensor([x], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -294,9 +307,9 @@ def main():
         """ranks_seen = all-reduce(sum) of ones; per-rank mean kernel time gathered to every rank."""
         if dist is None:
             return 1, [float(k_ms)]
-        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        ones = torch.ones(1, device=cdev, dtype=torch.int32)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
-        mine = torch.tensor([k_ms], device=dev, dtype=torch.float64)
+        mine = torch.tensor([k_ms], device=cdev, dtype=torch.float64)
         parts = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(parts, mine)
         return int(ones.item()), [float(p.item()) for p in parts]
@@ -315,7 +328,7 @@ def main():
         for i in range(args.warmup):
             model.render_views(poses_d[i], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
         if dist is not None:          # untimed: bring up the RCCL channels the timed all_gather will use (same shape)
-            dummy = torch.zeros((args.steps, H * W, 3), device=model.device)
+            dummy = torch.zeros((args.steps, H * W, 3), device=cdev)
             dist.all_gather([torch.empty_like(dummy) for _ in range(world)], dummy)
             del dummy
         barrier()
@@ -326,7 +339,7 @@ def main():
             kernel_ms.append(model.last_kernel_ms())      # HIP events on the launch stream (syncs on the stop event)
             images.append(out["rgb_map"])
         if dist is not None:                                # outer-loop boundary: gather the rendered images
-            mine = torch.stack(images, 0)
+            mine = torch.stack(images, 0).to(cdev)
             gathered = [torch.empty_like(mine) for _ in range(world)]
             dist.all_gather(gathered, mine)
         barrier()
@@ -344,7 +357,9 @@ def main():
                                        "persistent kernel (x16: 2 workgroups per CU, %s schedule), rays generated "
                                        "in-kernel" % model.schedule,
                            "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
-                           "parallelism": "views sharded over %d GPU(s), image all-gather at the end" % world},
+                           "parallelism": "views sharded over %d rank(s), image all-gather (%s) at the end%s"
+                                          % (world, "RCCL" if args.backend == "nccl" else "gloo via the host",
+                                             "; ranks SHARE a GPU (validation run)" if args.share_gpu else "")},
                 "rays_per_s": round(rays / dt, 1), "mlp_evals_per_s": round(rays * EVALS_PER_RAY / dt, 1),
                 "ranks_seen": ranks_seen,
                 "kernel_ms_per_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),

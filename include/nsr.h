@@ -61,15 +61,19 @@ typedef struct NsrConfig {
                               workgroups per CU (needs nsr_upload_weights16 / _bwd16); 32 = 32 points/wave, one
                               workgroup per CU (nsr_upload_weights / _bwd)                                   */
   int32_t flags;           /* NSR_FLAG_* render options (0 = the YCB-V configuration)                */
-  int32_t chunk;           /* x16 kernel: rays per chunk of the work queue; 0 = default (1).  Larger chunks trade
-                              load balance for L2 locality of the weight streams ("Chunk queue")  */
+  int32_t chunk;           /* x16 kernel, per-ray queue: rays per chunk of the work queue; 0 = default (1).  Larger chunks
+                              trade load balance for L2 locality of the weight streams ("Chunk queue").
+                              With NSR_FLAG_SCHED_PHASES: chunk - 1 = how many times a fine task looks for the handed-
+                              over depths before it recomputes them (0 = default 64 looks; 1 = never look: test hook)  */
 } NsrConfig;
 
 #define NSR_FLAG_WHITE_BKGD 1   /* white_bkgd (RN:384-385): rgb_map += 1 - acc_map, coarse and fine; also in the VJP */
 #define NSR_FLAG_LINDISP    2   /* lindisp (RN:443): coarse samples linear in inverse depth                          */
 #define NSR_FLAG_SCHED_PHASES 4 /* x16 forward kernel: "global phases" work schedule (k_render16p) -- bit-identical
                                    results; every workgroup streams the same network most of the time, which cuts the
-                                   L2-miss (fabric) traffic of the weight streams; see DESIGN.md 4 for speed vs traffic */
+                                   L2-miss (fabric) traffic of the weight streams; see DESIGN.md 4 for speed vs traffic.
+                                   The cross-workgroup hand-off it uses is non-blocking: a value that is not there in
+                                   time is recomputed locally (nsr_schedule_stats counts those rays)                   */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {
@@ -212,6 +216,11 @@ int nsr_sample_pose_nograd(nsr_handle h, const double* d_logits, const double* d
 
 /* Device self-test of the MFMA fragment-layout assumptions the packer relies on. Returns 0 if they hold. */
 int nsr_selftest(nsr_handle h, void* stream);
+
+/* Global-phases schedule: number of rays (cumulative over the handle's launches) whose fine task recomputed the coarse
+ * pass because the handed-over depths were not there in time -- 0 in normal operation, > 0 when the GPU is shared with
+ * other work; never an error.  0 for handles without NSR_FLAG_SCHED_PHASES.  Synchronises the device. */
+int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays);
 
 /* Debug build (`make -C neural_sim_nerf_amd/csrc debug` -> libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent
  * LDS / scratch index of the kernels (searchsorted results, merge ranks, hand-off slots) is range-checked; a violation

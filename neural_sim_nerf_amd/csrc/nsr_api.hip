@@ -138,7 +138,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   nsr_handle h = new nsr_handle_s();
   h->cfg = *cfg;
   h->n_cu = prop.multiProcessorCount;
-  h->chunk = cfg->chunk > 0 ? cfg->chunk : 1;
+  h->chunk = (cfg->chunk > 0 && !(cfg->flags & NSR_FLAG_SCHED_PHASES)) ? cfg->chunk : 1;
   // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
   NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
   for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
@@ -311,6 +311,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     a.sched_flags = h->d_sched_flags;
     a.status = h->d_status;
     a.super_lg = kSuperLg;
+    a.spin_max = h->cfg.chunk > 0 ? h->cfg.chunk - 1 : 64;   // looks at the ready flag before recomputing locally
     a.chunk = 1;
     NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
   } else if (x16) {
@@ -653,6 +654,16 @@ int nsr_selftest(nsr_handle h, void* stream) {
   return 0;
 }
 
+int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays) {
+  if (!h || !recomputed_rays) return fail("nsr_schedule_stats: null argument");
+  *recomputed_rays = 0u;
+  if (!h->d_status) return 0;                              // per-ray queue: nothing is ever handed over
+  NSR_DEVICE(h);
+  NSR_HIP(hipDeviceSynchronize());
+  NSR_HIP(hipMemcpy(recomputed_rays, h->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int nsr_debug_bounds_status(nsr_handle h, int* built_with_checks, unsigned* first_bad_line) {
   if (!h || !built_with_checks || !first_bad_line) return fail("nsr_debug_bounds_status: null argument");
   *first_bad_line = 0u;
@@ -673,11 +684,6 @@ int nsr_last_kernel_ms(nsr_handle h, float* ms) {
   NSR_DEVICE(h);
   NSR_HIP(hipEventSynchronize(h->ev1));
   NSR_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
-  if (h->d_status) {                                       // global-phases schedule: did any hand-off wait time out?
-    unsigned st = 0;
-    NSR_HIP(hipMemcpy(&st, h->d_status, sizeof(st), hipMemcpyDeviceToHost));
-    if (st != 0) return fail("k_render16p: a z hand-off wait timed out (results of that launch are invalid)");
-  }
   return 0;
 }
 

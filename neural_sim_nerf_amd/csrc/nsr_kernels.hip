@@ -109,6 +109,18 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   rg.pnet_off = rg.dd ? named : net * (int)rg.stride;
 }
 
+// The ring's scalar state is wave-uniform by construction.  When it is rewritten under control flow the compiler cannot
+// prove uniform (k_render16p's ring restart), SIFixSGPRCopies moves the whole state to VGPRs and every LDS-DMA load gets
+// a waterfall loop; re-asserting uniformity once per pass keeps it in SGPRs.
+__device__ __forceinline__ void ring_assert_uniform(Ring& rg) {
+  rg.pslab = __builtin_amdgcn_readfirstlane(rg.pslab);
+  rg.pslot = __builtin_amdgcn_readfirstlane(rg.pslot);
+  rg.pphase = __builtin_amdgcn_readfirstlane(rg.pphase);
+  rg.cslot = __builtin_amdgcn_readfirstlane(rg.cslot);
+  rg.pnet_off = __builtin_amdgcn_readfirstlane(rg.pnet_off);
+  rg.pnet_next = __builtin_amdgcn_readfirstlane(rg.pnet_next);
+}
+
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
 // A step = 4 chunks of 1 KiB = 4 float4 fragments per lane = 16 MFMAs; a slab = 4 steps.
 template <int NS = kRingSlots>
@@ -716,8 +728,9 @@ struct RenderArgs {
   float* zf_scratch;        // k_render16: [grid][chunk][192] sorted fine z values between the two phases of a chunk
   int chunk;                // k_render16: rays per workgroup per phase
   unsigned* sched_flags;    // k_render16p: [2][3 * super_rays] ready / taken generations of the z hand-off slots (zeroed per launch)
-  unsigned* status;         // k_render16p: set non-zero if a hand-off wait timed out (never expected; bounds every spin)
+  unsigned* status;         // k_render16p: number of fine tasks that recomputed their coarse pass (hand-off not there in time)
   int super_lg;             // k_render16p: log2 of the rays per super-chunk
+  int spin_max;             // k_render16p: looks at the ready flag before a fine task recomputes locally
   unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays
 };
 
@@ -1685,29 +1698,23 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
 // rays and ONE global queue hands out, per super-chunk, first its S coarse tasks (1 pass each) and then its S fine tasks
 // (3 passes each): all workgroups work on the same network most of the time whatever their individual speed, and any
 // workgroup may run the fine task of a ray whose coarse task another workgroup ran.
-//   * hand-off: the coarse task leaves the ray's 192 sorted z values in slot (ray mod 3S) of a global ring, written with
-//     agent-scope (sc1, write-through) stores, drained (vmcnt(0)) before lane 0 publishes ready[slot] = k + 1 (k = super-
-//     chunk); the fine task polls ready (one lane, relaxed agent loads, s_sleep), reads with agent-scope loads and then
-//     publishes taken[slot] = k + 1; the coarse task of super-chunk k + 3 waits for that before it reuses the slot.
-//     Every wait points at a task with a smaller queue index and waits happen only at task start, so the dependency
-//     graph is acyclic and all workgroups are resident (grid <= 2 per CU): no deadlock.  Every spin is bounded anyway;
-//     a timeout raises *status and disables further waiting.
+//   * hand-off: the coarse task leaves the ray's 192 sorted z values in slot (ray mod 3S) of a global ring.  The
+//     hand-off is an OPTIMISATION, never a dependency: nothing in this kernel blocks on another workgroup.
+//       - publisher (coarse task of super-chunk k): if the slot's previous content (super-chunk k-3) has been consumed
+//         (taken[slot] == k-2, one non-blocking look), it marks the slot busy, writes the values with agent-scope
+//         (sc1, write-through) stores, drains them (vmcnt(0)) and publishes ready[slot] = k+1; otherwise it skips;
+//       - consumer (fine task): one lane polls ready[slot] == k+1 at most `spin_max` times (default 64, about the time
+//         of one network pass), all lanes read with agent-scope loads, one lane re-reads the flag (seqlock: a publisher
+//         of a later generation raises "busy" before it touches the data) and sets taken[slot] = k+1.  If the value
+//         never showed up or changed under the read, the workgroup RECOMPUTES the coarse pass of that ray itself
+//         (ring reset to the coarse network, one extra pass, identical arithmetic -> identical bits) and carries on.
+//     So the result never depends on timing, residency or what else runs on the GPU (other streams, other processes:
+//     a descheduled publisher costs the consumer one extra pass); RenderArgs::status counts the recomputed rays.
 //   * the LDS-DMA producer runs two slabs ahead of the consumer, across pass boundaries, so the network of the pass
 //     AFTER the current one must be known when a pass starts: each workgroup holds its current AND its next task
 //     (the queue is pulled one task ahead) and names the following network in rg.pnet_next (Ring::dd).
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spin_until(const unsigned* flag, unsigned want, unsigned* status) {
-#ifdef NSR_EXP_NOSPIN        // timing experiment only (unsafe)
-  return;
-#endif
-  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-#pragma unroll 1
-  for (int it = 0; it < (1 << 18); ++it) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return;
-    __builtin_amdgcn_s_sleep(16);
-  }
-  __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+constexpr unsigned kSlotBusy = 0xffffffffu;
 
 __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1728,13 +1735,20 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
   const long long S = 1ll << lg;
   Ring rg;                                                 // (before any control flow: the descriptor stays in SGPRs)
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1, wave, lane);
-  long long* task_slot = (long long*)&st.res[0][6];        // 8-byte LDS slot that broadcasts a task id
+  long long* task_slot = (long long*)&st.res[0][6];        // 8-byte LDS slot that broadcasts a task id / a flag
   auto pull = [&]() -> long long {
     if (opaque_v(tid0) == 0) *task_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
     __syncthreads();
     const long long tv = uniform64(*task_slot);
     __syncthreads();
     return tv;
+  };
+  auto vote = [&](bool mine) -> bool {                     // thread 0's verdict for the whole workgroup
+    if (opaque_v(tid0) == 0) *task_slot = mine ? 1 : 0;
+    __syncthreads();
+    const bool v = uniform64(*task_slot) != 0;
+    __syncthreads();
+    return v;
   };
   // task t -> (super-chunk k, fine?, ray): super-chunk k owns ids [2kS, 2kS + 2 S_k), coarse tasks first
   auto decode = [&](long long t, long long& k, bool& is_fine, long long& ray) {
@@ -1769,19 +1783,27 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLds16Aux);
 
-  int pass = cur_fine ? 1 : 0;                             // 0 = the coarse task's pass, 1..3 = the fine task's passes
+  int pass = cur_fine ? 1 : 0;                             // 0 = a coarse pass, 1..3 = the fine task's passes
+  int local = 0;     // 0: normal; 1: this fine task is recomputing its own coarse pass; 2: ... and resumes its fine passes
 #pragma unroll 1
   while (true) {
     const long long slots = 3 * S;
     const long long slot = NSR_IDX64(rr % slots, slots);
-    if (pass <= 1) {                                       // a task starts
+    if (pass <= 1 && local == 0) {                         // a task starts
       const RenderArgs& a = *opaque_s(ap);
       const int tid = opaque_v(tid0);
       unsigned* ready = a.sched_flags;
       unsigned* taken = a.sched_flags + slots;
+      const unsigned gen = (unsigned)(k + 1);
+      bool got = false;
       if (tid == 0) {
-        if (pass == 1) spin_until(ready + slot, (unsigned)(k + 1), a.status);            // the coarse task's results
-        else if (k >= 3) spin_until(taken + slot, (unsigned)(k - 2), a.status);          // the slot's previous reader
+        if (pass == 1) {                                   // is the coarse task's result there?  (bounded look)
+#pragma unroll 1
+          for (int it = 0; it < a.spin_max && !got; ++it) {
+            got = __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
+            if (!got) __builtin_amdgcn_s_sleep(16);
+          }
+        }
         const float near_ = a.near_, far_ = a.far_;
         float o[3], d[3];
         if (a.camera) {
@@ -1799,28 +1821,47 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
         st.ray[0][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
-      __syncthreads();                                     // the wait is over for the whole workgroup
+      if (pass == 1) {
+        got = vote(got);
+        if (got) {
+          if (tid < 192)
+            st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)a.zf_scratch + slot * 192 + tid,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          __syncthreads();                                 // every lane's value has arrived (it was written to LDS)
+          // seqlock: still the same generation?  (a later publisher raises "busy" before it writes)
+          got = vote(tid == 0 && __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen);
+        }
+        if (tid == 0) {
+          __hip_atomic_store(taken + slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed or given up
+          if (!got) atomicAdd(a.status, 1u);
+        }
+        if (!got) {
+          // recompute the coarse pass of this ray here: restart the weight stream on the coarse network
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          rg.pslab = 0; rg.pslot = 0; rg.cslot = 0;
+          rg.pnet_off = 0;
+          ring_start<kRing16>(rg, A0, lane);
+          local = 1;
+          pass = 0;
+        }
+      }
       if (pass == 0) {
         if (tid < 64) st.zc[0][tid] = coarse_z(a.near_, a.far_, a.tcoarse[tid], a.lindisp);
-        __syncthreads();
-      } else {
-        if (tid < 192)
-          st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)a.zf_scratch + slot * 192 + tid,
-                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        __syncthreads();                                   // every lane's value has arrived (it was written to LDS)
-        if (tid == 0) __hip_atomic_store(taken + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      __syncthreads();
     }
     NSR_T(0);
     {
       // the network of the pass AFTER this one: the fine net inside a fine task, else the first pass of the next task
       bool nf = true;
-      if (pass == 0 || pass == 3) {
+      if ((pass == 0 && local == 0) || pass == 3) {
         long long k2, r2;
         nf = cur_fine;
         if (nxt < total) decode(nxt, k2, nf, r2);
       }
       rg.pnet_next = nf ? fine_off : 0;
+      ring_assert_uniform(rg);
     }
 
     // one network pass: 64 points; coarse: sample 16w + j; fine p: sample 64(p-1) + 16w + j
@@ -1829,8 +1870,8 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       const float z = (pass == 0) ? st.zc[0][i] : st.zf[0][i];
       const float* ry = st.ray[0];
       float raw[4];
-      mlp_pass16(rg, aux_c + (pass == 0 ? 0 : kAux16Floats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
-                 ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
+      mlp_pass16<false, true>(rg, aux_c + (pass == 0 ? 0 : kAux16Floats), A0, A1, lane, ry[0] + ry[3] * z,
+                              ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
 
@@ -1845,7 +1886,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         __syncthreads();
       }
       composite<64, 1>(st, &st.zc[0][0], &st.rawf[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
-      if (tid < 8) {
+      if (tid < 8) {                                       // (a recomputing fine task rewrites identical values)
         const int c = tid;
         const float v = st.res[0][c];
         if (c < 3) { if (a.rgb0) a.rgb0[rr * 3 + c] = v; }
@@ -1867,23 +1908,39 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       }
       if (a.dbg_zs && tid < 128) a.dbg_zs[rr * 128 + tid] = st.zs[0][tid];
       merge_sort_item<1>(st, tid);
+      if (a.dbg_zf && tid < 192) a.dbg_zf[rr * 192 + tid] = st.zf[0][tid];
       NSR_T(2);
-      if (tid < 192) {
-        const float zv = st.zf[0][tid];
-        __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(zv), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        if (a.dbg_zf) a.dbg_zf[rr * 192 + tid] = zv;
+      if (local == 1) {                                    // the fine passes follow right here, on the values in LDS
+        local = 2;                                         // (pass 1 must not look like the start of a task)
+        pass = 1;
+      } else {
+        // publish for the fine task -- if the slot's previous content has been consumed; never wait for it
+        unsigned* ready = a.sched_flags;
+        unsigned* taken = a.sched_flags + slots;
+        bool can = false;
+        if (tid == 0) {
+          can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k - 2);
+          if (can) {
+            __hip_atomic_store(ready + slot, kSlotBusy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // "busy" is out before any value is
+          }
+        }
+        can = vote(can);
+        if (can) {
+          if (tid < 192)
+            __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(st.zf[0][tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores have left (write-through) before the flag is raised
+          __syncthreads();
+          if (tid == 0)
+            __hip_atomic_store(ready + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        NSR_T(3);
+        task_done = true;
       }
-#ifndef NSR_EXP_NODRAIN      // timing experiment only (unsafe)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my stores have left (write-through) before the flag is raised
-#endif
-      __syncthreads();
-      if (tid == 0)
-        __hip_atomic_store(a.sched_flags + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      NSR_T(3);
-      task_done = true;
     } else if (pass < 3) {
       ++pass;
+      local = 0;
     } else {
       __syncthreads();
       if (a.dbg_raw) {

@@ -320,6 +320,13 @@ class NsrModel:
     def selftest(self):
         _lib.check(self.lib.nsr_selftest(self.h, _stream_ptr(self.device)))
 
+    def schedule_stats(self):
+        """Rays (cumulative) whose fine task recomputed its coarse pass instead of using the handed-over depths
+        (global-phases schedule; 0 in normal operation and for the per-ray queue)."""
+        n = C.c_uint()
+        _lib.check(self.lib.nsr_schedule_stats(self.h, C.byref(n)))
+        return int(n.value)
+
     def debug_bounds_status(self):
         """(built_with_checks, first_bad_source_line): see nsr_debug_bounds_status / `make debug`."""
         built, line = C.c_int(), C.c_uint()

@@ -740,32 +740,38 @@ def test_x16_chunked_schedule_is_result_invariant(model16, synth_nets, monkeypat
 
 def test_phases_schedule_is_result_invariant(model16, synth_nets, oracle):
     """NSR_FLAG_SCHED_PHASES (k_render16p, global phases: coarse and fine tasks of a ray may run on different
-    workgroups, z values handed over through a global ring with ready/taken flags) gives bit-identical results to the
-    default per-ray queue: a batch smaller than one super-chunk (4096 rays), and 3 views of 110x110 = 36 300 rays = 9
-    super-chunks, so that every hand-off slot is reused (slot = ray mod 12 288) and the taken-flag wait is exercised;
-    no hand-off wait may time out (last_kernel_ms raises if one did)."""
-    import torch
+    workgroups, the sorted depths handed over through a global ring) gives bit-identical results to the per-ray queue:
+    a batch smaller than one super-chunk (4096 rays), and 3 views of 110x110 = 36 300 rays = 9 super-chunks, so that
+    every hand-off slot is reused (slot = ray mod 12 288).  The hand-off is non-blocking: with `chunk=1` ("never look")
+    every fine task recomputes its coarse pass itself, with `chunk=2` (one look) some do -- same bits either way, and
+    schedule_stats counts them; in normal operation none does."""
     from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
-    mp = NsrModel(synth_nets[0], synth_nets[1], schedule="phases")
-    assert mp.schedule == "phases" and model16.schedule == "queue"      # (the engine's default is "phases")
     ro = np.tile(g["rays_o"], (8, 1))[:1500 + 7]
     rd = np.tile(g["rays_d"], (8, 1))[:1500 + 7]
-    want = model16.render_rays(ro, rd, near, far, debug=True)
-    got = mp.render_rays(ro, rd, near, far, debug=True)
-    mp.last_kernel_ms()
-    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std", "z_fine", "inds", "raw", "raw0", "weights0"):
-        assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), k
     poses = np.asarray(oracle.sweep_poses(3, seed=4))
     K = oracle.scaled_K(400.0 / 110)
-    for rep in range(2):                                   # twice: the flags are reset by every launch
-        want = model16.render_views(poses, 110, 110, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)
-        got = mp.render_views(poses, 110, 110, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)
-        mp.last_kernel_ms()
-        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
-            assert np.array_equal(cpu(got[k]), cpu(want[k]), equal_nan=True), (rep, k)
-    mp.close()
+    want_r = model16.render_rays(ro, rd, near, far, debug=True)
+    want_v = model16.render_views(poses, 110, 110, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    assert model16.schedule == "queue" and model16.schedule_stats() == 0
+    for looks, expect in ((None, "none"), (1, "all"), (2, "any")):
+        mp = NsrModel(synth_nets[0], synth_nets[1], schedule="phases", chunk=looks)
+        assert mp.schedule == "phases"
+        got = mp.render_rays(ro, rd, near, far, debug=True)
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std", "z_fine", "inds", "raw", "raw0", "weights0"):
+            assert np.array_equal(cpu(got[k]), cpu(want_r[k]), equal_nan=True), (looks, k)
+        n1 = mp.schedule_stats()
+        for rep in range(2):                               # twice: the flags are reset by every launch
+            got = mp.render_views(poses, 110, 110, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)
+            for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
+                assert np.array_equal(cpu(got[k]), cpu(want_v[k]), equal_nan=True), (looks, rep, k)
+        n2 = mp.schedule_stats()
+        if expect == "none":
+            assert n1 == 0 and n2 == 0, (n1, n2)           # an exclusive GPU: every hand-off arrives in time
+        elif expect == "all":
+            assert n1 == ro.shape[0] and n2 == n1 + 2 * 3 * 110 * 110, (n1, n2)
+        mp.close()
 
 
 def test_full_size_view_properties(synth_nets, oracle):
@@ -783,7 +789,7 @@ def test_full_size_view_properties(synth_nets, oracle):
     full = mp.render_views(poses[0], 400, 400, K, near, far)
     again = mp.render_views(poses[0], 400, 400, K, near, far)
     fq = mq.render_views(poses[0], 400, 400, K, near, far)
-    mp.last_kernel_ms()
+    assert mp.schedule_stats() == 0
     keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
     for k in keys:
         assert np.array_equal(cpu(full[k]), cpu(again[k]), equal_nan=True), k          # deterministic
@@ -941,3 +947,71 @@ def test_x16_coarse_only_config1(oracle, synth_nets):
     assert_close(cpu(r["rgb_map"]).reshape(64, 64, 3), g["rgb_c1"], atol=1e-5, what="config-1 rgb")
     assert_close(cpu(r["acc_map"]).reshape(64, 64), g["acc_c1"], atol=1e-5, what="config-1 acc")
     m1.close()
+
+
+# ------------------------------------------------------------------------------------------------------
+# N > 1 on hardware: every gpurun box has ONE GPU, so RCCL cannot run with two ranks; the same code path (process
+# group, self-sharding drop-in API, real kernels) runs here with two ranks sharing cuda:0 over gloo.
+# ------------------------------------------------------------------------------------------------------
+def _two_rank_worker(rank, world, port, tmp, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import nerf_oracle as O
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd import pose as P
+    nets = []
+    for sd in (O.synth_weights(0), O.synth_weights(1000, fine_of=O.synth_weights(0))):
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=O.YCBV_NEAR, far=O.YCBV_FAR)
+    H = W = 24
+    K = O.scaled_K(400.0 / H)
+    poses = torch.as_tensor(np.asarray(O.sweep_poses(3, seed=8)))
+    rgbs, disps = R.render_path(None, poses, [H, W, K[0][0]], K, 1024, kw, savedir=tmp, object_id=5)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g10_path_grad.npz"))
+    log = {"gumbel_noises": g["gumbel"].tolist(), "uniform_noises": g["uniform"].tolist(), "thetas": g["thetas"].tolist()}
+    prob = torch.softmax(torch.tensor(g["psi"]) / 0.25, 0).requires_grad_()
+    pg = P.sample_pose(prob, 2, 0.1, log)
+    grad_E = [{"grad_E": [torch.from_numpy(x)]} for x in g["grad_E"]]
+    Kg = g["K"].tolist()
+    r2, dl = R.render_path_grad(prob, pg, [8, 8, Kg[0][0]], Kg, 16, grad_E, kw, savedir=None)
+    os.environ["NSR_AUTO_SHARD"] = "0"
+    rgbs1, disps1 = R.render_path(None, poses, [H, W, K[0][0]], K, 1024, kw)
+    r21, dl1 = R.render_path_grad(prob, pg, [8, 8, Kg[0][0]], Kg, 16, grad_E, kw, savedir=None)
+    ok = np.array_equal(rgbs, rgbs1) and np.array_equal(disps, disps1, equal_nan=True) and np.array_equal(r2, r21)
+    ok = ok and len(dl) == len(dl1) == 8 and all(torch.equal(a, b) for a, b in zip(dl, dl1))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_shard_the_dropin_api(tmp_path):
+    """World size 2 with the REAL kernels (both ranks on cuda:0, gloo): render_path / render_path_grad shard their
+    poses over the ranks, gather, and every rank returns what the unsharded call returns, bit for bit; the PNGs of all
+    poses exist."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+    assert sorted(os.listdir(tmp_path / "5")) == ["000.png", "001.png", "002.png"]
