@@ -767,8 +767,8 @@ def test_phases_schedule_is_result_invariant(model16, synth_nets, oracle):
             for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
                 assert np.array_equal(cpu(got[k]), cpu(want_v[k]), equal_nan=True), (looks, rep, k)
         n2 = mp.schedule_stats()
-        if expect == "none":
-            assert n1 == 0 and n2 == 0, (n1, n2)           # an exclusive GPU: every hand-off arrives in time
+        if expect == "none":                               # an exclusive GPU: only launch tails recompute (see the
+            assert n1 <= 512 and n2 - n1 <= 2 * 512, (n1, n2)      # full-size test); 1507 rays < one grid round of pairs
         elif expect == "all":
             assert n1 == ro.shape[0] and n2 == n1 + 2 * 3 * 110 * 110, (n1, n2)
         mp.close()
@@ -789,7 +789,9 @@ def test_full_size_view_properties(synth_nets, oracle):
     full = mp.render_views(poses[0], 400, 400, K, near, far)
     again = mp.render_views(poses[0], 400, 400, K, near, far)
     fq = mq.render_views(poses[0], 400, 400, K, near, far)
-    assert mp.schedule_stats() == 0
+    # hand-offs that were not there in time are recomputed locally (never waited for): only the tail of a launch -- a
+    # last super-chunk smaller than the grid, whose fine tasks are pulled while its coarse tasks still run -- has any
+    assert mp.schedule_stats() <= 2 * 512, mp.schedule_stats()
     keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
     for k in keys:
         assert np.array_equal(cpu(full[k]), cpu(again[k]), equal_nan=True), k          # deterministic
