@@ -1412,9 +1412,9 @@ __device__ __forceinline__ f32x4 apply_mask4(f32x4 x, unsigned word, int shift) 
   return r;
 }
 
-// LOCAL_G: derive the per-group encoding constants (frequency, sin/cos, axis of column 15 g + t) from an opaque copy of
-// the lane group inside the pass instead of letting them be hoisted out of the kernel's main loop -- for kernels whose
-// other passes need the registers (k_render_vjp16); k_render16 keeps them resident (as lane masks in SGPRs).
+// LOCAL_G: derive everything that depends on the lane group (the two encoding constants, the aux base) from an opaque
+// copy of it inside the pass instead of letting it be hoisted out of the kernel's main loop -- for the kernel whose other
+// passes need every register (k_render_vjp16).
 template <bool CAPTURE = false, bool LOCAL_G = false>
 __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                            float px, float py, float pz, float vx, float vy, float vz,
@@ -1426,12 +1426,13 @@ __device__ __forceinline__ void mlp_pass16(Ring& rg, const float* aux, f32x4 (&A
   {
     const float p[3] = {enc_domain(px, kMultires), enc_domain(py, kMultires), enc_domain(pz, kMultires)};
     const float v[3] = {enc_domain(vx, kMultiresViews), enc_domain(vy, kMultiresViews), enc_domain(vz, kMultiresViews)};
+    // position columns: lane group g holds sin (g even) or cos (g odd) of the five octaves 5 (g >> 1) + f, f = t / 3,
+    // of axis t % 3 -- so only TWO per-lane constants exist (the group's base scale and its sin/cos selector) and the
+    // rest of the column assignment is compile-time (pack.py: eps16)
+    const float base = (g & 2) ? 32.0f : 1.0f;
+    const int sc = g & 1;
 #pragma unroll
-    for (int t = 0; t < 15; ++t) {
-      const int q = 15 * g + t, L = q / 6, sc = (q % 6) / 3, ax = q % 3;
-      const float x = ax == 0 ? p[0] : (ax == 1 ? p[1] : p[2]);
-      e[t] = enc_trig(ldexpf(x, L), sc);
-    }
+    for (int t = 0; t < 15; ++t) e[t] = enc_trig(p[t % 3] * ((float)(1 << (t / 3)) * base), sc);
 #pragma unroll
     for (int t = 0; t < 6; ++t) ed[t] = enc_trig(ldexpf(v[t % 3], g), t >= 3);
     e[15] = g == 0 ? px : (g == 1 ? py : (g == 2 ? pz : 0.0f));
@@ -1870,7 +1871,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       const float z = (pass == 0) ? st.zc[0][i] : st.zf[0][i];
       const float* ry = st.ray[0];
       float raw[4];
-      mlp_pass16<false, true>(rg, aux_c + (pass == 0 ? 0 : kAux16Floats), A0, A1, lane, ry[0] + ry[3] * z,
+      mlp_pass16<false, false>(rg, aux_c + (pass == 0 ? 0 : kAux16Floats), A0, A1, lane, ry[0] + ry[3] * z,
                               ry[1] + ry[4] * z, ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 16) *(f32x4*)st.rawf[0][i] = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
@@ -1982,7 +1983,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
 // backward, three backward passes through the transposed fine network (pack_network_backward16), per-ray reduction.
 // ------------------------------------------------------------------------------------------------------
 // d(encoding)/d(x) for the x16 encoding registers: lane group g holds G[t] = dL/d e[t] of ITS registers
-// (t < PER: column q = PER g + t -> frequency q / 6, sin or cos, axis q % 3; t = PER: identity column g).
+// (t < PER: see mlp_pass16 for the column each register holds; t = PER: identity column g).
 // Returns this group's contribution; the caller adds the four groups.
 template <int NFREQ>
 __device__ __forceinline__ void embed_bwd16(const float (&x)[3], const float* G, int g, float (&out)[3]) {
@@ -1997,14 +1998,10 @@ __device__ __forceinline__ void embed_bwd16(const float (&x)[3], const float* G,
       const int sc = t / 3, ax = t % 3;
       const float f = ldexpf(1.0f, g);
       out[ax] = __builtin_fmaf(f * G[t], enc_trig(xd[ax] * f, 1 + sc), out[ax]);   // d sin = f cos, d cos = -f sin
-    } else {
-      const int q = PER * g + t, L = q / 6, sc = (q % 6) / 3, ax = q % 3;
-      const float xa = ax == 0 ? xd[0] : (ax == 1 ? xd[1] : xd[2]);
-      const float f = ldexpf(1.0f, L);
-      const float c = (f * G[t]) * enc_trig(xa * f, 1 + sc);
-      out[0] += ax == 0 ? c : 0.0f;
-      out[1] += ax == 1 ? c : 0.0f;
-      out[2] += ax == 2 ? c : 0.0f;
+    } else {                               // PER = 15: octave 5 (g >> 1) + t / 3, sin (g even) / cos (g odd), axis t % 3
+      const int ax = t % 3;
+      const float f = (float)(1 << (t / 3)) * ((g & 2) ? 32.0f : 1.0f);
+      out[ax] = __builtin_fmaf(f * G[t], enc_trig(xd[ax] * f, 1 + (g & 1)), out[ax]);
     }
   }
 }

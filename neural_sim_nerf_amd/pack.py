@@ -207,11 +207,17 @@ def kappa16(t, g):
 
 
 def eps16(t, g, n_freq):
-    """Reference embedding column held in encoding register t of lane group g (-1 = padding).  The 6*n_freq
-    sin/cos columns (reference order, after the 3 identity columns) are dealt 6*n_freq/4 per group; the next
-    register holds the identity column g (x, y, z, pad)."""
+    """Reference embedding column held in encoding register t of lane group g (-1 = padding).  The 6*n_freq sin/cos
+    columns (reference order after the 3 identity columns: per frequency L, sin xyz then cos xyz) are dealt
+    6*n_freq/4 per group; the next register holds the identity column g (x, y, z, pad).
+      directions (n_freq = 4): group g holds frequency g: t = 3*sc + axis;
+      positions (n_freq = 10): group g holds sin (g even) or cos (g odd) of octaves 5*(g >> 1) + t // 3, axis t % 3 --
+        the kernel then needs two per-lane constants instead of fifteen (frequency, sin/cos, axis per register)."""
     per_group = 6 * n_freq // 4
     if t < per_group:
+        if n_freq == 10:
+            L, sc, ax = 5 * (g >> 1) + t // 3, g & 1, t % 3
+            return 3 + 6 * L + 3 * sc + ax
         return 3 + per_group * g + t
     if t == per_group:
         return g if g < 3 else -1

@@ -194,13 +194,20 @@ class Stream16(Stream):
                 acc[mo] = mfma16(frag[:, kk], bop(4 * tq + kk), acc[mo])
 
 
+def _enc16_column(t, g, nfreq):
+    """(octave, sin/cos, axis) of encoding register t in lane group g, as csrc mlp_pass16 assigns them."""
+    if nfreq == 10:
+        return 5 * (g >> 1) + t // 3, g & 1, np.full_like(g, t % 3)
+    q = (6 * nfreq // 4) * g + t                       # directions: group g = octave g, t = 3 sc + axis
+    return q // 6, (q % 6) // 3, q % 3
+
+
 def _encode16(X, nfreq, n):
     g = LANE >> 4
     per = 6 * nfreq // 4
     e = np.zeros((n, 64), np.float32)
     for t in range(per):
-        q = per * g + t
-        L, sc, ax = q // 6, (q % 6) // 3, q % 3
+        L, sc, ax = _enc16_column(t, g, nfreq)
         arg = (X[LANE, ax] * np.exp2(L).astype(np.float32)).astype(np.float32)
         e[t] = np.where(sc == 1, np.cos(arg), np.sin(arg)).astype(np.float32)
     e[per] = np.where(g < 3, X[LANE, np.minimum(g, 2)], 0.0)
@@ -269,8 +276,7 @@ def _embed_bwd16(X, G, nfreq):
     for ax in range(3):
         out[ax] = np.where(g == ax, G[per], 0.0)
     for t in range(per):
-        q = per * g + t
-        L, sc, ax = q // 6, (q % 6) // 3, q % 3
+        L, sc, ax = _enc16_column(t, g, nfreq)
         f = np.exp2(L).astype(np.float32)
         arg = (X[LANE, ax] * f).astype(np.float32)
         c = f * G[t] * np.where(sc == 1, -np.sin(arg), np.cos(arg))

@@ -78,6 +78,14 @@ def test_kappa_is_a_permutation():
     assert sorted(c for c in cols if c >= 0) == list(range(27))
 
 
+def test_eps16_covers_every_embedding_column_once():
+    from neural_sim_nerf_amd.pack import eps16
+    for n_freq, regs in ((10, 16), (4, 8)):
+        cols = [eps16(t, g, n_freq) for t in range(regs) for g in range(4)]
+        used = sorted(c for c in cols if c >= 0)
+        assert used == list(range(3 + 6 * n_freq)), (n_freq, used)
+
+
 def test_packer_through_kernel_emulation(oracle, synth_nets):
     """Lane-level numpy emulation of one wave of the kernel's forward and backward network pass, fed with the
     packed streams, against the oracle: pins pack.py and the kernel's fragment indexing on the CPU."""
