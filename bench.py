@@ -220,7 +220,7 @@ def pmc_traffic(pmc_file, schedule="phases"):
         return None, ("PMC profile %s was collected from other kernel sources (%s..., this tree %s...): not reported"
                       % (os.path.relpath(pmc_file, ROOT), str(prof.get("kernel_source_sha256"))[:12], here[:12]))
     blob = hashlib.sha1(b"blob %d\0" % os.path.getsize(pmc_file) + open(pmc_file, "rb").read()).hexdigest()
-    key = "x16_phases_schedule" if schedule == "phases" else "x16_default"
+    key = "x16_phases_schedule" if schedule == "phases" else "x16_queue_schedule"
     if key not in prof:
         return None, "PMC profile %s has no passes for the %s schedule" % (os.path.relpath(pmc_file, ROOT), schedule)
     t = prof[key]["derived"]["hbm_traffic_bytes_per_launch"]

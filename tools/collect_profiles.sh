@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects what profiles/rNN holds, on the GPU box (run through gpurun from the repo root):
 #   bench line, rocprofv3 kernel stats of the same command, separate --pmc passes (counters only + kernel trace) for
-#   the default forward kernel (bench.py), the same kernel with the global-phases schedule (tools/one_view.py 16 0
-#   phases), the x32 forward kernel (tools/one_view.py 32) and the VJP kernel (tools/bench_vjp.py), kernel stats of the VJP and of the hand-off kernels, and the sha256 of the kernel sources
+#   the default forward kernel (bench.py: k_render16p, global-phases schedule), the same kernel with the per-ray queue
+#   (tools/one_view.py 16 0 queue: k_render16), the x32 forward kernel (tools/one_view.py 32) and the VJP kernel (tools/bench_vjp.py), kernel stats of the VJP and of the hand-off kernels, and the sha256 of the kernel sources
 #   that were measured (bench.py only reports a PMC figure whose hash matches the tree it runs from).
 # Output under gpurun_out/prof/; tools/summarize_pmc.py rNN turns it into profiles/rNN/.
 # usage: collect_profiles.sh [quick]      (quick: kernel stats + FETCH/WRITE + MFMA-busy passes only)
@@ -15,6 +15,7 @@ python $R/bench.py --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_vjp -- python $R/tools/bench_vjp.py > $O/stats_vjp.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_handoff -- python $R/tools/bench_handoff.py > $O/stats_handoff.log 2>&1
+if [ "$1" = queue_only ]; then ONLY_QUEUE=1; fi
 if [ "$1" = quick ]; then
   SETS=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE")
 else
@@ -30,7 +31,7 @@ for set in "${SETS[@]}"; do
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16_$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_x16_$i.log 2>&1
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x32_$i -- python $R/tools/one_view.py 32 > $O/pmc_x32_$i.log 2>&1
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_vjp_$i -- python $R/tools/bench_vjp.py 400 1 > $O/pmc_vjp_$i.log 2>&1
-  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16p_$i -- python $R/tools/one_view.py 16 0 phases > $O/pmc_x16p_$i.log 2>&1
+  timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16q_$i -- python $R/tools/one_view.py 16 0 queue > $O/pmc_x16q_$i.log 2>&1
 done
 timeout 100 python $R/tools/one_view.py 16 0 queue 4 > $O/schedule_queue.log 2>&1
 timeout 100 python $R/tools/one_view.py 16 0 phases 4 > $O/schedule_phases.log 2>&1

@@ -6,8 +6,8 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
 os.makedirs(dst, exist_ok=True)
 out = {}
-FLOP = {"x16": 160000 * 303824896, "x16p": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568}
-for tag, key, kname in (("x16", "x16_default", "k_render16("), ("x16p", "x16_phases_schedule", "k_render16p"),
+FLOP = {"x16": 160000 * 303824896, "x16q": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568}
+for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", "x16_queue_schedule", "k_render16("),
                         ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp")):
     tot, disp, ns, first_id = {}, {}, None, {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
