@@ -227,8 +227,8 @@ def pmc_traffic(pmc_file, schedule="phases"):
     return t, ("offline measurement: bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
                "this kernel and schedule (%s [%s], git blob %s, kernel sources sha256 %s... = this tree); FETCH_SIZE counts "
                "L2 misses that Infinity Cache serves: re-streaming of the weight images (4.6 MiB of networks vs 4 MiB L2 per "
-               "XCD), not HBM reads; algorithmic HBM bytes are 7.0e6 per launch; the per-ray-queue schedule measures 5.3e10 "
-               "and is 0.3 %% faster (DESIGN.md 4)" % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
+               "XCD), not HBM reads; algorithmic HBM bytes are 7.0e6 per launch; the per-ray-queue schedule measures 2.1e10 to "
+               "8.8e10 depending on the run and is 0.4 %% faster (DESIGN.md 4)" % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
 
 
 def self_launch(args):
