@@ -190,7 +190,7 @@ def config1_workload(sd_c, c2w, device, cpu_setting):
     return out
 
 
-def vjp_roofline(model, c2w):
+def vjp_roofline(model, c2w, pmc_file=None):
     """The input-gradient kernel (nsr::k_render_vjp16 by default) on one 400x400 image = render_path_grad's per-pose
     launch: mean HIP-event time of 2 launches after one warm-up."""
     o, d = model.get_rays(H, W, S.YCBV_K, c2w)
@@ -201,8 +201,13 @@ def vjp_roofline(model, c2w):
         ms.append(model.last_kernel_ms())
     k_ms = float(np.mean(ms[1:]))
     ach = H * W * FLOP_PER_RAY_VJP / (k_ms * 1e-3) / 1e12
+    traffic = None
+    if pmc_file and os.path.exists(pmc_file) and model.variant != 32:
+        prof = json.load(open(pmc_file))
+        if prof.get("kernel_source_sha256") == _lib.kernel_source_hash() and "vjp" in prof:
+            traffic = prof["vjp"]["derived"].get("hbm_traffic_bytes_per_launch")     # same hash rule as roofline.traffic
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "kernel": "nsr::k_render_vjp" if model.variant == 32 else "nsr::k_render_vjp16",
             "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
             "flop_note": "per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
@@ -254,6 +259,8 @@ def main():
     ap.add_argument("--workload", choices=("view400", "sweep100", "models21"), default="view400")
     ap.add_argument("--views", type=int, default=100, help="sweep100: number of views in the sweep (config 3 uses 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full-view", action="store_true",
+                    help="also time the oracle on ONE full 400x400 64+128 view (SURVEY.md 8d; minutes of CPU time)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_vjp and the config-1 workload")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL over xGMI (the measured configuration); gloo stages collectives through the host")
@@ -376,8 +383,20 @@ def main():
                 cpu, par, cpu_setting = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
                 line["cpu_baseline"] = cpu
                 line["parity"] = par
+            if world == 1 and args.cpu_full_view and cpu_setting is not None:
+                O = _oracle()
+                O.set_backend(cpu_setting[0])
+                if cpu_setting[1]:
+                    torch.set_num_threads(cpu_setting[1])
+                t0c = time.perf_counter()
+                O.render(sd_c, sd_f, H, W, S.YCBV_K, c2w=poses[args.warmup][:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=4096)
+                dtc = time.perf_counter() - t0c
+                O.set_backend("numpy")
+                line["cpu_baseline"]["full_view"] = {"value": round(H * W * SAMPLES_PER_RAY / dtc / 1e6, 5),
+                                                     "unit": "Mray-samples/s", "seconds": round(dtc, 1),
+                                                     "sample": "one full 400x400 view, 64+128 samples"}
             if world == 1 and not args.no_extras:
-                line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup])
+                line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting)}
         model.close()
 
