@@ -159,6 +159,7 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
     NSR_HIP(hipMalloc(&h->d_status, sizeof(unsigned)));
     NSR_HIP(hipMemset(h->d_status, 0, sizeof(unsigned)));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
   }
   NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * zf_rays));
   NSR_HIP(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
@@ -417,9 +418,21 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   if (out) { a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc; }
   v.grad_rgb = d_grad_rgb; v.grad_o = d_grad_o; v.grad_d = d_grad_d; v.mask_scratch = h->d_mask_scratch;
   v.z_fine = d_z_fine;
+  // global-phases schedule (k_render_vjp16p) unless the caller supplies the depths itself (then nothing is handed over)
+  const bool phases = x16 && (h->cfg.flags & NSR_FLAG_SCHED_PHASES) && !d_z_fine;
+  if (phases) {
+    a.zf_scratch = h->d_zf_scratch;
+    a.sched_flags = h->d_sched_flags;
+    a.status = h->d_status;
+    a.super_lg = kSuperLg;
+    a.spin_max = h->cfg.chunk > 0 ? h->cfg.chunk - 1 : 64;
+    NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
+  }
   hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);   // also zeroes the work counter
   if (!capturing) NSR_HIP(hipEventRecord(h->ev0, s));
-  if (x16)
+  if (phases)
+    hipLaunchKernelGGL(nsr::k_render_vjp16p, dim3((int)grid), dim3(256), kVjp16Lds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  else if (x16)
     hipLaunchKernelGGL(nsr::k_render_vjp16, dim3((int)grid), dim3(256), kVjp16Lds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else
     hipLaunchKernelGGL(nsr::k_render_vjp, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);

@@ -2157,8 +2157,12 @@ __device__ __forceinline__ void composite_bwd_ray(ItemStateV16& st, int tid) {
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+// PHASES = false: per-ray queue, an item is the seven passes of one ray (k_render_vjp16).
+// PHASES = true : the global-phases schedule of k_render16p (k_render_vjp16p): per super-chunk first the coarse tasks
+//                 (one pass), then the "fine + backward" tasks (six passes) of its rays, any workgroup; the sorted depths
+//                 travel through the same non-blocking hand-off ring (a value that is not there in time is recomputed).
+template <bool PHASES>
+__device__ __forceinline__ void render_vjp16_body(const VjpArgs* __restrict__ vp, char* smem) {
   const VjpArgs& va_setup = *vp;
   const RenderArgs& a_setup = va_setup.r;
   const int tid0 = threadIdx.x;
@@ -2166,10 +2170,51 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int j = lane & 15;
   ItemStateV16& st = *(ItemStateV16*)(smem + kLds16State);
-  const long long n_items = a_setup.n_rays;                  // a work item is one ray
+  const long long n_rays = a_setup.n_rays;                   // per-ray queue: a work item is one ray
+  const long long total = PHASES ? 2 * n_rays : n_rays;      // tasks in the queue
+  const int lg = PHASES ? a_setup.super_lg : 0;
+  const long long S = 1ll << lg;
 
-  Ring rg;
+  Ring rg;                                                   // (before any control flow: the descriptor stays in SGPRs)
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);   // coarse | 3 x fine | 3 x fine^T per item
+  long long* item_slot = (long long*)&st.res[0][6];
+  auto pull = [&]() -> long long {
+    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
+    __syncthreads();
+    const long long v = uniform64(*item_slot);
+    __syncthreads();
+    return v;
+  };
+  auto vote = [&](bool mine) -> bool {                       // thread 0's verdict for the whole workgroup
+    if (opaque_v(tid0) == 0) *item_slot = mine ? 1 : 0;
+    __syncthreads();
+    const bool v = uniform64(*item_slot) != 0;
+    __syncthreads();
+    return v;
+  };
+  // PHASES: task t -> (super-chunk k, fine+backward?, ray): super-chunk k owns ids [2kS, 2kS + 2 S_k), coarse tasks first
+  auto decode = [&](long long t, long long& k, bool& is_fine, long long& ray) {
+    if (!PHASES) { k = 0; is_fine = false; ray = t; return; }
+    k = t >> (lg + 1);
+    const long long off = t & (2 * S - 1);
+    const long long left = n_rays - (k << lg);
+    const long long Sk = left < S ? left : S;
+    is_fine = off >= Sk;
+    ray = (k << lg) + off - (is_fine ? Sk : 0);
+  };
+  long long cur = pull();
+  if (cur >= total) return;
+  long long nxt = PHASES ? pull() : 0;
+  long long k, rr;
+  bool cur_fine;
+  decode(cur, k, cur_fine, rr);
+  const int stride = (int)a_setup.net_stride;
+  if (PHASES) {
+    rg.dd = 1;
+    rg.ppi = 0x7fffffff;
+    rg.pnet_off = cur_fine ? stride : 0;
+    rg.pnet_next = rg.pnet_off;
+  }
   f32x4 A0[4], A1[4];
   ring_start<kRing16>(rg, A0, lane);
   {
@@ -2185,24 +2230,28 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
   // relu-pattern scratch of this workgroup: uniform base (re-read from the argument block where it is used, so that
   // it lives in scalar registers only around the pass) + thread index at each access
   auto my_masks = [&]() { return (uint2*)opaque_s(vp)->mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256); };
-  long long* item_slot = (long long*)&st.res[0][6];
-  auto next_item = [&]() -> long long {
-    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
-    __syncthreads();
-    const long long v = uniform64(*item_slot);
-    __syncthreads();
-    return v;
-  };
-  long long item = next_item();
-  int pass = 0;
+  int pass = cur_fine ? 1 : 0;
+  int local = 0;     // PHASES: 1 = this fine task is recomputing its own coarse pass, 2 = ... and resumes at pass 1
 #pragma unroll 1
-  while (item < n_items) {
-    const long long rr = item;
-    if (pass == 0) {
+  while (true) {
+    const long long slots = 3 * S;
+    const long long slot = PHASES ? NSR_IDX64(rr % slots, slots) : 0;
+    if (pass == 0 || (PHASES && pass == 1 && local == 0)) {  // a ray enters the workgroup state
       const RenderArgs& a = opaque_s(vp)->r;               // see opaque_v / opaque_s
       const int tid = opaque_v(tid0);
       const float near_ = a.near_, far_ = a.far_;
+      unsigned* ready = a.sched_flags;
+      unsigned* taken = a.sched_flags + slots;
+      const unsigned gen = (unsigned)(k + 1);
+      bool got = false;
       if (tid == 0) {
+        if (PHASES && pass == 1) {                         // is the coarse task's result there?  (bounded look)
+#pragma unroll 1
+          for (int it = 0; it < a.spin_max && !got; ++it) {
+            got = __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen;
+            if (!got) __builtin_amdgcn_s_sleep(16);
+          }
+        }
         float o[3], d[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
@@ -2212,8 +2261,46 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
         st.ray[0][9] = near_; st.ray[0][10] = far_; st.ray[0][11] = nrm;
         st.ray[0][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
-      if (tid < 64) st.zc[0][tid] = coarse_z(near_, far_, a.tcoarse[tid], a.lindisp);
+      if (PHASES && pass == 1) {
+        got = vote(got);
+        if (got) {
+          if (tid < 192)
+            st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)a.zf_scratch + slot * 192 + tid,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          __syncthreads();
+          got = vote(tid == 0 && __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen);
+        }
+        if (tid == 0) {
+          __hip_atomic_store(taken + slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed or given up
+          if (!got) atomicAdd(a.status, 1u);
+        }
+        if (!got) {                                        // recompute the coarse pass here: restart the ring on net 0
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          rg.pslab = 0; rg.pslot = 0; rg.cslot = 0;
+          rg.pnet_off = 0;
+          ring_start<kRing16>(rg, A0, lane);
+          local = 1;
+          pass = 0;
+        }
+      }
+      if (pass == 0) {
+        if (tid < 64) st.zc[0][tid] = coarse_z(near_, far_, a.tcoarse[tid], a.lindisp);
+      }
       __syncthreads();
+    }
+    if (PHASES) {
+      // the network of the pass AFTER this one (0 coarse, 1 fine, 2 fine^T)
+      int nn;
+      if (pass == 0 && local != 0) nn = 1;
+      else if (pass == 0 || pass == 6) {
+        long long k2, r2;
+        bool nf = cur_fine;
+        if (nxt < total) decode(nxt, k2, nf, r2);
+        nn = nf ? 1 : 0;
+      } else nn = pass < 3 ? 1 : 2;
+      rg.pnet_next = nn * stride;
+      ring_assert_uniform(rg);
     }
 
     if (pass <= 3) {
@@ -2253,20 +2340,50 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
     const VjpArgs& va = *opaque_s(vp);                      // nothing below may be hoisted above the network passes
     const RenderArgs& a = va.r;
     const int tid = opaque_v(tid0);
+    bool task_done = false;
     if (pass == 0) {
       __syncthreads();
       composite<64, 1>(st, &st.zc[0][0], &st.rawf[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
       int64_t* none = nullptr;
       sample_pdf_item<1>(st, a.ufine, &st.w0[0][1], 64,
-                         [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, 1);
+                         [&](int r, int kk) { return 0.5f * (st.zc[r][kk + 1] + st.zc[r][kk]); }, none, 128, tid, 1);
       merge_sort_item<1>(st, tid);
-      if (va.z_fine) {                                       // caller-supplied depths replace the resampled ones
-        if (tid < 192) st.zf[0][tid] = va.z_fine[rr * 192 + tid];
-        __syncthreads();
+      if (!PHASES) {
+        if (va.z_fine) {                                     // caller-supplied depths replace the resampled ones
+          if (tid < 192) st.zf[0][tid] = va.z_fine[rr * 192 + tid];
+          __syncthreads();
+        }
+        pass = 1;
+      } else if (local == 1) {                               // the fine passes follow right here, on the values in LDS
+        local = 2;
+        pass = 1;
+      } else {
+        // publish for the fine+backward task -- if the slot's previous content has been consumed; never wait for it
+        unsigned* ready = a.sched_flags;
+        unsigned* taken = a.sched_flags + slots;
+        bool can = false;
+        if (tid == 0) {
+          can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k - 2);
+          if (can) {
+            __hip_atomic_store(ready + slot, kSlotBusy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // "busy" is out before any value is
+          }
+        }
+        can = vote(can);
+        if (can) {
+          if (tid < 192)
+            __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(st.zf[0][tid]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0)
+            __hip_atomic_store(ready + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        task_done = true;
       }
-      pass = 1;
     } else if (pass < 3) {
       ++pass;
+      local = 0;
     } else if (pass == 3) {
       __syncthreads();
       composite<192, 1>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid);
@@ -2305,11 +2422,32 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restri
         }
       }
       __syncthreads();
-      pass = 0;
-      item = next_item();
+      task_done = true;
+    }
+    if (task_done) {
+      if (PHASES) {
+        cur = nxt;
+        if (cur >= total) break;
+        nxt = pull();
+      } else {
+        cur = pull();
+        if (cur >= total) break;
+      }
+      decode(cur, k, cur_fine, rr);
+      pass = cur_fine ? 1 : 0;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
+}
+
+__global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp16_body<false>(vp, smem);
+}
+
+__global__ void __launch_bounds__(256, 2) k_render_vjp16p(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp16_body<true>(vp, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -29,11 +29,12 @@ def model(synth_nets):
     m.close()
 
 
-@pytest.fixture(scope="module", params=[16, 32])
+@pytest.fixture(scope="module", params=[(16, "phases"), (16, "queue"), (32, "queue")], ids=lambda p: "x%d-%s" % p)
 def vjp_model(request, synth_nets):
-    """Both input-gradient kernels: k_render_vjp16 (variant 16 = the default) and k_render_vjp (variant 32)."""
+    """The input-gradient kernels: k_render_vjp16p (variant 16 + global phases = the default), k_render_vjp16 (variant
+    16, per-ray queue; also what a call with caller-supplied depths uses) and k_render_vjp (variant 32)."""
     from neural_sim_nerf_amd.engine import NsrModel
-    m = NsrModel(synth_nets[0], synth_nets[1], variant=request.param)
+    m = NsrModel(synth_nets[0], synth_nets[1], variant=request.param[0], schedule=request.param[1])
     yield m
     m.close()
 
@@ -767,6 +768,15 @@ def test_phases_schedule_is_result_invariant(model16, synth_nets, oracle):
             for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
                 assert np.array_equal(cpu(got[k]), cpu(want_v[k]), equal_nan=True), (looks, rep, k)
         n2 = mp.schedule_stats()
+        # the input-gradient kernel under the same schedule (k_render_vjp16p) == the per-ray-queue kernel, bit for bit
+        cot = np.random.RandomState(3).standard_normal((ro.shape[0], 3)).astype(np.float32)
+        if looks is None:
+            want_g = model16.render_rays_vjp(ro, rd, near, far, cot, with_forward=True)
+        got_g = mp.render_rays_vjp(ro, rd, near, far, cot, with_forward=True)
+        assert np.array_equal(cpu(got_g[0]), cpu(want_g[0])) and np.array_equal(cpu(got_g[1]), cpu(want_g[1])), looks
+        assert np.array_equal(cpu(got_g[2]["rgb_map"]), cpu(want_g[2]["rgb_map"]))
+        if expect == "all":
+            assert mp.schedule_stats() == n2 + ro.shape[0]
         if expect == "none":                               # an exclusive GPU: only launch tails recompute (see the
             assert n1 <= 512 and n2 - n1 <= 2 * 512, (n1, n2)      # full-size test); 1507 rays < one grid round of pairs
         elif expect == "all":

@@ -6,9 +6,11 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01")
 os.makedirs(dst, exist_ok=True)
 out = {}
-FLOP = {"x16": 160000 * 303824896, "x16q": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568}
+FLOP = {"x16": 160000 * 303824896, "x16q": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568,
+        "vjpq": 160000 * 531693568}
 for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", "x16_queue_schedule", "k_render16("),
-                        ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp")):
+                        ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp16p"),
+                        ("vjpq", "vjp_queue_schedule", "k_render_vjp16(")):
     tot, disp, ns, first_id = {}, {}, None, {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
         if not os.path.isdir(d):
@@ -59,6 +61,15 @@ for name in ("queue", "phases"):
             sched[name] = {"kernel_ms_after_warmup": ms[1:], "mean_ms": sum(ms[1:]) / len(ms[1:])}
 if sched:
     out["schedule_timing_unprofiled"] = sched
+vj = {}
+for name in ("phases", "queue", "x32"):
+    f = os.path.join(src, "vjp_%s.log" % name)
+    if os.path.exists(f):
+        for l in open(f):
+            if l.startswith("{"):
+                vj[name] = json.loads(l)
+if vj:
+    out["vjp_timing_unprofiled"] = vj
 json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
 for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
                   ("stats_handoff", "kernel_stats_handoff.csv")):
