@@ -19,7 +19,7 @@ Prints ONE JSON line on rank 0.  Objects beside the contract fields:
                     fp32-input MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md) -- the datatype actually issued;
                     `traffic` comes from a rocprofv3 --pmc profile ONLY if that profile was collected from exactly
                     the kernel sources in this tree (hash check), else null;
-  roofline_vjp   -- the same for nsr::k_render_vjp16 (render_path_grad's forward+input-gradient launch, config 4's render leg);
+  roofline_vjp   -- the same for nsr::k_render_vjp16p (render_path_grad's forward+input-gradient launch, config 4's render leg);
   cpu_baseline   -- the oracle (CPU restatement of the reference path, "port") timed on this host's cores on a bounded
                     sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
   parity         -- PSNR / max-abs of the GPU render vs the oracle on that sample, exact-match rate of the indices;
@@ -208,7 +208,8 @@ def vjp_roofline(model, c2w, pmc_file=None):
             traffic = prof["vjp"]["derived"].get("hbm_traffic_bytes_per_launch")     # same hash rule as roofline.traffic
     return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "kernel": "nsr::k_render_vjp" if model.variant == 32 else "nsr::k_render_vjp16",
+            "kernel": "nsr::k_render_vjp" if model.variant == 32 else
+                      ("nsr::k_render_vjp16p" if model.schedule == "phases" else "nsr::k_render_vjp16"),
             "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
             "flop_note": "per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
                          "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP"}

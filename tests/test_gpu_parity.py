@@ -1027,3 +1027,41 @@ def test_two_ranks_on_one_gpu_shard_the_dropin_api(tmp_path):
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
     assert sorted(os.listdir(tmp_path / "5")) == ["000.png", "001.png", "002.png"]
+
+
+def test_c_host_matches_python_engine(tmp_path, synth_nets, oracle):
+    """The boundary is a C ABI: examples/c_host.c (plain C + the HIP runtime C API + include/nsr.h, no Python, no
+    torch) renders a view from packed weights and its seven outputs equal the Python engine's, bit for bit."""
+    import shutil
+    import subprocess
+    from neural_sim_nerf_amd import pack
+    from neural_sim_nerf_amd.engine import NsrModel, _host_tables
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the ROCm headers")
+    csrc = os.path.join(ROOT, "neural_sim_nerf_amd", "csrc")
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host.c"), "-L" + csrc, "-lnsr", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    H, W = 40, 56
+    K = oracle.scaled_K(400.0 / 48)
+    pose = np.asarray(oracle.sweep_poses(1, seed=13))[0]
+    t64, u128 = _host_tables()
+    parts = [pack.pack_network(synth_nets[0]), pack.pack_network(synth_nets[1]), pack.pack_network16(synth_nets[0]),
+             pack.pack_network16(synth_nets[1]), t64, u128, pose[:3, :4].reshape(-1).astype(np.float32),
+             np.asarray(K, np.float32).reshape(-1), np.array([oracle.YCBV_NEAR, oracle.YCBV_FAR], np.float32)]
+    np.concatenate([p.astype(np.float32).reshape(-1) for p in parts]).tofile(str(tmp_path / "in.bin"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(H), str(W)], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(str(tmp_path / "out.bin"), np.float32)
+    n = H * W
+    m = NsrModel(synth_nets[0], synth_nets[1])
+    K32 = np.asarray(K, np.float32).astype(np.float64).tolist()      # the C program widens the float32 intrinsics
+    want = m.render_views(pose, H, W, K32, float(np.float32(oracle.YCBV_NEAR)), float(np.float32(oracle.YCBV_FAR)))
+    off = 0
+    for key, width in (("rgb_map", 3), ("disp_map", 1), ("acc_map", 1), ("rgb0", 3), ("disp0", 1), ("acc0", 1), ("z_std", 1)):
+        assert np.array_equal(got[off:off + width * n], cpu(want[key]).reshape(-1), equal_nan=True), key
+        off += width * n
+    m.close()
