@@ -1702,8 +1702,10 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
 //   * hand-off: the coarse task leaves the ray's 192 sorted z values in slot (ray mod 3S) of a global ring.  The
 //     hand-off is an OPTIMISATION, never a dependency: nothing in this kernel blocks on another workgroup.
 //       - publisher (coarse task of super-chunk k): if the slot's previous content (super-chunk k-3) has been consumed
-//         (taken[slot] == k-2, one non-blocking look), it marks the slot busy, writes the values with agent-scope
-//         (sc1, write-through) stores, drains them (vmcnt(0)) and publishes ready[slot] = k+1; otherwise it skips;
+//         (taken[slot] == k-2, one non-blocking look) and it can CLAIM the slot (compare-and-swap of ready[slot] from
+//         an older generation to "busy": exclusive even against a publisher that was descheduled mid-write), it writes
+//         the values with agent-scope (sc1, write-through) stores, drains them (vmcnt(0)) and publishes ready[slot] =
+//         k+1; otherwise it skips;
 //       - consumer (fine task): one lane polls ready[slot] == k+1 at most `spin_max` times (default 64, about the time
 //         of one network pass), all lanes read with agent-scope loads, one lane re-reads the flag (seqlock: a publisher
 //         of a later generation raises "busy" before it touches the data) and sets taken[slot] = k+1.  If the value
@@ -1922,7 +1924,10 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         if (tid == 0) {
           can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k - 2);
           if (can) {
-            __hip_atomic_store(ready + slot, kSlotBusy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // claim the slot: it must hold an OLDER generation and nobody may be writing it (a publisher that was
+            // descheduled in the middle of its stores still owns it); the compare-and-swap makes the claim exclusive
+            const unsigned r = __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            can = r != kSlotBusy && r < (unsigned)(k + 1) && atomicCAS(ready + slot, r, kSlotBusy) == r;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // "busy" is out before any value is
           }
         }
@@ -2365,7 +2370,10 @@ __device__ __forceinline__ void render_vjp16_body(const VjpArgs* __restrict__ vp
         if (tid == 0) {
           can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k - 2);
           if (can) {
-            __hip_atomic_store(ready + slot, kSlotBusy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // claim the slot: it must hold an OLDER generation and nobody may be writing it (a publisher that was
+            // descheduled in the middle of its stores still owns it); the compare-and-swap makes the claim exclusive
+            const unsigned r = __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            can = r != kSlotBusy && r < (unsigned)(k + 1) && atomicCAS(ready + slot, r, kSlotBusy) == r;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // "busy" is out before any value is
           }
         }
