@@ -15,7 +15,7 @@ from .pack import pack_network, pack_network16, pack_network_backward, pack_netw
 N_SAMPLES = 64
 N_IMPORTANCE = 128
 # Work schedule of the x16 forward kernel (NSR_FLAG_SCHED_PHASES, include/nsr.h).  "phases" is the default: measured
-# 327.6 vs 326.2 ms per 400x400 view (+0.4 %) for 4-5 GB instead of 20-90 GB of L2-miss (fabric) traffic per view
+# 328.1 vs 326.6 ms per 400x400 view (+0.5 %) for 4-5 GB instead of 20-90 GB of L2-miss (fabric) traffic per view
 # (profiles/r02/pmc_k_render.json); results are bit-identical.
 DEFAULT_SCHEDULE = "phases"
 
