@@ -439,8 +439,8 @@ def main():
             phases["gather_f32"] += time.perf_counter() - t
             t = time.perf_counter()
             host = u8.cpu().numpy()
-            for k, i in enumerate(mine):                    # every rank writes its own views, named by pose index
-                png.imwrite(os.path.join(tmp, "%03d.png" % i), host[k])
+            png.imwrite_many([os.path.join(tmp, "%03d.png" % i) for i in mine],     # every rank writes its own views,
+                             [host[k] for k in range(len(mine))])                   # named by pose index
             phases["png"] += time.perf_counter() - t
         barrier()
         dt = allmax(time.perf_counter() - t0)

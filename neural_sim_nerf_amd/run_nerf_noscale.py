@@ -271,8 +271,8 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
         rgbs, disps = rgb.cpu().numpy(), disp.cpu().numpy()
     print("rendered %d views in %.3f s" % (rgbs.shape[0], time.time() - t))
     if savedir is not None:
-        for i in range(rgbs.shape[0]):
-            png.imwrite(os.path.join(savedir, str(object_id), "{:03d}.png".format(i)), to8b(rgbs[i]))
+        png.imwrite_many([os.path.join(savedir, str(object_id), "{:03d}.png".format(i)) for i in range(rgbs.shape[0])],
+                         [to8b(rgbs[i]) for i in range(rgbs.shape[0])])
     return rgbs, disps
 
 

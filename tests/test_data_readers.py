@@ -141,3 +141,17 @@ print("ok" if ok else "mismatch", raised)
 ''' % (ROOT, str(tmp_path), str(tmp_path), str(tmp_path))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "ok True", (out.stdout, out.stderr[-2000:])
+
+
+def test_imwrite_many_equals_imwrite(tmp_path):
+    sys.path.insert(0, ROOT)
+    from neural_sim_nerf_amd import png
+    rng = np.random.RandomState(2)
+    imgs = [rng.randint(0, 256, size=(20, 30, 3)).astype(np.uint8) for _ in range(9)]
+    png.imwrite_many([str(tmp_path / ("m%d.png" % i)) for i in range(9)], imgs, threads=4)
+    for i, im in enumerate(imgs):
+        png.imwrite(str(tmp_path / ("s%d.png" % i)), im)
+        assert open(tmp_path / ("m%d.png" % i), "rb").read() == open(tmp_path / ("s%d.png" % i), "rb").read()
+        assert np.array_equal(png.imread(str(tmp_path / ("m%d.png" % i))), im)
+    with pytest.raises(ValueError):
+        png.imwrite_many(["a.png"], [])
