@@ -23,6 +23,7 @@ Prints ONE JSON line on rank 0.  Objects beside the contract fields:
   cpu_baseline   -- the oracle (CPU restatement of the reference path, "port") timed on this host's cores on a bounded
                     sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
   parity         -- PSNR / max-abs of the GPU render vs the oracle on that sample, exact-match rate of the indices;
+  extra_workloads.handoff -- f-3: device to8b + bbox extraction of 100 images next to the host route (oracle) on 5;
   extra_workloads.config1 -- BASELINE configs[0] (64x64, 64 coarse samples only): GPU throughput next to the oracle at
                     chunk 512 (the reference's config) and 4096;
   ranks_seen, kernel_ms_per_rank -- what RCCL actually saw (sum of ones over ranks; per-rank kernel time spread).
@@ -187,6 +188,62 @@ def config1_workload(sd_c, c2w, device, cpu_setting):
         out["cpu_baseline"] = cpu
         out["max_abs_rgb_vs_oracle"] = float(np.abs(got["rgb_map"].cpu().numpy().reshape(side, side, 3) - ref["rgb_map"]).max())
     m1.close()
+    return out
+
+
+def handoff_workload(model, with_cpu):
+    """f-3: to8b (RH:14) + the detector's bbox extraction (NM:786-797) for 100 rendered-size images on the device
+    (HBM-bound byte kernels), next to the reference's route on the host -- to8b + PNG encode + PNG decode + the oracle's
+    restatement of the cv2 calls -- timed on 5 images (the oracle is the checker: boxes / masks must agree)."""
+    from neural_sim_nerf_amd import png
+    K_, H_, W_ = 100, 400, 400
+    rng = np.random.RandomState(0)
+    yy, xx = np.mgrid[:H_, :W_]
+    rgb = np.zeros((K_, H_, W_, 3), np.float32)
+    for i in range(K_):                                  # an object-like blob on black, plus a few specks
+        cy, cx, r = rng.randint(120, 280), rng.randint(120, 280), rng.randint(40, 110)
+        sel = (yy - cy) ** 2 + ((xx - cx) * rng.uniform(0.6, 1.4)) ** 2 <= r * r
+        rgb[i][sel] = rng.uniform(0.05, 1.0, (sel.sum(), 3))
+        for _ in range(5):
+            rgb[i][rng.randint(0, H_), rng.randint(0, W_)] = 0.5
+    x = torch.as_tensor(rgb, device=model.device)
+
+    def timed(fn, reps=20):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    img8 = model.to8b(x)
+    ms_to8b = timed(lambda: model.to8b(x))
+    ms_bbox = timed(lambda: model.find_bbox(img8, with_mask=True))
+    bbox, count, mask = model.find_bbox(img8, with_mask=True)
+    n = K_ * H_ * W_
+    out = {"workload": "to8b + find_bbox of 100 images 400x400x3 (f-3 hand-off)",
+           "to8b": {"ms": round(ms_to8b, 4), "algorithmic_bytes": n * 3 * 5, "GBps": round(n * 3 * 5 / ms_to8b / 1e6, 1),
+                    "frac_of_8TBps": round(n * 3 * 5 / ms_to8b / 1e6 / 8000, 4)},
+           "find_bbox": {"ms": round(ms_bbox, 4), "algorithmic_bytes": n * 4},
+           "views_per_s_gpu": round(K_ / ((ms_to8b + ms_bbox) * 1e-3), 1)}
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import handoff_oracle as HO
+        sample = 5
+        d = tempfile.mkdtemp(prefix="nsr_handoff_")
+        t0 = time.perf_counter()
+        for i in range(sample):
+            png.imwrite(os.path.join(d, "%03d.png" % i), HO.to8b(rgb[i]))
+        ok = True
+        for i in range(sample):
+            want, rows, mk = HO.get_annotation(png.imread(os.path.join(d, "%03d.png" % i)))
+            ok &= (list(bbox[i].cpu().numpy()) == [int(v) for v in want] and int(count[i]) == rows
+                   and np.array_equal(mask[i].cpu().numpy(), mk))
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(sample / dt, 2), "unit": "views/s", "cores": 1, "kind": "port",
+                               "cpu_model": cpu_model(), "sample": "%d images: to8b + PNG encode + PNG decode + "
+                               "oracle/handoff_oracle.get_annotation, %.2f s" % (sample, dt)}
+        out["parity_on_sample"] = bool(ok)
     return out
 
 
@@ -398,7 +455,8 @@ def main():
                                                      "sample": "one full 400x400 view, 64+128 samples"}
             if world == 1 and not args.no_extras:
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
-                line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting)}
+                line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),
+                                           "handoff": handoff_workload(model, not args.no_cpu_baseline)}
         model.close()
 
     # ------------------------------------------------------------------------------------------------------------

@@ -1,13 +1,13 @@
 """Hand-off throughput: to8b + find_bbox for 100 rendered-size views on the GPU, against the
-HBM roofline (these are byte kernels), beside the reference's route on the host: PNG encode + decode + the oracle's
-restatement of cv2 grey/threshold/connected components.  Prints one JSON object."""
+HBM roofline (these are byte kernels).  GPU only: the host route of the reference (PNG encode + decode + the oracle's
+restatement of cv2 grey / threshold / connected components) is timed beside it by bench.py
+(`extra_workloads.handoff.cpu_baseline`), the only place outside tests/ that may touch oracle/.  Prints one JSON object."""
 import json, os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
 import numpy as np, torch
 from neural_sim_nerf_amd import png
 from neural_sim_nerf_amd.run_nerf_noscale import _util_model
-import handoff_oracle as HO
 
 K, H, W = 100, 400, 400
 m = _util_model()
@@ -42,21 +42,4 @@ out = {"views": K, "H": H, "W": W,
        "find_bbox": {"ms": round(ms_bbox, 4), "algorithmic_bytes": n * 4, "GBps": round(n * 4 / ms_bbox / 1e6, 1),
                      "note": "5 kernels per batch of 16 images; 24 B/pixel of L2-resident scratch (union-find parents + per-root statistics)"},
        "views_per_s_gpu": round(K / ((ms_to8b + ms_bbox) * 1e-3), 1)}
-# host route of the reference on a sample of 5 views: to8b + PNG write + PNG read + annotation
-sample = 5
-host = rgb[:sample]
-d = tempfile.mkdtemp()
-t0 = time.perf_counter()
-for i in range(sample):
-    png.imwrite(os.path.join(d, "%03d.png" % i), HO.to8b(host[i]))
-t1 = time.perf_counter()
-ok = True
-for i in range(sample):
-    im = png.imread(os.path.join(d, "%03d.png" % i))
-    want, rows, mk = HO.get_annotation(im)
-    ok &= list(bbox[i].cpu().numpy()) == [int(v) for v in want] and int(count[i]) == rows and np.array_equal(mask[i].cpu().numpy(), mk)
-t2 = time.perf_counter()
-out["cpu_route"] = {"kind": "port", "cores": 1, "sample": "%d views: to8b + PNG encode %.3f s, PNG decode + oracle get_annotation %.3f s" % (sample, t1 - t0, t2 - t1),
-                    "views_per_s": round(sample / (t2 - t0), 2)}
-out["parity_on_sample"] = bool(ok)
 print(json.dumps(out))
