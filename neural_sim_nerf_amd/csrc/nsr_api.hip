@@ -76,8 +76,8 @@ struct nsr_handle_s {
   unsigned long long* d_work_counter = nullptr;  // work-queue head
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
   int zf_grid = 0;
-  unsigned* d_sched_flags = nullptr;  // k_render16p: ready / taken generations of the 3 * 2^kSuperLg hand-off slots
-  unsigned* d_status = nullptr;       // k_render16p: non-zero after a hand-off wait timed out
+  unsigned* d_sched_flags = nullptr;  // global phases: ready / taken generations of the 3 * 2^kSuperLg hand-off slots
+  unsigned* d_status = nullptr;       // global phases: rays whose fine task recomputed its coarse pass (nsr_schedule_stats)
   int* d_box_scratch = nullptr;       // nsr_find_bbox: parent + stats of one batch of images (nsr_reserve_bbox)
   size_t box_scratch_ints = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel timing (eager launches only)
@@ -106,6 +106,45 @@ static int stream_capturing(hipStream_t s, bool* capturing) {
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
   NSR_HIP(hipStreamIsCapturing(s, &st));
   *capturing = st != hipStreamCaptureStatusNone;
+  return 0;
+}
+
+// every device allocation, event and kernel attribute a handle needs for its launch calls (setup time only)
+static int allocate_handle(nsr_handle h) {
+  const NsrConfig* cfg = &h->cfg;
+  // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
+  NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
+  for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
+  NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
+  NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
+  NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
+  NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
+  NSR_HIP(hipMalloc(&h->d_work_counter, sizeof(unsigned long long)));
+  // k_render16's inter-phase scratch: bounded by the grid (2 workgroups per CU, or max_workgroups) x chunk
+  h->zf_grid = cfg->max_workgroups > 0 ? cfg->max_workgroups : 2 * h->n_cu;
+  size_t zf_rays = (size_t)h->zf_grid * h->chunk;
+  if (cfg->flags & NSR_FLAG_SCHED_PHASES) {                // the z hand-off ring of the global-phases schedule
+    if (const char* e = getenv("NSR_EXP_SUPER_LG")) {      // experiment knob (super-chunk size), read at setup only
+      const int v = atoi(e);
+      if (v >= 6 && v <= 20) kSuperLg = v;
+    }
+    zf_rays = (size_t)3 << kSuperLg;
+    NSR_HIP(hipMalloc(&h->d_sched_flags, sizeof(unsigned) * 2 * zf_rays));
+    NSR_HIP(hipMalloc(&h->d_status, sizeof(unsigned)));
+    NSR_HIP(hipMemset(h->d_status, 0, sizeof(unsigned)));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
+  }
+  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * zf_rays));
+  NSR_HIP(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
+  NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+  NSR_HIP(hipEventCreate(&h->ev0));
+  NSR_HIP(hipEventCreate(&h->ev1));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_run_network, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNetLds));
   return 0;
 }
 
@@ -139,36 +178,11 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   h->cfg = *cfg;
   h->n_cu = prop.multiProcessorCount;
   h->chunk = (cfg->chunk > 0 && !(cfg->flags & NSR_FLAG_SCHED_PHASES)) ? cfg->chunk : 1;
-  // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
-  NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
-  for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
-  NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
-  NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
-  NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
-  NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
-  NSR_HIP(hipMalloc(&h->d_work_counter, sizeof(unsigned long long)));
-  // k_render16's inter-phase scratch: bounded by the grid (2 workgroups per CU, or max_workgroups) x chunk
-  h->zf_grid = cfg->max_workgroups > 0 ? cfg->max_workgroups : 2 * h->n_cu;
-  size_t zf_rays = (size_t)h->zf_grid * h->chunk;
-  if (cfg->flags & NSR_FLAG_SCHED_PHASES) {                // the z hand-off ring of the global-phases schedule
-    if (const char* e = getenv("NSR_EXP_SUPER_LG")) kSuperLg = atoi(e);      // experiment knob, read at setup only
-    zf_rays = (size_t)3 << kSuperLg;
-    NSR_HIP(hipMalloc(&h->d_sched_flags, sizeof(unsigned) * 2 * zf_rays));
-    NSR_HIP(hipMalloc(&h->d_status, sizeof(unsigned)));
-    NSR_HIP(hipMemset(h->d_status, 0, sizeof(unsigned)));
-    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
-    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
+  if (int e = allocate_handle(h)) {          // nothing half-built escapes: free whatever was allocated
+    const std::string msg = g_err;
+    nsr_destroy(h);
+    return fail(msg);
   }
-  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * zf_rays));
-  NSR_HIP(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
-  NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
-  NSR_HIP(hipEventCreate(&h->ev0));
-  NSR_HIP(hipEventCreate(&h->ev1));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
-  NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_run_network, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNetLds));
   *out = h;
   return 0;
 }
@@ -189,9 +203,9 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_work_counter);
   hipFree(h->d_sched_flags);
   hipFree(h->d_status);
-  hipEventDestroy(h->ev0);
-  hipEventDestroy(h->ev1);
-  hipEventDestroy(h->ev_busy);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->ev_busy) hipEventDestroy(h->ev_busy);
   delete h;
   return 0;
 }
