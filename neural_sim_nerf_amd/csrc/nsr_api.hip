@@ -82,6 +82,7 @@ struct nsr_handle_s {
   size_t box_scratch_ints = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel timing (eager launches only)
   hipEvent_t ev_busy = nullptr;              // completion of the last launch that used the per-handle scratch
+  unsigned epoch = 0;                        // global phases: launches so far, modulo 4094 (+1): tags the hand-off values
   hipStream_t last_stream = nullptr;
   bool launched = false;
   bool timed = false;
@@ -137,7 +138,8 @@ static int allocate_handle(nsr_handle h) {
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
   }
-  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * zf_rays));
+  // (global phases: 8-byte {value, tag} granules, hence twice the floats)
+  NSR_HIP(hipMalloc(&h->d_zf_scratch, sizeof(float) * 192 * zf_rays * ((cfg->flags & NSR_FLAG_SCHED_PHASES) ? 2 : 1)));
   NSR_HIP(hipEventCreateWithFlags(&h->ev_busy, hipEventDisableTiming));
   NSR_HIP(hipMalloc(&h->d_vjp_args, sizeof(nsr::VjpArgs)));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
@@ -327,6 +329,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     a.status = h->d_status;
     a.super_lg = kSuperLg;
     a.spin_max = h->cfg.chunk > 0 ? h->cfg.chunk - 1 : 64;   // looks at the ready flag before recomputing locally
+    a.epoch = h->epoch = h->epoch % 4094u + 1u;
     a.chunk = 1;
     NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
   } else if (x16) {
@@ -440,6 +443,7 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
     a.status = h->d_status;
     a.super_lg = kSuperLg;
     a.spin_max = h->cfg.chunk > 0 ? h->cfg.chunk - 1 : 64;
+    a.epoch = h->epoch = h->epoch % 4094u + 1u;
     NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
   }
   hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);   // also zeroes the work counter

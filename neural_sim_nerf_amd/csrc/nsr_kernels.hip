@@ -731,6 +731,7 @@ struct RenderArgs {
   unsigned* status;         // k_render16p: number of fine tasks that recomputed their coarse pass (hand-off not there in time)
   int super_lg;             // k_render16p: log2 of the rays per super-chunk
   int spin_max;             // k_render16p: looks at the ready flag before a fine task recomputes locally
+  unsigned epoch;           // global phases: launch counter of the handle (1..4094), high bits of every generation tag
   unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays
 };
 
@@ -1706,10 +1707,11 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
 //         an older generation to "busy": exclusive even against a publisher that was descheduled mid-write), it writes
 //         the values with agent-scope (sc1, write-through) stores, drains them (vmcnt(0)) and publishes ready[slot] =
 //         k+1; otherwise it skips;
-//       - consumer (fine task): one lane polls ready[slot] == k+1 at most `spin_max` times (default 64, about the time
-//         of one network pass), all lanes read with agent-scope loads, one lane re-reads the flag (seqlock: a publisher
-//         of a later generation raises "busy" before it touches the data) and sets taken[slot] = k+1.  If the value
-//         never showed up or changed under the read, the workgroup RECOMPUTES the coarse pass of that ray itself
+//       - consumer (fine task): one lane polls ready[slot] == tag at most `spin_max` times (default 64, about the time
+//         of one network pass), all lanes read their 8-byte granule {value, tag} with one agent-scope load and compare
+//         the tag (every value proves its own generation: a stale line or a later publisher cannot pass), and
+//         taken[slot] = tag is raised.  If the values never showed up or any tag is wrong, the workgroup RECOMPUTES the
+//         coarse pass of that ray itself
 //         (ring reset to the coarse network, one extra pass, identical arithmetic -> identical bits) and carries on.
 //     So the result never depends on timing, residency or what else runs on the GPU (other streams, other processes:
 //     a descheduled publisher costs the consumer one extra pass); RenderArgs::status counts the recomputed rays.
@@ -1718,6 +1720,34 @@ __global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restric
 //     (the queue is pulled one task ahead) and names the following network in rg.pnet_next (Ring::dd).
 // ------------------------------------------------------------------------------------------------------
 constexpr unsigned kSlotBusy = 0xffffffffu;
+
+// generation tag of super-chunk k in launch `epoch` (the host counts launches per handle, 1..4094): unique across the
+// launches that can still have values in a cache, monotonic within a launch, never equal to kSlotBusy
+__device__ __forceinline__ unsigned handoff_tag(unsigned epoch, long long k) { return (epoch << 20) | (unsigned)(k + 1); }
+
+// every thread's `ok` AND-ed over the workgroup, through four LDS words
+__device__ __forceinline__ bool wg_all(bool ok, int* lds4, int tid) {
+  const bool wave_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+  if ((tid & 63) == 0) lds4[tid >> 6] = wave_ok ? 1 : 0;
+  __syncthreads();
+  const bool all = (lds4[0] & lds4[1] & lds4[2] & lds4[3]) != 0;
+  __syncthreads();
+  return all;
+}
+
+// Hand-off slot: 192 granules of 8 bytes {value bits, generation tag}, each written by ONE agent-scope 8-byte store and
+// read by one 8-byte load, so every value carries its own proof of freshness (MI355X_MICROARCH.md: data-tagged granules):
+// a granule from another generation -- a stale cache line, a publisher of a later super-chunk -- fails the tag compare.
+__device__ __forceinline__ void handoff_store(float* scratch, long long slot, int tid, float v, unsigned tag) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  __hip_atomic_store((unsigned long long*)scratch + slot * 192 + tid, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool handoff_load(const float* scratch, long long slot, int tid, unsigned tag, float& v) {
+  const unsigned long long g =
+      __hip_atomic_load((const unsigned long long*)scratch + slot * 192 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v = __uint_as_float((unsigned)g);
+  return (unsigned)(g >> 32) == tag;
+}
 
 __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1797,7 +1827,7 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       const int tid = opaque_v(tid0);
       unsigned* ready = a.sched_flags;
       unsigned* taken = a.sched_flags + slots;
-      const unsigned gen = (unsigned)(k + 1);
+      const unsigned gen = handoff_tag(a.epoch, k);
       bool got = false;
       if (tid == 0) {
         if (pass == 1) {                                   // is the coarse task's result there?  (bounded look)
@@ -1827,12 +1857,13 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
       if (pass == 1) {
         got = vote(got);
         if (got) {
-          if (tid < 192)
-            st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)a.zf_scratch + slot * 192 + tid,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          __syncthreads();                                 // every lane's value has arrived (it was written to LDS)
-          // seqlock: still the same generation?  (a later publisher raises "busy" before it writes)
-          got = vote(tid == 0 && __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen);
+          bool fresh = true;                               // every granule proves its own generation
+          if (tid < 192) {
+            float zv;
+            fresh = handoff_load(a.zf_scratch, slot, tid, gen, zv);
+            st.zf[0][tid] = zv;
+          }
+          got = wg_all(fresh, (int*)&st.res[0][0], tid);
         }
         if (tid == 0) {
           __hip_atomic_store(taken + slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed or given up
@@ -1922,24 +1953,22 @@ __global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restri
         unsigned* taken = a.sched_flags + slots;
         bool can = false;
         if (tid == 0) {
-          can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k - 2);
+          can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == handoff_tag(a.epoch, k - 3);
           if (can) {
             // claim the slot: it must hold an OLDER generation and nobody may be writing it (a publisher that was
             // descheduled in the middle of its stores still owns it); the compare-and-swap makes the claim exclusive
             const unsigned r = __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            can = r != kSlotBusy && r < (unsigned)(k + 1) && atomicCAS(ready + slot, r, kSlotBusy) == r;
+            can = r != kSlotBusy && r < handoff_tag(a.epoch, k) && atomicCAS(ready + slot, r, kSlotBusy) == r;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // "busy" is out before any value is
           }
         }
         can = vote(can);
         if (can) {
-          if (tid < 192)
-            __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(st.zf[0][tid]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+          if (tid < 192) handoff_store(a.zf_scratch, slot, tid, st.zf[0][tid], handoff_tag(a.epoch, k));
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // my stores have left (write-through) before the flag is raised
           __syncthreads();
           if (tid == 0)
-            __hip_atomic_store(ready + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ready + slot, handoff_tag(a.epoch, k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         NSR_T(3);
         task_done = true;
@@ -2247,7 +2276,7 @@ __device__ __forceinline__ void render_vjp16_body(const VjpArgs* __restrict__ vp
       const float near_ = a.near_, far_ = a.far_;
       unsigned* ready = a.sched_flags;
       unsigned* taken = a.sched_flags + slots;
-      const unsigned gen = (unsigned)(k + 1);
+      const unsigned gen = handoff_tag(a.epoch, k);
       bool got = false;
       if (tid == 0) {
         if (PHASES && pass == 1) {                         // is the coarse task's result there?  (bounded look)
@@ -2269,11 +2298,13 @@ __device__ __forceinline__ void render_vjp16_body(const VjpArgs* __restrict__ vp
       if (PHASES && pass == 1) {
         got = vote(got);
         if (got) {
-          if (tid < 192)
-            st.zf[0][tid] = __uint_as_float(__hip_atomic_load((const unsigned*)a.zf_scratch + slot * 192 + tid,
-                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          __syncthreads();
-          got = vote(tid == 0 && __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen);
+          bool fresh = true;                               // every granule proves its own generation
+          if (tid < 192) {
+            float zv;
+            fresh = handoff_load(a.zf_scratch, slot, tid, gen, zv);
+            st.zf[0][tid] = zv;
+          }
+          got = wg_all(fresh, (int*)&st.res[0][0], tid);
         }
         if (tid == 0) {
           __hip_atomic_store(taken + slot, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // consumed or given up
@@ -2368,24 +2399,22 @@ __device__ __forceinline__ void render_vjp16_body(const VjpArgs* __restrict__ vp
         unsigned* taken = a.sched_flags + slots;
         bool can = false;
         if (tid == 0) {
-          can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(k - 2);
+          can = k < 3 || __hip_atomic_load(taken + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == handoff_tag(a.epoch, k - 3);
           if (can) {
             // claim the slot: it must hold an OLDER generation and nobody may be writing it (a publisher that was
             // descheduled in the middle of its stores still owns it); the compare-and-swap makes the claim exclusive
             const unsigned r = __hip_atomic_load(ready + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            can = r != kSlotBusy && r < (unsigned)(k + 1) && atomicCAS(ready + slot, r, kSlotBusy) == r;
+            can = r != kSlotBusy && r < handoff_tag(a.epoch, k) && atomicCAS(ready + slot, r, kSlotBusy) == r;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // "busy" is out before any value is
           }
         }
         can = vote(can);
         if (can) {
-          if (tid < 192)
-            __hip_atomic_store((unsigned*)a.zf_scratch + slot * 192 + tid, __float_as_uint(st.zf[0][tid]), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+          if (tid < 192) handoff_store(a.zf_scratch, slot, tid, st.zf[0][tid], handoff_tag(a.epoch, k));
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           if (tid == 0)
-            __hip_atomic_store(ready + slot, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ready + slot, handoff_tag(a.epoch, k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         task_done = true;
       }
