@@ -1,2 +1,2 @@
-timeout 120 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "phases or vjp or full_size or graph" 2>&1 | tail -5
-timeout 60 python tools/one_view.py 16 0 phases 3 2>&1 | grep -v amdgpu.ids
+timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+timeout 900 bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -1 $O/collect.log
