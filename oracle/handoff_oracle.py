@@ -19,7 +19,11 @@ not installed in this image, so cv2 itself cannot be run here.  Its published al
     stats columns [left, top, width, height, area]; cross-checked below against scipy.ndimage.label.
   * numpy's argsort on the area column is treated as stable (it is for the <= 16 rows that occur in practice:
     insertion sort); equal areas are vanishingly rare and the rule is written down so the GPU can match it.
-to8b and the PNG round trip are pinned (numpy semantics; tests/test_host_logic.py round-trips the PNG writer).
+to8b and the PNG round trip are pinned (numpy semantics; PNG files against imageio 2.9.0 -- the library the reference
+writes and reads them with -- via tests/golden/io_*.png, oracle/gen_io_golden.py).  connected_components_with_stats is
+pinned to a second implementation of the same documented contract: scikit-image 0.18.3 measure.label(connectivity=2) +
+regionprops on 24 masks (tests/golden/g12_io.npz, tests/test_data_readers.py).  What stays a restated formula is the
+8-bit RGB2GRAY fixed-point conversion: nothing in this image implements OpenCV's.
 """
 import numpy as np
 from scipy import ndimage
