@@ -23,6 +23,29 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.nsr_abi_version() == _lib.ABI_VERSION
 
 
+def test_probe_and_debug_libraries_export_their_headers():
+    """include/nsr_probe.h <-> libnsr_probe.so; libnsr_debug.so exports the same ABI as libnsr.so (dlopen only: no
+    compute without a GPU)."""
+    import ctypes as C
+    import torch                                                  # one HIP runtime per process (see _lib.py)
+    hip = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+    csrc = os.path.join(ROOT, "neural_sim_nerf_amd", "csrc")
+    hdr = open(os.path.join(ROOT, "include", "nsr_probe.h")).read()
+    declared = set(re.findall(r"\b(nsr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {"nsr_probe", "nsr_probe_last_error"}
+    for so, names in (("libnsr_probe.so", declared),
+                      ("libnsr_debug.so", set(re.findall(r"\b(nsr_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "nsr.h")).read()))
+                       - {"nsr_handle_s"})):
+        path = os.path.join(csrc, so)
+        if not os.path.exists(path):
+            pytest.skip("%s not built (python -c 'import __graft_entry__ as g; g.build()')" % so)
+        lib = C.CDLL(path)
+        for name in names:
+            assert hasattr(lib, name), (so, name)
+
+
 def test_header_constants_match_packer():
     from neural_sim_nerf_amd import pack
     hdr = open(os.path.join(ROOT, "include", "nsr.h")).read()
