@@ -48,6 +48,9 @@ extern "C" {
 #define NSR_STREAM_SLABS  145                  /* slabs per network pass                            */
 #define NSR_AUX_FLOATS    3328                 /* biases + alpha/rgb heads, 13 KiB                  */
 #define NSR_PACKED_FLOATS (NSR_STREAM_SLABS * NSR_SLAB_FLOATS + NSR_AUX_FLOATS)
+/* the bf16x3 layout (NSR_FLAG_MLP_BF16X3): every weight as three bf16 pieces, 1.5x the stream */
+#define NSR_STREAM_SLABS_B3  219
+#define NSR_PACKED_B3_FLOATS (NSR_STREAM_SLABS_B3 * NSR_SLAB_FLOATS + NSR_AUX_FLOATS)
 
 typedef struct nsr_handle_s* nsr_handle;
 
@@ -74,6 +77,13 @@ typedef struct NsrConfig {
                                    L2-miss (fabric) traffic of the weight streams; see DESIGN.md 4 for speed vs traffic.
                                    The cross-workgroup hand-off it uses is non-blocking: a value that is not there in
                                    time is recomputed locally (nsr_schedule_stats counts those rays)                   */
+
+#define NSR_FLAG_MLP_BF16X3 8    /* forward render kernel k_render_b3: the layer GEMMs run on bf16 MFMAs with every fp32 operand
+                                   split exactly into three bf16 pieces and the six significant piece products
+                                   accumulated in fp32 -- fp32-grade results (same error against fp64 as an fp32 GEMM)
+                                   at ~1.9x the fp32-MFMA rate.  One workgroup per CU, 32 points per wave, per-item
+                                   queue; needs nsr_upload_weights_b3.  Everything else on the handle (input-gradient
+                                   kernel, stage kernels) follows `variant` as before                                   */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {
@@ -108,6 +118,10 @@ int nsr_upload_weights(nsr_handle h, int net_id, const float* packed, size_t n_f
 
 /* The same networks in the layout of the x16 forward kernel (pack.py: pack_network16). */
 int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n_floats);
+
+/* The same networks in the bf16x3 layout (pack.py: pack_network_b3; NSR_PACKED_B3_FLOATS floats: the stream holds
+ * packed bf16 pairs, the aux block is the fp32 one of nsr_upload_weights).  Handles created with NSR_FLAG_MLP_BF16X3. */
+int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t n_floats);
 
 /* Transposed stream of the FINE network for the input-gradient kernel (pack.py: pack_network_backward);
  * host buffer of NSR_STREAM_SLABS*NSR_SLAB_FLOATS floats.  Needed only by nsr_render_rays_vjp. */

@@ -19,6 +19,7 @@
 static_assert(NSR_SLAB_FLOATS == nsr::kSlabFloats, "header/kernels out of sync");
 static_assert(NSR_STREAM_SLABS == nsr::kStreamSlabs, "header/kernels out of sync");
 static_assert(NSR_AUX_FLOATS == nsr::kAuxFloats, "header/kernels out of sync");
+static_assert(NSR_STREAM_SLABS_B3 == nsr::kStreamSlabsB3, "header/kernels out of sync");
 
 namespace {
 
@@ -66,6 +67,8 @@ struct nsr_handle_s {
   bool have_net[3] = {false, false, false};
   float* d_nets16 = nullptr;                            // coarse | fine | fine transposed in the x16 layout
   bool have_net16[3] = {false, false, false};
+  float* d_nets_b3 = nullptr;                           // coarse | fine in the bf16x3 layout (NSR_FLAG_MLP_BF16X3)
+  bool have_net_b3[2] = {false, false};
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
@@ -119,6 +122,10 @@ static int allocate_handle(nsr_handle h) {
   NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
+  if (cfg->flags & NSR_FLAG_MLP_BF16X3) {
+    NSR_HIP(hipMalloc(&h->d_nets_b3, sizeof(float) * 2 * NSR_PACKED_B3_FLOATS));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+  }
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
@@ -160,7 +167,8 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
   if (cfg->n_samples != NSR_N_SAMPLES)
     return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
-  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP | NSR_FLAG_SCHED_PHASES)) return fail("nsr_create: unknown bits in flags");
+  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP | NSR_FLAG_SCHED_PHASES | NSR_FLAG_MLP_BF16X3))
+    return fail("nsr_create: unknown bits in flags");
   if ((cfg->flags & NSR_FLAG_SCHED_PHASES) && (cfg->variant == 32 || cfg->n_importance == 0))
     return fail("nsr_create: NSR_FLAG_SCHED_PHASES applies to the x16 coarse+fine forward kernel only");
   if (cfg->chunk < 0 || cfg->chunk > 256) return fail("nsr_create: chunk must be 0 (default) or 1..256");
@@ -195,6 +203,7 @@ int nsr_destroy(nsr_handle h) {
   hipDeviceSynchronize();
   hipFree(h->d_nets);
   hipFree(h->d_nets16);
+  hipFree(h->d_nets_b3);
   hipFree(h->d_tables);
   hipFree(h->d_scratch);
   hipFree(h->d_args);
@@ -230,6 +239,18 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
   NSR_HIP(hipMemcpy(h->d_nets16 + (size_t)net_id * NSR_PACKED_FLOATS, packed, sizeof(float) * n_floats,
                     hipMemcpyHostToDevice));
   h->have_net16[net_id] = true;
+  return 0;
+}
+
+int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t n_floats) {
+  if (!h || !packed) return fail("nsr_upload_weights_b3: null argument");
+  if (!(h->cfg.flags & NSR_FLAG_MLP_BF16X3)) return fail("nsr_upload_weights_b3: the handle was not created with NSR_FLAG_MLP_BF16X3");
+  if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights_b3: net_id must be 0 (coarse) or 1 (fine)");
+  if (n_floats != (size_t)NSR_PACKED_B3_FLOATS) return fail("nsr_upload_weights_b3: wrong packed size");
+  NSR_DEVICE(h);
+  NSR_HIP(hipMemcpy(h->d_nets_b3 + (size_t)net_id * NSR_PACKED_B3_FLOATS, packed, sizeof(float) * n_floats,
+                    hipMemcpyHostToDevice));
+  h->have_net_b3[net_id] = true;
   return 0;
 }
 
@@ -290,18 +311,23 @@ static bool use_x16(nsr_handle h) { return h->cfg.variant != 32; }
 static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* out, const NsrDebugOut* dbg,
                          void* stream) {
   const bool fine = h->cfg.n_importance > 0;
-  const bool x16 = use_x16(h);
+  const bool b3 = (h->cfg.flags & NSR_FLAG_MLP_BF16X3) != 0;
+  const bool x16 = use_x16(h) && !b3;
   if (int e = check_ready(h, fine)) return e;
   if (x16 && (!h->have_net16[0] || (fine && !h->have_net16[1])))
     return fail("variant 16 needs nsr_upload_weights16 for every network");
+  if (b3 && (!h->have_net_b3[0] || (fine && !h->have_net_b3[1])))
+    return fail("NSR_FLAG_MLP_BF16X3 needs nsr_upload_weights_b3 for every network");
   if (!out || !out->d_rgb || !out->d_disp || !out->d_acc) return fail("render: rgb/disp/acc outputs are required");
   if (a.n_rays <= 0) return 0;
   NSR_DEVICE(h);
-  float* nets = x16 ? h->d_nets16 : h->d_nets;
+  float* nets = b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets);
+  const size_t net_floats = b3 ? (size_t)NSR_PACKED_B3_FLOATS : (size_t)NSR_PACKED_FLOATS;
+  const size_t stream_floats = (size_t)(b3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
   a.nets = nets;
-  a.net_stride = (long long)sizeof(float) * NSR_PACKED_FLOATS;
-  a.aux[0] = nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
-  a.aux[1] = nets + (fine ? (size_t)NSR_PACKED_FLOATS : 0) + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+  a.net_stride = (long long)sizeof(float) * (long long)net_floats;
+  a.aux[0] = nets + stream_floats;
+  a.aux[1] = nets + (fine ? net_floats : 0) + stream_floats;
   a.tcoarse = h->d_tables;
   a.ufine = h->d_tables + 64;
   a.fine = fine ? 1 : 0;
@@ -354,6 +380,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     hipLaunchKernelGGL(nsr::k_render16p, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   else if (x16)
     hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
+  else if (b3)
+    hipLaunchKernelGGL(nsr::k_render_b3, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   else
     hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   NSR_HIP(hipGetLastError());

@@ -81,7 +81,7 @@ __device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base
   rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
 
-template <int NS = kRingSlots>
+template <int NS = kRingSlots, int SLABS = kStreamSlabs>
 __device__ __forceinline__ void ring_issue(Ring& rg) {
   char* l = rg.smem + rg.pslot * kSlabBytes + rg.wave_lds;
 #ifndef NSR_EXP_NODMA        // (NODMA: timing experiment only)
@@ -99,7 +99,7 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   // branch-free advance (scalar selects only): a branch here would split the basic block and stop the scheduler
   // from interleaving the DMA issue with the MFMAs around it
   const int nslab = rg.pslab + 1;
-  const bool wrap = nslab == kStreamSlabs;
+  const bool wrap = nslab == SLABS;
   rg.pslab = wrap ? 0 : nslab;
   const int nphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
   rg.pphase = wrap ? nphase : rg.pphase;
@@ -123,10 +123,10 @@ __device__ __forceinline__ void ring_assert_uniform(Ring& rg) {
 
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
 // A step = 4 chunks of 1 KiB = 4 float4 fragments per lane = 16 MFMAs; a slab = 4 steps.
-template <int NS = kRingSlots>
+template <int NS = kRingSlots, int SLABS = kStreamSlabs>
 __device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[4], int lane) {
 #pragma unroll 1
-  for (int s = 0; s < NS; ++s) ring_issue<NS>(rg);
+  for (int s = 0; s < NS; ++s) ring_issue<NS, SLABS>(rg);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
@@ -275,6 +275,8 @@ __device__ __forceinline__ void load_bias(const float* bias, int h4 /* 4 * lane 
     }
 }
 
+#include "nsr_b3.inc"
+
 // ------------------------------------------------------------------------------------------------------
 // One network pass for this lane's point.  Lane (j = lane&31, h = lane>>5): both halves work on point j and
 // hold complementary halves of every feature vector.  Returns raw = (r,g,b logits, sigma) in all lanes.
@@ -338,7 +340,9 @@ __device__ __forceinline__ float enc_poison(float px, float py, float pz, float 
   return __builtin_fabsf(a + b);      // +0 or NaN
 }
 
-template <bool CAPTURE>
+// B3: the layer GEMMs run on bf16 MFMAs with three-way split operands (nsr_b3.inc) instead of fp32 MFMAs; the
+// encodings, biases, activations and the two VALU heads are the same code.
+template <bool CAPTURE, bool B3 = false>
 __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                          float px, float py, float pz, float vx, float vy, float vz,
                                          float (&raw)[4], uint4* mask_dst = nullptr /* uniform */, int mask_tid = 0) {
@@ -369,8 +373,11 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   f32x16 acc[8];
   f32x16 in[8];
   // layer 0
+  auto enc_src = [&](int kb, int i) { return e[(8 * kb + i) & 31]; };
+  auto in_src = [&](int kb, int i) { return in[(kb >> 1) & 7][8 * (kb & 1) + i]; };
   load_bias<8>(aux + kAuxBias, h4, acc);
-  seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
+  if constexpr (B3) gemm_b3<8, 2>(rg, A0, A1, enc_src, acc, lane);
+  else seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
   if (CAPTURE) mask_dst[mask_tid] = relu_mask<8>(acc);
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
@@ -380,7 +387,10 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 #pragma unroll 1
   for (int L = 1; L <= 8; ++L) {
     load_bias<8>(aux + kAuxBias + L * 256, h4, acc);
-    if (L == 5) seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);  // skip: cat([input_pts, h]) -> input columns first (RH:105)
+    if (L == 5) {                                                // skip: cat([input_pts, h]) -> input columns first (RH:105)
+      if constexpr (B3) gemm_b3<8, 2>(rg, A0, A1, enc_src, acc, lane);
+      else seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
+    }
     if (L == 8) {
       // alpha_linear on h7 (RH:109): VALU dot product over this lane's 128 features, halves summed below
       const float* wa = aux + kAuxWAlpha;
@@ -392,7 +402,8 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
           alpha_part = __builtin_fmaf(w[kk], in[(4 * tq + kk) >> 4][(4 * tq + kk) & 15], alpha_part);
       }
     }
-    seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
+    if constexpr (B3) gemm_b3<8, 8>(rg, A0, A1, in_src, acc, lane);
+    else seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
     if (CAPTURE && L < 8) mask_dst[L * 256 + mask_tid] = relu_mask<8>(acc);
     const int thr = (L == 8) ? (int)0x80000000 : 0;      // feature_linear has no activation
 #pragma unroll
@@ -402,7 +413,14 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   // views_linears.0 (RH:111-115): cat([feature, input_views]) -> 128, ReLU
   f32x16 av[4];
   load_bias<4>(aux + kAuxBiasV, h4, av);
-  seg<4, 36>(rg, A0, A1, BViews{in, ed}, av, lane);
+  if constexpr (B3) {        // 16 blocks of features, 2 of direction encoding, 2 of padding (a group is 4 blocks)
+    auto v_src = [&](int kb, int i) {
+      return kb < 16 ? in[(kb >> 1) & 7][8 * (kb & 1) + i] : (kb < 18 ? ed[(8 * (kb - 16) + i) & 15] : 0.0f);
+    };
+    gemm_b3<4, 5>(rg, A0, A1, v_src, av, lane);
+  } else {
+    seg<4, 36>(rg, A0, A1, BViews{in, ed}, av, lane);
+  }
   if (CAPTURE) mask_dst[8 * 256 + mask_tid] = relu_mask<4>(av);
 
   // rgb_linear (RH:117) on relu(av): VALU
@@ -758,8 +776,8 @@ __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; *a.w
 #define NSR_T(i) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool B3>
+__device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap, char* smem) {
   const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -780,7 +798,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 4 : 1, wave, lane);
 
   f32x4 A0[4], A1[4];
-  ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
+  ring_start<kRingSlots, B3 ? kStreamSlabsB3 : kStreamSlabs>(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
 
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
@@ -853,7 +871,7 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass<false>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+      mlp_pass<false, B3>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
@@ -934,6 +952,16 @@ __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict_
   if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)      // diagnostic hijack: dbg_inds receives [grid][8] cycle totals
     for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
 #endif
+}
+
+__global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<false>(ap, smem);
+}
+// the same kernel with the layer GEMMs on bf16 MFMAs, fp32 operands split three ways (nsr_b3.inc)
+__global__ void __launch_bounds__(256, 1) k_render_b3(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<true>(ap, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -14,6 +14,15 @@ __global__ void k_probe_fill(float* p, long long n) {     // non-trivial operand
     p[i] = ((float)(x & 0xffff) - 32768.0f) * (1.0f / 262144.0f);
   }
 }
+__global__ void k_probe_fill_bf16(unsigned* p, long long n) {     // two bf16 weight pieces per word, |w| < 1/8
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    const float a = ((float)(x & 0xffff) - 32768.0f) * (1.0f / 262144.0f);
+    const float b = ((float)(x >> 16) - 32768.0f) * (1.0f / 262144.0f);
+    p[i] = (__float_as_uint(a) >> 16) | (__float_as_uint(b) & 0xffff0000u);
+  }
+}
 }  // namespace nsr
 
 #include <cstdio>
@@ -39,13 +48,13 @@ const char* nsr_probe_last_error(void) { return g_perr.c_str(); }
 
 int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   if (!ms) return pfail("nsr_probe: null argument");
-  if (mode < 0 || mode > 10 || iters <= 0) return pfail("nsr_probe: mode in 0..10, iters > 0");
+  if (mode < 0 || mode > 15 || iters <= 0) return pfail("nsr_probe: mode in 0..15, iters > 0");
   NSRP_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   NSRP_HIP(hipGetDeviceProperties(&prop, device));
   const int n_cu = prop.multiProcessorCount;
   hipStream_t s = nullptr;
-  const long long n_stream = (long long)nsr::kStreamSlabs * nsr::kSlabFloats + nsr::kAuxFloats;
+  const long long n_stream = (long long)nsr::kStreamSlabsB3 * nsr::kSlabFloats + nsr::kAuxFloats;   // the longer of the two streams
   float *wstream = nullptr, *out = nullptr;
   int* done = nullptr;
   hipEvent_t ev0, ev1;
@@ -55,7 +64,8 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   NSRP_HIP(hipMemset(done, 0, sizeof(int)));
   NSRP_HIP(hipEventCreate(&ev0));
   NSRP_HIP(hipEventCreate(&ev1));
-  hipLaunchKernelGGL(nsr::k_probe_fill, dim3(1024), dim3(256), 0, s, wstream, n_stream);
+  if (mode >= 11) hipLaunchKernelGGL(nsr::k_probe_fill_bf16, dim3(1024), dim3(256), 0, s, (unsigned*)wstream, n_stream);
+  else hipLaunchKernelGGL(nsr::k_probe_fill, dim3(1024), dim3(256), 0, s, wstream, n_stream);
   const size_t lds = nsr::kRingSlots * nsr::kSlabBytes, l16 = nsr::kRing16 * nsr::kSlabBytes, lepi = lds + 1024;
 #define NSRP_LDS(K, L) NSRP_HIP(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(L)))
   NSRP_LDS(nsr::k_probe<0>, lds); NSRP_LDS(nsr::k_probe<1>, lds); NSRP_LDS(nsr::k_probe<2>, lds);
@@ -63,6 +73,8 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   NSRP_LDS(nsr::k_probe_epi<9>, lepi); NSRP_LDS(nsr::k_probe_epi<10>, lepi);
   NSRP_LDS(nsr::k_probe16_pair<0>, l16); NSRP_LDS(nsr::k_probe16_pair<1>, l16); NSRP_LDS(nsr::k_probe16_pair<2>, l16);
   NSRP_LDS(nsr::k_probe16_pair<3>, l16); NSRP_LDS(nsr::k_probe16_pair<4>, l16);
+  NSRP_LDS(nsr::k_probe_b3<11>, lepi); NSRP_LDS(nsr::k_probe_b3<12>, lepi); NSRP_LDS(nsr::k_probe_b3<13>, lepi);
+  NSRP_LDS(nsr::k_probe_b3<14>, lepi); NSRP_LDS(nsr::k_probe_b3<15>, lepi);
   NSRP_HIP(hipDeviceSynchronize());
   NSRP_HIP(hipEventRecord(ev0, s));
   const dim3 b(256), g1(n_cu), g2(2 * n_cu);
@@ -78,6 +90,11 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
     case 8: hipLaunchKernelGGL(nsr::k_probe16_pair<4>, g2, b, l16, s, wstream, out, iters, done, n_cu, partner_prio); break;
     case 9: hipLaunchKernelGGL(nsr::k_probe_epi<9>, g1, b, lepi, s, wstream, out, iters); break;
     case 10: hipLaunchKernelGGL(nsr::k_probe_epi<10>, g1, b, lepi, s, wstream, out, iters); break;
+    case 11: hipLaunchKernelGGL(nsr::k_probe_b3<11>, g1, b, lepi, s, wstream, out, iters); break;
+    case 12: hipLaunchKernelGGL(nsr::k_probe_b3<12>, g1, b, lepi, s, wstream, out, iters); break;
+    case 13: hipLaunchKernelGGL(nsr::k_probe_b3<13>, g1, b, lepi, s, wstream, out, iters); break;
+    case 14: hipLaunchKernelGGL(nsr::k_probe_b3<14>, g1, b, lepi, s, wstream, out, iters); break;
+    case 15: hipLaunchKernelGGL(nsr::k_probe_b3<15>, g1, b, lepi, s, wstream, out, iters); break;
   }
   NSRP_HIP(hipGetLastError());
   NSRP_HIP(hipEventRecord(ev1, s));

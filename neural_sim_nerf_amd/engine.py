@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .pack import pack_network, pack_network16, pack_network_backward, pack_network_backward16, PACKED_FLOATS
+from .pack import (pack_network, pack_network16, pack_network_backward, pack_network_backward16, pack_network_b3,
+                   PACKED_FLOATS, PACKED_B3_FLOATS)
 
 N_SAMPLES = 64
 N_IMPORTANCE = 128
@@ -18,6 +19,7 @@ N_IMPORTANCE = 128
 # 328.1 vs 326.6 ms per 400x400 view (+0.5 %) for 4-5 GB instead of 20-90 GB of L2-miss (fabric) traffic per view
 # (profiles/r02/pmc_k_render.json); results are bit-identical.
 DEFAULT_SCHEDULE = "phases"
+DEFAULT_MLP = "fp32"             # layer-GEMM arithmetic of the forward render kernel: "fp32" or "bf16x3" (NsrModel)
 
 
 def _host_tables():
@@ -41,12 +43,15 @@ def _stream_ptr(device):
 
 class NsrModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0,
-                 white_bkgd=False, lindisp=False, chunk=None, schedule=None):
+                 white_bkgd=False, lindisp=False, chunk=None, schedule=None, mlp=None):
         """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu).
         white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration).
         chunk: rays per work-queue chunk of the x16 kernel (None: $NSR_CHUNK, read HERE once, else the library default).
         schedule: "queue" (per-ray queue) or "phases" (global phases, NSR_FLAG_SCHED_PHASES); None: $NSR_SCHEDULE, else
-        the library default.  Both give bit-identical results."""
+        the library default.  Both give bit-identical results.
+        mlp: arithmetic of the layer GEMMs of the FORWARD render kernel: "fp32" (fp32 MFMAs) or "bf16x3" (bf16 MFMAs on
+        fp32 operands split exactly into three bf16 pieces, NSR_FLAG_MLP_BF16X3: fp32-grade results, ~1.9x the MFMA
+        rate); None: $NSR_MLP, else DEFAULT_MLP."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
@@ -61,6 +66,11 @@ class NsrModel:
             schedule = os.environ.get("NSR_SCHEDULE", DEFAULT_SCHEDULE)
         if schedule not in ("queue", "phases"):
             raise ValueError("schedule must be 'queue' or 'phases'")
+        if mlp is None:
+            mlp = os.environ.get("NSR_MLP", DEFAULT_MLP)
+        if mlp not in ("fp32", "bf16x3"):
+            raise ValueError("mlp must be 'fp32' or 'bf16x3'")
+        self.mlp = mlp
         phases = schedule == "phases" and variant != 32 and n_importance > 0      # the x16 coarse+fine kernel only
         self.schedule = "phases" if phases else "queue"
         if n_importance not in (0, N_IMPORTANCE):
@@ -73,7 +83,8 @@ class NsrModel:
         self.variant = variant
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant,
-                             (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0), int(chunk))
+                             (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0)
+                             | (8 if mlp == "bf16x3" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
@@ -91,6 +102,9 @@ class NsrModel:
         if self.variant != 32:                       # 0 = library default = x16
             p = pack_network16(sd_c)
             _lib.check(self.lib.nsr_upload_weights16(self.h, 0, _fptr(p), PACKED_FLOATS))
+        if self.mlp == "bf16x3":
+            p = pack_network_b3(sd_c)
+            _lib.check(self.lib.nsr_upload_weights_b3(self.h, 0, _fptr(p), PACKED_B3_FLOATS))
         self._sd_fine_np = None
         self._bwd_ready = False
         if sd_fine is not None:
@@ -100,6 +114,9 @@ class NsrModel:
             if self.variant != 32:
                 p = pack_network16(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights16(self.h, 1, _fptr(p), PACKED_FLOATS))
+            if self.mlp == "bf16x3":
+                p = pack_network_b3(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights_b3(self.h, 1, _fptr(p), PACKED_B3_FLOATS))
 
     def close(self):
         if getattr(self, "h", None):

@@ -309,3 +309,91 @@ def pack_network_backward16(sd):
     stream = np.concatenate([x.reshape(-1) for x in segs]).astype(np.float32)
     assert stream.size == STREAM_SLABS * SLAB_FLOATS
     return stream
+
+
+# ----------------------------------------------------------------------------------------------------------
+# "bf16x3" forward layout (csrc/nsr_b3.inc, k_render_b3): v_mfma_f32_32x32x16_bf16, every fp32 weight as three bf16 pieces
+# ----------------------------------------------------------------------------------------------------------
+# One MFMA consumes, per lane l, A[row l&31][8 k-slots of lane half l>>5] (8 bf16 = 16 bytes).  Slot i of k16 block kb is
+# k-step t = 8*kb + i of the fp32 x32 layout above, for both lane halves, so the column tables (kappa / eps) are shared.
+# A chunk (1 KiB = [64 lanes][8] bf16) is ONE piece of ONE (k16 block, output block) fragment; a step is 4 chunks, a
+# group 12 steps = 3 slabs; the tables mirror B3Sched<8> / B3Sched<4> in csrc/nsr_b3.inc.
+STREAM_SLABS_B3 = 219
+PACKED_B3_FLOATS = STREAM_SLABS_B3 * SLAB_FLOATS + AUX_FLOATS
+B3_STEPS8 = ([(0, 0), (1, 1), (1, 2), (2, 3)], [(0, 1), (0, 3), (2, 0), (2, 2)], [(0, 2), (1, 3), (1, 4), (2, 5)],
+             [(0, 4), (1, 5), (1, 6), (2, 7)], [(0, 5), (0, 7), (2, 4), (2, 6)], [(0, 6), (1, 7), (1, 0), (2, 1)])
+B3_STEPS4 = ([(0, 0), (1, 1), (1, 2), (2, 3)], [(0, 1), (0, 3), (2, 0), (2, 2)], [(0, 2), (1, 3), (1, 0), (2, 1)])
+
+
+def bf16_round(x):
+    """fp32 -> nearest-even bf16, returned as fp32 (low 16 bits zero)."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32)
+    return r.view(np.float32)
+
+
+def split_bf16x3(x):
+    """x (fp32) -> three bf16-valued fp32 arrays with x == p0 + p1 + p2 exactly (|x| well inside the fp32 range)."""
+    x = np.ascontiguousarray(x, np.float32)
+    p0 = bf16_round(x)
+    r1 = (x - p0).astype(np.float32)
+    p1 = bf16_round(r1)
+    r2 = (r1 - p1).astype(np.float32)
+    p2 = bf16_round(r2)
+    return p0, p1, p2
+
+
+def _pack_b3(W, cols, n_mo):
+    """W [32*n_mo, K]; cols [n_ksteps, 2] (reference column or -1).  Returns uint16 [n_groups*48, 64, 8]: the chunks of
+    the segment in stream order.  n_ksteps is padded with zero blocks to whole groups."""
+    steps = B3_STEPS8 if n_mo == 8 else B3_STEPS4
+    spk = len(steps)                         # steps per k16 block
+    nb = 12 // spk                           # k16 blocks per group
+    assert W.shape[0] == 32 * n_mo and cols.shape[0] % 8 == 0
+    n_kb = cols.shape[0] // 8
+    n_groups = -(-n_kb // nb)
+    cols = np.concatenate([cols, np.full((8 * (n_groups * nb - n_kb), 2), -1, cols.dtype)], 0)
+    Wp = np.concatenate([W, np.zeros((W.shape[0], 1), W.dtype)], 1)       # column -1 -> zeros
+    lane = np.arange(64)
+    row, h = lane & 31, lane >> 5
+    frag = np.empty((n_groups * nb, n_mo, 64, 8), np.float32)             # [k16 block][output block][lane][slot]
+    for kb in range(n_groups * nb):
+        for i in range(8):
+            c = cols[8 * kb + i][h]
+            for mo in range(n_mo):
+                frag[kb, mo, :, i] = Wp[32 * mo + row, c]
+    pieces = [(p.view(np.uint32) >> 16).astype(np.uint16) for p in split_bf16x3(frag)]
+    out = np.empty((n_groups * 48, 64, 8), np.uint16)
+    n = 0
+    for g in range(n_groups):
+        for G in range(12):
+            kb = nb * g + G // spk
+            for piece, mo in steps[G % spk]:
+                out[n] = pieces[piece][kb, mo]
+                n += 1
+    return out
+
+
+def pack_network_b3(sd):
+    """The forward stream of pack_network with every weight as three bf16 pieces, in the chunk order of k_render_b3,
+    followed by the SAME fp32 aux block.  Returns float32 [PACKED_B3_FLOATS] (the stream part is packed bf16 pairs
+    viewed as floats)."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    aux = pack_network(sd)[STREAM_SLABS * SLAB_FLOATS:]                  # also validates the shapes
+    t = np.arange(128)
+    cols_main = np.stack([kappa(t, 0), kappa(t, 1)], 1)
+    cols_enc = np.array([[eps(tt, 0, 10), eps(tt, 1, 10)] for tt in range(32)])
+    cols_dir = np.array([[eps(tt, 0, 4), eps(tt, 1, 4)] for tt in range(16)])
+    segs = [_pack_b3(g("pts_linears.0.weight"), cols_enc, 8)]
+    for i in range(1, 8):
+        W = g("pts_linears.%d.weight" % i)
+        if i == 5:
+            segs.append(_pack_b3(W[:, :63], cols_enc, 8))
+            W = W[:, 63:]
+        segs.append(_pack_b3(W, cols_main, 8))
+    segs.append(_pack_b3(g("feature_linear.weight"), cols_main, 8))
+    cols_views = np.concatenate([cols_main, np.where(cols_dir >= 0, cols_dir + 256, -1)], 0)
+    segs.append(_pack_b3(g("views_linears.0.weight"), cols_views, 4))
+    stream = np.concatenate([x.reshape(-1) for x in segs])
+    assert stream.size * 2 == STREAM_SLABS_B3 * SLAB_FLOATS * 4
+    return np.concatenate([stream.view(np.float32), aux]).astype(np.float32, copy=False)

@@ -319,3 +319,119 @@ def mlp_bwd_pass16(packed16_fwd, stream_bwd16, masks, pts, dirs, g_raw):
     assert st.pos == 145 * 16
     dp = _embed_bwd16(P, [genc[t >> 2][:, t & 3] for t in range(16)], 10)
     return dp, dv
+
+
+# ----------------------------------------------------------------------------------------------------------
+# bf16x3 forward pass (csrc/nsr_b3.inc, mlp_pass<.., B3 = true>): v_mfma_f32_32x32x16_bf16 modelled as
+#     A[i][k] = a[lane = i + 32 (k // 8)][slot k % 8],  B[k][j] = b[lane = j + 32 (k // 8)][slot k % 8],
+# same C/D fragment as the fp32 32x32 MFMA.  (Any other pairing of slots with k is equivalent as long as it is
+# the same for A and B, which is what the kernel relies on.)
+# ----------------------------------------------------------------------------------------------------------
+B3_PIECE8 = [[0, 1, 1, 2], [0, 0, 2, 2], [0, 1, 1, 2], [0, 1, 1, 2], [0, 0, 2, 2], [0, 1, 1, 2]]      # B3Sched<8>
+B3_BLOCK8 = [[0, 1, 2, 3], [1, 3, 0, 2], [2, 3, 4, 5], [4, 5, 6, 7], [5, 7, 4, 6], [6, 7, 0, 1]]
+B3_PIECE4 = [[0, 1, 1, 2], [0, 0, 2, 2], [0, 1, 1, 2]]                                                # B3Sched<4>
+B3_BLOCK4 = [[0, 1, 2, 3], [1, 3, 0, 2], [2, 3, 0, 1]]
+
+
+def _bf16_bits_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def mfma_b3(a, b, acc):
+    """a, b: [64, 8] bf16-valued floats (4 VGPRs each); acc: [64,16]."""
+    A = a.reshape(2, 32, 8).transpose(1, 0, 2).reshape(32, 16)       # [i, k = 8 half + slot]
+    B = b.reshape(2, 32, 8).transpose(0, 2, 1).reshape(16, 32)       # [k, j]
+    D = A.astype(np.float64) @ B.astype(np.float64)
+    out = acc.copy()
+    out += D[ROW_OF, COL_OF].astype(np.float32)
+    return out
+
+
+def split_trunc(x):
+    """split_pair of nsr_b3.inc: three truncation pieces of an fp32 array (exact sum), as bf16-valued floats."""
+    x = np.ascontiguousarray(x, np.float32)
+    m = np.uint32(0xffff0000)
+    p0 = (x.view(np.uint32) & m).view(np.float32)
+    r1 = (x - p0).astype(np.float32)
+    p1 = (r1.view(np.uint32) & m).view(np.float32)
+    r2 = (r1 - p1).astype(np.float32)
+    p2 = (r2.view(np.uint32) & m).view(np.float32)
+    assert np.array_equal(p2, r2)                                     # the third residual IS a bf16
+    return p0, p1, p2
+
+
+class StreamB3:
+    """The bf16x3 stream as the kernel sees it: consecutive 1 KiB chunks of [64 lanes][8 bf16]."""
+
+    def __init__(self, stream_floats):
+        self.chunks = _bf16_bits_to_f32(stream_floats.view(np.uint16).reshape(-1, 64, 8))
+        self.pos = 0
+
+    def gemm(self, nmo, ngroups, src, acc):
+        """gemm_b3<NMO, NGROUPS>: src(kb) -> [64, 8] fp32 (this lane's slots of k16 block kb)."""
+        piece, block = (B3_PIECE8, B3_BLOCK8) if nmo == 8 else (B3_PIECE4, B3_BLOCK4)
+        spk = len(piece)
+        nb = 12 // spk
+        for g in range(ngroups):
+            b = [split_trunc(src(nb * g + i)) for i in range(nb)]
+            for G in range(12):
+                s, bb = G % spk, b[G // spk]
+                A = [self.chunks[self.pos + c] for c in range(4)]
+                self.pos += 4
+                for j in range(3):                                   # consume_b3: rounds, then chunks
+                    for c in range(4):
+                        if piece[s][c] + j <= 2:
+                            mo = block[s][c]
+                            acc[mo] = mfma_b3(A[c], bb[j], acc[mo])
+
+
+def mlp_pass_b3(packed_b3, pts, dirs):
+    """pts, dirs: [32,3] -> raw [32,4]: one wave of mlp_pass<false, true>."""
+    from neural_sim_nerf_amd import pack as PK
+    st = StreamB3(packed_b3[:PK.STREAM_SLABS_B3 * PK.SLAB_FLOATS])
+    aux = packed_b3[PK.STREAM_SLABS_B3 * PK.SLAB_FLOATS:]
+    h = LANE >> 5
+    P = np.concatenate([pts, pts], 0).astype(np.float32)
+    V = np.concatenate([dirs, dirs], 0).astype(np.float32)
+    e = _encode(P, 10, 32)
+    ed = _encode(V, 4, 16)
+    enc_src = lambda kb: np.stack([e[8 * kb + i] for i in range(8)], 1)
+    acc = load_bias(aux, PK.AUX_BIAS, 8)
+    st.gemm(8, 2, enc_src, acc)
+    inp = np.maximum(acc, 0)
+    in_src = lambda kb: inp[kb >> 1][:, 8 * (kb & 1):8 * (kb & 1) + 8]
+    alpha_part = np.zeros(64, np.float32)
+    for L in range(1, 9):
+        acc = load_bias(aux, PK.AUX_BIAS + L * 256, 8)
+        if L == 5:
+            st.gemm(8, 2, enc_src, acc)
+        if L == 8:
+            for tq in range(32):
+                for kk in range(4):
+                    w = aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk]
+                    alpha_part = alpha_part + w * inp[(4 * tq + kk) >> 4][:, (4 * tq + kk) & 15]
+        st.gemm(8, 8, in_src, acc)
+        inp = np.maximum(acc, 0) if L < 8 else acc.copy()
+    av = load_bias(aux, PK.AUX_BIAS_V, 4)
+
+    def v_src(kb):
+        if kb < 16:
+            return in_src(kb)
+        if kb < 18:
+            return np.stack([ed[8 * (kb - 16) + i] for i in range(8)], 1)
+        return np.zeros((64, 8), np.float32)
+    st.gemm(4, 5, v_src, av)
+    assert st.pos == PK.STREAM_SLABS_B3 * 16
+    part = np.zeros((4, 64), np.float32)
+    part[3] = alpha_part
+    for c in range(3):
+        for mo in range(4):
+            for rq in range(4):
+                for ri in range(4):
+                    w = aux[PK.AUX_W_RGB + c * 128 + ((mo * 4 + rq) * 2 + h) * 4 + ri]
+                    part[c] = part[c] + w * np.maximum(av[mo][:, rq * 4 + ri], 0)
+    raw = np.zeros((32, 4), np.float32)
+    for c in range(4):
+        bias = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
+        raw[:, c] = part[c][:32] + part[c][32:] + bias
+    return raw

@@ -698,6 +698,43 @@ def test_x16_stagewise_and_golden(model16, oracle, synth_nets):
     assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0
 
 
+@pytest.fixture(scope="module")
+def model_b3(synth_nets):
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3")      # k_render_b3: bf16 MFMAs on three-way split fp32 operands
+    yield m
+    m.close()
+
+
+def test_bf16x3_stagewise_and_golden(model_b3, model, oracle, synth_nets):
+    """NSR_FLAG_MLP_BF16X3: the SAME bounds as the fp32-MFMA kernels, stage by stage against the oracle and against what
+    the reference produced (fp32-grade results are the claim; nothing is loosened for this kernel)."""
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    r = model_b3.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
+    _stagewise(model_b3, oracle, synth_nets, r, g["rays_o"], g["rays_d"], near, far)
+    assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+    assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
+    assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
+    assert (cpu(r["inds"]) == g["inds"]).mean() > 0.99
+    assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0
+    assert np.abs(cpu(r["rgb_map"]) - g["rgb"]).mean() < 2e-4
+    assert np.abs(cpu(r["acc_map"]) - g["acc"]).mean() < 2e-4
+    # against the fp32-MFMA kernel on the same rays: network outputs agree to fp32 rounding, but are not the same bits
+    r32 = model.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
+    d = np.abs(cpu(r["raw0"]) - cpu(r32["raw0"]))
+    assert 0 < d.max() < 2e-5, d.max()
+    # chunk invariance (RN:67-68) and odd counts
+    for n in (1, 3, 77):
+        rn = model_b3.render_rays(g["rays_o"][:n], g["rays_d"][:n], near, far)
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+            assert np.array_equal(cpu(rn[k]), cpu(r[k])[:n], equal_nan=True), (k, n)
+    g7 = load_golden("g7_render")
+    rv = model_b3.render_views(g7["c2w_b"], 32, 32, g7["K32"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+    assert_close(cpu(rv["rgb0"]).reshape(32, 32, 3), g7["rgb0_c2"], atol=1e-5, what="rgb0")
+    assert oracle.psnr(cpu(rv["rgb_map"]).reshape(32, 32, 3), g7["rgb_c2"]) > 55.0
+
+
 def test_x16_chunk_invariance_and_views(model16, model, oracle):
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])

@@ -132,6 +132,66 @@ def test_packer_through_kernel_emulation(oracle, synth_nets):
     assert np.abs(dv - rv).max() < 1e-5 * np.abs(rv).max()
 
 
+def test_packer_b3_through_kernel_emulation(oracle, synth_nets):
+    """The bf16x3 forward pass (csrc/nsr_b3.inc): lane-level emulation of one wave, chunk by chunk in the kernel's
+    group / step / round order, fed with pack_network_b3's stream, against the oracle AND against the fp32 emulation:
+    pins the packer's chunk tables, the slot <-> k-step map and the six-product scheme on the CPU."""
+    from neural_sim_nerf_amd import pack
+    import kernel_emulator as E
+    sd = synth_nets[1]
+    p3 = pack.pack_network_b3(sd)
+    assert p3.shape == (pack.PACKED_B3_FLOATS,) and p3.dtype == np.float32
+    assert np.array_equal(p3[pack.STREAM_SLABS_B3 * pack.SLAB_FLOATS:], pack.pack_network(sd)[pack.STREAM_SLABS * pack.SLAB_FLOATS:])
+    rng = np.random.RandomState(0)
+    pts = rng.uniform(-1.5, 1.5, (32, 3)).astype(np.float32)
+    d = rng.standard_normal((32, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    raw3 = E.mlp_pass_b3(p3, pts, d)
+    raw32 = E.mlp_pass(pack.pack_network(sd), pts, d)
+    want = oracle.mlp(sd, np.concatenate([oracle.embed(pts, 10), oracle.embed(d, 4)], -1))
+    assert np.abs(raw3 - want).max() < 2e-5                       # the same bound as the fp32 kernel's emulation
+    assert np.abs(raw3 - raw32).max() < 2e-5
+    assert np.abs(raw3 - raw32).max() > 0                         # it IS a different arithmetic (not the same code path)
+
+
+def test_bf16x3_split_is_fp32_grade(oracle, synth_nets):
+    """The claim in csrc/nsr_b3.inc: the three-piece split is exact, and the six kept piece products leave the whole
+    MLP as close to an fp64 evaluation as an fp32 GEMM chain is (2048 points, both networks' layer shapes)."""
+    from neural_sim_nerf_amd import pack
+    rng = np.random.RandomState(3)
+    x = (rng.standard_normal(100000) * np.exp(rng.uniform(-20, 20, 100000))).astype(np.float32)
+    p0, p1, p2 = pack.split_bf16x3(x)
+    assert np.array_equal(p0.astype(np.float64) + p1 + p2, x.astype(np.float64))
+    for p in (p0, p1, p2):
+        assert not (p.view(np.uint32) & 0xffff).any()             # every piece is a bf16
+    import kernel_emulator as E
+    t0, t1, t2 = E.split_trunc(x)                                 # the kernel's activation split (truncation)
+    assert np.array_equal(t0.astype(np.float64) + t1 + t2, x.astype(np.float64))
+
+    sd = synth_nets[1]
+    W = [np.asarray(sd["pts_linears.%d.weight" % i], np.float32) for i in range(1, 5)]
+    B = [np.asarray(sd["pts_linears.%d.bias" % i], np.float32) for i in range(1, 5)]
+    h0 = np.abs(rng.standard_normal((256, 512))).astype(np.float32)
+
+    def chain(mm, dt):
+        h = h0.astype(dt)
+        for w, b in zip(W, B):
+            h = np.maximum(mm(w.astype(dt), h) + b.astype(dt)[:, None], 0).astype(dt)
+        return h
+
+    def mm_b3(w, h):
+        ws, hs = pack.split_bf16x3(w), E.split_trunc(h)
+        acc = np.zeros((w.shape[0], h.shape[1]), np.float32)
+        for k in range(0, w.shape[1], 16):
+            for i, j in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)):
+                acc = (acc + ws[i][:, k:k + 16].astype(np.float64) @ hs[j][k:k + 16].astype(np.float64)).astype(np.float32)
+        return acc
+    ref = chain(lambda w, h: w @ h, np.float64)
+    e32 = np.abs(chain(lambda w, h: (w @ h).astype(np.float32), np.float32) - ref).max()
+    e3 = np.abs(chain(mm_b3, np.float32) - ref).max()
+    assert e3 < 2 * e32 + 1e-7, (e3, e32)
+
+
 def test_packer_rejects_other_architectures(synth_nets):
     from neural_sim_nerf_amd.pack import pack_network
     sd = dict(synth_nets[0])
