@@ -55,7 +55,69 @@ EVALS_PER_RAY = 64 + 192                   # network evaluations per ray (RN:477
 FLOP_PER_RAY = EVALS_PER_RAY * S.FLOP_PER_POINT          # 303 824 896
 FLOP_PER_RAY_VJP = (EVALS_PER_RAY + 192) * S.FLOP_PER_POINT   # + 192 transposed evaluations of the fine net: 531.7 M
 PEAK_F32_MFMA_TFLOPS = 157.3               # v_mfma_f32_32x32x2_f32 / 16x16x4, dense (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0             # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md: ~2.5 PF)
+# bf16x3 (NSR_FLAG_MLP_BF16X3): MFMA FLOP issued per point = 6 piece products x the k16-padded layer shapes
+B3_ISSUED_FLOP_PER_POINT = 2 * 6 * (256 * 64 + 4 * 256 * 256 + 256 * (64 + 256) + 2 * 256 * 256 + 256 * 256 + 128 * 320)
 METRIC = "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP"
+
+
+def forward_kernel_name(model):
+    if model.mlp == "bf16x3":
+        return "nsr::k_render_b3"
+    if model.variant == 32:
+        return "nsr::k_render"
+    return "nsr::k_render16p" if model.schedule == "phases" else "nsr::k_render16"
+
+
+def forward_roofline(model, k_ms, n_rays=H * W):
+    """roofline object of the forward render kernel for one launch of n_rays rays taking k_ms (HIP events)."""
+    ach = n_rays * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "achieved": round(ach, 2), "unit": "TFLOP/s", "kernel": forward_kernel_name(model),
+         "kernel_ms": round(k_ms, 3), "flop_per_launch": n_rays * FLOP_PER_RAY}
+    if model.mlp == "bf16x3":
+        issued = n_rays * EVALS_PER_RAY * B3_ISSUED_FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
+        r.update({"peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                  "issued": round(issued, 1), "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                  "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
+                  "note": "`achieved` counts ALGORITHMIC fp32 FLOP (as for the fp32 kernels); the datatype issued is bf16 "
+                          "(peak 2.5 PFLOP/s dense): every fp32 product costs six bf16 piece products, so the kernel "
+                          "issues `issued` TFLOP/s of bf16 MFMA work = `issued_frac` of that peak, and delivers "
+                          "`achieved_over_fp32_mfma_peak` x what the fp32 MFMA pipe could at 100 %"})
+    else:
+        r.update({"peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4)})
+    return r
+
+
+def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3):
+    """extra_workloads.bf16x3: the SAME 400x400 view through the forward kernel with NSR_FLAG_MLP_BF16X3 (k_render_b3:
+    layer GEMMs on bf16 MFMAs, fp32 operands split exactly into three bf16 pieces, fp32 accumulate), timed like the
+    main line (HIP events per launch + wall clock), and compared with the fp32-MFMA kernel's image `ref` of that view."""
+    m = NsrModel(sd_c, sd_f, device=device, mlp="bf16x3")
+    pose = torch.as_tensor(c2w[:3, :4], device=m.device)
+    out = m.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)            # warm-up
+    torch.cuda.synchronize()
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        out = m.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+        ms.append(m.last_kernel_ms())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms = float(np.mean(ms))
+    d = {k: (out[k] - ref[k]).abs() for k in ("rgb_map", "acc_map", "rgb0")}
+    mse = float(((out["rgb_map"] - ref["rgb_map"]).double() ** 2).mean())
+    res = {"value": round(launches * H * W * SAMPLES_PER_RAY / dt / 1e6, 3), "unit": "Mray-samples/s",
+           "ms_per_view": round(dt / launches * 1e3, 3), "launches": launches,
+           "dtype": "bf16x3: fp32 operands as three bf16 pieces each, six piece products per fp32 product, fp32 accumulate",
+           "roofline": forward_roofline(m, k_ms),
+           "vs_fp32_mfma_kernel_same_view": {
+               "psnr_db": round(-10.0 * np.log10(mse), 2) if mse > 0 else None,
+               "rgb_max_abs": float(d["rgb_map"].max()), "acc_max_abs": float(d["acc_map"].max()),
+               "rgb0_max_abs": float(d["rgb0"].max()),
+               "rays_with_rgb_diff_above_1e-4": int((d["rgb_map"].max(-1).values > 1e-4).sum())},
+           "how_to_enable": "NsrModel(..., mlp='bf16x3') / NSR_MLP=bf16x3 / bench.py --mlp bf16x3; NsrConfig.flags |= NSR_FLAG_MLP_BF16X3"}
+    m.close()
+    return res
 
 
 def cpu_model():
@@ -283,15 +345,16 @@ def pmc_traffic(pmc_file, schedule="phases"):
         return None, ("PMC profile %s was collected from other kernel sources (%s..., this tree %s...): not reported"
                       % (os.path.relpath(pmc_file, ROOT), str(prof.get("kernel_source_sha256"))[:12], here[:12]))
     blob = hashlib.sha1(b"blob %d\0" % os.path.getsize(pmc_file) + open(pmc_file, "rb").read()).hexdigest()
-    key = "x16_phases_schedule" if schedule == "phases" else "x16_queue_schedule"
+    key = {"phases": "x16_phases_schedule", "bf16x3": "bf16x3"}.get(schedule, "x16_queue_schedule")
     if key not in prof:
         return None, "PMC profile %s has no passes for the %s schedule" % (os.path.relpath(pmc_file, ROOT), schedule)
     t = prof[key]["derived"]["hbm_traffic_bytes_per_launch"]
     return t, ("offline measurement: bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
                "this kernel and schedule (%s [%s], git blob %s, kernel sources sha256 %s... = this tree); FETCH_SIZE counts "
-               "L2 misses that Infinity Cache serves: re-streaming of the weight images (4.6 MiB of networks vs 4 MiB L2 per "
-               "XCD), not HBM reads; algorithmic HBM bytes are 7.0e6 per launch; the per-ray-queue schedule measures 2.1e10 to "
-               "8.8e10 depending on the run and is 0.4 %% faster (DESIGN.md 4)" % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
+               "L2 misses that Infinity Cache serves: re-streaming of the weight images (4.6 MiB of fp32 networks, 6.9 MiB "
+               "in the bf16x3 layout, vs 4 MiB L2 per XCD), not HBM reads; algorithmic HBM bytes are 7.0e6 per launch; the "
+               "x16 per-ray-queue schedule measures 2.1e10 to 8.8e10 depending on the run and is 0.4 %% faster (DESIGN.md 4)"
+               % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
 
 
 def self_launch(args):
@@ -326,6 +389,8 @@ def main():
                     help="validation only: ranks share the visible GPUs round-robin (e.g. --gpus 2 --backend gloo on a "
                          "1-GPU box exercises the N>1 code path end to end; the number is not a scaling result)")
     ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r02", "pmc_k_render.json"))
+    ap.add_argument("--mlp", choices=("fp32", "bf16x3"), default=None,
+                    help="layer-GEMM arithmetic of the forward kernel (default: the engine's, engine.DEFAULT_MLP / $NSR_MLP)")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -386,7 +451,7 @@ def main():
 
     # ------------------------------------------------------------------------------------------------------------
     if args.workload == "view400":
-        model = NsrModel(sd_c, sd_f, device=local)
+        model = NsrModel(sd_c, sd_f, device=local, mlp=args.mlp)
         n_total = args.warmup + args.steps
         poses = S.sweep_poses(n_total * world, seed=0)[rank::world]      # view i -> rank i mod world
         poses_d = torch.as_tensor(poses[:, :3, :4], device=model.device)
@@ -413,14 +478,20 @@ def main():
         ranks_seen, per_rank = rank_stats(k_ms)
         if rank == 0:
             rays = args.steps * H * W * world
-            achieved = H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
-            traffic, traffic_note = pmc_traffic(args.pmc_file, model.schedule)
+            roof = forward_roofline(model, k_ms)
+            if model.mlp == "bf16x3":
+                traffic, traffic_note = pmc_traffic(args.pmc_file, "bf16x3")
+                kernel_desc = "fused persistent kernel k_render_b3 (one workgroup per CU, 32 points per wave, layer GEMMs on bf16 MFMAs with three-way split fp32 operands)"
+                line["dtype"] = "bf16x3"
+            else:
+                traffic, traffic_note = pmc_traffic(args.pmc_file, model.schedule)
+                kernel_desc = "fp32, fused persistent kernel (x16: 2 workgroups per CU, %s schedule)" % model.schedule
+            roof.update({"traffic": traffic, "traffic_note": traffic_note})
             line.update({
                 "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
-                                       "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), fp32, fused "
-                                       "persistent kernel (x16: 2 workgroups per CU, %s schedule), rays generated "
-                                       "in-kernel" % model.schedule,
+                                       "samples/ray, 8x256 NeRF MLP pair (seeded synthetic weights), %s, rays generated "
+                                       "in-kernel" % kernel_desc,
                            "rays_per_step_per_gpu": H * W, "mlp_evals_per_ray": EVALS_PER_RAY,
                            "parallelism": "views sharded over %d rank(s), image all-gather (%s) at the end%s"
                                           % (world, "RCCL" if args.backend == "nccl" else "gloo via the host",
@@ -429,12 +500,7 @@ def main():
                 "ranks_seen": ranks_seen,
                 "kernel_ms_per_rank": {"min": round(min(per_rank), 3), "max": round(max(per_rank), 3),
                                        "mean": round(float(np.mean(per_rank)), 3)},
-                "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                             "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                             "traffic_note": traffic_note,
-                             "kernel": "nsr::k_render16p" if model.schedule == "phases" else "nsr::k_render16",
-                             "kernel_ms": round(k_ms, 3),
-                             "flop_per_launch": H * W * FLOP_PER_RAY},
+                "roofline": roof,
             })
             cpu_setting = None
             if world == 1 and not args.no_cpu_baseline:
@@ -457,6 +523,9 @@ def main():
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),
                                            "handoff": handoff_workload(model, not args.no_cpu_baseline)}
+                if model.mlp != "bf16x3":
+                    ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+                    line["extra_workloads"]["bf16x3"] = bf16x3_workload(sd_c, sd_f, local, poses[args.warmup], ref)
         model.close()
 
     # ------------------------------------------------------------------------------------------------------------

@@ -199,14 +199,22 @@ def test_render_rays_odd_and_single(model, oracle, synth_nets):
             assert np.array_equal(cpu(r[k]), cpu(full[k])[:n], equal_nan=True), (k, n)   # chunk-invariant (RN:67-68)
 
 
-@pytest.mark.parametrize("variant", [16, 32])
+def _mk(synth_nets, variant, **kw):
+    """variant 16 / 32: the fp32-MFMA kernels; "b3": the default handle with the bf16x3 forward kernel."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    if variant == "b3":
+        return NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3", **kw)
+    return NsrModel(synth_nets[0], synth_nets[1], variant=variant, **kw)
+
+
+@pytest.mark.parametrize("variant", [16, 32, "b3"])
 def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
     """white_bkgd (RN:384-385) and lindisp (RN:443): forward stage-wise and against the reference (g11), the
     raw2outputs stage entry, and the VJP (the white background adds -sum(g) to dL/dw)."""
     from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g11_options")
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
-    m = NsrModel(synth_nets[0], synth_nets[1], variant=variant, white_bkgd=True, lindisp=True)
+    m = _mk(synth_nets, variant, white_bkgd=True, lindisp=True)
     ro, rd = g["rays_o"], g["rays_d"]
     r = m.render_rays(ro, rd, near, far, debug=True)
     _stagewise(m, oracle, synth_nets, r, ro, rd, near, far, white_bkgd=True, lindisp=True)
@@ -218,8 +226,9 @@ def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
     outs = m.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd)
     want = oracle.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd, white_bkgd=True)
     assert_close(cpu(outs[0]), want[0], atol=3e-6, what="raw2outputs stage, white_bkgd")
-    # VJP (compared on the same handle's forward's own sample positions)
-    if True:
+    # VJP (compared on the same handle's forward's own sample positions); a "b3" handle's input-gradient kernel is
+    # the fp32 x16 one, covered by variant 16
+    if variant != "b3":
         n = g["cot"].shape[0]
         fwd = m.render_rays(ro[:n], rd[:n], near, far, debug=True)
         go, gd, f2 = m.render_rays_vjp(ro[:n], rd[:n], near, far, g["cot"], with_forward=True)
@@ -237,7 +246,7 @@ def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
         assert _relfro(cpu(gd), g["grad_rays"][1]) < 1e-4, _relfro(cpu(gd), g["grad_rays"][1])
         assert_close(cpu(f3["rgb_map"]), g["vjp_rgb"], atol=2e-5, what="VJP-launch forward vs reference at its depths")
     # the options are per handle: the default handle is unaffected
-    plain = NsrModel(synth_nets[0], synth_nets[1], variant=variant)
+    plain = _mk(synth_nets, variant)
     p = plain.render_rays(ro[:8], rd[:8], near, far)
     assert not np.allclose(cpu(p["rgb_map"]), cpu(r["rgb_map"])[:8], atol=1e-3)
     m.close(); plain.close()
@@ -264,7 +273,7 @@ def test_sort_merge_both_paths(model):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("variant", [16, 32])
+@pytest.mark.parametrize("variant", [16, 32, "b3"])
 def test_degenerate_rays_terminate_and_stay_local(oracle, synth_nets, variant):
     """NaN / inf / zero-length / far-away rays and near >= far: the kernels terminate, the bad rays come back NaN or
     finite garbage like any NaN input would in the reference, and the healthy rays next to them are untouched."""
@@ -272,7 +281,7 @@ def test_degenerate_rays_terminate_and_stay_local(oracle, synth_nets, variant):
     from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
-    m = NsrModel(synth_nets[0], synth_nets[1], variant=variant)
+    m = _mk(synth_nets, variant)
     ro, rd = g["rays_o"][:64].copy(), g["rays_d"][:64].copy()
     want = m.render_rays(ro, rd, near, far)
     bad_o, bad_d = ro.copy(), rd.copy()
@@ -873,6 +882,53 @@ def test_full_size_view_properties(synth_nets, oracle):
     mp.close(); mq.close()
 
 
+def test_bf16x3_full_size_view_properties(synth_nets, oracle):
+    """The bf16x3 forward kernel on BASELINE configs[1] at FULL size: determinism, ray independence (a random subset
+    rendered alone is bit-equal to those pixels of the full view), multi-view launch == single views, range invariants,
+    the oracle on 384 random rays at the fp32 kernels' bounds, and the fp32-MFMA kernel on the whole view: every output
+    within fp32-MLP rounding of it except where a resampling index flips (the same ill-conditioning any two fp32
+    evaluations of the network show), PSNR between the two images far above the 0.1 dB budget of BASELINE.json."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.YCBV_K
+    poses = np.asarray(oracle.sweep_poses(2, seed=21))
+    m3 = NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3")
+    m32 = NsrModel(synth_nets[0], synth_nets[1])
+    full = m3.render_views(poses[0], 400, 400, K, near, far)
+    again = m3.render_views(poses[0], 400, 400, K, near, far)
+    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+    for k in keys:
+        assert np.array_equal(cpu(full[k]), cpu(again[k]), equal_nan=True), k
+    rgb, acc = cpu(full["rgb_map"]), cpu(full["acc_map"])
+    assert np.isfinite(rgb).all() and rgb.min() >= 0.0 and rgb.max() <= 1.0 + 1e-5
+    assert acc.min() >= 0.0 and acc.max() <= 1.0 + 1e-5 and (cpu(full["z_std"]) >= 0).all()
+    two = m3.render_views(poses, 400, 400, K, near, far)
+    assert np.array_equal(cpu(two["rgb_map"])[:160000], rgb)
+    assert np.array_equal(cpu(two["rgb_map"])[160000:], cpu(m3.render_views(poses[1], 400, 400, K, near, far)["rgb_map"]))
+    ro, rd = m3.get_rays(400, 400, K, poses[0])
+    ro, rd = cpu(ro).reshape(-1, 3), cpu(rd).reshape(-1, 3)
+    sel = np.random.RandomState(0).choice(160000, 20001, replace=False)
+    sub = m3.render_rays(ro[sel], rd[sel], near, far, debug=True)
+    for k in keys:
+        assert np.array_equal(cpu(sub[k]), cpu(full[k])[sel], equal_nan=True), k
+    zf = cpu(sub["z_fine"])
+    assert (np.diff(zf, axis=1) >= 0).all() and zf.min() >= near * (1 - 1e-6) and zf.max() <= far * (1 + 1e-6)
+    sm = sel[:384]
+    ref = oracle.render(synth_nets[0], synth_nets[1], 400, 400, K, rays=(ro[sm], rd[sm]), near=near, far=far)
+    assert_close(cpu(full["rgb0"])[sm], ref["rgb0"], atol=1e-5, what="coarse rgb vs oracle at full size")
+    assert oracle.psnr(rgb[sm], ref["rgb_map"]) > 55.0
+    f32 = m32.render_views(poses[0], 400, 400, K, near, far)
+    # coarse image: fp32 rounding only -- except a ray whose LAST sample has sigma ~ 0: its dist is 1e10 (RN:358), so the
+    # sign of a 1e-7 sigma switches that sample's alpha between 0 and 1 (the reference has the same cliff)
+    d0 = np.abs(cpu(f32["rgb0"]) - cpu(full["rgb0"])).max(-1)
+    assert (d0 > 1e-5).sum() <= 16 and np.median(d0) < 2e-7, ((d0 > 1e-5).sum(), np.median(d0))
+    assert (np.abs(cpu(f32["acc0"]) - cpu(full["acc0"])) > 1e-5).sum() <= 16
+    d = np.abs(cpu(f32["rgb_map"]) - rgb).max(-1)
+    assert (d > 1e-4).mean() < 0.01, (d > 1e-4).mean()                            # a flipped resampling index moves a ray
+    assert oracle.psnr(rgb, cpu(f32["rgb_map"])) > 60.0
+    m3.close(); m32.close()
+
+
 def test_debug_bounds_build_is_clean(tmp_path):
     """`make debug` (libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent LDS / scratch index is range-checked.
     A fresh process renders ordinary and degenerate rays (NaN, inf, zero directions, far-away origins), both forward
@@ -928,8 +984,8 @@ def test_launch_is_graph_capturable_and_replays_bit_identically(synth_nets, orac
     g8 = load_golden("g8_backward")
     K = g["K32"].tolist() if "K32" in g else oracle.scaled_K(400.0 / 32)
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
-    for variant in (16, 32):
-        m = NsrModel(synth_nets[0], synth_nets[1], variant=variant)
+    for variant in (16, 32, "b3"):
+        m = _mk(synth_nets, variant)
         poses = torch.as_tensor(np.asarray(oracle.sweep_poses(2, seed=11))[:, :3, :4], dtype=torch.float32, device=m.device)
         cam = poses[0:1].clone()
         eager = [cpu(m.render_views(poses[i], 32, 32, K, near, far)["rgb_map"]) for i in range(2)]
