@@ -1047,11 +1047,12 @@ def test_calls_leave_the_current_device_alone(synth_nets):
 def test_x16_coarse_only_config1(oracle, synth_nets):
     from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g7_render")
-    m1 = NsrModel(synth_nets[0], None, n_importance=0, variant=16)
-    r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
-    assert_close(cpu(r["rgb_map"]).reshape(64, 64, 3), g["rgb_c1"], atol=1e-5, what="config-1 rgb")
-    assert_close(cpu(r["acc_map"]).reshape(64, 64), g["acc_c1"], atol=1e-5, what="config-1 acc")
-    m1.close()
+    for kw in (dict(variant=16), dict(mlp="bf16x3")):
+        m1 = NsrModel(synth_nets[0], None, n_importance=0, **kw)
+        r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+        assert_close(cpu(r["rgb_map"]).reshape(64, 64, 3), g["rgb_c1"], atol=1e-5, what="config-1 rgb %s" % kw)
+        assert_close(cpu(r["acc_map"]).reshape(64, 64), g["acc_c1"], atol=1e-5, what="config-1 acc %s" % kw)
+        m1.close()
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -7,9 +7,9 @@ dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(dst, exist_ok=True)
 out = {}
 FLOP = {"x16": 160000 * 303824896, "x16q": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568,
-        "vjpq": 160000 * 531693568}
+        "vjpq": 160000 * 531693568, "b3": 160000 * 303824896}
 for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", "x16_queue_schedule", "k_render16("),
-                        ("x32", "x32", "k_render("), ("vjp", "vjp", "k_render_vjp16p"),
+                        ("x32", "x32", "k_render("), ("b3", "bf16x3", "k_render_b3"), ("vjp", "vjp", "k_render_vjp16p"),
                         ("vjpq", "vjp_queue_schedule", "k_render_vjp16(")):
     tot, disp, ns, first_id = {}, {}, None, {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
@@ -53,7 +53,7 @@ for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", 
 hf = os.path.join(src, "kernel_source_sha256.txt")
 out["kernel_source_sha256"] = open(hf).read().strip() if os.path.exists(hf) else None
 sched = {}
-for name in ("queue", "phases"):
+for name in ("queue", "phases", "bf16x3", "x32"):
     f = os.path.join(src, "schedule_%s.log" % name)
     if os.path.exists(f):
         ms = [float(l.split()[-1]) for l in open(f) if l.startswith("variant")]
@@ -71,7 +71,11 @@ for name in ("phases", "queue", "x32"):
 if vj:
     out["vjp_timing_unprofiled"] = vj
 json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
-for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
+pf = os.path.join(src, "probe_bf16x3.log")
+if os.path.exists(pf):
+    out["layer_gemm_probe"] = {"lines": [l.strip() for l in open(pf) if l.startswith("mode")],
+                               "modes": "2 = fp32 x32 production segment, 12 = bf16x3 MFMAs only, 11 = bf16x3 production groups (tools/probe_bf16x3.py)"}
+for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_b3", "kernel_stats_bench_bf16x3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
                   ("stats_handoff", "kernel_stats_handoff.csv")):
     for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         rows = list(csv.reader(open(f)))          # keep our kernels + the top rows, drop torch's kilobyte-long template names
