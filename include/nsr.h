@@ -51,6 +51,7 @@ extern "C" {
 /* the bf16x3 layout (NSR_FLAG_MLP_BF16X3): every weight as three bf16 pieces, 1.5x the stream */
 #define NSR_STREAM_SLABS_B3  219
 #define NSR_PACKED_B3_FLOATS (NSR_STREAM_SLABS_B3 * NSR_SLAB_FLOATS + NSR_AUX_FLOATS)
+#define NSR_STREAM_SLABS_B3_BWD 234            /* slabs of the transposed fine network in that layout */
 
 typedef struct nsr_handle_s* nsr_handle;
 
@@ -82,8 +83,9 @@ typedef struct NsrConfig {
                                    split exactly into three bf16 pieces and the six significant piece products
                                    accumulated in fp32 -- fp32-grade results (same error against fp64 as an fp32 GEMM)
                                    at ~1.9x the fp32-MFMA rate.  One workgroup per CU, 32 points per wave, per-item
-                                   queue; needs nsr_upload_weights_b3.  Everything else on the handle (input-gradient
-                                   kernel, stage kernels) follows `variant` as before                                   */
+                                   queue; needs nsr_upload_weights_b3.  nsr_render_rays_vjp runs the same scheme
+                                   (k_render_vjp_b3, forward and transposed GEMMs) and needs nsr_upload_weights_bwd_b3;
+                                   the stage kernels follow `variant` as before                                         */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {
@@ -122,6 +124,10 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
 /* The same networks in the bf16x3 layout (pack.py: pack_network_b3; NSR_PACKED_B3_FLOATS floats: the stream holds
  * packed bf16 pairs, the aux block is the fp32 one of nsr_upload_weights).  Handles created with NSR_FLAG_MLP_BF16X3. */
 int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t n_floats);
+
+/* Transposed stream of the FINE network in the bf16x3 layout (pack.py: pack_network_backward_b3;
+ * NSR_STREAM_SLABS_B3_BWD * NSR_SLAB_FLOATS floats), for nsr_render_rays_vjp on an NSR_FLAG_MLP_BF16X3 handle. */
+int nsr_upload_weights_bwd_b3(nsr_handle h, const float* stream, size_t n_floats);
 
 /* Transposed stream of the FINE network for the input-gradient kernel (pack.py: pack_network_backward);
  * host buffer of NSR_STREAM_SLABS*NSR_SLAB_FLOATS floats.  Needed only by nsr_render_rays_vjp. */

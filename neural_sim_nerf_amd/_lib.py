@@ -35,6 +35,7 @@ SIGNATURES = {
     "nsr_upload_weights": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights16": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_b3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "nsr_upload_weights_bwd_b3": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_bwd16": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),

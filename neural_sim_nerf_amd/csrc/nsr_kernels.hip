@@ -81,7 +81,8 @@ __device__ __forceinline__ void ring_init(Ring& rg, char* smem, const void* base
   rg.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
 }
 
-template <int NS = kRingSlots, int SLABS = kStreamSlabs>
+// SLABS: slabs per forward pass stream; SLABS_BWD: slabs of a backward pass (net 2) where that differs (bf16x3)
+template <int NS = kRingSlots, int SLABS = kStreamSlabs, int SLABS_BWD = SLABS>
 __device__ __forceinline__ void ring_issue(Ring& rg) {
   char* l = rg.smem + rg.pslot * kSlabBytes + rg.wave_lds;
 #ifndef NSR_EXP_NODMA        // (NODMA: timing experiment only)
@@ -99,7 +100,7 @@ __device__ __forceinline__ void ring_issue(Ring& rg) {
   // branch-free advance (scalar selects only): a branch here would split the basic block and stop the scheduler
   // from interleaving the DMA issue with the MFMAs around it
   const int nslab = rg.pslab + 1;
-  const bool wrap = nslab == SLABS;
+  const bool wrap = nslab == ((SLABS_BWD != SLABS && rg.pphase >= rg.pn1) ? SLABS_BWD : SLABS);
   rg.pslab = wrap ? 0 : nslab;
   const int nphase = (rg.pphase + 1 == rg.ppi) ? 0 : rg.pphase + 1;
   rg.pphase = wrap ? nphase : rg.pphase;
@@ -123,10 +124,10 @@ __device__ __forceinline__ void ring_assert_uniform(Ring& rg) {
 
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
 // A step = 4 chunks of 1 KiB = 4 float4 fragments per lane = 16 MFMAs; a slab = 4 steps.
-template <int NS = kRingSlots, int SLABS = kStreamSlabs>
+template <int NS = kRingSlots, int SLABS = kStreamSlabs, int SLABS_BWD = SLABS>
 __device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[4], int lane) {
 #pragma unroll 1
-  for (int s = 0; s < NS; ++s) ring_issue<NS, SLABS>(rg);
+  for (int s = 0; s < NS; ++s) ring_issue<NS, SLABS, SLABS_BWD>(rg);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
@@ -798,7 +799,8 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 4 : 1, wave, lane);
 
   f32x4 A0[4], A1[4];
-  ring_start<kRingSlots, B3 ? kStreamSlabsB3 : kStreamSlabs>(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
+  if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
+  else ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
 
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
@@ -997,6 +999,9 @@ __device__ __forceinline__ void embed_bwd(const float (&x)[3], const float* G /*
     }
 }
 
+// B3: the transposed GEMMs on bf16 MFMAs (nsr_b3.inc): every 9- or 10-block segment becomes an 8-block GEMM for the hidden
+// features plus a 4-block GEMM for the encoding rows (1 or 2 real blocks; the packer pads with zero weights).
+template <bool B3 = false>
 __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                              const uint4* mask_src /* uniform */, int mask_tid, float g0, float g1,
                                              float g2, float gs, const float* ry /* LDS: the ray block */,
@@ -1025,12 +1030,38 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
       }
   }
   // views^T: 256 feature rows (blocks 0-7) + 32 direction-encoding rows (block 8), K = 128
-  f32x16 accv[9];
-  seg<9, 16, kRingSlots, true>(rg, A0, A1, BRegs16<4>{gv}, accv, lane);
+  f32x16 gin[8];
+  f32x16 acc[B3 ? 8 : 10];    // 0-7: gradient w.r.t. the 256 hidden features; fp32: 8-9 = gradient w.r.t. the 64 encoding registers
+  auto gv_src = [&](int kb, int i) { return gv[(kb >> 1) & 3][8 * (kb & 1) + i]; };
+  auto gin_src = [&](int kb, int i) { return gin[(kb >> 1) & 7][8 * (kb & 1) + i]; };
+  // B3: the encoding rows are their own 4-block GEMM, run BEFORE the 8-block one of the same layer so that its
+  // accumulators are dead again when the big one starts; embed_bwd is linear, so the position-encoding gradients of L5^T
+  // and L0^T go through it separately and are added as d/dp
+  auto point = [&](float (&p)[3]) {
+    const float z = zrow[opaque_v(lane) & 31];
+    p[0] = ry[0] + ry[3] * z; p[1] = ry[1] + ry[4] * z; p[2] = ry[2] + ry[5] * z;
+  };
+  float dp5[3] = {0.0f, 0.0f, 0.0f};
   {
     float Gd[16];
+    if constexpr (B3) {
+      {
+        f32x16 ae[4];
+        gemm_b3<4, 2, true, false>(rg, A0, A1, gv_src, ae, lane);
 #pragma unroll
-    for (int t = 0; t < 16; ++t) Gd[t] = accv[8][t];
+        for (int t = 0; t < 16; ++t) Gd[t] = ae[0][t];
+      }
+      gemm_b3<8, 4, true>(rg, A0, A1, gv_src, acc, lane);
+#pragma unroll
+      for (int mo = 0; mo < 8; ++mo) gin[mo] = acc[mo];          // feature_linear has no activation
+    } else {
+      f32x16 accv[9];
+      seg<9, 16, kRingSlots, true>(rg, A0, A1, BRegs16<4>{gv}, accv, lane);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) Gd[t] = accv[8][t];
+#pragma unroll
+      for (int mo = 0; mo < 8; ++mo) gin[mo] = accv[mo];         // feature_linear has no activation
+    }
     const float v[3] = {ry[6], ry[7], ry[8]};              // re-read where needed: not kept alive across the GEMMs
     float part[3];
     embed_bwd<kMultiresViews>(v, Gd, h, part);
@@ -1038,16 +1069,26 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
     for (int ax = 0; ax < 3; ++ax) dv[ax] = part[ax] + __shfl_xor(part[ax], 32);
   }
 
-  f32x16 gin[8];
-  f32x16 acc[10];   // 0-7: gradient w.r.t. the 256 hidden features; 8-9: gradient w.r.t. the 64 encoding registers
-#pragma unroll
-  for (int mo = 0; mo < 8; ++mo) gin[mo] = accv[mo];          // feature_linear has no activation
   // idx: 0 feature^T (+alpha head), 1 L7^T, 2 L6^T, 3 L5^T (10 blocks: first use of acc[8..9]), 4..7 L4^T..L1^T
 #pragma unroll 1
   for (int idx = 0; idx < 8; ++idx) {
     const uint4 mk = mask_src[(7 - idx) * 256 + mask_tid];   // relu pattern of the layer this GEMM feeds back to
-    if (idx == 3) seg<10, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
-    else seg<8, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+    if constexpr (B3) {
+      if (idx == 3) {
+        f32x16 ae[4];
+        gemm_b3<4, 4, true, false>(rg, A0, A1, gin_src, ae, lane);
+        float Ge[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) Ge[t] = ae[t >> 4][t & 15];
+        float p[3];
+        point(p);
+        embed_bwd<kMultires>(p, Ge, h, dp5);
+      }
+      gemm_b3<8, 8, true>(rg, A0, A1, gin_src, acc, lane);
+    } else {
+      if (idx == 3) seg<10, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+      else seg<8, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+    }
     if (idx == 0) {
       const float* wa = aux + kAuxWAlpha;                    // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
 #pragma unroll
@@ -1064,17 +1105,27 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
     for (int mo = 0; mo < 8; ++mo) gin[mo] = apply_mask(acc[mo], mw[mo >> 1], (mo & 1) * 16);
   }
   // L0^T: the remaining 64 encoding rows
-  seg<2, 32>(rg, A0, A1, BRegs16<8>{gin}, *(f32x16(*)[2]) & acc[8], lane);
   {
     float Ge[32];
+    if constexpr (B3) {
+      f32x16 ae[4];
+      gemm_b3<4, 4, true, false>(rg, A0, A1, gin_src, ae, lane);
 #pragma unroll
-    for (int t = 0; t < 32; ++t) Ge[t] = acc[8 + (t >> 4)][t & 15];
-    const float z = zrow[opaque_v(lane) & 31];
-    const float p[3] = {ry[0] + ry[3] * z, ry[1] + ry[4] * z, ry[2] + ry[5] * z};
+      for (int t = 0; t < 32; ++t) Ge[t] = ae[t >> 4][t & 15];
+    } else {
+      seg<2, 32>(rg, A0, A1, BRegs16<8>{gin}, *(f32x16(*)[2]) & acc[B3 ? 0 : 8], lane);
+#pragma unroll
+      for (int t = 0; t < 32; ++t) Ge[t] = acc[(B3 ? 0 : 8) + (t >> 4)][t & 15];
+    }
+    float p[3];
+    point(p);
     float part[3];
     embed_bwd<kMultires>(p, Ge, h, part);
 #pragma unroll
-    for (int ax = 0; ax < 3; ++ax) dp[ax] = part[ax] + __shfl_xor(part[ax], 32);
+    for (int ax = 0; ax < 3; ++ax) {
+      const float both = part[ax] + dp5[ax];
+      dp[ax] = both + __shfl_xor(both, 32);
+    }
   }
 }
 
@@ -1156,8 +1207,8 @@ __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; *a.r.w
 //   pass 4-6    fine backward through the transposed network -> dL/d pts, dL/d viewdir per sample
 //   --          per-ray reduction: dL/d rays_o, dL/d rays_d
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool B3>
+__device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp, char* smem) {
   const VjpArgs& va_setup = *vp;
   const RenderArgs& a_setup = va_setup.r;
   const int tid0 = threadIdx.x;
@@ -1174,7 +1225,8 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);
 
   f32x4 A0[4], A1[4];
-  ring_start(rg, A0, lane);
+  if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
+  else ring_start(rg, A0, lane);
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
   if (tid0 < 128) st.ufine[tid0] = a_setup.ufine[tid0];
@@ -1239,8 +1291,8 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass<true>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
-                     ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
+      mlp_pass<true, B3>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+                         ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     } else {
       // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
@@ -1250,8 +1302,8 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
       const float* ry = st.ray[r];
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
-      mlp_bwd_pass(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
-                   ry, &st.zf[r][i - j], dp, dv);
+      mlp_bwd_pass<B3>(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
+                       ry, &st.zf[r][i - j], dp, dv);
       // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
       float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
 #pragma unroll
@@ -1332,6 +1384,16 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<false>(vp, smem);
+}
+// the same kernel with every GEMM, forward and transposed, on bf16 MFMAs with three-way split operands (nsr_b3.inc)
+__global__ void __launch_bounds__(256, 1) k_render_vjp_b3(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<true>(vp, smem);
 }
 
 // dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):

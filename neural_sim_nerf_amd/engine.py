@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from .pack import (pack_network, pack_network16, pack_network_backward, pack_network_backward16, pack_network_b3,
+                   pack_network_backward_b3,
                    PACKED_FLOATS, PACKED_B3_FLOATS)
 
 N_SAMPLES = 64
@@ -189,7 +190,10 @@ class NsrModel:
         if self.n_importance == 0:
             raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
         if not self._bwd_ready:                      # the transposed stream is packed on first use only
-            if self.variant == 32:
+            if self.mlp == "bf16x3":
+                b = pack_network_backward_b3(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights_bwd_b3(self.h, _fptr(b), b.size))
+            elif self.variant == 32:
                 b = pack_network_backward(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
             else:                                    # 0 = library default = x16

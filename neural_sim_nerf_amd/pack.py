@@ -397,3 +397,35 @@ def pack_network_b3(sd):
     stream = np.concatenate([x.reshape(-1) for x in segs])
     assert stream.size * 2 == STREAM_SLABS_B3 * SLAB_FLOATS * 4
     return np.concatenate([stream.view(np.float32), aux]).astype(np.float32, copy=False)
+
+
+STREAM_SLABS_B3_BWD = 234
+
+
+def pack_network_backward_b3(sd):
+    """Transposed stream of one network for k_render_vjp_b3, bf16x3 layout.  Every segment of pack_network_backward that
+    has encoding rows is split into a 4-block GEMM for those rows (1 or 2 real blocks, zero-padded) FOLLOWED by the
+    8-block GEMM for the 256 hidden features (the kernel runs the small one first so that its accumulators are dead
+    when the big one starts).  Order: views^T enc | views^T | feature^T | L7^T | L6^T | L5^T enc | L5^T | L4^T..L1^T |
+    L0^T enc.  Returns float32 [STREAM_SLABS_B3_BWD * SLAB_FLOATS] (packed bf16 pairs viewed as floats)."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    t128, t64 = np.arange(128), np.arange(64)
+    cols256 = np.stack([kappa(t128, 0), kappa(t128, 1)], 1)              # K = 256: 16 k16 blocks
+    cols128 = np.stack([kappa(t64, 0), kappa(t64, 1)], 1)                # K = 128 (views layer's outputs): 8 blocks
+    pad4 = lambda M: np.concatenate([M, np.zeros((128 - M.shape[0], M.shape[1]), np.float32)], 0)
+    segs = []
+    Wv = g("views_linears.0.weight")                                     # [128, 256 + 27]
+    segs.append(_pack_b3(pad4(_enc_rows_T(Wv[:, 256:], 4, 1)), cols128, 4))
+    segs.append(_pack_b3(np.ascontiguousarray(Wv[:, :256].T), cols128, 8))
+    segs.append(_pack_b3(np.ascontiguousarray(g("feature_linear.weight").T), cols256, 8))
+    for l in (7, 6):
+        segs.append(_pack_b3(np.ascontiguousarray(g("pts_linears.%d.weight" % l).T), cols256, 8))
+    W5 = g("pts_linears.5.weight")                                       # [256, 63 + 256], input columns first
+    segs.append(_pack_b3(pad4(_enc_rows_T(W5[:, :63], 10, 2)), cols256, 4))
+    segs.append(_pack_b3(np.ascontiguousarray(W5[:, 63:].T), cols256, 8))
+    for l in (4, 3, 2, 1):
+        segs.append(_pack_b3(np.ascontiguousarray(g("pts_linears.%d.weight" % l).T), cols256, 8))
+    segs.append(_pack_b3(pad4(_enc_rows_T(g("pts_linears.0.weight"), 10, 2)), cols256, 4))
+    stream = np.concatenate([x.reshape(-1) for x in segs])
+    assert stream.size * 2 == STREAM_SLABS_B3_BWD * SLAB_FLOATS * 4
+    return stream.view(np.float32)

@@ -367,8 +367,10 @@ class StreamB3:
         self.chunks = _bf16_bits_to_f32(stream_floats.view(np.uint16).reshape(-1, 64, 8))
         self.pos = 0
 
-    def gemm(self, nmo, ngroups, src, acc):
-        """gemm_b3<NMO, NGROUPS>: src(kb) -> [64, 8] fp32 (this lane's slots of k16 block kb)."""
+    def gemm(self, nmo, ngroups, src, acc, zero=False):
+        """gemm_b3<NMO, NGROUPS, ZERO>: src(kb) -> [64, 8] fp32 (this lane's slots of k16 block kb)."""
+        if zero:
+            acc[:nmo] = 0
         piece, block = (B3_PIECE8, B3_BLOCK8) if nmo == 8 else (B3_PIECE4, B3_BLOCK4)
         spk = len(piece)
         nb = 12 // spk
@@ -385,8 +387,8 @@ class StreamB3:
                             acc[mo] = mfma_b3(A[c], bb[j], acc[mo])
 
 
-def mlp_pass_b3(packed_b3, pts, dirs):
-    """pts, dirs: [32,3] -> raw [32,4]: one wave of mlp_pass<false, true>."""
+def mlp_pass_b3(packed_b3, pts, dirs, masks=None):
+    """pts, dirs: [32,3] -> raw [32,4]: one wave of mlp_pass<CAPTURE, true> (`masks`: filled like the fp32 emulation)."""
     from neural_sim_nerf_amd import pack as PK
     st = StreamB3(packed_b3[:PK.STREAM_SLABS_B3 * PK.SLAB_FLOATS])
     aux = packed_b3[PK.STREAM_SLABS_B3 * PK.SLAB_FLOATS:]
@@ -398,6 +400,8 @@ def mlp_pass_b3(packed_b3, pts, dirs):
     enc_src = lambda kb: np.stack([e[8 * kb + i] for i in range(8)], 1)
     acc = load_bias(aux, PK.AUX_BIAS, 8)
     st.gemm(8, 2, enc_src, acc)
+    if masks is not None:
+        masks[0] = acc > 0
     inp = np.maximum(acc, 0)
     in_src = lambda kb: inp[kb >> 1][:, 8 * (kb & 1):8 * (kb & 1) + 8]
     alpha_part = np.zeros(64, np.float32)
@@ -411,6 +415,8 @@ def mlp_pass_b3(packed_b3, pts, dirs):
                     w = aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk]
                     alpha_part = alpha_part + w * inp[(4 * tq + kk) >> 4][:, (4 * tq + kk) & 15]
         st.gemm(8, 8, in_src, acc)
+        if masks is not None and L < 8:
+            masks[L] = acc > 0
         inp = np.maximum(acc, 0) if L < 8 else acc.copy()
     av = load_bias(aux, PK.AUX_BIAS_V, 4)
 
@@ -421,6 +427,8 @@ def mlp_pass_b3(packed_b3, pts, dirs):
             return np.stack([ed[8 * (kb - 16) + i] for i in range(8)], 1)
         return np.zeros((64, 8), np.float32)
     st.gemm(4, 5, v_src, av)
+    if masks is not None:
+        masks[8] = av > 0
     assert st.pos == PK.STREAM_SLABS_B3 * 16
     part = np.zeros((4, 64), np.float32)
     part[3] = alpha_part
@@ -435,3 +443,45 @@ def mlp_pass_b3(packed_b3, pts, dirs):
         bias = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
         raw[:, c] = part[c][:32] + part[c][32:] + bias
     return raw
+
+
+def mlp_bwd_pass_b3(packed_b3_fwd, stream_bwd_b3, masks, pts, dirs, g_raw):
+    """One wave of mlp_bwd_pass<true>: g_raw [32,4] -> (dL/dpts [32,3], dL/ddirs [32,3])."""
+    from neural_sim_nerf_amd import pack as PK
+    st = StreamB3(stream_bwd_b3)
+    aux = packed_b3_fwd[PK.STREAM_SLABS_B3 * PK.SLAB_FLOATS:]
+    h = LANE >> 5
+    P = np.concatenate([pts, pts], 0).astype(np.float32)
+    V = np.concatenate([dirs, dirs], 0).astype(np.float32)
+    G = np.concatenate([g_raw, g_raw], 0).astype(np.float32)
+    gv = np.zeros((4, 64, 16), np.float32)
+    for mo in range(4):
+        for rq in range(4):
+            for ri in range(4):
+                idx = ((mo * 4 + rq) * 2 + h) * 4 + ri
+                v = (aux[PK.AUX_W_RGB + idx] * G[:, 0] + aux[PK.AUX_W_RGB + 128 + idx] * G[:, 1]
+                     + aux[PK.AUX_W_RGB + 256 + idx] * G[:, 2])
+                gv[mo][:, rq * 4 + ri] = np.where(masks[8][mo][:, rq * 4 + ri], v, 0)
+    frag_src = lambda arr: (lambda kb: arr[kb >> 1][:, 8 * (kb & 1):8 * (kb & 1) + 8])
+    ae = np.zeros((4, 64, 16), np.float32)
+    st.gemm(4, 2, frag_src(gv), ae, zero=True)
+    dv = _embed_bwd(V, [ae[0][:, t] for t in range(16)], 4)
+    acc = np.zeros((8, 64, 16), np.float32)
+    st.gemm(8, 4, frag_src(gv), acc, zero=True)
+    gin = acc.copy()
+    dp5 = None
+    for idx in range(8):
+        if idx == 3:
+            st.gemm(4, 4, frag_src(gin), ae, zero=True)
+            dp5 = _embed_bwd(P, [ae[t >> 4][:, t & 15] for t in range(32)], 10)
+        st.gemm(8, 8, frag_src(gin), acc, zero=True)
+        if idx == 0:
+            for tq in range(32):
+                for kk in range(4):
+                    t = 4 * tq + kk
+                    acc[t >> 4][:, t & 15] += aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk] * G[:, 3]
+        gin = np.where(masks[7 - idx], acc, 0).astype(np.float32)
+    st.gemm(4, 4, frag_src(gin), ae, zero=True)
+    assert st.pos == PK.STREAM_SLABS_B3_BWD * 16
+    dp = _embed_bwd(P, [ae[t >> 4][:, t & 15] for t in range(32)], 10) + dp5
+    return dp, dv

@@ -29,12 +29,17 @@ def model(synth_nets):
     m.close()
 
 
-@pytest.fixture(scope="module", params=[(16, "phases"), (16, "queue"), (32, "queue")], ids=lambda p: "x%d-%s" % p)
+@pytest.fixture(scope="module", params=[(16, "phases"), (16, "queue"), (32, "queue"), ("b3", "queue")],
+                ids=lambda p: "x%s-%s" % p)
 def vjp_model(request, synth_nets):
     """The input-gradient kernels: k_render_vjp16p (variant 16 + global phases = the default), k_render_vjp16 (variant
-    16, per-ray queue; also what a call with caller-supplied depths uses) and k_render_vjp (variant 32)."""
+    16, per-ray queue; also what a call with caller-supplied depths uses), k_render_vjp (variant 32) and
+    k_render_vjp_b3 (mlp="bf16x3": forward and transposed GEMMs on bf16 MFMAs with three-way split operands)."""
     from neural_sim_nerf_amd.engine import NsrModel
-    m = NsrModel(synth_nets[0], synth_nets[1], variant=request.param[0], schedule=request.param[1])
+    if request.param[0] == "b3":
+        m = NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3")
+    else:
+        m = NsrModel(synth_nets[0], synth_nets[1], variant=request.param[0], schedule=request.param[1])
     yield m
     m.close()
 
@@ -226,9 +231,8 @@ def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
     outs = m.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd)
     want = oracle.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd, white_bkgd=True)
     assert_close(cpu(outs[0]), want[0], atol=3e-6, what="raw2outputs stage, white_bkgd")
-    # VJP (compared on the same handle's forward's own sample positions); a "b3" handle's input-gradient kernel is
-    # the fp32 x16 one, covered by variant 16
-    if variant != "b3":
+    # VJP (compared on the same handle's forward's own sample positions)
+    if True:
         n = g["cot"].shape[0]
         fwd = m.render_rays(ro[:n], rd[:n], near, far, debug=True)
         go, gd, f2 = m.render_rays_vjp(ro[:n], rd[:n], near, far, g["cot"], with_forward=True)
@@ -1049,9 +1053,15 @@ def test_x16_coarse_only_config1(oracle, synth_nets):
     g = load_golden("g7_render")
     for kw in (dict(variant=16), dict(mlp="bf16x3")):
         m1 = NsrModel(synth_nets[0], None, n_importance=0, **kw)
-        r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR)
-        assert_close(cpu(r["rgb_map"]).reshape(64, 64, 3), g["rgb_c1"], atol=1e-5, what="config-1 rgb %s" % kw)
-        assert_close(cpu(r["acc_map"]).reshape(64, 64), g["acc_c1"], atol=1e-5, what="config-1 acc %s" % kw)
+        r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR, debug=True)
+        d_rgb = np.abs(cpu(r["rgb_map"]).reshape(64, 64, 3) - g["rgb_c1"]).max(-1).ravel()
+        d_acc = np.abs(cpu(r["acc_map"]) - g["acc_c1"].ravel())
+        bad = np.where((d_rgb > 1e-5) | (d_acc > 1e-5))[0]
+        # the reference's own cliff: the LAST sample's dist is 1e10 (RN:358), so |sigma| ~ 1e-6 there decides between
+        # alpha = 0 and alpha = 1; a ray may differ from the golden image only if it sits on that cliff
+        assert len(bad) <= 2, (kw, len(bad), d_rgb.max())
+        for b in bad:
+            assert abs(float(cpu(r["raw0"])[b, -1, 3])) < 1e-4, (kw, b, cpu(r["raw0"])[b, -1, 3])
         m1.close()
 
 

@@ -146,12 +146,21 @@ def test_packer_b3_through_kernel_emulation(oracle, synth_nets):
     pts = rng.uniform(-1.5, 1.5, (32, 3)).astype(np.float32)
     d = rng.standard_normal((32, 3)).astype(np.float32)
     d /= np.linalg.norm(d, axis=-1, keepdims=True)
-    raw3 = E.mlp_pass_b3(p3, pts, d)
+    masks = {}
+    raw3 = E.mlp_pass_b3(p3, pts, d, masks)
     raw32 = E.mlp_pass(pack.pack_network(sd), pts, d)
     want = oracle.mlp(sd, np.concatenate([oracle.embed(pts, 10), oracle.embed(d, 4)], -1))
     assert np.abs(raw3 - want).max() < 2e-5                       # the same bound as the fp32 kernel's emulation
     assert np.abs(raw3 - raw32).max() < 2e-5
     assert np.abs(raw3 - raw32).max() > 0                         # it IS a different arithmetic (not the same code path)
+    # backward: the transposed stream (4-block encoding GEMMs ahead of the 8-block ones) against the oracle's VJP
+    b3 = pack.pack_network_backward_b3(sd)
+    assert b3.shape == (pack.STREAM_SLABS_B3_BWD * pack.SLAB_FLOATS,)
+    g = rng.standard_normal((32, 4)).astype(np.float32)
+    dp, dv = E.mlp_bwd_pass_b3(p3, b3, masks, pts, d, g)
+    rp, rv = oracle.network_vjp(sd, pts, d, g)
+    assert np.abs(dp - rp).max() < 1e-5 * np.abs(rp).max()
+    assert np.abs(dv - rv).max() < 1e-5 * np.abs(rv).max()
 
 
 def test_bf16x3_split_is_fp32_grade(oracle, synth_nets):

@@ -14,5 +14,5 @@ for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 2):
     m.render_rays_vjp(o.reshape(-1, 3), d.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot)
     ms = m.last_kernel_ms()
 flop = H * W * (64 + 192 + 192) * S.FLOP_PER_POINT
-print(json.dumps({"variant": m.variant, "vjp_kernel_ms": ms, "rays": H * W, "tflops_algorithmic(fwd 256 + bwd 192 evals/ray)": flop / ms / 1e9,
+print(json.dumps({"variant": m.variant, "mlp": m.mlp, "vjp_kernel_ms": ms, "rays": H * W, "tflops_algorithmic(fwd 256 + bwd 192 evals/ray)": flop / ms / 1e9,
                   "Mray-samples/s": H * W * 192 / ms / 1e3}))

@@ -70,11 +70,11 @@ for name in ("phases", "queue", "x32"):
                 vj[name] = json.loads(l)
 if vj:
     out["vjp_timing_unprofiled"] = vj
-json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
 pf = os.path.join(src, "probe_bf16x3.log")
 if os.path.exists(pf):
-    out["layer_gemm_probe"] = {"lines": [l.strip() for l in open(pf) if l.startswith("mode")],
+    out["layer_gemm_probe"] = {"lines": [l.strip() for l in open(pf) if l.lstrip().startswith("mode")],
                                "modes": "2 = fp32 x32 production segment, 12 = bf16x3 MFMAs only, 11 = bf16x3 production groups (tools/probe_bf16x3.py)"}
+json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
 for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_b3", "kernel_stats_bench_bf16x3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
                   ("stats_handoff", "kernel_stats_handoff.csv")):
     for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
@@ -87,4 +87,4 @@ if os.path.exists(os.path.join(src, "bench.json")):
     lines = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
     if lines:
         open(os.path.join(dst, "bench_final_kernel.json"), "w").write(lines[-1])
-print(json.dumps({k: v["derived"] for k, v in out.items() if isinstance(v, dict)}, indent=1))
+print(json.dumps({k: v["derived"] for k, v in out.items() if isinstance(v, dict) and "derived" in v}, indent=1))
