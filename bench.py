@@ -58,6 +58,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3               # v_mfma_f32_32x32x2_f32 / 16x16x4, d
 PEAK_BF16_MFMA_TFLOPS = 2500.0             # v_mfma_f32_32x32x16_bf16, dense (MI355X_MICROARCH.md: ~2.5 PF)
 # bf16x3 (NSR_FLAG_MLP_BF16X3): MFMA FLOP issued per point = 6 piece products x the k16-padded layer shapes
 B3_ISSUED_FLOP_PER_POINT = 2 * 6 * (256 * 64 + 4 * 256 * 256 + 256 * (64 + 256) + 2 * 256 * 256 + 256 * 256 + 128 * 320)
+# ... and per transposed evaluation (4-block zero-padded encoding GEMMs + 8-block GEMMs, csrc/nsr_b3.inc)
+B3_ISSUED_FLOP_PER_POINT_BWD = 2 * 6 * ((128 + 256) * 128 + 256 * 256 + 2 * 256 * 256 + (128 + 256) * 256 + 4 * 256 * 256 + 128 * 256)
 METRIC = "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP"
 
 
@@ -110,6 +112,7 @@ def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3):
            "ms_per_view": round(dt / launches * 1e3, 3), "launches": launches,
            "dtype": "bf16x3: fp32 operands as three bf16 pieces each, six piece products per fp32 product, fp32 accumulate",
            "roofline": forward_roofline(m, k_ms),
+           "roofline_vjp": vjp_roofline(m, c2w),
            "vs_fp32_mfma_kernel_same_view": {
                "psnr_db": round(-10.0 * np.log10(mse), 2) if mse > 0 else None,
                "rgb_max_abs": float(d["rgb_map"].max()), "acc_max_abs": float(d["acc_map"].max()),
@@ -320,6 +323,16 @@ def vjp_roofline(model, c2w, pmc_file=None):
         ms.append(model.last_kernel_ms())
     k_ms = float(np.mean(ms[1:]))
     ach = H * W * FLOP_PER_RAY_VJP / (k_ms * 1e-3) / 1e12
+    flop_note = ("per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
+                 "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP")
+    if model.mlp == "bf16x3":
+        issued = H * W * (EVALS_PER_RAY * B3_ISSUED_FLOP_PER_POINT + 192 * B3_ISSUED_FLOP_PER_POINT_BWD) / (k_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "issued": round(issued, 1),
+                "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": None,
+                "kernel": "nsr::k_render_vjp_b3", "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
+                "flop_note": flop_note}
     traffic = None
     if pmc_file and os.path.exists(pmc_file) and model.variant != 32:
         prof = json.load(open(pmc_file))
@@ -329,9 +342,7 @@ def vjp_roofline(model, c2w, pmc_file=None):
             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "kernel": "nsr::k_render_vjp" if model.variant == 32 else
                       ("nsr::k_render_vjp16p" if model.schedule == "phases" else "nsr::k_render_vjp16"),
-            "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
-            "flop_note": "per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
-                         "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP"}
+            "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP, "flop_note": flop_note}
 
 
 def pmc_traffic(pmc_file, schedule="phases"):

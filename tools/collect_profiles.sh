@@ -33,12 +33,14 @@ for set in "${SETS[@]}"; do
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16_$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $O/pmc_x16_$i.log 2>&1
   NSR_MLP=bf16x3 timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_b3_$i -- python $R/tools/one_view.py 16 > $O/pmc_b3_$i.log 2>&1
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_vjp_$i -- python $R/tools/bench_vjp.py 400 1 > $O/pmc_vjp_$i.log 2>&1
+  NSR_MLP=bf16x3 timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_vjpb3_$i -- python $R/tools/bench_vjp.py 400 1 > $O/pmc_vjpb3_$i.log 2>&1
   NSR_SCHEDULE=queue timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_vjpq_$i -- python $R/tools/bench_vjp.py 400 1 > $O/pmc_vjpq_$i.log 2>&1
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_x16q_$i -- python $R/tools/one_view.py 16 0 queue > $O/pmc_x16q_$i.log 2>&1
 done
 timeout 100 python $R/tools/bench_vjp.py 400 3 > $O/vjp_phases.log 2>&1
 NSR_SCHEDULE=queue timeout 100 python $R/tools/bench_vjp.py 400 3 > $O/vjp_queue.log 2>&1
 timeout 100 python $R/tools/bench_vjp.py 400 3 32 > $O/vjp_x32.log 2>&1
+NSR_MLP=bf16x3 timeout 100 python $R/tools/bench_vjp.py 400 3 > $O/vjp_bf16x3.log 2>&1
 timeout 100 python $R/tools/one_view.py 16 0 queue 4 > $O/schedule_queue.log 2>&1
 timeout 100 python $R/tools/one_view.py 16 0 phases 4 > $O/schedule_phases.log 2>&1
 NSR_MLP=bf16x3 timeout 100 python $R/tools/one_view.py 16 0 phases 4 > $O/schedule_bf16x3.log 2>&1

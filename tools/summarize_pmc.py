@@ -7,10 +7,10 @@ dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(dst, exist_ok=True)
 out = {}
 FLOP = {"x16": 160000 * 303824896, "x16q": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568,
-        "vjpq": 160000 * 531693568, "b3": 160000 * 303824896}
+        "vjpq": 160000 * 531693568, "b3": 160000 * 303824896, "vjpb3": 160000 * 531693568}
 for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", "x16_queue_schedule", "k_render16("),
                         ("x32", "x32", "k_render("), ("b3", "bf16x3", "k_render_b3"), ("vjp", "vjp", "k_render_vjp16p"),
-                        ("vjpq", "vjp_queue_schedule", "k_render_vjp16(")):
+                        ("vjpq", "vjp_queue_schedule", "k_render_vjp16("), ("vjpb3", "vjp_bf16x3", "k_render_vjp_b3")):
     tot, disp, ns, first_id = {}, {}, None, {}
     for d in sorted(glob.glob(os.path.join(src, "pmc_%s_*" % tag))):
         if not os.path.isdir(d):
@@ -62,7 +62,7 @@ for name in ("queue", "phases", "bf16x3", "x32"):
 if sched:
     out["schedule_timing_unprofiled"] = sched
 vj = {}
-for name in ("phases", "queue", "x32"):
+for name in ("phases", "queue", "x32", "bf16x3"):
     f = os.path.join(src, "vjp_%s.log" % name)
     if os.path.exists(f):
         for l in open(f):
