@@ -547,7 +547,7 @@ def main():
         # render_path returns, 1.92 MB/view).  A step = one whole sweep.
         from neural_sim_nerf_amd import png
         n_views = args.views
-        model = NsrModel(sd_c, sd_f, device=local)
+        model = NsrModel(sd_c, sd_f, device=local, mlp=args.mlp)
         poses = S.sweep_poses(n_views, seed=0)
         mine = D.shard_indices(n_views, world, rank)
         poses_d = torch.as_tensor(poses[mine][:, :3, :4], device=model.device)
@@ -613,7 +613,7 @@ def main():
         models, streams = [], []
         for m in mine:
             c = S.synth_weights(m)
-            models.append(NsrModel(c, S.synth_weights(1000 + m, fine_of=c), device=local))
+            models.append(NsrModel(c, S.synth_weights(1000 + m, fine_of=c), device=local, mlp=args.mlp))
             streams.append(torch.cuda.Stream(device=dev))
         poses = torch.as_tensor(S.sweep_poses(n_models, seed=3)[:, :3, :4], device=dev)
 
@@ -652,6 +652,9 @@ def main():
             m.close()
 
     if rank == 0:
+        if args.workload != "view400" and (args.mlp or os.environ.get("NSR_MLP")) == "bf16x3":
+            line["dtype"] = "bf16x3"
+            line["config"]["mlp"] = "bf16x3 (layer GEMMs on bf16 MFMAs, fp32 operands split into three bf16 pieces)"
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()
