@@ -163,6 +163,32 @@ def test_packer_b3_through_kernel_emulation(oracle, synth_nets):
     assert np.abs(dv - rv).max() < 1e-5 * np.abs(rv).max()
 
 
+def test_bf16x3_chunk_tables_match_the_kernel_source():
+    """pack.B3_STEPS8 / B3_STEPS4 (and the emulator's copies) mirror B3Sched<8> / B3Sched<4> in csrc/nsr_b3.inc by hand:
+    parse the constexpr tables out of the source and compare, and check the properties the schedule relies on (every
+    step 8 MFMAs, four different output blocks per step, every (piece, block) pair exactly once per k16 block)."""
+    import re
+    from neural_sim_nerf_amd import pack
+    import kernel_emulator as E
+    src = open(os.path.join(ROOT, "neural_sim_nerf_amd", "csrc", "nsr_b3.inc")).read()
+
+    def table(struct, fn):
+        body = src[src.index("template <> struct B3Sched<%d>" % struct):]
+        m = re.search(r"static constexpr int %s\(int s, int c\) \{ constexpr int t\[\d\]\[4\] = \{(.*?)\}; return" % fn, body)
+        return [[int(x) for x in row.split(",")] for row in re.findall(r"\{([\d, ]+)\}", m.group(1))]
+    for nmo, steps, ep, eb in ((8, pack.B3_STEPS8, E.B3_PIECE8, E.B3_BLOCK8), (4, pack.B3_STEPS4, E.B3_PIECE4, E.B3_BLOCK4)):
+        piece, block = table(nmo, "piece"), table(nmo, "block")
+        assert piece == ep and block == eb
+        assert [[(p, b) for p, b in zip(pr, br)] for pr, br in zip(piece, block)] == [list(s) for s in steps]
+        seen = set()
+        for pr, br in zip(piece, block):
+            assert sum(3 - p for p in pr) == 8 and len(set(br)) == 4
+            seen |= set(zip(pr, br))
+        assert seen == {(p, b) for p in range(3) for b in range(nmo)} and len(piece) * 4 == 3 * nmo
+    assert int(re.search(r"kStreamSlabsB3 = (\d+)", src).group(1)) == pack.STREAM_SLABS_B3
+    assert int(re.search(r"kStreamSlabsB3Bwd = (\d+)", src).group(1)) == pack.STREAM_SLABS_B3_BWD
+
+
 def test_bf16x3_split_is_fp32_grade(oracle, synth_nets):
     """The claim in csrc/nsr_b3.inc: the three-piece split is exact, and the six kept piece products leave the whole
     MLP as close to an fp64 evaluation as an fp32 GEMM chain is (2048 points, both networks' layer shapes)."""
