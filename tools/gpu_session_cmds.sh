@@ -1,2 +1,1 @@
-mkdir -p $O/extra
-timeout 300 python bench.py --steps 3 --warmup 1 > $O/extra/bench.json 2> $O/extra/bench.err; tail -c 600 $O/extra/bench.json
+MODES=11,11,16,17,11,16,17,11,16 timeout 200 python tools/probe_bf16x3.py 2>&1 | grep -v amdgpu.ids | tail -9
