@@ -112,6 +112,12 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   NSRP_HIP(hipEventSynchronize(ev1));
   NSRP_HIP(hipEventElapsedTime(ms, ev0, ev1));
   int rc = 0;
+  if (mode >= 11 && getenv("NSR_PROBE_VERBOSE")) {     // shader cycles and 100 MHz ticks of workgroup 0's loop
+    float cw[2];
+    NSRP_HIP(hipMemcpy(cw, out + (size_t)n_cu * 256, sizeof(cw), hipMemcpyDeviceToHost));
+    fprintf(stderr, "nsr_probe mode %d: %.0f shader cycles in %.0f ticks of 10 ns -> %.3f GHz, %.2f cycles per MFMA\n", mode,
+            cw[0], cw[1], cw[0] / cw[1] / 10.0, cw[0] / ((double)iters * 768.0));
+  }
   if (mode >= 4 && mode <= 8) {        // mean duration of the GEMM workgroups (100 MHz ticks -> ms), not the whole kernel
     std::vector<float> host(2 * n_cu);
     NSRP_HIP(hipMemcpy(host.data(), out, sizeof(float) * host.size(), hipMemcpyDeviceToHost));
