@@ -1,1 +1,3 @@
-NSR_PROBE_VERBOSE=1 MODES=11,11,17,12,25,11,17,12,25 timeout 200 python tools/probe_bf16x3.py 2>&1 | grep -v amdgpu.ids | tail -18
+timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -2
+timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 200 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | cut -c1-400
