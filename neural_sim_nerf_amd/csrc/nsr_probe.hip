@@ -48,7 +48,7 @@ const char* nsr_probe_last_error(void) { return g_perr.c_str(); }
 
 int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   if (!ms) return pfail("nsr_probe: null argument");
-  if (mode < 0 || mode > 25 || iters <= 0) return pfail("nsr_probe: mode in 0..25, iters > 0");
+  if (mode < 0 || mode > 27 || iters <= 0) return pfail("nsr_probe: mode in 0..27, iters > 0");
   NSRP_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   NSRP_HIP(hipGetDeviceProperties(&prop, device));
@@ -75,7 +75,7 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   NSRP_LDS(nsr::k_probe16_pair<3>, l16); NSRP_LDS(nsr::k_probe16_pair<4>, l16);
   NSRP_LDS(nsr::k_probe_b3<11>, lepi); NSRP_LDS(nsr::k_probe_b3<12>, lepi); NSRP_LDS(nsr::k_probe_b3<13>, lepi);
   NSRP_LDS(nsr::k_probe_b3<14>, lepi); NSRP_LDS(nsr::k_probe_b3<15>, lepi); NSRP_LDS(nsr::k_probe_b3<16>, lepi); NSRP_LDS(nsr::k_probe_b3<17>, lepi); NSRP_LDS(nsr::k_probe_b3<18>, lepi);
-  NSRP_LDS(nsr::k_probe_b3<19>, lepi); NSRP_LDS(nsr::k_probe_b3<20>, lepi); NSRP_LDS(nsr::k_probe_b3<21>, lepi); NSRP_LDS(nsr::k_probe_b3<22>, lepi); NSRP_LDS(nsr::k_probe_b3<23>, lepi); NSRP_LDS(nsr::k_probe_b3<24>, lepi); NSRP_LDS(nsr::k_probe_b3<25>, lepi);
+  NSRP_LDS(nsr::k_probe_b3<19>, lepi); NSRP_LDS(nsr::k_probe_b3<20>, lepi); NSRP_LDS(nsr::k_probe_b3<21>, lepi); NSRP_LDS(nsr::k_probe_b3<22>, lepi); NSRP_LDS(nsr::k_probe_b3<23>, lepi); NSRP_LDS(nsr::k_probe_b3<24>, lepi); NSRP_LDS(nsr::k_probe_b3<25>, lepi); NSRP_LDS(nsr::k_probe_b3<26>, lepi); NSRP_LDS(nsr::k_probe_b3<27>, lepi);
   NSRP_HIP(hipDeviceSynchronize());
   NSRP_HIP(hipEventRecord(ev0, s));
   const dim3 b(256), g1(n_cu), g2(2 * n_cu);
@@ -106,6 +106,8 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
     case 23: hipLaunchKernelGGL(nsr::k_probe_b3<23>, g1, b, lepi, s, wstream, out, iters); break;
     case 24: hipLaunchKernelGGL(nsr::k_probe_b3<24>, g1, b, lepi, s, wstream, out, iters); break;
     case 25: hipLaunchKernelGGL(nsr::k_probe_b3<25>, g1, b, lepi, s, wstream, out, iters); break;
+    case 26: hipLaunchKernelGGL(nsr::k_probe_b3<26>, g1, b, lepi, s, wstream, out, iters); break;
+    case 27: hipLaunchKernelGGL(nsr::k_probe_b3<27>, g1, b, lepi, s, wstream, out, iters); break;
   }
   NSRP_HIP(hipGetLastError());
   NSRP_HIP(hipEventRecord(ev1, s));
