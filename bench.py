@@ -90,7 +90,7 @@ def forward_roofline(model, k_ms, n_rays=H * W):
     return r
 
 
-def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3):
+def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3, sample=None):
     """extra_workloads.bf16x3: the SAME 400x400 view through the forward kernel with NSR_FLAG_MLP_BF16X3 (k_render_b3:
     layer GEMMs on bf16 MFMAs, fp32 operands split exactly into three bf16 pieces, fp32 accumulate), timed like the
     main line (HIP events per launch + wall clock), and compared with the fp32-MFMA kernel's image `ref` of that view."""
@@ -119,6 +119,8 @@ def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3):
                "rgb0_max_abs": float(d["rgb0"].max()),
                "rays_with_rgb_diff_above_1e-4": int((d["rgb_map"].max(-1).values > 1e-4).sum())},
            "how_to_enable": "NsrModel(..., mlp='bf16x3') / NSR_MLP=bf16x3 / bench.py --mlp bf16x3; NsrConfig.flags |= NSR_FLAG_MLP_BF16X3"}
+    if sample is not None:                   # the same `parity` object as the main line's, against the same oracle output
+        res["parity"] = parity_vs_oracle(m, sample)
     m.close()
     return res
 
@@ -173,6 +175,19 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
     ref = run(side)
     dt = time.perf_counter() - t0
     O.set_backend("numpy")
+    cpu = {"value": round(side * side * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
+           "kind": "port", "cpu_model": cpu_model(), "host_logical_cpus": ncpu,
+           "sample": "one %dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
+           "oracle/nerf_oracle.py, fastest of {torch-CPU ops x thread counts, numpy+OpenBLAS} on this host: %s backend, "
+           "%d threads; %.1f s" % (side, side, side * side, backend, n_threads, dt)}
+    sample = {"ref": ref, "side": side, "c2w": c2w}
+    return cpu, parity_vs_oracle(model, sample), (backend, threads), sample
+
+
+def parity_vs_oracle(model, sample):
+    """`parity` object: `model` on the CPU sample of cpu_baseline_and_parity against the oracle's output of it."""
+    O = _oracle()
+    ref, side, c2w = sample["ref"], sample["side"], sample["c2w"]
     got = model.render_views(c2w, side, side, S.scaled_K(400.0 / side), S.YCBV_NEAR, S.YCBV_FAR, debug=True)
     rgb = got["rgb_map"].cpu().numpy().reshape(side, side, 3)
     rgb0 = got["rgb0"].cpu().numpy().reshape(side, side, 3)
@@ -190,21 +205,15 @@ def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
             return float(np.nanmax(np.abs(a - b)))
     # PSNR delta against a pseudo ground truth T = oracle + N(0, 0.01^2)
     T = ref["rgb_map"] + np.random.RandomState(0).normal(0, 0.01, ref["rgb_map"].shape).astype(np.float32)
-    cpu = {"value": round(side * side * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
-           "kind": "port", "cpu_model": cpu_model(), "host_logical_cpus": ncpu,
-           "sample": "one %dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
-           "oracle/nerf_oracle.py, fastest of {torch-CPU ops x thread counts, numpy+OpenBLAS} on this host: %s backend, "
-           "%d threads; %.1f s" % (side, side, side * side, backend, n_threads, dt)}
-    par = {"psnr_vs_oracle_db": round(O.psnr(rgb, ref["rgb_map"]), 2),
-           "psnr_delta_db": round(abs(O.psnr(rgb, T) - O.psnr(ref["rgb_map"], T)), 4),
-           "max_abs_rgb_coarse": float(np.abs(rgb0 - ref["rgb0"]).max()),
-           "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
-           "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()),
-           "max_abs_acc": maxabs("acc_map", (side, side)), "max_abs_disp": maxabs("disp_map", (side, side)),
-           "max_abs_z_std": maxabs("z_std", (side, side)),
-           "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
-           "sample": "%dx%d view; indices/samples: oracle sample_pdf on the kernel's own coarse weights" % (side, side)}
-    return cpu, par, (backend, threads)
+    return {"psnr_vs_oracle_db": round(O.psnr(rgb, ref["rgb_map"]), 2),
+            "psnr_delta_db": round(abs(O.psnr(rgb, T) - O.psnr(ref["rgb_map"], T)), 4),
+            "max_abs_rgb_coarse": float(np.abs(rgb0 - ref["rgb0"]).max()),
+            "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
+            "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()),
+            "max_abs_acc": maxabs("acc_map", (side, side)), "max_abs_disp": maxabs("disp_map", (side, side)),
+            "max_abs_z_std": maxabs("z_std", (side, side)),
+            "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
+            "sample": "%dx%d view; indices/samples: oracle sample_pdf on the kernel's own coarse weights" % (side, side)}
 
 
 def config1_workload(sd_c, c2w, device, cpu_setting):
@@ -513,9 +522,9 @@ def main():
                                        "mean": round(float(np.mean(per_rank)), 3)},
                 "roofline": roof,
             })
-            cpu_setting = None
+            cpu_setting, cpu_sample = None, None
             if world == 1 and not args.no_cpu_baseline:
-                cpu, par, cpu_setting = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
+                cpu, par, cpu_setting, cpu_sample = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
                 line["cpu_baseline"] = cpu
                 line["parity"] = par
             if world == 1 and args.cpu_full_view and cpu_setting is not None:
@@ -536,7 +545,8 @@ def main():
                                            "handoff": handoff_workload(model, not args.no_cpu_baseline)}
                 if model.mlp != "bf16x3":
                     ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
-                    line["extra_workloads"]["bf16x3"] = bf16x3_workload(sd_c, sd_f, local, poses[args.warmup], ref)
+                    line["extra_workloads"]["bf16x3"] = bf16x3_workload(sd_c, sd_f, local, poses[args.warmup], ref,
+                                                                         sample=cpu_sample)
         model.close()
 
     # ------------------------------------------------------------------------------------------------------------
