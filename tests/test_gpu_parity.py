@@ -1022,16 +1022,19 @@ def test_second_stream_on_a_busy_handle_is_refused(synth_nets, oracle):
     from neural_sim_nerf_amd import _lib
     from neural_sim_nerf_amd.engine import NsrModel
     m = NsrModel(synth_nets[0], synth_nets[1])
-    pose = np.asarray(oracle.sweep_poses(1, seed=2))[0]
-    K = oracle.scaled_K(2.0)
-    a = m.render_views(pose, 200, 200, K, oracle.YCBV_NEAR, oracle.YCBV_FAR)          # ~80 ms of work in flight
+    pose = torch.as_tensor(np.asarray(oracle.sweep_poses(1, seed=2))[0][:3, :4], dtype=torch.float32, device=m.device)
+    small = lambda: m.render_views(pose, 8, 8, oracle.scaled_K(50.0), oracle.YCBV_NEAR, oracle.YCBV_FAR)
     other = torch.cuda.Stream()
     with torch.cuda.stream(other):
+        small()          # warm-up: that stream's allocator pool and the code objects exist before the timed part (a first
+    torch.cuda.synchronize()      # allocation on a new stream is a hipMalloc, which may wait for the device)
+    a = m.render_views(pose, 400, 400, oracle.YCBV_K, oracle.YCBV_NEAR, oracle.YCBV_FAR)      # ~330 ms of work in flight
+    with torch.cuda.stream(other):
         with pytest.raises(_lib.NsrError, match="busy on another stream"):
-            m.render_views(pose, 8, 8, oracle.scaled_K(50.0), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+            small()
     torch.cuda.synchronize()
     with torch.cuda.stream(other):
-        b = m.render_views(pose, 8, 8, oracle.scaled_K(50.0), oracle.YCBV_NEAR, oracle.YCBV_FAR)
+        b = small()
     torch.cuda.synchronize()
     assert np.isfinite(cpu(a["acc_map"])).all() and np.isfinite(cpu(b["acc_map"])).all()
     m.close()
