@@ -1,0 +1,203 @@
+"""Cliff / flip census: per-ray attribution of end-to-end differences between a render and the oracle's render of
+the same rays.  TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), the parity leg of bench.py).
+
+The render path has three built-in discontinuities.  At each of them an implementation that agrees with the
+reference to fp32 rounding in every stage can still land on the other side, and the pixel then differs by far more
+than rounding:
+
+  * sigma_last cliff (RN:358-359): the last interval is 1e10 long, so alpha_last = 1 - exp(-relu(sigma_last) * 1e10 *
+    |d|) is 0 for sigma_last <= 0 and 1 for sigma_last > ~1e-9: the SIGN of a network output decides whether the
+    remaining transmittance T_last is added to acc (and T_last * rgb_last to the pixel).  Exists in the coarse and in
+    the fine pass;
+  * resampling index (RH:227): searchsorted(cdf, u, right=True) of a u that sits on a cdf entry;
+  * denominator switch (RH:238-239): denom < 1e-5 -> 1; for an opaque ray every empty bin has denom = 1e-5 / sum(w +
+    1e-5), i.e. within an ulp or two of the threshold.
+In between, the inverse CDF divides by denom >= 1e-5 (RH:240), so a 1e-7 change of a coarse weight can move a sample
+by 1e-2 of a bin (continuous, ill-conditioned).
+
+census() takes a render WITH its debug taps and the oracle's end-to-end render of the same rays and, for every ray
+whose rgb or acc differs by more than `tol`, proves where the difference comes from:
+
+  P1  the fine pass is faithful at the render's OWN sample depths: the oracle's fine network + compositing at those
+      depths reproduces the render's pixel to `tol_stage` -- after, if alpha_last differs between the two (a fine
+      sigma_last cliff), the render's sigma_last is replaced by the oracle's;
+  P2  if the depths are the oracle's own depths, the ray must be a fine cliff; if they moved, the move must have an
+      identified cause: a coarse sigma_last cliff, a flipped index, a denominator switch -- or none of them, and then
+      every sample's shift must be within the conditioning bound  |dz| <= binwidth * 4 * max|dcdf| / denom  computed
+      from the two cdfs (both recomputed here by the oracle's sample_pdf from the respective coarse weights).
+A flagged ray that satisfies neither is `unattributed`; the tests demand zero of those.
+
+Coarse-only renders (BASELINE configs[0]) have only the first discontinuity."""
+import numpy as np
+
+import nerf_oracle as O
+
+f32 = np.float32
+TOL = 1e-4            # end-to-end tolerance on rgb and acc
+TOL_STAGE = 3e-5      # fine pass at identical depths: raw outputs agree to 5e-5 (stage tests), the pixel to this
+TOL_DISP_REL = 1e-3   # disp, relative, on rays that are not flagged and have acc > 1e-3
+
+
+def alpha_last(sigma_last, rays_d):
+    """alpha of the last sample, RN:356 with the 1e10 interval of RN:358-361."""
+    d = (f32(1e10) * O.dir_norm(rays_d)).astype(f32)
+    with np.errstate(over="ignore"):
+        return (f32(1) - np.exp((-np.maximum(sigma_last.astype(f32), f32(0)) * d).astype(f32))).astype(f32)
+
+
+def _pdf_terms(z_coarse, w0):
+    """cdf and, per importance sample, (index, denominator as computed, switched flag) -- RH:199-240 via the oracle."""
+    z_mid = (f32(0.5) * (z_coarse[:, 1:] + z_coarse[:, :-1])).astype(f32)
+    zs, inds, cdf = O.sample_pdf(z_mid, w0[:, 1:-1])
+    below = np.maximum(inds - 1, 0)
+    above = np.minimum(inds, cdf.shape[-1] - 1)
+    den = (np.take_along_axis(cdf, above, -1) - np.take_along_axis(cdf, below, -1)).astype(f32)
+    binw = (np.take_along_axis(z_mid, above, -1) - np.take_along_axis(z_mid, below, -1)).astype(f32)
+    return zs, inds, cdf, den, binw
+
+
+def psnr_delta(rgb, rgb_oracle, mask=None):
+    """|PSNR(render, T) - PSNR(oracle, T)| against the pseudo ground truth T = oracle + N(0, 0.01^2)
+    (seed 0); `mask` restricts both to a subset of rays."""
+    a = rgb.reshape(-1, 3)
+    b = rgb_oracle.reshape(-1, 3)
+    T = b + np.random.RandomState(0).normal(0, 0.01, b.shape).astype(f32)
+    if mask is not None:
+        a, b, T = a[mask], b[mask], T[mask]
+    return abs(O.psnr(a, T) - O.psnr(b, T))
+
+
+def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STAGE, white_bkgd=False, lindisp=False,
+           coarse_only=False, max_listed=8):
+    """nets = (sd_coarse, sd_fine); rays [N,3]; got: the render's outputs as numpy arrays [N, ...] -- rgb_map, acc_map,
+    disp_map, raw0 [N,64,4] and, unless coarse_only, weights0, inds, z_samples, z_fine, raw [N,192,4], rgb0, acc0;
+    ref: the oracle's render of the same rays with extras (O.render_rays(..., extras=True): rgb_map, acc_map, disp_map,
+    raw0, weights0, inds, z_samples, z_fine, raw_sigma_last or raw, rgb0, acc0).
+    Returns a JSON-able dict of counts; `unattributed` must be 0 for the render to pass."""
+    sd_c, sd_f = nets
+    rays_o = np.ascontiguousarray(rays_o, f32).reshape(-1, 3)
+    rays_d = np.ascontiguousarray(rays_d, f32).reshape(-1, 3)
+    n = rays_o.shape[0]
+    g = {k: np.asarray(v).reshape((n,) + np.asarray(v).shape[np.asarray(v).ndim - _trail(k):]) for k, v in got.items()
+         if v is not None and k in _TRAIL}
+    r = {k: np.asarray(v).reshape((n,) + np.asarray(v).shape[np.asarray(v).ndim - _trail(k):]) for k, v in ref.items()
+         if v is not None and k in _TRAIL}
+    vd = O.normalize_dirs(rays_d)
+    zc = O.coarse_z(np.full(n, near, f32), np.full(n, far, f32), lindisp=lindisp)
+
+    d_rgb = np.abs(g["rgb_map"] - r["rgb_map"]).max(-1)
+    d_acc = np.abs(g["acc_map"] - r["acc_map"])
+    flagged = (d_rgb > tol) | (d_acc > tol) | ~np.isfinite(d_rgb) | ~np.isfinite(d_acc)
+    out = {"rays": int(n), "tol": tol, "tol_stage": tol_stage,
+           "rays_above_tol": int(flagged.sum()),
+           "rays_rgb_above_tol": int((d_rgb > tol).sum()), "rays_acc_above_tol": int((d_acc > tol).sum()),
+           "max_abs_rgb": float(np.nanmax(d_rgb)), "max_abs_acc": float(np.nanmax(d_acc))}
+
+    # the coarse image has its own cliff (it is an output too: rgb0 / acc0, or the image itself when coarse_only)
+    ck = ("rgb_map", "acc_map") if coarse_only else ("rgb0", "acc0")
+    a0_g = alpha_last(g["raw0"][:, -1, 3], rays_d)
+    a0_r = alpha_last(r["raw0"][:, -1, 3], rays_d)
+    coarse_cliff = np.abs(a0_g - a0_r) > 1e-3
+    d0 = np.maximum(np.abs(g[ck[0]] - r[ck[0]]).max(-1), np.abs(g[ck[1]] - r[ck[1]]))
+    flagged0 = d0 > tol
+    out["coarse_rays_above_tol"] = int(flagged0.sum())
+    out["coarse_cliff_rays"] = int(coarse_cliff.sum())
+    un0 = np.zeros(n, bool)
+    idx0 = np.nonzero(flagged0)[0]
+    if idx0.size:
+        # counterfactual: the render's own coarse raw with the oracle's sigma_last must give the oracle's coarse pixel
+        raw_cf = g["raw0"][idx0].copy()
+        raw_cf[:, -1, 3] = r["raw0"][idx0, -1, 3]
+        rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zc[idx0], rays_d[idx0], white_bkgd)
+        ok = coarse_cliff[idx0] & (np.abs(rgb_cf - r[ck[0]][idx0]).max(-1) <= tol_stage) & \
+            (np.abs(acc_cf - r[ck[1]][idx0]) <= tol_stage)
+        un0[idx0[~ok]] = True
+    out["coarse_unattributed"] = int(un0.sum())
+    if coarse_only:
+        out.update(cliff_rays=int((flagged & coarse_cliff).sum()), index_flip_rays=0, denom_switch_rays=0,
+                   illconditioned_shift_rays=0, unattributed=int(un0.sum()),
+                   unattributed_rays=[int(i) for i in np.nonzero(un0)[0][:max_listed]])
+        out["psnr_delta_db"] = round(psnr_delta(g["rgb_map"], r["rgb_map"]), 4)
+        out["psnr_delta_db_excluding_attributed"] = round(psnr_delta(g["rgb_map"], r["rgb_map"], ~(flagged & ~un0)), 4)
+        out["psnr_vs_oracle_db"] = round(O.psnr(g["rgb_map"], r["rgb_map"]), 2)
+        return out
+
+    idx = np.nonzero(flagged)[0]
+    cat = {k: np.zeros(n, bool) for k in ("fine_cliff", "coarse_cliff", "index_flip", "denom_switch", "illcond_shift",
+                                         "unattributed")}
+    worst = []
+    if idx.size:
+        ro, rd, v = rays_o[idx], rays_d[idx], vd[idx]
+        zf_g, zf_r = g["z_fine"][idx], r["z_fine"][idx]
+        # P1: the oracle's fine pass at the render's own depths
+        pts = O._add(ro[:, None, :], (rd[:, None, :] * zf_g[:, :, None]).astype(f32))
+        raw_rep = O.run_network(sd_f if sd_f is not None else sd_c, pts, v)
+        rgb_rep, _, acc_rep, _, _ = O.raw2outputs(raw_rep, zf_g, rd, white_bkgd)
+        fine_cliff = np.abs(alpha_last(g["raw"][idx, -1, 3], rd) - alpha_last(raw_rep[:, -1, 3], rd)) > 1e-3
+        raw_cf = g["raw"][idx].copy()
+        raw_cf[fine_cliff, -1, 3] = raw_rep[fine_cliff, -1, 3]
+        rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zf_g, rd, white_bkgd)
+        own = O.raw2outputs(g["raw"][idx], zf_g, rd, white_bkgd)             # the render's compositing of its own raw
+        p1 = (np.abs(rgb_cf - rgb_rep).max(-1) <= tol_stage) & (np.abs(acc_cf - acc_rep) <= tol_stage) & \
+            (np.abs(own[0] - g["rgb_map"][idx]).max(-1) <= tol_stage) & (np.abs(own[2] - g["acc_map"][idx]) <= tol_stage)
+        # P2: why the depths moved
+        moved = (zf_g != zf_r).any(-1)
+        zs_g, inds_g, cdf_g, den_g, binw = _pdf_terms(zc[idx], g["weights0"][idx])
+        zs_r, inds_r, cdf_r, den_r, _ = _pdf_terms(zc[idx], r["weights0"][idx])
+        consistent = (inds_g == g["inds"][idx]).all(-1) & (zs_g == g["z_samples"][idx]).all(-1) & \
+            (inds_r == r["inds"][idx]).all(-1) & (zs_r == r["z_samples"][idx]).all(-1)   # the bit-exact stage, again
+        flip = (inds_g != inds_r).any(-1)
+        switch = ((den_g < f32(1e-5)) != (den_r < f32(1e-5))).any(-1)
+        ccl = coarse_cliff[idx]
+        dcdf = np.abs(cdf_g - cdf_r).max(-1, keepdims=True)
+        den = np.where(np.minimum(den_g, den_r) < f32(1e-5), f32(1), np.minimum(den_g, den_r))
+        bound = np.abs(binw) * 4.0 * dcdf / den + 4e-7
+        smooth_ok = (np.abs(zs_g - zs_r) <= bound).all(-1)
+        p2 = np.where(moved, ccl | flip | switch | smooth_ok, fine_cliff)
+        # the oracle's end-to-end fine pass has its own sigma_last: a ray whose depths moved can also sit on the cliff
+        # between the replay and the oracle's render -- the cause is still the move (different depths, different sigma)
+        ok = p1 & p2 & consistent
+        cat["fine_cliff"][idx] = fine_cliff
+        cat["coarse_cliff"][idx] = moved & ccl
+        cat["index_flip"][idx] = moved & flip
+        cat["denom_switch"][idx] = moved & switch
+        cat["illcond_shift"][idx] = moved & ~(ccl | flip | switch) & smooth_ok
+        cat["unattributed"][idx] = ~ok
+        order = np.argsort(-np.maximum(d_rgb[idx], d_acc[idx]))[:max_listed]
+        for j in order:
+            worst.append({"ray": int(idx[j]), "d_rgb": float(d_rgb[idx[j]]), "d_acc": float(d_acc[idx[j]]),
+                          "fine_cliff": bool(fine_cliff[j]), "coarse_cliff": bool(ccl[j]), "index_flip": bool(flip[j]),
+                          "denom_switch": bool(switch[j]), "moved": bool(moved[j]), "attributed": bool(ok[j]),
+                          "sigma_last": float(g["raw"][idx[j], -1, 3]), "sigma_last_replay": float(raw_rep[j, -1, 3])})
+    un = cat["unattributed"] | un0
+    out.update(cliff_rays=int((cat["fine_cliff"] | cat["coarse_cliff"]).sum()),
+               fine_cliff_rays=int(cat["fine_cliff"].sum()), index_flip_rays=int(cat["index_flip"].sum()),
+               denom_switch_rays=int(cat["denom_switch"].sum()), illconditioned_shift_rays=int(cat["illcond_shift"].sum()),
+               unattributed=int(un.sum()), unattributed_rays=[int(i) for i in np.nonzero(un)[0][:max_listed]],
+               worst=worst)
+    # everything that is not flagged is inside the tolerance by definition; disp is checked on those rays
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.abs(g["disp_map"] - r["disp_map"]) / np.abs(r["disp_map"])
+    keep = ~flagged & (r["acc_map"] > 1e-3) & np.isfinite(rel)
+    out["max_rel_disp_unflagged"] = float(rel[keep].max()) if keep.any() else 0.0
+    out["disp_nan_pattern_equal"] = bool(np.array_equal(np.isnan(g["disp_map"][~flagged]), np.isnan(r["disp_map"][~flagged])))
+    out["inds_equal_rate_end_to_end"] = float((g["inds"] == r["inds"]).mean())
+    out["psnr_vs_oracle_db"] = round(O.psnr(g["rgb_map"], r["rgb_map"]), 2)
+    out["psnr_delta_db"] = round(psnr_delta(g["rgb_map"], r["rgb_map"]), 4)
+    out["psnr_delta_db_excluding_attributed"] = round(psnr_delta(g["rgb_map"], r["rgb_map"], ~(flagged & ~un)), 4)
+    return out
+
+
+_TRAIL = {"rgb_map": 1, "acc_map": 0, "disp_map": 0, "rgb0": 1, "acc0": 0, "raw0": 2, "raw": 2, "weights0": 1,
+          "inds": 1, "z_samples": 1, "z_fine": 1}
+
+
+def _trail(k):
+    return _TRAIL[k]
+
+
+def passes(c):
+    """The end-to-end acceptance rule the tests enforce: every ray is within `tol` on rgb and acc, or is
+    attributed to one of the reference's own discontinuities; disp within TOL_DISP_REL on the rest."""
+    return c["unattributed"] == 0 and c.get("coarse_unattributed", 0) == 0 and \
+        c.get("max_rel_disp_unflagged", 0.0) <= TOL_DISP_REL and c.get("disp_nan_pattern_equal", True)

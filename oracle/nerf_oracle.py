@@ -347,7 +347,7 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
     far = np.broadcast_to(np.asarray(far, f32), (N,))
     z = coarse_z(near, far, n_samples, lindisp)
     pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32))
-    raw = run_network(sd_coarse, pts, viewdirs)
+    raw = raw0 = run_network(sd_coarse, pts, viewdirs)
     rgb_map, disp_map, acc_map, weights, _ = raw2outputs(raw, z, rays_d, white_bkgd)
     ret = {}
     if n_importance > 0:
@@ -361,7 +361,9 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
         ret["z_std"] = np.std(z_samples.astype(f64), -1).astype(f32)   # RN:495 (unbiased=False)
         if extras:
             ret.update(z_samples=z_samples, inds=inds, cdf=cdf, z_fine=z_fine, weights0=weights,
-                       weights=weights_f, raw=raw)
+                       weights=weights_f, raw=raw, raw0=raw0)
+    elif extras:
+        ret.update(raw0=raw0, weights0=weights)
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)
     return ret
 
