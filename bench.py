@@ -61,6 +61,7 @@ B3_ISSUED_FLOP_PER_POINT = 2 * 6 * (256 * 64 + 4 * 256 * 256 + 256 * (64 + 256) 
 # ... and per transposed evaluation (4-block zero-padded encoding GEMMs + 8-block GEMMs, csrc/nsr_b3.inc)
 B3_ISSUED_FLOP_PER_POINT_BWD = 2 * 6 * ((128 + 256) * 128 + 256 * 256 + 2 * 256 * 256 + (128 + 256) * 256 + 4 * 256 * 256 + 128 * 256)
 METRIC = "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP"
+MLP_MODES = ("fp32", "bf16x3")             # layer-GEMM arithmetics of the forward kernels (engine.NsrModel(mlp=...))
 
 
 def forward_kernel_name(model):
@@ -159,61 +160,74 @@ def _fastest_cpu_setting(O, run):
     return best
 
 
-def cpu_baseline_and_parity(model, sd_c, sd_f, c2w):
-    """Oracle on a bounded sample (one smaller view, 64+128) -- the checker, timed; never the thing shipped."""
+def cpu_baseline_and_parity(model, sd_c, sd_f, c2w, side=400):
+    """The oracle -- the checker, timed; never the thing shipped -- on ONE view of the metric's own configuration
+    (400x400, 64+128: SURVEY.md 8d; ~2-3 min of CPU time on the GPU boxes' hosts; `--cpu-sample-side` shrinks the view).
+    Its render, kept with the intermediates the census reads, is what every `parity` object of the line is computed
+    against."""
     O = _oracle()
-    run = lambda side: O.render(sd_c, sd_f, side, side, S.scaled_K(400.0 / side), c2w=c2w[:3, :4], near=S.YCBV_NEAR,
-                                far=S.YCBV_FAR, chunk=4096)
+    run = lambda sd, extras=False: O.render(sd_c, sd_f, sd, sd, S.scaled_K(400.0 / sd), c2w=c2w[:3, :4], near=S.YCBV_NEAR,
+                                            far=S.YCBV_FAR, chunk=4096, extras=extras)
     ncpu = os.cpu_count() or 1
     t32, backend, threads = _fastest_cpu_setting(O, run)
     O.set_backend(backend)
     if threads:
         torch.set_num_threads(threads)
     n_threads = threads if threads else min(ncpu, 64)        # scipy-openblas is built with MAX_THREADS=64
-    side = int(min(160, max(48, 16 * round(32 * (15.0 / t32) ** 0.5 / 16))))      # aim at ~15 s of CPU work
     t0 = time.perf_counter()
-    ref = run(side)
+    ref = run(side, True)
     dt = time.perf_counter() - t0
     O.set_backend("numpy")
+    ref = {k: v.reshape((side * side,) + v.shape[2:]) for k, v in ref.items() if k not in ("raw", "weights", "cdf")}
+    ref["sigma0_last"] = ref.pop("raw0")[:, -1, 3].copy()
     cpu = {"value": round(side * side * SAMPLES_PER_RAY / dt / 1e6, 5), "unit": "Mray-samples/s", "cores": n_threads,
            "kind": "port", "cpu_model": cpu_model(), "host_logical_cpus": ncpu,
-           "sample": "one %dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
+           "sample": "one %s%dx%d view (%d rays x (64+128) samples, same scene, camera and networks), "
            "oracle/nerf_oracle.py, fastest of {torch-CPU ops x thread counts, numpy+OpenBLAS} on this host: %s backend, "
-           "%d threads; %.1f s" % (side, side, side * side, backend, n_threads, dt)}
-    sample = {"ref": ref, "side": side, "c2w": c2w}
+           "%d threads; %.1f s" % ("full " if side == H else "", side, side, side * side, backend, n_threads, dt)}
+    sample = {"ref": ref, "side": side, "c2w": c2w, "nets": (sd_c, sd_f)}
     return cpu, parity_vs_oracle(model, sample), (backend, threads), sample
 
 
 def parity_vs_oracle(model, sample):
-    """`parity` object: `model` on the CPU sample of cpu_baseline_and_parity against the oracle's output of it."""
+    """`parity` object: `model` on the view of cpu_baseline_and_parity against the oracle's render of it, end to end.
+    `census` (oracle/census.py) counts the rays beyond 1e-4 on rgb / acc and proves for each that it sits on one of the
+    reference's own discontinuities (sigma_last cliff, resampling index, denominator switch) or in its 1/denom
+    conditioning; `unattributed` must be 0.  PSNR-delta is SURVEY.md 8d's, on the whole view, cliffs included."""
     O = _oracle()
+    import census as C
     ref, side, c2w = sample["ref"], sample["side"], sample["c2w"]
-    got = model.render_views(c2w, side, side, S.scaled_K(400.0 / side), S.YCBV_NEAR, S.YCBV_FAR, debug=True)
-    rgb = got["rgb_map"].cpu().numpy().reshape(side, side, 3)
-    rgb0 = got["rgb0"].cpu().numpy().reshape(side, side, 3)
-    # resampling indices (the bit-exact quantity, SURVEY 8d): the oracle's sample_pdf on the kernel's own coarse weights
+    K = S.scaled_K(400.0 / side)
+    got = model.render_views(c2w, side, side, K, S.YCBV_NEAR, S.YCBV_FAR, debug=True)
+    taps = {k: got[k].cpu().numpy() for k in ("rgb_map", "acc_map", "disp_map", "rgb0", "acc0", "raw0", "weights0", "inds",
+                                              "z_samples", "z_fine", "raw", "z_std")}
+    del got
     n = side * side
+    # resampling indices (the bit-exact quantity, SURVEY 8d): the oracle's sample_pdf on the kernel's own coarse weights
     z = O.coarse_z(np.full(n, S.YCBV_NEAR, np.float32), np.full(n, S.YCBV_FAR, np.float32))
-    zs, inds, _ = O.sample_pdf((np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32),
-                               got["weights0"].cpu().numpy()[:, 1:-1])
-    inds_match = float((got["inds"].cpu().numpy() == inds).mean())
-    zs_match = float((got["z_samples"].cpu().numpy() == zs).mean())
+    zs, inds, _ = O.sample_pdf((np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32), taps["weights0"][:, 1:-1])
+    inds_match = float((taps["inds"] == inds).mean())
+    zs_match = float((taps["z_samples"] == zs).mean())
+    ro, rd = O.get_rays(side, side, K, c2w[:3, :4])
+    c = C.census(sample["nets"], ro.reshape(-1, 3), rd.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, taps, ref)
 
-    def maxabs(key, shape):
-        a, b = got[key].cpu().numpy().reshape(shape), ref[key].reshape(shape)
+    def maxabs(key):
         with np.errstate(invalid="ignore"):
-            return float(np.nanmax(np.abs(a - b)))
-    # PSNR delta against a pseudo ground truth T = oracle + N(0, 0.01^2) (SURVEY.md 8d)
-    T = ref["rgb_map"] + np.random.RandomState(0).normal(0, 0.01, ref["rgb_map"].shape).astype(np.float32)
-    return {"psnr_vs_oracle_db": round(O.psnr(rgb, ref["rgb_map"]), 2),
-            "psnr_delta_db": round(abs(O.psnr(rgb, T) - O.psnr(ref["rgb_map"], T)), 4),
-            "max_abs_rgb_coarse": float(np.abs(rgb0 - ref["rgb0"]).max()),
-            "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
-            "max_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).max()),
-            "max_abs_acc": maxabs("acc_map", (side, side)), "max_abs_disp": maxabs("disp_map", (side, side)),
-            "max_abs_z_std": maxabs("z_std", (side, side)),
+            return float(np.nanmax(np.abs(taps[key] - ref[key])))
+    rgb = taps["rgb_map"]
+    return {"psnr_vs_oracle_db": c["psnr_vs_oracle_db"], "psnr_delta_db": c["psnr_delta_db"],
+            "psnr_delta_db_excluding_attributed_rays": c["psnr_delta_db_excluding_attributed"],
+            "max_abs_rgb_coarse": maxabs("rgb0"), "mean_abs_rgb": float(np.abs(rgb - ref["rgb_map"]).mean()),
+            "max_abs_rgb": maxabs("rgb_map"), "max_abs_acc": maxabs("acc_map"), "max_abs_disp": maxabs("disp_map"),
+            "max_abs_z_std": maxabs("z_std"),
             "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
-            "sample": "%dx%d view; indices/samples: oracle sample_pdf on the kernel's own coarse weights" % (side, side)}
+            "census": {k: c[k] for k in ("rays", "tol", "rays_above_tol", "cliff_rays", "fine_cliff_rays", "coarse_cliff_rays",
+                                         "index_flip_rays", "denom_switch_rays", "illconditioned_shift_rays", "unattributed",
+                                         "coarse_rays_above_tol", "coarse_unattributed", "max_rel_disp_unflagged",
+                                         "inds_equal_rate_end_to_end")},
+            "passes": bool(C.passes(c)),
+            "sample": "%dx%d view, end to end against the oracle's render of the same rays; inds/z_samples_exact_match_rate: "
+                      "the oracle's sample_pdf on the kernel's own coarse weights (the bit-exact stage)" % (side, side)}
 
 
 def config1_workload(sd_c, c2w, device, cpu_setting):
@@ -260,7 +274,23 @@ def config1_workload(sd_c, c2w, device, cpu_setting):
         cpu.update(kind="port", cores=threads if threads else min(os.cpu_count() or 1, 64), backend=backend,
                    cpu_model=cpu_model())
         out["cpu_baseline"] = cpu
-        out["max_abs_rgb_vs_oracle"] = float(np.abs(got["rgb_map"].cpu().numpy().reshape(side, side, 3) - ref["rgb_map"]).max())
+        # end to end against the oracle, per forward kernel: a coarse-only render has one discontinuity, the sigma_last
+        # cliff (RN:358-359); every ray beyond 1e-4 must be one (oracle/census.py)
+        import census as C
+        ro, rd = O.get_rays(side, side, K, c2w[:3, :4])
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        ref1 = O.render_rays(sd_c, None, ro, rd, O.normalize_dirs(rd), S.YCBV_NEAR, S.YCBV_FAR, n_importance=0, extras=True)
+        out["parity"] = {}
+        for mlp in MLP_MODES:
+            mk = NsrModel(sd_c, None, device=device, n_importance=0, mlp=mlp)
+            g1 = mk.render_views(pose, side, side, K, S.YCBV_NEAR, S.YCBV_FAR, debug=True)
+            c = C.census((sd_c, None), ro, rd, S.YCBV_NEAR, S.YCBV_FAR,
+                         {k: g1[k].cpu().numpy() for k in ("rgb_map", "acc_map", "disp_map", "raw0")}, ref1, coarse_only=True)
+            out["parity"][mlp] = {k: c[k] for k in ("rays", "tol", "rays_above_tol", "cliff_rays", "unattributed", "max_abs_rgb",
+                                                    "max_abs_acc", "psnr_vs_oracle_db", "psnr_delta_db",
+                                                    "psnr_delta_db_excluding_attributed")}
+            out["parity"][mlp]["passes"] = bool(C.passes(c))
+            mk.close()
     m1.close()
     return out
 
@@ -400,8 +430,9 @@ def main():
     ap.add_argument("--workload", choices=("view400", "sweep100", "models21"), default="view400")
     ap.add_argument("--views", type=int, default=100, help="sweep100: number of views in the sweep (config 3 uses 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-full-view", action="store_true",
-                    help="also time the oracle on ONE full 400x400 64+128 view (SURVEY.md 8d; minutes of CPU time)")
+    ap.add_argument("--cpu-sample-side", type=int, default=400,
+                    help="side of the view the oracle renders for cpu_baseline and parity (default: the metric's own "
+                         "400x400 view, ~2-3 min of CPU time; e.g. 128 for a quick run)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline_vjp and the config-1 workload")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="nccl = RCCL over xGMI (the measured configuration); gloo stages collectives through the host")
@@ -524,21 +555,10 @@ def main():
             })
             cpu_setting, cpu_sample = None, None
             if world == 1 and not args.no_cpu_baseline:
-                cpu, par, cpu_setting, cpu_sample = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup])
+                cpu, par, cpu_setting, cpu_sample = cpu_baseline_and_parity(model, sd_c, sd_f, poses[args.warmup],
+                                                                            side=args.cpu_sample_side)
                 line["cpu_baseline"] = cpu
                 line["parity"] = par
-            if world == 1 and args.cpu_full_view and cpu_setting is not None:
-                O = _oracle()
-                O.set_backend(cpu_setting[0])
-                if cpu_setting[1]:
-                    torch.set_num_threads(cpu_setting[1])
-                t0c = time.perf_counter()
-                O.render(sd_c, sd_f, H, W, S.YCBV_K, c2w=poses[args.warmup][:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=4096)
-                dtc = time.perf_counter() - t0c
-                O.set_backend("numpy")
-                line["cpu_baseline"]["full_view"] = {"value": round(H * W * SAMPLES_PER_RAY / dtc / 1e6, 5),
-                                                     "unit": "Mray-samples/s", "seconds": round(dtc, 1),
-                                                     "sample": "one full 400x400 view, 64+128 samples"}
             if world == 1 and not args.no_extras:
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),

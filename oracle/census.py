@@ -45,10 +45,10 @@ def alpha_last(sigma_last, rays_d):
         return (f32(1) - np.exp((-np.maximum(sigma_last.astype(f32), f32(0)) * d).astype(f32))).astype(f32)
 
 
-def _pdf_terms(z_coarse, w0):
+def _pdf_terms(z_coarse, w0_inner):
     """cdf and, per importance sample, (index, denominator as computed, switched flag) -- RH:199-240 via the oracle."""
     z_mid = (f32(0.5) * (z_coarse[:, 1:] + z_coarse[:, :-1])).astype(f32)
-    zs, inds, cdf = O.sample_pdf(z_mid, w0[:, 1:-1])
+    zs, inds, cdf = O.sample_pdf(z_mid, w0_inner)
     below = np.maximum(inds - 1, 0)
     above = np.minimum(inds, cdf.shape[-1] - 1)
     den = (np.take_along_axis(cdf, above, -1) - np.take_along_axis(cdf, below, -1)).astype(f32)
@@ -72,7 +72,8 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
     """nets = (sd_coarse, sd_fine); rays [N,3]; got: the render's outputs as numpy arrays [N, ...] -- rgb_map, acc_map,
     disp_map, raw0 [N,64,4] and, unless coarse_only, weights0, inds, z_samples, z_fine, raw [N,192,4], rgb0, acc0;
     ref: the oracle's render of the same rays with extras (O.render_rays(..., extras=True): rgb_map, acc_map, disp_map,
-    raw0, weights0, inds, z_samples, z_fine, raw_sigma_last or raw, rgb0, acc0).
+    raw0 (or sigma0_last [N]), weights0 (or pdf_weights [N,62] = weights0[:, 1:-1]), inds, z_samples, z_fine, rgb0,
+    acc0) -- or the same quantities captured from the reference itself (tests/golden/g13_census.npz).
     Returns a JSON-able dict of counts; `unattributed` must be 0 for the render to pass."""
     sd_c, sd_f = nets
     rays_o = np.ascontiguousarray(rays_o, f32).reshape(-1, 3)
@@ -84,6 +85,11 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
          if v is not None and k in _TRAIL}
     vd = O.normalize_dirs(rays_d)
     zc = O.coarse_z(np.full(n, near, f32), np.full(n, far, f32), lindisp=lindisp)
+    for d in (g, r):
+        if "inds" in d:
+            d["inds"] = d["inds"].astype(np.int64)
+        if "z_fine" not in d and "z_samples" in d:
+            d["z_fine"] = np.sort(np.concatenate([zc, d["z_samples"]], -1), -1)          # RN:477
 
     d_rgb = np.abs(g["rgb_map"] - r["rgb_map"]).max(-1)
     d_acc = np.abs(g["acc_map"] - r["acc_map"])
@@ -95,8 +101,8 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
 
     # the coarse image has its own cliff (it is an output too: rgb0 / acc0, or the image itself when coarse_only)
     ck = ("rgb_map", "acc_map") if coarse_only else ("rgb0", "acc0")
-    a0_g = alpha_last(g["raw0"][:, -1, 3], rays_d)
-    a0_r = alpha_last(r["raw0"][:, -1, 3], rays_d)
+    a0_g = alpha_last(_sigma0_last(g), rays_d)
+    a0_r = alpha_last(_sigma0_last(r), rays_d)
     coarse_cliff = np.abs(a0_g - a0_r) > 1e-3
     d0 = np.maximum(np.abs(g[ck[0]] - r[ck[0]]).max(-1), np.abs(g[ck[1]] - r[ck[1]]))
     flagged0 = d0 > tol
@@ -107,7 +113,7 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
     if idx0.size:
         # counterfactual: the render's own coarse raw with the oracle's sigma_last must give the oracle's coarse pixel
         raw_cf = g["raw0"][idx0].copy()
-        raw_cf[:, -1, 3] = r["raw0"][idx0, -1, 3]
+        raw_cf[:, -1, 3] = _sigma0_last(r)[idx0]
         rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zc[idx0], rays_d[idx0], white_bkgd)
         ok = coarse_cliff[idx0] & (np.abs(rgb_cf - r[ck[0]][idx0]).max(-1) <= tol_stage) & \
             (np.abs(acc_cf - r[ck[1]][idx0]) <= tol_stage)
@@ -142,8 +148,8 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
             (np.abs(own[0] - g["rgb_map"][idx]).max(-1) <= tol_stage) & (np.abs(own[2] - g["acc_map"][idx]) <= tol_stage)
         # P2: why the depths moved
         moved = (zf_g != zf_r).any(-1)
-        zs_g, inds_g, cdf_g, den_g, binw = _pdf_terms(zc[idx], g["weights0"][idx])
-        zs_r, inds_r, cdf_r, den_r, _ = _pdf_terms(zc[idx], r["weights0"][idx])
+        zs_g, inds_g, cdf_g, den_g, binw = _pdf_terms(zc[idx], _w0_inner(g)[idx])
+        zs_r, inds_r, cdf_r, den_r, _ = _pdf_terms(zc[idx], _w0_inner(r)[idx])
         consistent = (inds_g == g["inds"][idx]).all(-1) & (zs_g == g["z_samples"][idx]).all(-1) & \
             (inds_r == r["inds"][idx]).all(-1) & (zs_r == r["z_samples"][idx]).all(-1)   # the bit-exact stage, again
         flip = (inds_g != inds_r).any(-1)
@@ -189,7 +195,16 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
 
 
 _TRAIL = {"rgb_map": 1, "acc_map": 0, "disp_map": 0, "rgb0": 1, "acc0": 0, "raw0": 2, "raw": 2, "weights0": 1,
-          "inds": 1, "z_samples": 1, "z_fine": 1}
+          "inds": 1, "z_samples": 1, "z_fine": 1, "sigma0_last": 0, "pdf_weights": 1}
+
+
+def _sigma0_last(d):
+    return d["raw0"][:, -1, 3] if "raw0" in d else d["sigma0_last"]
+
+
+def _w0_inner(d):
+    """coarse weights[..., 1:-1], what sample_pdf is given (RN:474)"""
+    return d["weights0"][:, 1:-1] if "weights0" in d else d["pdf_weights"]
 
 
 def _trail(k):

@@ -112,6 +112,23 @@ def main():
     SEED = 7
     nets, kwargs, embed_fn, embeddirs_fn = build_nets(RN, RH, SEED)
 
+    # the census (oracle/census.py) needs the sigma of the LAST sample of both passes (the 1e10 interval, RN:358-359):
+    # raw2outputs is wrapped to note the raw outputs it is given (coarse call, then fine call, per chunk)
+    sig_last = []
+    orig_r2o = RN.raw2outputs
+
+    def r2o(raw, *a, **k):
+        sig_last.append(raw[..., -1, 3].detach().numpy().copy())
+        return orig_r2o(raw, *a, **k)
+    RN.raw2outputs = r2o
+
+    def take_sig(fine=True):
+        """(coarse, fine) sigma_last of the render calls since the last take, concatenated over chunks"""
+        c = np.concatenate(sig_last[0::2] if fine else sig_last)
+        f = np.concatenate(sig_last[1::2]) if fine else None
+        del sig_last[:]
+        return c, f
+
     # ---- G9 poses (LL:89-94) ----------------------------------------------------------------
     angles = np.array([[90.0, 30.0 - 180.0], [85.5, 200.0 - 180.0], [94.2, 311.0 - 180.0], [88.0, -170.0]])
     poses = np.stack([LL.pose_spherical_nograd(t, p, 1.01).numpy() for t, p in angles])
@@ -197,12 +214,14 @@ def main():
     sel = rng.choice(160000, size=192, replace=False)
     ro = o32.reshape(-1, 3)[sel]
     rd = d32.reshape(-1, 3)[sel]
+    del sig_last[:]
     with Capture(RN, RH) as cap:
         with torch.no_grad():
             rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=64, rays=torch.stack([ro, rd], 0),
                                            retraw=True, **kwargs)
     cat = lambda k: np.concatenate([c[k] for c in cap.log], 0)
-    save("g6_render_rays", seed=np.int64(SEED), rays_o=ro.numpy(), rays_d=rd.numpy(),
+    s0_6, s1_6 = take_sig()
+    save("g6_render_rays", sigma0_last=s0_6, sigma_last=s1_6, seed=np.int64(SEED), rays_o=ro.numpy(), rays_d=rd.numpy(),
          near=np.float64(O.YCBV_NEAR), far=np.float64(O.YCBV_FAR),
          rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(), raw=ex["raw"].numpy(),
          rgb0=ex["rgb0"].numpy(), disp0=ex["disp0"].numpy(), acc0=ex["acc0"].numpy(), z_std=ex["z_std"].numpy(),
@@ -261,11 +280,13 @@ def main():
     sel = rng.choice(160000, size=160, replace=False)
     ro11 = o32.reshape(-1, 3)[sel]
     rd11 = d32.reshape(-1, 3)[sel]
+    del sig_last[:]
     with Capture(RN, RH) as cap:
         with torch.no_grad():
             rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=160, rays=torch.stack([ro11, rd11], 0),
                                            retraw=True, **kw11)
-    fwd11 = dict(rays_o=ro11.numpy(), rays_d=rd11.numpy(), rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(),
+    s0_11, s1_11 = take_sig()
+    fwd11 = dict(sigma0_last=s0_11, sigma_last=s1_11, pdf_weights=cap.log[0]["weights"], rays_o=ro11.numpy(), rays_d=rd11.numpy(), rgb=rgb.numpy(), disp=disp.numpy(), acc=acc.numpy(),
                  rgb0=ex["rgb0"].numpy(), disp0=ex["disp0"].numpy(), acc0=ex["acc0"].numpy(),
                  z_std=ex["z_std"].numpy(), raw=ex["raw"].numpy(), inds=cap.log[0]["inds"],
                  z_samples=cap.log[0]["samples"])
@@ -276,6 +297,28 @@ def main():
     (g,) = torch.autograd.grad(rgb_p, rays, grad_outputs=cot)
     save("g11_options", seed=np.int64(SEED), cot=cot.numpy(), vjp_rgb=rgb_p.detach().numpy(), grad_rays=g.numpy(),
          vjp_z_samples=cap.log[0]["samples"], **fwd11)
+
+    # ---- G13 what the cliff / flip census (oracle/census.py) needs from the reference itself: a config-2-shaped view
+    # (40x40, 64+128, the reference's chunk 512, CF:25) with the coarse weights its sample_pdf saw, its indices and
+    # samples, and the sigma of the LAST sample of both passes (the 1e10 interval of RN:358-359); and the same sigma
+    # for the config-1 view of g7 (64x64, coarse only).
+    del sig_last[:]
+    K40 = O.scaled_K(10.0)
+    with Capture(RN, RH) as cap:
+        with torch.no_grad():
+            rgb, disp, acc, ex = RN.render(40, 40, K40, chunk=512, c2w=torch.from_numpy(poses[1])[:3, :4], **kwargs)
+    catc = lambda k: np.concatenate([c[k] for c in cap.log], 0)
+    s0, s1 = take_sig()
+    g13 = dict(seed=np.int64(SEED), c2w=poses[1], K40=np.array(K40), rgb=rgb.numpy().reshape(-1, 3),
+               disp=disp.numpy().ravel(), acc=acc.numpy().ravel(), rgb0=ex["rgb0"].numpy().reshape(-1, 3),
+               disp0=ex["disp0"].numpy().ravel(), acc0=ex["acc0"].numpy().ravel(), z_std=ex["z_std"].numpy().ravel(),
+               pdf_weights=catc("weights"), inds=catc("inds").astype(np.int8), z_samples=catc("samples"),
+               sigma0_last=s0, sigma_last=s1)
+    with torch.no_grad():
+        rgb, disp, acc, _ = RN.render(64, 64, K64, chunk=512, c2w=c2w[:3, :4], **kw0)
+    assert np.array_equal(rgb.numpy(), g7["rgb_c1"])             # the very render g7 holds
+    g13.update(c1_sigma0_last=take_sig(fine=False)[0])
+    save("g13_census", **g13)
 
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())

@@ -48,3 +48,13 @@ def assert_close(a, b, atol=0.0, rtol=0.0, what=""):
         ok = both_nan | (err <= atol + rtol * np.abs(b.astype(np.float64)))
     assert ok.all(), "%s: %d/%d out of tolerance, max abs err %.3e" % (
         what, (~ok).sum(), ok.size, np.nanmax(np.where(both_nan, 0, err)))
+
+
+def census_ref(g):
+    """The reference's own end-to-end quantities held by a golden file (g6 / g11 / g13) in the form oracle/census.py
+    takes as `ref`: pixels, the sigma of the last coarse sample, the coarse weights its sample_pdf saw, its indices and
+    samples -- every one produced by running the reference (oracle/gen_golden.py)."""
+    flat = lambda a, t: np.asarray(a).reshape((-1,) + np.asarray(a).shape[np.asarray(a).ndim - t:])
+    return dict(rgb_map=flat(g["rgb"], 1), acc_map=flat(g["acc"], 0), disp_map=flat(g["disp"], 0),
+                rgb0=flat(g["rgb0"], 1), acc0=flat(g["acc0"], 0), sigma0_last=g["sigma0_last"],
+                pdf_weights=g["pdf_weights"], inds=g["inds"], z_samples=g["z_samples"])

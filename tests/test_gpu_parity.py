@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import assert_close, load_golden
+from conftest import assert_close, census_ref, load_golden
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
@@ -179,6 +179,19 @@ def _stagewise(model, oracle, nets, r, rays_o, rays_d, near, far, white_bkgd=Fal
     assert_close(cpu(r["disp_map"]), disp, rtol=2e-5, what="disp | kernel raw")
 
 
+_TAPS = ("rgb_map", "acc_map", "disp_map", "rgb0", "acc0", "raw0", "weights0", "inds", "z_samples", "z_fine", "raw")
+
+
+def _census(nets, r, ro, rd, near, far, ref, **kw):
+    """End to end against `ref` (the reference's own outputs from a golden file, or the oracle's render): every ray beyond
+    1e-4 on rgb / acc must be attributed to one of the reference's own discontinuities by oracle/census.py -- the
+    end-to-end acceptance rule of BASELINE.md; returns the census."""
+    import census as C
+    c = C.census(nets, ro, rd, near, far, {k: cpu(r[k]) for k in _TAPS if k in r and r[k] is not None}, ref, **kw)
+    assert C.passes(c), c
+    return c
+
+
 def test_render_rays_stagewise_and_golden(model, oracle, synth_nets):
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
@@ -188,10 +201,8 @@ def test_render_rays_stagewise_and_golden(model, oracle, synth_nets):
     assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
     assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
     assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
-    assert (cpu(r["inds"]) == g["inds"]).mean() > 0.99
-    assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0
-    assert np.abs(cpu(r["rgb_map"]) - g["rgb"]).mean() < 2e-4
-    assert np.abs(cpu(r["acc_map"]) - g["acc"]).mean() < 2e-4
+    c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
+    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
 
 
 def test_render_rays_odd_and_single(model, oracle, synth_nets):
@@ -225,8 +236,8 @@ def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
     _stagewise(m, oracle, synth_nets, r, ro, rd, near, far, white_bkgd=True, lindisp=True)
     assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
     assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
-    assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0 and np.abs(cpu(r["rgb_map"]) - g["rgb"]).mean() < 3e-4
-    assert (cpu(r["inds"]) == g["inds"]).mean() > 0.99
+    c = _census(synth_nets, r, ro, rd, near, far, census_ref(g), white_bkgd=True, lindisp=True)
+    assert c["rays_above_tol"] <= 0.08 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
     # stage entry
     outs = m.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd)
     want = oracle.raw2outputs(cpu(r["raw"]), cpu(r["z_fine"]), rd, white_bkgd=True)
@@ -707,8 +718,8 @@ def test_x16_stagewise_and_golden(model16, oracle, synth_nets):
     r = model16.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
     _stagewise(model16, oracle, synth_nets, r, g["rays_o"], g["rays_d"], near, far)
     assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
-    assert (cpu(r["inds"]) == g["inds"]).mean() > 0.99
-    assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0
+    c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
+    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
 
 
 @pytest.fixture(scope="module")
@@ -729,10 +740,8 @@ def test_bf16x3_stagewise_and_golden(model_b3, model, oracle, synth_nets):
     assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
     assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
     assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
-    assert (cpu(r["inds"]) == g["inds"]).mean() > 0.99
-    assert oracle.psnr(cpu(r["rgb_map"]), g["rgb"]) > 55.0
-    assert np.abs(cpu(r["rgb_map"]) - g["rgb"]).mean() < 2e-4
-    assert np.abs(cpu(r["acc_map"]) - g["acc"]).mean() < 2e-4
+    c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
+    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
     # against the fp32-MFMA kernel on the same rays: network outputs agree to fp32 rounding, but are not the same bits
     r32 = model.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
     d = np.abs(cpu(r["raw0"]) - cpu(r32["raw0"]))
@@ -1051,21 +1060,79 @@ def test_calls_leave_the_current_device_alone(synth_nets):
     m.close()
 
 
-def test_x16_coarse_only_config1(oracle, synth_nets):
+KERNELS = {"x16-phases": dict(variant=16, schedule="phases"), "x16-queue": dict(variant=16, schedule="queue"),
+           "x32": dict(variant=32), "bf16x3": dict(mlp="bf16x3")}
+
+
+@pytest.mark.parametrize("kernel", list(KERNELS))
+def test_census_on_the_baseline_config_views_against_the_reference(oracle, synth_nets, kernel):
+    """BASELINE configs[0] (64x64, 64 coarse samples only: the view of g7) and the configs[1] shape (64+128) on the 40x40
+    view of g13, every forward kernel, END TO END against what the reference itself rendered: each ray beyond 1e-4 on
+    rgb / acc is proven to be one of the reference's own discontinuities (sigma_last cliff RN:358-359, searchsorted index
+    RH:227, denominator switch RH:238-239) or its 1/denom conditioning -- none is left unattributed (oracle/census.py).
+    The reference's OWN two CPU evaluations (torch GEMMs vs the oracle's numpy GEMMs) differ on 43 of these 1600 rays
+    (tests/test_oracle_golden.py), which is the yardstick for `rays_above_tol` here."""
     from neural_sim_nerf_amd.engine import NsrModel
-    g = load_golden("g7_render")
-    for kw in (dict(variant=16), dict(mlp="bf16x3")):
-        m1 = NsrModel(synth_nets[0], None, n_importance=0, **kw)
-        r = m1.render_views(g["c2w"], 64, 64, g["K64"].tolist(), oracle.YCBV_NEAR, oracle.YCBV_FAR, debug=True)
-        d_rgb = np.abs(cpu(r["rgb_map"]).reshape(64, 64, 3) - g["rgb_c1"]).max(-1).ravel()
-        d_acc = np.abs(cpu(r["acc_map"]) - g["acc_c1"].ravel())
-        bad = np.where((d_rgb > 1e-5) | (d_acc > 1e-5))[0]
-        # the reference's own cliff: the LAST sample's dist is 1e10 (RN:358), so |sigma| ~ 1e-6 there decides between
-        # alpha = 0 and alpha = 1; a ray may differ from the golden image only if it sits on that cliff
-        assert len(bad) <= 2, (kw, len(bad), d_rgb.max())
-        for b in bad:
-            assert abs(float(cpu(r["raw0"])[b, -1, 3])) < 1e-4, (kw, b, cpu(r["raw0"])[b, -1, 3])
-        m1.close()
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    g7, g13 = load_golden("g7_render"), load_golden("g13_census")
+    m1 = NsrModel(synth_nets[0], None, n_importance=0, **KERNELS[kernel])
+    r = m1.render_views(g7["c2w"], 64, 64, g7["K64"].tolist(), near, far, debug=True)
+    ro, rd = oracle.get_rays(64, 64, g7["K64"].tolist(), g7["c2w"][:3, :4])
+    ref = dict(rgb_map=g7["rgb_c1"].reshape(-1, 3), acc_map=g7["acc_c1"].ravel(), disp_map=g7["disp_c1"].ravel(),
+               sigma0_last=g13["c1_sigma0_last"])
+    c1 = _census((synth_nets[0], None), r, ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, ref, coarse_only=True)
+    assert c1["rays_above_tol"] == c1["cliff_rays"] <= 4 and c1["psnr_delta_db_excluding_attributed"] <= 1e-3, c1
+    assert_close(cpu(r["raw0"])[:, -1, 3], g13["c1_sigma0_last"], atol=5e-5, rtol=5e-5, what="config-1 sigma_last")
+    m1.close()
+    m = NsrModel(synth_nets[0], synth_nets[1], **KERNELS[kernel])
+    r = m.render_views(g13["c2w"], 40, 40, g13["K40"].tolist(), near, far, debug=True)
+    ro, rd = oracle.get_rays(40, 40, g13["K40"].tolist(), g13["c2w"][:3, :4])
+    c2 = _census(synth_nets, r, ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, census_ref(g13))
+    assert c2["rays_above_tol"] <= 0.05 * c2["rays"] and c2["psnr_delta_db_excluding_attributed"] <= 1e-3, c2
+    assert c2["psnr_delta_db"] <= 0.1, c2                       # north_star's budget, on the whole view, cliffs included
+    print("census %s: config1 %s | config2-shape %s" % (kernel, {k: c1[k] for k in ("rays_above_tol", "cliff_rays", "psnr_delta_db")},
+                                                        {k: c2[k] for k in ("rays_above_tol", "cliff_rays", "index_flip_rays", "denom_switch_rays",
+                                                                            "illconditioned_shift_rays", "psnr_delta_db")}))
+    m.close()
+
+
+@pytest.fixture(scope="module")
+def oracle_full_view(oracle, synth_nets):
+    """BASELINE configs[1] itself: ONE full 400x400 view, 64+128, through the oracle (minutes of CPU time; torch-CPU ops
+    on up to 32 threads, the setting bench.py finds fastest on the GPU boxes)."""
+    import torch
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    pose = np.asarray(oracle.sweep_poses(1, seed=11))[0]
+    ro, rd = oracle.get_rays(400, 400, oracle.YCBV_K, pose[:3, :4])
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    oracle.set_backend("torch")
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        ref = oracle.render(synth_nets[0], synth_nets[1], 400, 400, oracle.YCBV_K, rays=(ro, rd), near=near, far=far,
+                            chunk=8192, extras=True)
+    finally:
+        oracle.set_backend("numpy")
+        torch.set_num_threads(old)
+    ref = {k: v for k, v in ref.items() if k not in ("raw", "weights", "cdf")}        # 0.7 GB the census does not read
+    ref["sigma0_last"] = ref.pop("raw0")[:, -1, 3].copy()
+    return pose, ro, rd, ref
+
+
+@pytest.mark.parametrize("kernel", ["x16-phases", "bf16x3"])
+def test_census_full_size_view_against_the_oracle(oracle, synth_nets, oracle_full_view, kernel):
+    """BASELINE configs[1] at FULL size (400x400, 64+128), end to end against the oracle's render of the same 160 000
+    rays: every ray beyond 1e-4 attributed, PSNR-delta of the whole view inside north_star's 0.1 dB."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    pose, ro, rd, ref = oracle_full_view
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    m = NsrModel(synth_nets[0], synth_nets[1], **KERNELS[kernel])
+    r = m.render_views(pose, 400, 400, oracle.YCBV_K, near, far, debug=True)
+    c = _census(synth_nets, r, ro, rd, near, far, ref)
+    print("census %s full view:" % kernel, {k: v for k, v in c.items() if k not in ("worst",)})
+    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 1e-3, c
+    assert c["psnr_delta_db"] <= 0.1, c
+    m.close()
 
 
 # ------------------------------------------------------------------------------------------------------

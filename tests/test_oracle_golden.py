@@ -6,7 +6,7 @@ cdf, searchsorted indices, inverse-CDF samples); ~1 ulp-level tolerances downstr
 which numpy's libm and torch's Sleef round differently."""
 import numpy as np
 
-from conftest import assert_close
+from conftest import assert_close, census_ref
 
 
 def test_tables_exact(golden, oracle):
@@ -92,12 +92,10 @@ def test_render_rays_end_to_end(golden, oracle, synth_nets):
     assert_close(r["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
     assert_close(r["acc0"], g["acc0"], atol=1e-5, what="acc0")
     assert_close(r["disp0"], g["disp0"], rtol=1e-4, what="disp0")
-    assert (r["inds"] == g["inds"]).mean() > 0.99
-    assert_close(r["z_samples"], g["z_samples"], atol=3e-3, what="z_samples")
-    for k, kk in (("rgb_map", "rgb"), ("acc_map", "acc")):
-        assert_close(r[k], g[kk], atol=5e-3, what=k)
-        assert np.abs(r[k] - g[kk]).mean() < 1e-4
-    assert oracle.psnr(r["rgb_map"], g["rgb"]) > 60.0
+    import census as C
+    c = C.census(synth_nets, g["rays_o"], g["rays_d"], float(g["near"]), float(g["far"]), r, census_ref(g))
+    assert C.passes(c) and c["psnr_delta_db"] <= 0.01 and c["rays_above_tol"] <= 0.05 * c["rays"], c
+    assert_close(r["raw"][:, -1, 3], g["sigma_last"], atol=2e-3, rtol=1e-3, what="fine sigma_last (depths may have moved)")
 
 
 def test_render_options_white_bkgd_lindisp(golden, oracle, synth_nets):
@@ -111,10 +109,10 @@ def test_render_options_white_bkgd_lindisp(golden, oracle, synth_nets):
                            lindisp=True)
     assert_close(r["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
     assert_close(r["acc0"], g["acc0"], atol=1e-5, what="acc0")
-    assert (r["inds"] == g["inds"]).mean() > 0.99
-    assert_close(r["z_samples"], g["z_samples"], atol=3e-3, what="z_samples")
-    # (same ill-conditioning as in test_render_rays_end_to_end: 0.3 % of the indices flip and move a few rays)
-    assert np.abs(r["rgb_map"] - g["rgb"]).mean() < 3e-4 and oracle.psnr(r["rgb_map"], g["rgb"]) > 58.0
+    import census as C
+    c = C.census(synth_nets, g["rays_o"], g["rays_d"], near, far, r, census_ref(g), white_bkgd=True, lindisp=True)
+    # (160 scattered rays: one moved sample is visible in a PSNR over so few pixels, hence "excluding attributed")
+    assert C.passes(c) and c["psnr_delta_db_excluding_attributed"] <= 0.01 and c["rays_above_tol"] <= 0.08 * c["rays"], c
     assert_close(r["z_std"], g["z_std"], atol=2e-3, what="z_std")
     # the white background really is in there: rgb0 - (1 - acc0) is the plain composite, inside [0, 1]
     plain = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, lindisp=True)
@@ -148,3 +146,31 @@ def test_render_image(golden, oracle, synth_nets):
 def test_to8b_truncates(oracle):
     x = np.array([-0.2, 0.0, 0.5, 0.999, 1.0, 1.7], np.float32)
     assert oracle.to8b(x).tolist() == [0, 0, 127, 254, 255, 255]
+
+
+def test_oracle_end_to_end_census_against_the_reference(golden, oracle, synth_nets):
+    """End to end the oracle (numpy GEMMs) and the reference (torch GEMMs) differ by fp32 rounding in every network
+    output, so they can land on different sides of the reference's own discontinuities.  The census proves that this is
+    ALL that separates them: every ray of the 40x40 config-2-shaped view beyond 1e-4 is attributed (oracle/census.py);
+    the bound the loose asserts above only summarise.  Same for the config-1 view (coarse only) of g7."""
+    import census as C
+    g = golden("g13_census")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = oracle.get_rays(40, 40, g["K40"].tolist(), g["c2w"][:3, :4])
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    got = oracle.render_rays(synth_nets[0], synth_nets[1], ro, rd, oracle.normalize_dirs(rd), near, far, extras=True)
+    c = C.census(synth_nets, ro, rd, near, far, got, census_ref(g))
+    assert C.passes(c), c
+    # (measured: 43 of 1600 rays beyond 1e-4 -- 29 index flips that are also denominator switches, 14 shifts inside
+    # almost-empty bins -- from coarse weights that differ by 1.8e-7: that is the conditioning of the reference's own
+    # path, and it is why "1e-4 on every ray" cannot be the end-to-end bar for ANY second implementation)
+    assert c["psnr_delta_db"] <= 0.01 and c["rays_above_tol"] <= 0.05 * c["rays"], c
+    g7 = golden("g7_render")
+    ro, rd = oracle.get_rays(64, 64, g7["K64"].tolist(), g7["c2w"][:3, :4])
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    got = oracle.render_rays(synth_nets[0], None, ro, rd, oracle.normalize_dirs(rd), near, far, n_importance=0, extras=True)
+    ref = dict(rgb_map=g7["rgb_c1"].reshape(-1, 3), acc_map=g7["acc_c1"].ravel(), disp_map=g7["disp_c1"].ravel(),
+               sigma0_last=g["c1_sigma0_last"])
+    c1 = C.census((synth_nets[0], None), ro, rd, near, far, got, ref, coarse_only=True)
+    assert C.passes(c1), c1
+    assert_close(got["raw0"][:, -1, 3], g["c1_sigma0_last"], atol=2e-5, rtol=1e-5, what="config-1 sigma_last")
