@@ -61,12 +61,19 @@ B3_ISSUED_FLOP_PER_POINT = 2 * 6 * (256 * 64 + 4 * 256 * 256 + 256 * (64 + 256) 
 # ... and per transposed evaluation (4-block zero-padded encoding GEMMs + 8-block GEMMs, csrc/nsr_b3.inc)
 B3_ISSUED_FLOP_PER_POINT_BWD = 2 * 6 * ((128 + 256) * 128 + 256 * 256 + 2 * 256 * 256 + (128 + 256) * 256 + 4 * 256 * 256 + 128 * 256)
 METRIC = "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP"
-MLP_MODES = ("fp32", "bf16x3")             # layer-GEMM arithmetics of the forward kernels (engine.NsrModel(mlp=...))
+MLP_MODES = ("fp32", "bf16x3", "f16x2")    # layer-GEMM arithmetics of the forward kernels (engine.NsrModel(mlp=...))
+# f16x2 (NSR_FLAG_MLP_F16X2): 3 piece products x the k16-padded layer shapes (csrc/nsr_h2.inc); fp16 MFMA peak = bf16's
+H2_ISSUED_FLOP_PER_POINT = 2 * 3 * (256 * 64 + 4 * 256 * 256 + 256 * (64 + 256) + 2 * 256 * 256 + 256 * 256 + 128 * 288)
+MLP_DTYPE = {"bf16x3": "bf16x3: fp32 operands as three bf16 pieces each, six piece products per fp32 product, fp32 accumulate",
+             "f16x2": "f16x2: fp32 operands as two fp16 pieces each (power-of-two range management), three piece products per "
+                      "fp32 product, fp32 accumulate"}
 
 
 def forward_kernel_name(model):
     if model.mlp == "bf16x3":
         return "nsr::k_render_b3"
+    if model.mlp == "f16x2":
+        return "nsr::k_render_h2"
     if model.variant == 32:
         return "nsr::k_render"
     return "nsr::k_render16p" if model.schedule == "phases" else "nsr::k_render16"
@@ -77,25 +84,29 @@ def forward_roofline(model, k_ms, n_rays=H * W):
     ach = n_rays * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12
     r = {"bound": "mfma", "achieved": round(ach, 2), "unit": "TFLOP/s", "kernel": forward_kernel_name(model),
          "kernel_ms": round(k_ms, 3), "flop_per_launch": n_rays * FLOP_PER_RAY}
-    if model.mlp == "bf16x3":
-        issued = n_rays * EVALS_PER_RAY * B3_ISSUED_FLOP_PER_POINT / (k_ms * 1e-3) / 1e12
+    if model.mlp in ("bf16x3", "f16x2"):
+        per_point, n_prod, dt = ((B3_ISSUED_FLOP_PER_POINT, "six", "bf16") if model.mlp == "bf16x3" else
+                                 (H2_ISSUED_FLOP_PER_POINT, "three", "fp16"))
+        issued = n_rays * EVALS_PER_RAY * per_point / (k_ms * 1e-3) / 1e12
         r.update({"peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                   "issued": round(issued, 1), "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
                   "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
-                  "note": "`achieved` counts ALGORITHMIC fp32 FLOP (as for the fp32 kernels); the datatype issued is bf16 "
-                          "(peak 2.5 PFLOP/s dense): every fp32 product costs six bf16 piece products, so the kernel "
-                          "issues `issued` TFLOP/s of bf16 MFMA work = `issued_frac` of that peak, and delivers "
-                          "`achieved_over_fp32_mfma_peak` x what the fp32 MFMA pipe could at 100 %"})
+                  "note": "`achieved` counts ALGORITHMIC fp32 FLOP (as for the fp32 kernels); the datatype issued is %s "
+                          "(peak 2.5 PFLOP/s dense): every fp32 product costs %s %s piece products, so the kernel "
+                          "issues `issued` TFLOP/s of %s MFMA work = `issued_frac` of that peak, and delivers "
+                          "`achieved_over_fp32_mfma_peak` x what the fp32 MFMA pipe could at 100 %%" % (dt, n_prod, dt, dt)})
     else:
         r.update({"peak": PEAK_F32_MFMA_TFLOPS, "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4)})
     return r
 
 
-def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3, sample=None):
-    """extra_workloads.bf16x3: the SAME 400x400 view through the forward kernel with NSR_FLAG_MLP_BF16X3 (k_render_b3:
-    layer GEMMs on bf16 MFMAs, fp32 operands split exactly into three bf16 pieces, fp32 accumulate), timed like the
-    main line (HIP events per launch + wall clock), and compared with the fp32-MFMA kernel's image `ref` of that view."""
-    m = NsrModel(sd_c, sd_f, device=device, mlp="bf16x3")
+def alt_mlp_workload(mlp, sd_c, sd_f, device, c2w, ref, launches=3, sample=None):
+    """extra_workloads.<mlp>: the SAME 400x400 view through a forward kernel with another layer-GEMM arithmetic --
+    "bf16x3" (k_render_b3: bf16 MFMAs, fp32 operands split exactly into three bf16 pieces), "f16x2" (k_render_h2: fp16
+    MFMAs, two fp16 pieces, power-of-two range management) or "fp32" (k_render16p, when the main line is one of the
+    others) -- timed like the main line (HIP events per launch + wall clock), compared with the main line's image `ref`
+    of that view, and with the same `parity` object against the same oracle render."""
+    m = NsrModel(sd_c, sd_f, device=device, mlp=mlp)
     pose = torch.as_tensor(c2w[:3, :4], device=m.device)
     out = m.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)            # warm-up
     torch.cuda.synchronize()
@@ -111,15 +122,16 @@ def bf16x3_workload(sd_c, sd_f, device, c2w, ref, launches=3, sample=None):
     mse = float(((out["rgb_map"] - ref["rgb_map"]).double() ** 2).mean())
     res = {"value": round(launches * H * W * SAMPLES_PER_RAY / dt / 1e6, 3), "unit": "Mray-samples/s",
            "ms_per_view": round(dt / launches * 1e3, 3), "launches": launches,
-           "dtype": "bf16x3: fp32 operands as three bf16 pieces each, six piece products per fp32 product, fp32 accumulate",
+           "dtype": MLP_DTYPE.get(mlp, "f32"),
            "roofline": forward_roofline(m, k_ms),
-           "roofline_vjp": vjp_roofline(m, c2w),
-           "vs_fp32_mfma_kernel_same_view": {
+           "vs_main_line_kernel_same_view": {
                "psnr_db": round(-10.0 * np.log10(mse), 2) if mse > 0 else None,
                "rgb_max_abs": float(d["rgb_map"].max()), "acc_max_abs": float(d["acc_map"].max()),
                "rgb0_max_abs": float(d["rgb0"].max()),
                "rays_with_rgb_diff_above_1e-4": int((d["rgb_map"].max(-1).values > 1e-4).sum())},
-           "how_to_enable": "NsrModel(..., mlp='bf16x3') / NSR_MLP=bf16x3 / bench.py --mlp bf16x3; NsrConfig.flags |= NSR_FLAG_MLP_BF16X3"}
+           "how_to_enable": "NsrModel(..., mlp='%s') / NSR_MLP=%s / bench.py --mlp %s" % (mlp, mlp, mlp)}
+    if mlp != "f16x2":                       # an f16x2 handle's input gradients run on the fp32 kernels (the main line's)
+        res["roofline_vjp"] = vjp_roofline(m, c2w)
     if sample is not None:                   # the same `parity` object as the main line's, against the same oracle output
         res["parity"] = parity_vs_oracle(m, sample)
     m.close()
@@ -223,7 +235,7 @@ def parity_vs_oracle(model, sample):
             "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
             "census": {k: c[k] for k in ("rays", "tol", "rays_above_tol", "cliff_rays", "fine_cliff_rays", "coarse_cliff_rays",
                                          "index_flip_rays", "denom_switch_rays", "illconditioned_shift_rays", "unattributed",
-                                         "coarse_rays_above_tol", "coarse_unattributed", "max_rel_disp_unflagged",
+                                         "coarse_rays_above_tol", "coarse_unattributed", "max_rel_disp_unflagged", "max_rel_disp_times_acc_unflagged",
                                          "inds_equal_rate_end_to_end")},
             "passes": bool(C.passes(c)),
             "sample": "%dx%d view, end to end against the oracle's render of the same rays; inds/z_samples_exact_match_rate: "
@@ -395,7 +407,7 @@ def pmc_traffic(pmc_file, schedule="phases"):
         return None, ("PMC profile %s was collected from other kernel sources (%s..., this tree %s...): not reported"
                       % (os.path.relpath(pmc_file, ROOT), str(prof.get("kernel_source_sha256"))[:12], here[:12]))
     blob = hashlib.sha1(b"blob %d\0" % os.path.getsize(pmc_file) + open(pmc_file, "rb").read()).hexdigest()
-    key = {"phases": "x16_phases_schedule", "bf16x3": "bf16x3"}.get(schedule, "x16_queue_schedule")
+    key = {"phases": "x16_phases_schedule", "bf16x3": "bf16x3", "f16x2": "f16x2"}.get(schedule, "x16_queue_schedule")
     if key not in prof:
         return None, "PMC profile %s has no passes for the %s schedule" % (os.path.relpath(pmc_file, ROOT), schedule)
     t = prof[key]["derived"]["hbm_traffic_bytes_per_launch"]
@@ -440,7 +452,7 @@ def main():
                     help="validation only: ranks share the visible GPUs round-robin (e.g. --gpus 2 --backend gloo on a "
                          "1-GPU box exercises the N>1 code path end to end; the number is not a scaling result)")
     ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r02", "pmc_k_render.json"))
-    ap.add_argument("--mlp", choices=("fp32", "bf16x3"), default=None,
+    ap.add_argument("--mlp", choices=MLP_MODES, default=None,
                     help="layer-GEMM arithmetic of the forward kernel (default: the engine's, engine.DEFAULT_MLP / $NSR_MLP)")
     args = ap.parse_args()
 
@@ -534,6 +546,10 @@ def main():
                 traffic, traffic_note = pmc_traffic(args.pmc_file, "bf16x3")
                 kernel_desc = "fused persistent kernel k_render_b3 (one workgroup per CU, 32 points per wave, layer GEMMs on bf16 MFMAs with three-way split fp32 operands)"
                 line["dtype"] = "bf16x3"
+            elif model.mlp == "f16x2":
+                traffic, traffic_note = pmc_traffic(args.pmc_file, "f16x2")
+                kernel_desc = "fused persistent kernel k_render_h2 (one workgroup per CU, 32 points per wave, layer GEMMs on fp16 MFMAs with two-way split fp32 operands and power-of-two range management)"
+                line["dtype"] = "f16x2"
             else:
                 traffic, traffic_note = pmc_traffic(args.pmc_file, model.schedule)
                 kernel_desc = "fp32, fused persistent kernel (x16: 2 workgroups per CU, %s schedule)" % model.schedule
@@ -563,10 +579,11 @@ def main():
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),
                                            "handoff": handoff_workload(model, not args.no_cpu_baseline)}
-                if model.mlp != "bf16x3":
-                    ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
-                    line["extra_workloads"]["bf16x3"] = bf16x3_workload(sd_c, sd_f, local, poses[args.warmup], ref,
-                                                                         sample=cpu_sample)
+                ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+                for mlp in MLP_MODES:
+                    if mlp != model.mlp:
+                        line["extra_workloads"][mlp] = alt_mlp_workload(mlp, sd_c, sd_f, local, poses[args.warmup], ref,
+                                                                        sample=cpu_sample)
         model.close()
 
     # ------------------------------------------------------------------------------------------------------------
@@ -682,9 +699,9 @@ def main():
             m.close()
 
     if rank == 0:
-        if args.workload != "view400" and (args.mlp or os.environ.get("NSR_MLP")) == "bf16x3":
-            line["dtype"] = "bf16x3"
-            line["config"]["mlp"] = "bf16x3 (layer GEMMs on bf16 MFMAs, fp32 operands split into three bf16 pieces)"
+        if args.workload != "view400" and (args.mlp or os.environ.get("NSR_MLP")) in MLP_DTYPE:
+            line["dtype"] = args.mlp or os.environ.get("NSR_MLP")
+            line["config"]["mlp"] = MLP_DTYPE[line["dtype"]]
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -87,6 +87,16 @@ typedef struct NsrConfig {
                                    (k_render_vjp_b3, forward and transposed GEMMs) and needs nsr_upload_weights_bwd_b3;
                                    the stage kernels follow `variant` as before                                         */
 
+#define NSR_FLAG_MLP_F16X2 16    /* forward render kernel k_render_h2: the layer GEMMs run on fp16 MFMAs with every fp32 operand
+                                   split into two fp16 pieces (hi = fp16(x), lo = fp16(x - hi): 22 significand bits) and
+                                   the three significant piece products accumulated in fp32; weights and biases carry exact
+                                   power-of-two scales chosen by the packer so that no piece leaves the fp16 range -- fp32-
+                                   grade results (error against fp64 within that of an fp32 GEMM chain) at half the MFMA
+                                   work of bf16x3.  Domain: a hidden activation whose scaled magnitude reaches 65504 makes
+                                   that point's outputs NaN (loud, never a wrong number).  One workgroup per CU, 32 points
+                                   per wave; needs nsr_upload_weights_h2.  Mutually exclusive with NSR_FLAG_MLP_BF16X3.
+                                   nsr_render_rays_vjp on such a handle runs the fp32 input-gradient kernels.           */
+
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {
   float*   d_weights0;   /* [N,64]   coarse weights             (RN:467)   */
@@ -124,6 +134,11 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
 /* The same networks in the bf16x3 layout (pack.py: pack_network_b3; NSR_PACKED_B3_FLOATS floats: the stream holds
  * packed bf16 pairs, the aux block is the fp32 one of nsr_upload_weights).  Handles created with NSR_FLAG_MLP_BF16X3. */
 int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t n_floats);
+
+/* The same networks in the f16x2 layout (pack.py: pack_network_h2; NSR_PACKED_FLOATS floats: the stream holds packed
+ * fp16 pairs -- 2 pieces x 2 bytes = the fp32 stream's size -- the aux block holds the scaled biases / heads and the
+ * activation scales).  Handles created with NSR_FLAG_MLP_F16X2. */
+int nsr_upload_weights_h2(nsr_handle h, int net_id, const float* packed, size_t n_floats);
 
 /* Transposed stream of the FINE network in the bf16x3 layout (pack.py: pack_network_backward_b3;
  * NSR_STREAM_SLABS_B3_BWD * NSR_SLAB_FLOATS floats), for nsr_render_rays_vjp on an NSR_FLAG_MLP_BF16X3 handle. */

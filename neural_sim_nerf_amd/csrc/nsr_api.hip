@@ -73,6 +73,8 @@ struct nsr_handle_s {
   bool have_net16[3] = {false, false, false};
   float* d_nets_b3 = nullptr;                           // coarse | fine | fine transposed in the bf16x3 layout
   bool have_net_b3[3] = {false, false, false};          // (NSR_FLAG_MLP_BF16X3)
+  float* d_nets_h2 = nullptr;                           // coarse | fine in the f16x2 layout, NSR_PACKED_FLOATS apart
+  bool have_net_h2[2] = {false, false};                 // (NSR_FLAG_MLP_F16X2)
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
@@ -131,6 +133,10 @@ static int allocate_handle(nsr_handle h) {
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   }
+  if (cfg->flags & NSR_FLAG_MLP_F16X2) {
+    NSR_HIP(hipMalloc(&h->d_nets_h2, sizeof(float) * 2 * NSR_PACKED_FLOATS));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+  }
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
@@ -172,7 +178,9 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
   if (cfg->n_samples != NSR_N_SAMPLES)
     return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
-  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP | NSR_FLAG_SCHED_PHASES | NSR_FLAG_MLP_BF16X3))
+  if ((cfg->flags & NSR_FLAG_MLP_BF16X3) && (cfg->flags & NSR_FLAG_MLP_F16X2))
+    return fail("nsr_create: NSR_FLAG_MLP_BF16X3 and NSR_FLAG_MLP_F16X2 are mutually exclusive");
+  if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP | NSR_FLAG_SCHED_PHASES | NSR_FLAG_MLP_BF16X3 | NSR_FLAG_MLP_F16X2))
     return fail("nsr_create: unknown bits in flags");
   if ((cfg->flags & NSR_FLAG_SCHED_PHASES) && (cfg->variant == 32 || cfg->n_importance == 0))
     return fail("nsr_create: NSR_FLAG_SCHED_PHASES applies to the x16 coarse+fine forward kernel only");
@@ -209,6 +217,7 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_nets);
   hipFree(h->d_nets16);
   hipFree(h->d_nets_b3);
+  hipFree(h->d_nets_h2);
   hipFree(h->d_tables);
   hipFree(h->d_scratch);
   hipFree(h->d_args);
@@ -275,6 +284,17 @@ int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats) {
   return 0;
 }
 
+int nsr_upload_weights_h2(nsr_handle h, int net_id, const float* packed, size_t n_floats) {
+  if (!h || !packed) return fail("nsr_upload_weights_h2: null argument");
+  if (!(h->cfg.flags & NSR_FLAG_MLP_F16X2)) return fail("nsr_upload_weights_h2: the handle was not created with NSR_FLAG_MLP_F16X2");
+  if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights_h2: net_id must be 0 (coarse) or 1 (fine)");
+  if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights_h2: wrong packed size");
+  NSR_DEVICE(h);
+  NSR_HIP(hipMemcpy(h->d_nets_h2 + (size_t)net_id * NSR_PACKED_FLOATS, packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  h->have_net_h2[net_id] = true;
+  return 0;
+}
+
 int nsr_upload_weights_bwd_b3(nsr_handle h, const float* stream, size_t n_floats) {
   if (!h || !stream) return fail("nsr_upload_weights_bwd_b3: null argument");
   if (!(h->cfg.flags & NSR_FLAG_MLP_BF16X3)) return fail("nsr_upload_weights_bwd_b3: the handle was not created with NSR_FLAG_MLP_BF16X3");
@@ -327,8 +347,11 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
                          void* stream) {
   const bool fine = h->cfg.n_importance > 0;
   const bool b3 = (h->cfg.flags & NSR_FLAG_MLP_BF16X3) != 0;
-  const bool x16 = use_x16(h) && !b3;
+  const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) != 0;
+  const bool x16 = use_x16(h) && !b3 && !h2;
   if (int e = check_ready(h, fine)) return e;
+  if (h2 && (!h->have_net_h2[0] || (fine && !h->have_net_h2[1])))
+    return fail("NSR_FLAG_MLP_F16X2 needs nsr_upload_weights_h2 for every network");
   if (x16 && (!h->have_net16[0] || (fine && !h->have_net16[1])))
     return fail("variant 16 needs nsr_upload_weights16 for every network");
   if (b3 && (!h->have_net_b3[0] || (fine && !h->have_net_b3[1])))
@@ -336,7 +359,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   if (!out || !out->d_rgb || !out->d_disp || !out->d_acc) return fail("render: rgb/disp/acc outputs are required");
   if (a.n_rays <= 0) return 0;
   NSR_DEVICE(h);
-  float* nets = b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets);
+  float* nets = h2 ? h->d_nets_h2 : (b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets));
   const size_t net_floats = b3 ? kB3Stride : (size_t)NSR_PACKED_FLOATS;
   const size_t stream_floats = (size_t)(b3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
   a.nets = nets;
@@ -397,6 +420,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   else if (b3)
     hipLaunchKernelGGL(nsr::k_render_b3, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
+  else if (h2)
+    hipLaunchKernelGGL(nsr::k_render_h2, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   else
     hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   NSR_HIP(hipGetLastError());

@@ -277,6 +277,12 @@ __device__ __forceinline__ void load_bias(const float* bias, int h4 /* 4 * lane 
 }
 
 #include "nsr_b3.inc"
+#include "nsr_h2.inc"
+
+// arithmetic of the layer GEMMs of a network pass
+constexpr int kMlpF32 = 0;      // fp32 MFMAs (seg)
+constexpr int kMlpB3 = 1;       // bf16 MFMAs, operands split three ways (nsr_b3.inc)
+constexpr int kMlpH2 = 2;       // fp16 MFMAs, operands split two ways + power-of-two range management (nsr_h2.inc)
 
 // ------------------------------------------------------------------------------------------------------
 // One network pass for this lane's point.  Lane (j = lane&31, h = lane>>5): both halves work on point j and
@@ -341,9 +347,10 @@ __device__ __forceinline__ float enc_poison(float px, float py, float pz, float 
   return __builtin_fabsf(a + b);      // +0 or NaN
 }
 
-// B3: the layer GEMMs run on bf16 MFMAs with three-way split operands (nsr_b3.inc) instead of fp32 MFMAs; the
-// encodings, biases, activations and the two VALU heads are the same code.
-template <bool CAPTURE, bool B3 = false>
+// MODE kMlpB3 / kMlpH2: the layer GEMMs run on bf16 / fp16 MFMAs with split operands (nsr_b3.inc, nsr_h2.inc) instead of
+// fp32 MFMAs; the encodings, biases, activations and the two VALU heads are the same code (for kMlpH2 the packer has
+// folded the layers' power-of-two scales into the biases and head weights of the aux block).
+template <bool CAPTURE, int MODE = kMlpF32>
 __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                          float px, float py, float pz, float vx, float vy, float vz,
                                          float (&raw)[4], uint4* mask_dst = nullptr /* uniform */, int mask_tid = 0) {
@@ -376,8 +383,13 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   // layer 0
   auto enc_src = [&](int kb, int i) { return e[(8 * kb + i) & 31]; };
   auto in_src = [&](int kb, int i) { return in[(kb >> 1) & 7][8 * (kb & 1) + i]; };
+  constexpr bool B3 = MODE == kMlpB3;
+  constexpr bool H2M = MODE == kMlpH2;
+  float amax = 0.0f;                       // kMlpH2: largest |scaled activation| this lane has split so far
+  const float* h2s = aux + kAuxH2Scale;
   load_bias<8>(aux + kAuxBias, h4, acc);
   if constexpr (B3) gemm_b3<8, 2>(rg, A0, A1, enc_src, acc, lane);
+  else if constexpr (H2M) gemm_h2<8, 4>(rg, A0, A1, enc_src, H2Scale{{h2s[0], 0.0f}, 4}, acc, lane, amax);
   else seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
   if (CAPTURE) mask_dst[mask_tid] = relu_mask<8>(acc);
 #pragma unroll
@@ -390,6 +402,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
     load_bias<8>(aux + kAuxBias + L * 256, h4, acc);
     if (L == 5) {                                                // skip: cat([input_pts, h]) -> input columns first (RH:105)
       if constexpr (B3) gemm_b3<8, 2>(rg, A0, A1, enc_src, acc, lane);
+      else if constexpr (H2M) gemm_h2<8, 4>(rg, A0, A1, enc_src, H2Scale{{h2s[9], 0.0f}, 4}, acc, lane, amax);
       else seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
     }
     if (L == 8) {
@@ -404,6 +417,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
       }
     }
     if constexpr (B3) gemm_b3<8, 8>(rg, A0, A1, in_src, acc, lane);
+    else if constexpr (H2M) gemm_h2<8, 16>(rg, A0, A1, in_src, H2Scale{{h2s[L], 0.0f}, 16}, acc, lane, amax);
     else seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
     if (CAPTURE && L < 8) mask_dst[L * 256 + mask_tid] = relu_mask<8>(acc);
     const int thr = (L == 8) ? (int)0x80000000 : 0;      // feature_linear has no activation
@@ -419,6 +433,9 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
       return kb < 16 ? in[(kb >> 1) & 7][8 * (kb & 1) + i] : (kb < 18 ? ed[(8 * (kb - 16) + i) & 15] : 0.0f);
     };
     gemm_b3<4, 5>(rg, A0, A1, v_src, av, lane);
+  } else if constexpr (H2M) {  // 16 k16 blocks of features, 2 of direction encoding
+    auto v_src = [&](int kb, int i) { return kb < 16 ? in[(kb >> 1) & 7][8 * (kb & 1) + i] : ed[(8 * (kb - 16) + i) & 15]; };
+    gemm_h2<4, 18>(rg, A0, A1, v_src, H2Scale{{h2s[10], h2s[11]}, 16}, av, lane, amax);
   } else {
     seg<4, 36>(rg, A0, A1, BViews{in, ed}, av, lane);
   }
@@ -426,6 +443,11 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 
   // rgb_linear (RH:117) on relu(av): VALU
   float part[4] = {0.0f, 0.0f, 0.0f, alpha_part};
+  if constexpr (H2M) {         // a scaled activation beyond the fp16 range: the point's outputs are NaN, not garbage
+    const float ov = amax > kH2Max ? __builtin_nanf("") : 0.0f;
+    part[0] = part[1] = part[2] = ov;
+    part[3] = alpha_part + ov;
+  }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float* wr = aux + kAuxWRgb + c * 128;
@@ -777,8 +799,9 @@ __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; *a.w
 #define NSR_T(i) do { } while (0)
 #endif
 
-template <bool B3>
+template <int MODE>
 __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap, char* smem) {
+  constexpr bool B3 = MODE == kMlpB3;
   const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -873,7 +896,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass<false, B3>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+      mlp_pass<false, MODE>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
@@ -958,12 +981,17 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 
 __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<false>(ap, smem);
+  render32_body<kMlpF32>(ap, smem);
 }
 // the same kernel with the layer GEMMs on bf16 MFMAs, fp32 operands split three ways (nsr_b3.inc)
 __global__ void __launch_bounds__(256, 1) k_render_b3(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<true>(ap, smem);
+  render32_body<kMlpB3>(ap, smem);
+}
+// ... and on fp16 MFMAs, fp32 operands split two ways with power-of-two range management (nsr_h2.inc)
+__global__ void __launch_bounds__(256, 1) k_render_h2(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<kMlpH2>(ap, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from .pack import (pack_network, pack_network16, pack_network_backward, pack_network_backward16, pack_network_b3,
-                   pack_network_backward_b3,
+                   pack_network_backward_b3, pack_network_h2,
                    PACKED_FLOATS, PACKED_B3_FLOATS)
 
 N_SAMPLES = 64
@@ -20,7 +20,8 @@ N_IMPORTANCE = 128
 # 328.1 vs 326.6 ms per 400x400 view (+0.5 %) for 4-5 GB instead of 20-90 GB of L2-miss (fabric) traffic per view
 # (profiles/r02/pmc_k_render.json); results are bit-identical.
 DEFAULT_SCHEDULE = "phases"
-DEFAULT_MLP = "fp32"             # layer-GEMM arithmetic of the forward render kernel: "fp32" or "bf16x3" (NsrModel)
+DEFAULT_MLP = "fp32"             # layer-GEMM arithmetic of the forward render kernel (NsrModel)
+MLP_MODES = ("fp32", "bf16x3", "f16x2")
 
 
 def _host_tables():
@@ -52,7 +53,9 @@ class NsrModel:
         the library default.  Both give bit-identical results.
         mlp: arithmetic of the layer GEMMs of the FORWARD render kernel: "fp32" (fp32 MFMAs) or "bf16x3" (bf16 MFMAs on
         fp32 operands split exactly into three bf16 pieces, NSR_FLAG_MLP_BF16X3: fp32-grade results, ~1.9x the MFMA
-        rate); None: $NSR_MLP, else DEFAULT_MLP."""
+        rate) or "f16x2" (fp16 MFMAs on fp32 operands split into two fp16 pieces with power-of-two range management,
+        NSR_FLAG_MLP_F16X2: fp32-grade results at half of bf16x3's MFMA work; forward kernel only -- input gradients of
+        such a handle run on the fp32 kernels); None: $NSR_MLP, else DEFAULT_MLP."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
@@ -69,10 +72,11 @@ class NsrModel:
             raise ValueError("schedule must be 'queue' or 'phases'")
         if mlp is None:
             mlp = os.environ.get("NSR_MLP", DEFAULT_MLP)
-        if mlp not in ("fp32", "bf16x3"):
-            raise ValueError("mlp must be 'fp32' or 'bf16x3'")
+        if mlp not in MLP_MODES:
+            raise ValueError("mlp must be one of %s" % (MLP_MODES,))
         self.mlp = mlp
-        phases = schedule == "phases" and variant != 32 and n_importance > 0      # the x16 coarse+fine kernel only
+        # the x16 coarse+fine kernels only (an "f16x2" handle runs its input gradients on them; "bf16x3" never does)
+        phases = schedule == "phases" and variant != 32 and n_importance > 0 and mlp != "bf16x3"
         self.schedule = "phases" if phases else "queue"
         if n_importance not in (0, N_IMPORTANCE):
             raise NotImplementedError("N_importance must be 128 (or 0 for coarse-only); got %r" % (n_importance,))
@@ -85,7 +89,7 @@ class NsrModel:
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant,
                              (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0)
-                             | (8 if mlp == "bf16x3" else 0), int(chunk))
+                             | (8 if mlp == "bf16x3" else 0) | (16 if mlp == "f16x2" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
@@ -106,6 +110,9 @@ class NsrModel:
         if self.mlp == "bf16x3":
             p = pack_network_b3(sd_c)
             _lib.check(self.lib.nsr_upload_weights_b3(self.h, 0, _fptr(p), PACKED_B3_FLOATS))
+        if self.mlp == "f16x2":
+            p = pack_network_h2(sd_c)
+            _lib.check(self.lib.nsr_upload_weights_h2(self.h, 0, _fptr(p), PACKED_FLOATS))
         self._sd_fine_np = None
         self._bwd_ready = False
         if sd_fine is not None:
@@ -118,6 +125,9 @@ class NsrModel:
             if self.mlp == "bf16x3":
                 p = pack_network_b3(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_b3(self.h, 1, _fptr(p), PACKED_B3_FLOATS))
+            if self.mlp == "f16x2":
+                p = pack_network_h2(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights_h2(self.h, 1, _fptr(p), PACKED_FLOATS))
 
     def close(self):
         if getattr(self, "h", None):

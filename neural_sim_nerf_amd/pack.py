@@ -429,3 +429,125 @@ def pack_network_backward_b3(sd):
     stream = np.concatenate([x.reshape(-1) for x in segs])
     assert stream.size * 2 == STREAM_SLABS_B3_BWD * SLAB_FLOATS * 4
     return stream.view(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# "f16x2" forward layout (csrc/nsr_h2.inc, k_render_h2): v_mfma_f32_32x32x16_f16, every fp32 weight as two fp16 pieces
+# ----------------------------------------------------------------------------------------------------------
+# Same MFMA operand layout as bf16x3 (8 k-slots per lane, slot i of k16 block kb = k-step 8 kb + i of the fp32 x32 layout),
+# 2 pieces x 2 bytes per weight: the stream has the fp32 stream's size and segment order (STREAM_SLABS).  A step is the 4
+# chunks [hi(b), hi(b+1), lo(b), lo(b+1)] of two consecutive output blocks of one k16 block.
+# Range management (all exact powers of two):
+#   sw[l]   weights of layer l are stored as W * 2^sw[l] with max|W| * 2^sw[l] in [2^14, 2^15)          (l = 0..9, 8 =
+#           feature_linear, 9 = views_linears.0; the two column groups of L5 and of the views layer share one sw)
+#   ca[l]   the activations entering layer l are multiplied so that the fp16 pieces are those of x * 2^ca[l]  (0 unless
+#           `act_scale_log2` says otherwise)
+#   the accumulators of layer l then hold 2^(sw[l] + ca[l]) * (W x + b): biases are stored times that factor, and the
+#   registers the NEXT layer reads carry it (P[l+1] = sw[l] + ca[l]); the multiplier applied before its split is
+#   2^(ca[l+1] - P[l+1]).  The two VALU heads read scaled registers too: their weights are stored times 2^-P.
+AUX_H2_SCALE = 3080
+H2_WEIGHT_TOP_LOG2 = 15          # scaled weights stay below 2^15 (fp16 max is 65504 = 2^16 - 32)
+
+
+def f16_round(x):
+    """fp32 -> nearest-even fp16 (subnormals kept), returned as fp32"""
+    with np.errstate(over="ignore"):
+        return np.ascontiguousarray(x, np.float32).astype(np.float16).astype(np.float32)
+
+
+def split_f16x2(x):
+    """x (fp32) -> (hi, lo) fp16-valued fp32 arrays, hi = fp16(x), lo = fp16(x - hi)"""
+    x = np.ascontiguousarray(x, np.float32)
+    hi = f16_round(x)
+    lo = f16_round((x - hi).astype(np.float32))
+    return hi, lo
+
+
+def h2_weight_scale_log2(*mats):
+    """sw: the power of two that puts the largest |entry| of the given matrices into [2^14, 2^15)"""
+    top = max(float(np.abs(np.asarray(m, np.float32)).max()) for m in mats)
+    if not np.isfinite(top):
+        raise ValueError("pack_network_h2: non-finite weight")
+    if top == 0.0:
+        return 0
+    return int(H2_WEIGHT_TOP_LOG2 - 1 - np.floor(np.log2(top)))
+
+
+def _pack_h2(W, cols, n_mo):
+    """W [32*n_mo, K] (ALREADY scaled); cols [n_ksteps, 2] (reference column or -1), n_ksteps a multiple of 8.  Returns uint16
+    [n_kb * n_mo * 2 chunks, 64, 8]: per k16 block, per pair of output blocks, the chunks hi(b), hi(b+1), lo(b), lo(b+1)."""
+    assert W.shape[0] == 32 * n_mo and cols.shape[0] % 8 == 0 and n_mo % 2 == 0
+    n_kb = cols.shape[0] // 8
+    Wp = np.concatenate([W, np.zeros((W.shape[0], 1), W.dtype)], 1)       # column -1 -> zeros
+    lane = np.arange(64)
+    row, h = lane & 31, lane >> 5
+    frag = np.empty((n_kb, n_mo, 64, 8), np.float32)                      # [k16 block][output block][lane][slot]
+    for kb in range(n_kb):
+        for i in range(8):
+            c = cols[8 * kb + i][h]
+            for mo in range(n_mo):
+                frag[kb, mo, :, i] = Wp[32 * mo + row, c]
+    hi, lo = (p.astype(np.float16).view(np.uint16) for p in split_f16x2(frag))
+    out = np.empty((n_kb * n_mo * 2, 64, 8), np.uint16)
+    n = 0
+    for kb in range(n_kb):
+        for b in range(0, n_mo, 2):
+            for piece, mo in ((hi, b), (hi, b + 1), (lo, b), (lo, b + 1)):
+                out[n] = piece[kb, mo]
+                n += 1
+    return out
+
+
+def h2_scales(sd, act_scale_log2=None):
+    """(sw[10], ca[10]) of pack_network_h2 for this network; act_scale_log2: None (all 0) or 10 integers ca[l]."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    sw = [h2_weight_scale_log2(g("pts_linears.%d.weight" % l)) for l in range(8)]
+    sw.append(h2_weight_scale_log2(g("feature_linear.weight")))
+    sw.append(h2_weight_scale_log2(g("views_linears.0.weight")))
+    ca = [0] * 10 if act_scale_log2 is None else [int(v) for v in act_scale_log2]
+    assert len(ca) == 10
+    return sw, ca
+
+
+def pack_network_h2(sd, act_scale_log2=None):
+    """The forward stream of pack_network with every (scaled) weight as two fp16 pieces, in the chunk order of k_render_h2,
+    followed by the aux block with scaled biases / head weights and the activation multipliers.  Returns float32
+    [PACKED_FLOATS] (the stream part is packed fp16 pairs viewed as floats)."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    aux = pack_network(sd)[STREAM_SLABS * SLAB_FLOATS:].copy()          # also validates the shapes
+    sw, ca = h2_scales(sd, act_scale_log2)
+    p2 = lambda e: np.float32(2.0) ** np.float32(e)
+    t = np.arange(128)
+    cols_main = np.stack([kappa(t, 0), kappa(t, 1)], 1)
+    cols_enc = np.array([[eps(tt, 0, 10), eps(tt, 1, 10)] for tt in range(32)])
+    cols_dir = np.array([[eps(tt, 0, 4), eps(tt, 1, 4)] for tt in range(16)])
+    segs = [_pack_h2(g("pts_linears.0.weight") * p2(sw[0]), cols_enc, 8)]
+    for i in range(1, 8):
+        W = g("pts_linears.%d.weight" % i) * p2(sw[i])
+        if i == 5:
+            segs.append(_pack_h2(W[:, :63], cols_enc, 8))
+            W = W[:, 63:]
+        segs.append(_pack_h2(np.ascontiguousarray(W), cols_main, 8))
+    segs.append(_pack_h2(g("feature_linear.weight") * p2(sw[8]), cols_main, 8))
+    cols_views = np.concatenate([cols_main, np.where(cols_dir >= 0, cols_dir + 256, -1)], 0)
+    segs.append(_pack_h2(g("views_linears.0.weight") * p2(sw[9]), cols_views, 4))
+    stream = np.concatenate([x.reshape(-1) for x in segs])
+    assert stream.size * 2 == STREAM_SLABS * SLAB_FLOATS * 4
+    # aux: biases times 2^(sw + ca); head weights times 2^-P of the registers they read
+    P = [0] + [sw[l] + ca[l] for l in range(9)]                         # P[l]: scale carried by the hidden input of layer l (1..9)
+    for L in range(9):
+        aux[AUX_BIAS + L * 256:AUX_BIAS + (L + 1) * 256] *= p2(sw[L] + ca[L])
+    aux[AUX_BIAS_V:AUX_BIAS_V + 128] *= p2(sw[9] + ca[9])
+    aux[AUX_W_ALPHA:AUX_W_ALPHA + 256] *= p2(-P[8])                     # alpha_linear reads h7 = the input of feature_linear
+    aux[AUX_W_RGB:AUX_W_RGB + 384] *= p2(-(sw[9] + ca[9]))              # rgb_linear reads the views layer's output
+    sc = np.zeros(16, np.float32)
+    sc[0] = p2(ca[0])                                                   # encoding @ L0
+    for L in range(1, 9):
+        sc[L] = p2(ca[L] - P[L])                                        # hidden input of L1..L7, feature_linear
+    sc[9] = p2(ca[5])                                                   # encoding @ L5 (shares L5's sw and ca)
+    sc[10] = p2(ca[9] - P[9])                                           # feature @ views layer
+    sc[11] = p2(ca[9])                                                  # direction encoding @ views layer
+    aux[AUX_H2_SCALE:AUX_H2_SCALE + 16] = sc
+    if not np.isfinite(aux).all():
+        raise ValueError("pack_network_h2: a scaled bias / head weight left the fp32 range")
+    return np.concatenate([stream.view(np.float32), aux]).astype(np.float32, copy=False)

@@ -485,3 +485,95 @@ def mlp_bwd_pass_b3(packed_b3_fwd, stream_bwd_b3, masks, pts, dirs, g_raw):
     assert st.pos == PK.STREAM_SLABS_B3_BWD * 16
     dp = _embed_bwd(P, [ae[t >> 4][:, t & 15] for t in range(32)], 10) + dp5
     return dp, dv
+
+
+# ----------------------------------------------------------------------------------------------------------
+# f16x2 (csrc/nsr_h2.inc): fp16 MFMAs on two-piece split operands with power-of-two range management
+# ----------------------------------------------------------------------------------------------------------
+H2_MAX = np.float32(65504.0 * (1.0 - 1.0 / 4096.0))
+
+
+def split_h2(x, m):
+    """split_pair_h2 of nsr_h2.inc: (hi, lo) fp16-valued floats of x * m, and max |x * m|"""
+    t = (np.ascontiguousarray(x, np.float32) * np.float32(m)).astype(np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        hi = t.astype(np.float16).astype(np.float32)
+        lo = (t - hi).astype(np.float32).astype(np.float16).astype(np.float32)
+    return hi, lo, float(np.abs(t).max())
+
+
+class StreamH2:
+    """The f16x2 stream as the kernel sees it: consecutive 1 KiB chunks of [64 lanes][8 fp16]."""
+
+    def __init__(self, stream_floats):
+        self.chunks = stream_floats.view(np.float16).reshape(-1, 64, 8).astype(np.float32)
+        self.pos = 0
+        self.amax = np.zeros(64, np.float32)
+
+    def gemm(self, nmo, nkb, src, scale, acc):
+        """gemm_h2<NMO, NKB>: src(kb) -> [64, 8] fp32 (this lane's slots of k16 block kb), scale(kb) -> multiplier."""
+        for kb in range(nkb):
+            t = (src(kb) * np.float32(scale(kb))).astype(np.float32)
+            self.amax = np.maximum(self.amax, np.abs(t).max(1))
+            hi, lo, _ = split_h2(src(kb), scale(kb))
+            for b0 in range(0, nmo, 2):                              # one step: hi(b0), hi(b0+1), lo(b0), lo(b0+1)
+                A = [self.chunks[self.pos + c] for c in range(4)]
+                self.pos += 4
+                for a, bb, mo in ((A[2], hi, b0), (A[3], hi, b0 + 1), (A[0], lo, b0), (A[1], lo, b0 + 1),
+                                  (A[0], hi, b0), (A[1], hi, b0 + 1)):
+                    acc[mo] = mfma_b3(a, bb, acc[mo])                # same operand layout as the bf16 MFMA
+
+
+def mlp_pass_h2(packed_h2, pts, dirs, masks=None):
+    """pts, dirs: [32,3] -> raw [32,4]: one wave of mlp_pass<CAPTURE, kMlpH2>."""
+    from neural_sim_nerf_amd import pack as PK
+    st = StreamH2(packed_h2[:PK.STREAM_SLABS * PK.SLAB_FLOATS])
+    aux = packed_h2[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
+    sc = aux[PK.AUX_H2_SCALE:PK.AUX_H2_SCALE + 16]
+    h = LANE >> 5
+    P = np.concatenate([pts, pts], 0).astype(np.float32)
+    V = np.concatenate([dirs, dirs], 0).astype(np.float32)
+    e = _encode(P, 10, 32)
+    ed = _encode(V, 4, 16)
+    enc_src = lambda kb: np.stack([e[8 * kb + i] for i in range(8)], 1)
+    acc = load_bias(aux, PK.AUX_BIAS, 8)
+    st.gemm(8, 4, enc_src, lambda kb: sc[0], acc)
+    if masks is not None:
+        masks[0] = acc > 0
+    inp = np.maximum(acc, 0)
+    in_src = lambda kb: inp[kb >> 1][:, 8 * (kb & 1):8 * (kb & 1) + 8]
+    alpha_part = np.zeros(64, np.float32)
+    for L in range(1, 9):
+        acc = load_bias(aux, PK.AUX_BIAS + L * 256, 8)
+        if L == 5:
+            st.gemm(8, 4, enc_src, lambda kb: sc[9], acc)
+        if L == 8:
+            for tq in range(32):
+                for kk in range(4):
+                    w = aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk]
+                    alpha_part = alpha_part + w * inp[(4 * tq + kk) >> 4][:, (4 * tq + kk) & 15]
+        st.gemm(8, 16, in_src, lambda kb, L=L: sc[L], acc)
+        if masks is not None and L < 8:
+            masks[L] = acc > 0
+        inp = np.maximum(acc, 0) if L < 8 else acc.copy()
+    av = load_bias(aux, PK.AUX_BIAS_V, 4)
+    v_src = lambda kb: in_src(kb) if kb < 16 else np.stack([ed[8 * (kb - 16) + i] for i in range(8)], 1)
+    st.gemm(4, 18, v_src, lambda kb: sc[10] if kb < 16 else sc[11], av)
+    if masks is not None:
+        masks[8] = av > 0
+    assert st.pos == PK.STREAM_SLABS * 16
+    ov = np.where(st.amax > H2_MAX, np.float32(np.nan), np.float32(0))
+    part = np.zeros((4, 64), np.float32)
+    part[3] = alpha_part
+    part += ov[None, :]
+    for c in range(3):
+        for mo in range(4):
+            for rq in range(4):
+                for ri in range(4):
+                    w = aux[PK.AUX_W_RGB + c * 128 + ((mo * 4 + rq) * 2 + h) * 4 + ri]
+                    part[c] = part[c] + w * np.maximum(av[mo][:, rq * 4 + ri], 0)
+    raw = np.zeros((32, 4), np.float32)
+    for c in range(4):
+        bias = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
+        raw[:, c] = part[c][:32] + part[c][32:] + bias
+    return raw

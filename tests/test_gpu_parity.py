@@ -757,6 +757,82 @@ def test_bf16x3_stagewise_and_golden(model_b3, model, oracle, synth_nets):
     assert oracle.psnr(cpu(rv["rgb_map"]).reshape(32, 32, 3), g7["rgb_c2"]) > 55.0
 
 
+
+# ------------------------------------------------------------------------------------------------------
+# f16x2 forward kernel (k_render_h2): fp16 MFMAs on two-piece split operands, power-of-two range management
+# ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def model_h2(synth_nets):
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1], mlp="f16x2")
+    yield m
+    m.close()
+
+
+def test_f16x2_stagewise_and_golden(model_h2, model, oracle, synth_nets):
+    """NSR_FLAG_MLP_F16X2: the SAME bounds as the fp32-MFMA kernels, stage by stage against the oracle on the kernel's own
+    intermediates (raw network outputs 5e-5, indices and samples bit-exact given its own weights, ...), the coarse image
+    against the reference to 1e-5, and end to end by the census against what the reference produced."""
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    r = model_h2.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
+    _stagewise(model_h2, oracle, synth_nets, r, g["rays_o"], g["rays_d"], near, far)
+    assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+    assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
+    assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
+    c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
+    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
+    # against the fp32-MFMA kernel on the same rays: network outputs agree to fp32 rounding, but are not the same bits
+    r32 = model.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
+    d = np.abs(cpu(r["raw0"]) - cpu(r32["raw0"]))
+    assert 0 < d.max() < 2e-5, d.max()
+    # how close to the fp64 truth, next to the fp32 kernel (the oracle's float64 network on the coarse sample points)
+    zc = oracle.coarse_z(np.full(len(g["rays_o"]), near, np.float32), np.full(len(g["rays_o"]), far, np.float32))
+    pts = (g["rays_o"][:, None, :] + g["rays_d"][:, None, :] * zc[:, :, None]).astype(np.float32)
+    vd = oracle.normalize_dirs(g["rays_d"])
+    f64 = oracle._network_forward64(synth_nets[0], pts.reshape(-1, 3), np.repeat(vd, 64, 0))
+    truth = np.concatenate([f64["rgb_raw"], f64["sigma"][:, None]], -1).reshape(-1, 64, 4)
+    e2, e32 = np.abs(cpu(r["raw0"]) - truth).max(), np.abs(cpu(r32["raw0"]) - truth).max()
+    print("raw0 max error vs fp64: f16x2 %.3e, fp32 MFMA %.3e" % (e2, e32))
+    assert e2 <= 3 * e32 + 1e-6, (e2, e32)
+    # chunk invariance (RN:67-68) and odd counts
+    for n in (1, 3, 77):
+        rn = model_h2.render_rays(g["rays_o"][:n], g["rays_d"][:n], near, far)
+        for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+            assert np.array_equal(cpu(rn[k]), cpu(r[k])[:n], equal_nan=True), (k, n)
+    # the render options live outside the MLP: white background + lindisp, forward, against the reference (g11)
+    from neural_sim_nerf_amd.engine import NsrModel
+    g11 = load_golden("g11_options")
+    mo = NsrModel(synth_nets[0], synth_nets[1], mlp="f16x2", white_bkgd=True, lindisp=True)
+    ro = mo.render_rays(g11["rays_o"], g11["rays_d"], oracle.YCBV_NEAR, oracle.YCBV_FAR, debug=True)
+    _stagewise(mo, oracle, synth_nets, ro, g11["rays_o"], g11["rays_d"], oracle.YCBV_NEAR, oracle.YCBV_FAR, white_bkgd=True, lindisp=True)
+    _census(synth_nets, ro, g11["rays_o"], g11["rays_d"], oracle.YCBV_NEAR, oracle.YCBV_FAR, census_ref(g11), white_bkgd=True, lindisp=True)
+    mo.close()
+
+
+def test_f16x2_out_of_range_activation_is_nan(oracle, synth_nets):
+    """The domain of NSR_FLAG_MLP_F16X2 (include/nsr.h): a hidden activation whose scaled magnitude reaches the fp16
+    maximum makes the point's outputs NaN -- loud -- and just below it the results are still the oracle's."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    ro, rd = g["rays_o"][:64], g["rays_d"][:64]
+    for bias, finite in ((6.0e4, True), (7.0e4, False)):
+        big = {k: np.array(v, copy=True) for k, v in synth_nets[0].items()}
+        big["pts_linears.0.bias"][7] = bias
+        m = NsrModel(big, None, n_importance=0, mlp="f16x2")
+        r = m.render_rays(ro, rd, near, far, debug=True)
+        raw0 = cpu(r["raw0"])
+        if finite:
+            zc = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
+            want = oracle.run_network(big, (ro[:, None] + rd[:, None] * zc[..., None]).astype(np.float32), oracle.normalize_dirs(rd))
+            assert np.isfinite(raw0).all()
+            assert_close(raw0, want, atol=5e-5 * max(1.0, np.abs(want).max()), rtol=5e-5, what="just inside the fp16 range")
+        else:
+            assert np.isnan(raw0).all() and np.isnan(cpu(r["rgb_map"])).all()
+        m.close()
+
+
 def test_x16_chunk_invariance_and_views(model16, model, oracle):
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
@@ -1061,7 +1137,7 @@ def test_calls_leave_the_current_device_alone(synth_nets):
 
 
 KERNELS = {"x16-phases": dict(variant=16, schedule="phases"), "x16-queue": dict(variant=16, schedule="queue"),
-           "x32": dict(variant=32), "bf16x3": dict(mlp="bf16x3")}
+           "x32": dict(variant=32), "bf16x3": dict(mlp="bf16x3"), "f16x2": dict(mlp="f16x2")}
 
 
 @pytest.mark.parametrize("kernel", list(KERNELS))
@@ -1119,7 +1195,7 @@ def oracle_full_view(oracle, synth_nets):
     return pose, ro, rd, ref
 
 
-@pytest.mark.parametrize("kernel", ["x16-phases", "bf16x3"])
+@pytest.mark.parametrize("kernel", ["x16-phases", "bf16x3", "f16x2"])
 def test_census_full_size_view_against_the_oracle(oracle, synth_nets, oracle_full_view, kernel):
     """BASELINE configs[1] at FULL size (400x400, 64+128), end to end against the oracle's render of the same 160 000
     rays: every ray beyond 1e-4 attributed, PSNR-delta of the whole view inside north_star's 0.1 dB."""
