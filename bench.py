@@ -235,11 +235,58 @@ def parity_vs_oracle(model, sample):
             "inds_exact_match_rate": inds_match, "z_samples_exact_match_rate": zs_match,
             "census": {k: c[k] for k in ("rays", "tol", "rays_above_tol", "cliff_rays", "fine_cliff_rays", "coarse_cliff_rays",
                                          "index_flip_rays", "denom_switch_rays", "illconditioned_shift_rays", "unattributed",
-                                         "coarse_rays_above_tol", "coarse_unattributed", "max_rel_disp_unflagged", "max_rel_disp_times_acc_unflagged",
+                                         "coarse_rays_above_tol", "coarse_unattributed", "rays_disp_above_tol",
                                          "inds_equal_rate_end_to_end")},
             "passes": bool(C.passes(c)),
             "sample": "%dx%d view, end to end against the oracle's render of the same rays; inds/z_samples_exact_match_rate: "
                       "the oracle's sample_pdf on the kernel's own coarse weights (the bit-exact stage)" % (side, side)}
+
+
+def api_overhead_workload(sd_c, sd_f, device, reps=60):
+    """What the drop-in API costs on top of the engine: run_nerf_noscale.render(c2w=...) of a 64x64 view and render(rays=...)
+    of a 512-ray patch (the bilevel loop's call pattern, RN:156-168) against the same launches through NsrModel.  Per call
+    the API checks its kwargs, looks its native handle up -- which includes the content fingerprint of both networks'
+    parameters (NeRF.weights_version: one native kernel + an 8-byte read-back per network) -- and reshapes the outputs."""
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    dev = torch.device("cuda", device)
+    nets = []
+    for sd in (sd_c, sd_f):
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        nets.append(n.to(dev))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64, network_fn=nets[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False, near=S.YCBV_NEAR, far=S.YCBV_FAR)
+    side = 64
+    K = S.scaled_K(400.0 / side)
+    pose = torch.as_tensor(S.sweep_poses(1, seed=5)[0][:3, :4], device=dev)
+    eng = NsrModel(sd_c, sd_f, device=device)
+    ro, rd = eng.get_rays(side, side, K, pose)
+    patch = torch.stack([ro.reshape(-1, 3)[:512], rd.reshape(-1, 3)[:512]], 0).contiguous()
+
+    def timed(fn):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    with torch.no_grad():
+        api_view = timed(lambda: R.render(side, side, K, chunk=32768, c2w=pose, **kw))
+        eng_view = timed(lambda: eng.render_views(pose, side, side, K, S.YCBV_NEAR, S.YCBV_FAR))
+        api_patch = timed(lambda: R.render(side, side, K, chunk=32768, rays=patch, **kw))
+        eng_patch = timed(lambda: eng.render_rays(patch[0], patch[1], S.YCBV_NEAR, S.YCBV_FAR))
+        fp = timed(lambda: nets[0].weights_version())
+    eng.close()
+    for n in nets:
+        n.invalidate()
+    return {"workload": "drop-in API vs engine, 64+128 samples, %d calls each, wall clock per call" % reps,
+            "view_64x64_ms": {"api": round(api_view, 4), "engine": round(eng_view, 4),
+                              "overhead_frac": round(api_view / eng_view - 1.0, 4)},
+            "patch_512_rays_ms": {"api": round(api_patch, 4), "engine": round(eng_patch, 4),
+                                  "overhead_frac": round(api_patch / eng_patch - 1.0, 4)},
+            "weights_version_ms_per_network": round(fp, 4)}
 
 
 def config1_workload(sd_c, c2w, device, cpu_setting):
@@ -578,7 +625,8 @@ def main():
             if world == 1 and not args.no_extras:
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),
-                                           "handoff": handoff_workload(model, not args.no_cpu_baseline)}
+                                           "handoff": handoff_workload(model, not args.no_cpu_baseline),
+                                           "api_overhead": api_overhead_workload(sd_c, sd_f, local)}
                 ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
                 for mlp in MLP_MODES:
                     if mlp != model.mlp:

@@ -232,6 +232,13 @@ int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int 
                   int32_t* d_count, uint8_t* d_mask, void* stream);
 int nsr_reserve_bbox(nsr_handle h, int H, int W);
 
+/* Content fingerprint of n_tensors device buffers (d_ptrs[i]: n_words[i] 32-bit words; both tables in device memory):
+ * an order-independent 64-bit hash of (tensor, index, bits) written to *d_out.  LAUNCH call (a memset node + one
+ * kernel).  The drop-in API keys its packed-weight cache on it, so that in-place parameter writes which bump no autograd
+ * version are seen without concatenating and reducing 0.6 M parameters per render call. */
+int nsr_fingerprint(nsr_handle h, const void* const* d_ptrs, const int64_t* d_n_words, int n_tensors, uint64_t* d_out,
+                    void* stream);
+
 /* psi -> camera pose on the device (LL = optimization/utils/load_LINEMOD_noscale.py, GU = utils/gumble.py).
  * The random draws stay where the reference makes them (numpy on the host, recorded in sample_log, LL:273-297); these
  * are the deterministic maps (probabilities, recorded noise) -> poses, written straight into device memory.

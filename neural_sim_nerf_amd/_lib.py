@@ -67,6 +67,7 @@ SIGNATURES = {
     "nsr_sort_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsr_selftest": (C.c_int, [C.c_void_p, C.c_void_p]),
     "nsr_reserve_bbox": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "nsr_fingerprint": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nsr_schedule_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
     "nsr_debug_bounds_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
     "nsr_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

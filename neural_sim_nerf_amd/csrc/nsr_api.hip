@@ -575,6 +575,18 @@ int nsr_to8b(nsr_handle h, const float* d_x, int64_t n, uint8_t* d_out, void* st
   return 0;
 }
 
+int nsr_fingerprint(nsr_handle h, const void* const* d_ptrs, const int64_t* d_n_words, int n_tensors, uint64_t* d_out,
+                    void* stream) {
+  if (!h || !d_ptrs || !d_n_words || !d_out) return fail("nsr_fingerprint: null argument");
+  if (n_tensors <= 0 || n_tensors > 65535) return fail("nsr_fingerprint: 1..65535 tensors");
+  NSR_DEVICE(h);
+  NSR_HIP(hipMemsetAsync(d_out, 0, sizeof(uint64_t), (hipStream_t)stream));
+  hipLaunchKernelGGL(nsr::k_fingerprint, dim3(16, (unsigned)n_tensors), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned* const*)d_ptrs, (const long long*)d_n_words, (unsigned long long*)d_out);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
 int nsr_find_bbox(nsr_handle h, const uint8_t* d_rgb8, int n_images, int H, int W, int32_t* d_bbox,
                   int32_t* d_count, uint8_t* d_mask, void* stream) {
   if (h && n_images == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)

@@ -226,4 +226,28 @@ __global__ void __launch_bounds__(256) k_box_select(BoxArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Content fingerprint of a set of device tensors (the drop-in API's packed-weight cache key, RH:70-122 parameters): an
+// order-independent 64-bit sum of per-word hashes h(tensor, index, bits) -- one pass over the bytes (HBM-bound: 2.4 MB per
+// network), one 8-byte result, no temporaries.  Catches in-place writes that bump no autograd version (p.data.copy_()).
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_fingerprint(const unsigned* const* __restrict__ ptrs, const long long* __restrict__ n_words,
+                              unsigned long long* __restrict__ out) {
+  const int t = blockIdx.y;
+  const unsigned* p = ptrs[t];
+  const long long n = n_words[t];
+  unsigned long long acc = 0ull;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned long long x = ((unsigned long long)(unsigned)t << 40) ^ ((unsigned long long)i << 1) ^ ((unsigned long long)p[i] << 32 | p[i]);
+    x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 32; x *= 0x94d049bb133111ebull; x ^= x >> 29;   // splitmix64 finaliser
+    acc += x;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned lo = __shfl_xor((unsigned)acc, m), hi = __shfl_xor((unsigned)(acc >> 32), m);
+    acc += ((unsigned long long)hi << 32) | lo;
+  }
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 }  // namespace nsr

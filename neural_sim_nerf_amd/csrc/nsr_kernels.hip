@@ -353,7 +353,14 @@ __device__ __forceinline__ float enc_poison(float px, float py, float pz, float 
 template <bool CAPTURE, int MODE = kMlpF32>
 __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                          float px, float py, float pz, float vx, float vy, float vz,
-                                         float (&raw)[4], uint4* mask_dst = nullptr /* uniform */, int mask_tid = 0) {
+                                         float (&raw)[4], uint4* mask_dst = nullptr /* uniform */, int mask_tid = 0,
+                                         long long* tp = nullptr /* NSR_PHASE_TIMING: [4] encodings, GEMMs, between, heads */) {
+#ifdef NSR_PHASE_TIMING
+  long long tpl = clock64();
+#define NSR_TP(i) do { if (tp) { const long long t_ = clock64(); tp[i] += t_ - tpl; tpl = t_; } } while (0)
+#else
+#define NSR_TP(i) do { } while (0)
+#endif
   const int h = lane >> 5;
   const int h4 = aux_half(lane);
   const float poison = enc_poison(px, py, pz, vx, vy, vz);
@@ -387,10 +394,13 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   constexpr bool H2M = MODE == kMlpH2;
   float amax = 0.0f;                       // kMlpH2: largest |scaled activation| this lane has split so far
   const float* h2s = aux + kAuxH2Scale;
+  NSR_TP(0);
   load_bias<8>(aux + kAuxBias, h4, acc);
+  NSR_TP(2);
   if constexpr (B3) gemm_b3<8, 2>(rg, A0, A1, enc_src, acc, lane);
   else if constexpr (H2M) gemm_h2<8, 4>(rg, A0, A1, enc_src, H2Scale{{h2s[0], 0.0f}, 4}, acc, lane, amax);
   else seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
+  NSR_TP(1);
   if (CAPTURE) mask_dst[mask_tid] = relu_mask<8>(acc);
 #pragma unroll
   for (int mo = 0; mo < 8; ++mo) in[mo] = relu16(acc[mo]);
@@ -400,10 +410,12 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 #pragma unroll 1
   for (int L = 1; L <= 8; ++L) {
     load_bias<8>(aux + kAuxBias + L * 256, h4, acc);
+    NSR_TP(2);
     if (L == 5) {                                                // skip: cat([input_pts, h]) -> input columns first (RH:105)
       if constexpr (B3) gemm_b3<8, 2>(rg, A0, A1, enc_src, acc, lane);
       else if constexpr (H2M) gemm_h2<8, 4>(rg, A0, A1, enc_src, H2Scale{{h2s[9], 0.0f}, 4}, acc, lane, amax);
       else seg<8, 8>(rg, A0, A1, BArr<32>{e}, acc, lane);
+      NSR_TP(1);
     }
     if (L == 8) {
       // alpha_linear on h7 (RH:109): VALU dot product over this lane's 128 features, halves summed below
@@ -419,6 +431,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
     if constexpr (B3) gemm_b3<8, 8>(rg, A0, A1, in_src, acc, lane);
     else if constexpr (H2M) gemm_h2<8, 16>(rg, A0, A1, in_src, H2Scale{{h2s[L], 0.0f}, 16}, acc, lane, amax);
     else seg<8, 32>(rg, A0, A1, BRegs16<8>{in}, acc, lane);
+    NSR_TP(1);
     if (CAPTURE && L < 8) mask_dst[L * 256 + mask_tid] = relu_mask<8>(acc);
     const int thr = (L == 8) ? (int)0x80000000 : 0;      // feature_linear has no activation
 #pragma unroll
@@ -428,6 +441,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   // views_linears.0 (RH:111-115): cat([feature, input_views]) -> 128, ReLU
   f32x16 av[4];
   load_bias<4>(aux + kAuxBiasV, h4, av);
+  NSR_TP(2);
   if constexpr (B3) {        // 16 blocks of features, 2 of direction encoding, 2 of padding (a group is 4 blocks)
     auto v_src = [&](int kb, int i) {
       return kb < 16 ? in[(kb >> 1) & 7][8 * (kb & 1) + i] : (kb < 18 ? ed[(8 * (kb - 16) + i) & 15] : 0.0f);
@@ -439,6 +453,7 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
   } else {
     seg<4, 36>(rg, A0, A1, BViews{in, ed}, av, lane);
   }
+  NSR_TP(1);
   if (CAPTURE) mask_dst[8 * 256 + mask_tid] = relu_mask<4>(av);
 
   // rgb_linear (RH:117) on relu(av): VALU
@@ -468,6 +483,8 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
     float hi_half = h ? part[c] : other;
     raw[c] = ((lo_half + hi_half) + aux[(c < 3) ? (kAuxBRgb + c) : kAuxBAlpha]) + poison;
   }
+  NSR_TP(3);
+#undef NSR_TP
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -805,7 +822,11 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long tpass[4] = {0, 0, 0, 0};
   long long tlast = clock64();
+#define NSR_TPASS tpass
+#else
+#define NSR_TPASS nullptr
 #endif
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63;
@@ -897,7 +918,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       const float* ry = st.ray[r];
       float raw[4];
       mlp_pass<false, MODE>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
-               ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw);
+               ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, nullptr, 0, NSR_TPASS);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     }
     NSR_T(1);
@@ -976,7 +997,10 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 #ifdef NSR_PHASE_TIMING
   if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)      // diagnostic hijack: dbg_inds receives [grid][8] cycle totals
     for (int i = 0; i < 8; ++i) a_setup.dbg_inds[blockIdx.x * 8 + i] = tacc[i];
+  if (tid0 == 0 && a_setup.dbg_raw == nullptr && a_setup.dbg_inds)      // ... and [grid][4] network-pass breakdowns behind them
+    for (int i = 0; i < 4; ++i) a_setup.dbg_inds[(long long)gridDim.x * 8 + blockIdx.x * 4 + i] = tpass[i];
 #endif
+#undef NSR_TPASS
 }
 
 __global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {

@@ -5,10 +5,13 @@ outer-loop boundary -- one all-gather of the rendered images (1.92 MB fp32 per 4
 bilevel gradient, one all-reduce of the 8-float psi-gradient sum plus its patch count (NM:191 takes the mean
 over all patches of all poses, and every patch has the same weight)."""
 import os
+import time
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+LAST_TIMINGS = {}          # per-phase seconds of the last render_path_distributed call (max over ranks) when NSR_DIST_TIMING=1
 
 
 def world_info(group=None):
@@ -43,6 +46,31 @@ def _comm_device(group=None):
     return torch.device("cpu")
 
 
+_DEVICES_CHECKED = set()
+
+
+def check_distinct_devices(group=None):
+    """One process per GPU: with the nccl (= RCCL) backend every rank of a node must sit on its OWN device.  A script
+    that never calls torch.cuda.set_device(LOCAL_RANK) leaves every rank on GPU 0 -- RCCL then fails with a
+    duplicate-GPU error deep inside the first collective, or the ranks silently serialise on one device.  Checked once
+    per group, before the first sharded render: (hostname, device) pairs are all-gathered and must be distinct.
+    NSR_ALLOW_SHARED_GPU=1 (validation runs with gloo on a one-GPU box) skips it."""
+    key = id(group)
+    if key in _DEVICES_CHECKED or os.environ.get("NSR_ALLOW_SHARED_GPU", "0") == "1":
+        return
+    world, rank = world_info(group)
+    if world > 1 and dist.get_backend(group) == "nccl":
+        import socket
+        mine = (socket.gethostname(), torch.cuda.current_device())
+        seen = [None] * world
+        dist.all_gather_object(seen, mine, group=group)
+        if len(set(seen)) != world:
+            raise RuntimeError("view sharding over RCCL needs one GPU per rank, but the ranks sit on %s: call "
+                               "torch.cuda.set_device(int(os.environ['LOCAL_RANK'])) before the first render (INTEGRATION.md "
+                               "5), or set NSR_AUTO_SHARD=0" % (sorted(seen),))
+    _DEVICES_CHECKED.add(key)
+
+
 def check_same_poses(poses, group=None, tol=1e-6):
     """Sharding by index only makes sense if every rank holds the SAME pose list.  The reference seeds its pose
     sampler from the wall clock (LL:273), so ranks of an unchanged script can disagree: fail loudly then."""
@@ -72,28 +100,48 @@ def gather_views(local, n_total, group=None):
         local = local.to(_comm_device(group))
     pad = torch.zeros((k_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    out = torch.empty((n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        idx = shard_indices(n_total, world, r)
-        out[idx] = parts[r][:len(idx)]
-    return out
+    flat = torch.empty((world * k_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(flat, pad, group=group) if _has_into_tensor(group) else \
+        dist.all_gather(list(flat.chunk(world, 0)), pad, group=group)
+    # row r * k_max + j of `flat` is view r + j * world: ONE index_select puts the views in pose order
+    v = torch.arange(n_total, device=local.device)
+    return flat.index_select(0, (v % world) * k_max + v // world)
 
 
-def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, group=None, writer=None):
+def _has_into_tensor(group=None):
+    return hasattr(dist, "all_gather_into_tensor") and dist.get_backend(group) == "nccl"
+
+
+def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, group=None, writer=None,
+                            gather_disp=True):
     """render_path (RN:213-255) over all ranks.  `render_fn(poses [k,4,4]) -> (rgb [k,H,W,3], disp [k,H,W])`
     tensors on this rank's device (production: NsrModel.render_views; tests: any deterministic function).
     Returns (rgbs, disps) numpy arrays in pose order on every rank; savedir/<object_id>/%03d.png are written by the
-    rank that rendered them (pose index in the name, as RN:248-249)."""
+    rank that rendered them (pose index in the name, as RN:248-249).  gather_disp=False: a caller that drops the
+    disparities (NM:128 does) skips their all-gather and gets None.
+    NSR_DIST_TIMING=1: the seconds spent in render / png / gather_rgb / gather_disp (max over ranks, device-synchronised
+    per phase) are left in dist.LAST_TIMINGS and printed by rank 0 -- the numbers a first multi-GPU run is compared with
+    (per rank ceil(K / N) views x 0.33 s of rendering; every other phase must stay in the milliseconds)."""
     from .run_nerf_helpers import to8b
     from . import png
     world, rank = world_info(group)
+    timing = os.environ.get("NSR_DIST_TIMING", "0") == "1"
+    marks = {}
+
+    def mark(name, t0):
+        if timing:
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            marks[name] = marks.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
     poses = torch.as_tensor(render_poses, dtype=torch.float32).detach()
     n = poses.shape[0]
+    check_distinct_devices(group)
     check_same_poses(poses, group)
     mine = shard_indices(n, world, rank)
+    t0 = time.perf_counter()
     rgb, disp = render_fn(poses[mine])
+    t0 = mark("render", t0)
     if savedir is not None:                      # every rank writes its own views (one node, one file system):
         d = os.path.join(savedir, str(object_id))         # 6.5 ms of zlib per 400x400 PNG would otherwise serialise
         os.makedirs(d, exist_ok=True)                     # on rank 0 (100 views: 0.65 s against 4.2 s of rendering)
@@ -104,10 +152,22 @@ def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, 
         else:
             for k, name in enumerate(names):
                 writer(name, to8b(local[k]))
+    t0 = mark("png", t0)
     rgbs = gather_views(rgb, n, group).cpu().numpy()
-    disps = gather_views(disp, n, group).cpu().numpy()
+    t0 = mark("gather_rgb", t0)
+    disps = gather_views(disp, n, group).cpu().numpy() if gather_disp else None
+    t0 = mark("gather_disp", t0)
     if savedir is not None and world > 1:
         dist.barrier(group=group)                # the files of all ranks exist when any rank returns
+    if timing:
+        names = ("render", "png", "gather_rgb", "gather_disp")
+        buf = torch.tensor([marks.get(k, 0.0) for k in names], dtype=torch.float64, device=_comm_device(group))
+        if world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
+        LAST_TIMINGS.clear()
+        LAST_TIMINGS.update({k: float(v) for k, v in zip(names, buf.cpu().tolist())}, views=n, ranks=world)
+        if rank == 0:
+            print("render_path over %d rank(s), %d views: %s" % (world, n, ", ".join("%s %.4f s" % (k, LAST_TIMINGS[k]) for k in names)))
     return rgbs, disps
 
 

@@ -280,6 +280,13 @@ class NsrModel:
         _lib.check(self.lib.nsr_to8b(self.h, _dev(x), x.numel(), _dev(out), _stream_ptr(self.device)))
         return out
 
+    def fingerprint(self, ptr_table, n_words, out):
+        """64-bit content hash of the device buffers listed in ptr_table (int64 device tensor of addresses) with n_words
+        (int64 device tensor of 32-bit word counts) into `out` (int64 device tensor, 1 element); enqueue only."""
+        _lib.check(self.lib.nsr_fingerprint(self.h, _dev(ptr_table), _dev(n_words), int(ptr_table.numel()), _dev(out),
+                                            _stream_ptr(self.device)))
+        return out
+
     def find_bbox(self, rgb8, with_mask=False):
         """get_annotation / find_bbox (NM:786-797) on device: uint8 [K,H,W,3] RGB -> (bbox [K,4] int32 XYWH,
         count [K] int32[, mask [K,H,W] uint8])."""

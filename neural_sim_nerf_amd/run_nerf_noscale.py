@@ -30,6 +30,7 @@ DEBUG = False
 # native handles
 # ------------------------------------------------------------------------------------------------------
 _UTIL = {}
+_MAX_HANDLES_PER_MODULE = 8        # (render options, device, stream) handles kept per network pair, least recently used out
 
 
 def _util_model(dev=None):
@@ -57,7 +58,15 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     p0 = next(network_fn.parameters())
     dev = p0.device.index if p0.is_cuda else torch.cuda.current_device()
     stream_id = torch.cuda.current_stream(dev).cuda_stream
-    cache = network_fn.__dict__.setdefault("_nsr_pair", {}).setdefault((white, lindisp, dev, stream_id), {})
+    pair = network_fn.__dict__.setdefault("_nsr_pair", {})
+    slot = (white, lindisp, dev, stream_id)
+    cache = pair.pop(slot, None) or {}
+    pair[slot] = cache                                    # most recently used last
+    while len(pair) > _MAX_HANDLES_PER_MODULE:            # each handle holds 3 x 2 packed networks + ~19 MB of scratch
+        _, old = next(iter(pair.items()))
+        if old.get("model") is not None:
+            old["model"].close()
+        del pair[next(iter(pair))]
     if cache.get("key") != key:
         if cache.get("model") is not None:
             cache["model"].close()
@@ -308,6 +317,7 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
     shard = D.auto_shard_enabled()
     world, rank = D.world_info() if shard else (1, 0)
     if shard:
+        D.check_distinct_devices()
         D.check_same_poses(torch.stack([torch.as_tensor(p, dtype=torch.float32).detach() for p in render_poses[:n_poses]])
                            if n_poses else torch.zeros(0, 4, 4))
     mine = D.shard_indices(n_poses, world, rank)

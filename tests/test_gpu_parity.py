@@ -202,7 +202,7 @@ def test_render_rays_stagewise_and_golden(model, oracle, synth_nets):
     assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
     assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
     c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
-    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
+    assert c["rays_above_tol"] <= 0.08 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
 
 
 def test_render_rays_odd_and_single(model, oracle, synth_nets):
@@ -719,7 +719,7 @@ def test_x16_stagewise_and_golden(model16, oracle, synth_nets):
     _stagewise(model16, oracle, synth_nets, r, g["rays_o"], g["rays_d"], near, far)
     assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
     c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
-    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
+    assert c["rays_above_tol"] <= 0.08 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
 
 
 @pytest.fixture(scope="module")
@@ -741,7 +741,7 @@ def test_bf16x3_stagewise_and_golden(model_b3, model, oracle, synth_nets):
     assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
     assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
     c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
-    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
+    assert c["rays_above_tol"] <= 0.08 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
     # against the fp32-MFMA kernel on the same rays: network outputs agree to fp32 rounding, but are not the same bits
     r32 = model.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
     d = np.abs(cpu(r["raw0"]) - cpu(r32["raw0"]))
@@ -781,7 +781,7 @@ def test_f16x2_stagewise_and_golden(model_h2, model, oracle, synth_nets):
     assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
     assert_close(cpu(r["disp0"]), g["disp0"], rtol=1e-4, what="disp0 vs reference")
     c = _census(synth_nets, r, g["rays_o"], g["rays_d"], near, far, census_ref(g))
-    assert c["rays_above_tol"] <= 0.05 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
+    assert c["rays_above_tol"] <= 0.08 * c["rays"] and c["psnr_delta_db_excluding_attributed"] <= 0.01, c
     # against the fp32-MFMA kernel on the same rays: network outputs agree to fp32 rounding, but are not the same bits
     r32 = model.render_rays(g["rays_o"], g["rays_d"], near, far, debug=True)
     d = np.abs(cpu(r["raw0"]) - cpu(r32["raw0"]))

@@ -11,13 +11,14 @@ H = W = 400
 c2w = torch.as_tensor(S.sweep_poses(1, 0)[0][:3, :4], device=m.device)[None].contiguous()
 n = H * W
 o, ro, _ = m._outs(n, False)
-t = torch.zeros(512 * 8, dtype=torch.int64, device=m.device)
+t = torch.zeros(512 * 12, dtype=torch.int64, device=m.device)
 dbg = _lib.NsrDebugOut(None, None, _dev(t), None, None, None)
 K9 = (C.c_double * 9)(*[float(S.YCBV_K[i][j]) for i in range(3) for j in range(3)])
 for _ in range(2):
     _lib.check(m.lib.nsr_render_views(m.h, _dev(c2w), 1, H, W, K9, S.YCBV_NEAR, S.YCBV_FAR, C.byref(ro), C.byref(dbg), _stream_ptr(m.device)))
     ms = m.last_kernel_ms()
-tt = t.cpu().numpy().reshape(512, 8).astype(np.float64)
+raw_t = t.cpu().numpy().astype(np.float64)
+tt = raw_t[:512 * 8].reshape(512, 8)
 tt = tt[tt.sum(1) > 0]
 print('variant', V, 'workgroups', len(tt))
 names = ["stage rays", "network passes", "coarse composite+out", "sample_pdf", "z_std+dbg", "merge sort", "fine composite+out", "-"]
@@ -27,3 +28,10 @@ tot = tt.sum(1).mean()
 print("kernel ms %.2f  total cycles/WG %.3e (100 MHz counter? ratio to ms: %.1f MHz)" % (ms, tot, tot / ms / 1e3))
 for i, nm in enumerate(names):
     print("%-22s %6.2f %%   %.3e cycles/WG" % (nm, 100 * tt[:, i].mean() / tot, tt[:, i].mean()))
+
+if V == 32 and m.schedule != "phases":          # the x32-structured kernels also break the network passes down
+    g = len(tt)
+    tp = raw_t[g * 8:g * 8 + g * 4].reshape(g, 4)
+    ptot = tp.sum(1).mean()
+    for i, nm in enumerate(["encodings", "GEMMs", "between GEMMs (epilogue, bias, first split)", "heads + output"]):
+        print("  pass: %-44s %6.2f %% of the passes   %.3e cycles/WG" % (nm, 100 * tp[:, i].mean() / ptot, tp[:, i].mean()))
