@@ -7,13 +7,16 @@
  *
  *   gcc -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_host.c \
  *       -Lneural_sim_nerf_amd/csrc -lnsr -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/neural_sim_nerf_amd/csrc -o c_host
- *   ./c_host inputs.bin out.bin H W
+ *   ./c_host inputs.bin out.bin H W [fp32|f16x2]
  *
- * inputs.bin (float32, little endian): packed32 coarse | packed32 fine | packed16 coarse | packed16 fine (each
- * NSR_PACKED_FLOATS, from pack.py) | t_coarse[64] | u_fine[128] | c2w[12] | K[9] | near | far
+ * inputs.bin (float32, little endian): packed32 coarse | packed32 fine | packed16 coarse | packed16 fine | packed f16x2
+ * coarse | packed f16x2 fine (each NSR_PACKED_FLOATS, from pack.py) | t_coarse[64] | u_fine[128] | c2w[12] | K[9] | near | far
+ * The 5th argument picks the forward kernel: fp32 (k_render16p, the default here) or f16x2 (NSR_FLAG_MLP_F16X2, k_render_h2:
+ * the Python engine's default).
  */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <hip/hip_runtime_api.h>
 #include "nsr.h"
 
@@ -21,9 +24,10 @@
 #define CHECK_NSR(x) do { if ((x) != 0) { fprintf(stderr, "%s: %s\n", #x, nsr_last_error()); return 3; } } while (0)
 
 int main(int argc, char** argv) {
-  if (argc != 5) { fprintf(stderr, "usage: %s inputs.bin out.bin H W\n", argv[0]); return 1; }
+  if (argc != 5 && argc != 6) { fprintf(stderr, "usage: %s inputs.bin out.bin H W [fp32|f16x2]\n", argv[0]); return 1; }
   const int H = atoi(argv[3]), W = atoi(argv[4]);
-  const size_t n_in = 4 * (size_t)NSR_PACKED_FLOATS + 64 + 128 + 12 + 9 + 2;
+  const int h2 = argc == 6 && strcmp(argv[5], "f16x2") == 0;
+  const size_t n_in = 6 * (size_t)NSR_PACKED_FLOATS + 64 + 128 + 12 + 9 + 2;
   float* in = (float*)malloc(n_in * sizeof(float));
   FILE* f = fopen(argv[1], "rb");
   if (!f || fread(in, sizeof(float), n_in, f) != n_in) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
@@ -32,7 +36,9 @@ int main(int argc, char** argv) {
   const float* p32f = p32c + NSR_PACKED_FLOATS;
   const float* p16c = p32f + NSR_PACKED_FLOATS;
   const float* p16f = p16c + NSR_PACKED_FLOATS;
-  const float* t64 = p16f + NSR_PACKED_FLOATS;
+  const float* ph2c = p16f + NSR_PACKED_FLOATS;
+  const float* ph2f = ph2c + NSR_PACKED_FLOATS;
+  const float* t64 = ph2f + NSR_PACKED_FLOATS;
   const float* u128 = t64 + 64;
   const float* c2w = u128 + 128;
   const float* Kf = c2w + 12;
@@ -40,13 +46,18 @@ int main(int argc, char** argv) {
   double K9[9];
   for (int i = 0; i < 9; ++i) K9[i] = (double)Kf[i];
 
-  NsrConfig cfg = {NSR_ABI_VERSION, 0, NSR_N_SAMPLES, NSR_N_IMPORTANCE, 0, 0, NSR_FLAG_SCHED_PHASES, 0};
+  NsrConfig cfg = {NSR_ABI_VERSION, 0, NSR_N_SAMPLES, NSR_N_IMPORTANCE, 0, 0,
+                   NSR_FLAG_SCHED_PHASES | (h2 ? NSR_FLAG_MLP_F16X2 : 0), 0};
   nsr_handle h = NULL;
   CHECK_NSR(nsr_create(&cfg, &h));
   CHECK_NSR(nsr_upload_weights(h, 0, p32c, NSR_PACKED_FLOATS));
   CHECK_NSR(nsr_upload_weights(h, 1, p32f, NSR_PACKED_FLOATS));
   CHECK_NSR(nsr_upload_weights16(h, 0, p16c, NSR_PACKED_FLOATS));
   CHECK_NSR(nsr_upload_weights16(h, 1, p16f, NSR_PACKED_FLOATS));
+  if (h2) {
+    CHECK_NSR(nsr_upload_weights_h2(h, 0, ph2c, NSR_PACKED_FLOATS));
+    CHECK_NSR(nsr_upload_weights_h2(h, 1, ph2f, NSR_PACKED_FLOATS));
+  }
   CHECK_NSR(nsr_upload_tables(h, t64, 64, u128, 128));
   CHECK_NSR(nsr_selftest(h, NULL));
 

@@ -20,7 +20,11 @@ N_IMPORTANCE = 128
 # 328.1 vs 326.6 ms per 400x400 view (+0.5 %) for 4-5 GB instead of 20-90 GB of L2-miss (fabric) traffic per view
 # (profiles/r02/pmc_k_render.json); results are bit-identical.
 DEFAULT_SCHEDULE = "phases"
-DEFAULT_MLP = "fp32"             # layer-GEMM arithmetic of the forward render kernel (NsrModel)
+# Layer-GEMM arithmetic of the forward render kernel (NsrModel(mlp=...)).  r03: "f16x2" -- 112-115 ms per 400x400 view against
+# 328 (fp32 MFMAs) and 192 (bf16x3), network outputs as close to an fp64 evaluation as the fp32-MFMA kernel's (4.9e-6 vs
+# 4.6e-6 max error on the golden rays), every BASELINE config view inside the end-to-end acceptance rule with PSNR-delta
+# 0.000 dB (tests/test_gpu_parity.py census tests, bench.py `parity`).  NSR_MLP=fp32 in the environment restores r02's default.
+DEFAULT_MLP = "f16x2"
 MLP_MODES = ("fp32", "bf16x3", "f16x2")
 
 
@@ -55,7 +59,8 @@ class NsrModel:
         fp32 operands split exactly into three bf16 pieces, NSR_FLAG_MLP_BF16X3: fp32-grade results, ~1.9x the MFMA
         rate) or "f16x2" (fp16 MFMAs on fp32 operands split into two fp16 pieces with power-of-two range management,
         NSR_FLAG_MLP_F16X2: fp32-grade results at half of bf16x3's MFMA work; forward kernel only -- input gradients of
-        such a handle run on the fp32 kernels); None: $NSR_MLP, else DEFAULT_MLP."""
+        such a handle run on the fp32 kernels); None: "fp32" when `variant` (16 / 32) or `schedule` is given -- they name
+        fp32 forward kernels --, else $NSR_MLP, else DEFAULT_MLP."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
@@ -66,12 +71,14 @@ class NsrModel:
             chunk = int(os.environ.get("NSR_CHUNK", "0") or 0)
         if not 0 <= int(chunk) <= 256:
             raise ValueError("chunk must be in 0..256")
+        schedule_given = schedule is not None
         if schedule is None:
             schedule = os.environ.get("NSR_SCHEDULE", DEFAULT_SCHEDULE)
         if schedule not in ("queue", "phases"):
             raise ValueError("schedule must be 'queue' or 'phases'")
         if mlp is None:
-            mlp = os.environ.get("NSR_MLP", DEFAULT_MLP)
+            # `variant` 16 / 32 and `schedule` name fp32 forward kernels: a caller who asks for one of them gets it
+            mlp = "fp32" if (variant in (16, 32) or schedule_given) else os.environ.get("NSR_MLP", DEFAULT_MLP)
         if mlp not in MLP_MODES:
             raise ValueError("mlp must be one of %s" % (MLP_MODES,))
         self.mlp = mlp

@@ -435,8 +435,8 @@ def pack_network_backward_b3(sd):
 # "f16x2" forward layout (csrc/nsr_h2.inc, k_render_h2): v_mfma_f32_32x32x16_f16, every fp32 weight as two fp16 pieces
 # ----------------------------------------------------------------------------------------------------------
 # Same MFMA operand layout as bf16x3 (8 k-slots per lane, slot i of k16 block kb = k-step 8 kb + i of the fp32 x32 layout),
-# 2 pieces x 2 bytes per weight: the stream has the fp32 stream's size and segment order (STREAM_SLABS).  A step is the 4
-# chunks [hi(b), hi(b+1), lo(b), lo(b+1)] of two consecutive output blocks of one k16 block.
+# 2 pieces x 2 bytes per weight: the stream has the fp32 stream's size and segment order (STREAM_SLABS).  Step st of a k16
+# block is the 4 chunks [hi(2st), hi(2st+1), lo(2(st^1)), lo(2(st^1)+1)].
 # Range management (all exact powers of two):
 #   sw[l]   weights of layer l are stored as W * 2^sw[l] with max|W| * 2^sw[l] in [2^14, 2^15)          (l = 0..9, 8 =
 #           feature_linear, 9 = views_linears.0; the two column groups of L5 and of the views layer share one sw)
@@ -475,7 +475,8 @@ def h2_weight_scale_log2(*mats):
 
 def _pack_h2(W, cols, n_mo):
     """W [32*n_mo, K] (ALREADY scaled); cols [n_ksteps, 2] (reference column or -1), n_ksteps a multiple of 8.  Returns uint16
-    [n_kb * n_mo * 2 chunks, 64, 8]: per k16 block, per pair of output blocks, the chunks hi(b), hi(b+1), lo(b), lo(b+1)."""
+    [n_kb * n_mo * 2 chunks, 64, 8]: per k16 block, per step st, the chunks hi(2st), hi(2st+1), lo(2(st^1)), lo(2(st^1)+1)
+    (csrc/nsr_h2.inc: the six MFMAs of a step then touch four different accumulators)."""
     assert W.shape[0] == 32 * n_mo and cols.shape[0] % 8 == 0 and n_mo % 2 == 0
     n_kb = cols.shape[0] // 8
     Wp = np.concatenate([W, np.zeros((W.shape[0], 1), W.dtype)], 1)       # column -1 -> zeros
@@ -491,8 +492,9 @@ def _pack_h2(W, cols, n_mo):
     out = np.empty((n_kb * n_mo * 2, 64, 8), np.uint16)
     n = 0
     for kb in range(n_kb):
-        for b in range(0, n_mo, 2):
-            for piece, mo in ((hi, b), (hi, b + 1), (lo, b), (lo, b + 1)):
+        for st in range(n_mo // 2):                      # step st: hi pieces of blocks 2st, 2st+1, lo pieces of the partner pair
+            hb, lb = 2 * st, 2 * (st ^ 1)
+            for piece, mo in ((hi, hb), (hi, hb + 1), (lo, lb), (lo, lb + 1)):
                 out[n] = piece[kb, mo]
                 n += 1
     return out

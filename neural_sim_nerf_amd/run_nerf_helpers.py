@@ -66,6 +66,28 @@ class NeRF(nn.Module):
         self._native = None
         self._native_key = None
 
+    @staticmethod
+    def weights_version_of(*nets):
+        """weights_version() of several modules with ONE fingerprint launch and ONE read-back when they all sit on one HIP
+        device (render()'s cache key covers network_fn and network_fine: two launches + two syncs per call otherwise)."""
+        nets = [n for n in nets if n is not None]
+        ps = [p for n in nets for p in n.parameters()]
+        if len(nets) < 2 or not ps or not all(p.is_cuda and p.device == ps[0].device and p.dtype == torch.float32
+                                              and p.is_contiguous() for p in ps):
+            return tuple(n.weights_version() for n in nets)
+        from .run_nerf_noscale import _util_model
+        dev = ps[0].device
+        ident = tuple((p.data_ptr(), p._version) for p in ps)
+        ptrs = tuple(p.data_ptr() for p in ps)
+        st = nets[0].__dict__.get("_fp_pair_state")
+        if st is None or st["ptrs"] != ptrs or st["dev"] != dev:
+            st = {"ptrs": ptrs, "dev": dev, "table": torch.tensor(ptrs, dtype=torch.int64, device=dev),
+                  "words": torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=dev),
+                  "out": torch.zeros(1, dtype=torch.int64, device=dev)}
+            nets[0].__dict__["_fp_pair_state"] = st
+        _util_model(dev).fingerprint(st["table"], st["words"], st["out"])
+        return ident, (int(st["out"].item()),)
+
     def weights_version(self):
         """Key of the packed-weight cache: storage identity + autograd version of every parameter (catches
         load_state_dict, optimizer steps, `.data = ...`) AND a content fingerprint, because in-place writes through
@@ -117,7 +139,7 @@ class NeRF(nn.Module):
             if self._native is not None:
                 self._native.close()
             p0 = next(self.parameters())
-            self._native = NsrModel(self.state_dict(), None, n_importance=0,
+            self._native = NsrModel(self.state_dict(), None, n_importance=0, mlp="fp32",       # k_run_network (stage kernel)
                                     device=p0.device.index if p0.is_cuda else None)     # the module's device, not the current one
             self._native_key = key
         return self._native

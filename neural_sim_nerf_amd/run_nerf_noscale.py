@@ -39,7 +39,7 @@ def _util_model(dev=None):
     from .synthetic import synth_weights
     idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
     if idx not in _UTIL:
-        _UTIL[idx] = NsrModel(synth_weights(0), None, device=idx, n_importance=0)
+        _UTIL[idx] = NsrModel(synth_weights(0), None, device=idx, n_importance=0, mlp="fp32")   # stage kernels only
     return _UTIL[idx]
 
 
@@ -50,8 +50,7 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
         raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
     white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
-    key = (n_importance, network_fn.weights_version(),
-           network_fine.weights_version() if network_fine is not None else None,
+    key = (n_importance, NeRF.weights_version_of(network_fn, network_fine),
            os.environ.get("NSR_MLP"))           # forward-kernel arithmetic (engine.NsrModel: "fp32" / "bf16x3")
     # a native handle owns ONE argument block / work queue / scratch set (include/nsr.h: one handle per (model,
     # stream)), so the cache is also keyed on the device and on the torch stream the launch will be issued on

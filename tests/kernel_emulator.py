@@ -516,11 +516,12 @@ class StreamH2:
             t = (src(kb) * np.float32(scale(kb))).astype(np.float32)
             self.amax = np.maximum(self.amax, np.abs(t).max(1))
             hi, lo, _ = split_h2(src(kb), scale(kb))
-            for b0 in range(0, nmo, 2):                              # one step: hi(b0), hi(b0+1), lo(b0), lo(b0+1)
+            for st in range(nmo // 2):                               # one step: hi(HB), hi(HB+1), lo(LB), lo(LB+1)
+                hb, lb = 2 * st, 2 * (st ^ 1)
                 A = [self.chunks[self.pos + c] for c in range(4)]
                 self.pos += 4
-                for a, bb, mo in ((A[2], hi, b0), (A[3], hi, b0 + 1), (A[0], lo, b0), (A[1], lo, b0 + 1),
-                                  (A[0], hi, b0), (A[1], hi, b0 + 1)):
+                for a, bb, mo in ((A[0], lo, hb), (A[1], lo, hb + 1), (A[2], hi, lb), (A[3], hi, lb + 1),
+                                  (A[0], hi, hb), (A[1], hi, hb + 1)):
                     acc[mo] = mfma_b3(a, bb, acc[mo])                # same operand layout as the bf16 MFMA
 
 

@@ -982,7 +982,7 @@ def test_bf16x3_full_size_view_properties(synth_nets, oracle):
     K = oracle.YCBV_K
     poses = np.asarray(oracle.sweep_poses(2, seed=21))
     m3 = NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3")
-    m32 = NsrModel(synth_nets[0], synth_nets[1])
+    m32 = NsrModel(synth_nets[0], synth_nets[1], mlp="fp32")
     full = m3.render_views(poses[0], 400, 400, K, near, far)
     again = m3.render_views(poses[0], 400, 400, K, near, far)
     keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
@@ -1298,20 +1298,22 @@ def test_c_host_matches_python_engine(tmp_path, synth_nets, oracle):
     pose = np.asarray(oracle.sweep_poses(1, seed=13))[0]
     t64, u128 = _host_tables()
     parts = [pack.pack_network(synth_nets[0]), pack.pack_network(synth_nets[1]), pack.pack_network16(synth_nets[0]),
-             pack.pack_network16(synth_nets[1]), t64, u128, pose[:3, :4].reshape(-1).astype(np.float32),
+             pack.pack_network16(synth_nets[1]), pack.pack_network_h2(synth_nets[0]), pack.pack_network_h2(synth_nets[1]),
+             t64, u128, pose[:3, :4].reshape(-1).astype(np.float32),
              np.asarray(K, np.float32).reshape(-1), np.array([oracle.YCBV_NEAR, oracle.YCBV_FAR], np.float32)]
     np.concatenate([p.astype(np.float32).reshape(-1) for p in parts]).tofile(str(tmp_path / "in.bin"))
     env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
-    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(H), str(W)], capture_output=True,
-                       text=True, timeout=120, env=env)
-    assert r.returncode == 0, r.stderr
-    got = np.fromfile(str(tmp_path / "out.bin"), np.float32)
     n = H * W
-    m = NsrModel(synth_nets[0], synth_nets[1])
     K32 = np.asarray(K, np.float32).astype(np.float64).tolist()      # the C program widens the float32 intrinsics
-    want = m.render_views(pose, H, W, K32, float(np.float32(oracle.YCBV_NEAR)), float(np.float32(oracle.YCBV_FAR)))
-    off = 0
-    for key, width in (("rgb_map", 3), ("disp_map", 1), ("acc_map", 1), ("rgb0", 3), ("disp0", 1), ("acc0", 1), ("z_std", 1)):
-        assert np.array_equal(got[off:off + width * n], cpu(want[key]).reshape(-1), equal_nan=True), key
-        off += width * n
-    m.close()
+    for mlp in ("fp32", "f16x2"):                                     # k_render16p, and the engine's default k_render_h2
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin"), str(H), str(W), mlp],
+                           capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+        got = np.fromfile(str(tmp_path / "out.bin"), np.float32)
+        m = NsrModel(synth_nets[0], synth_nets[1], mlp=mlp)
+        want = m.render_views(pose, H, W, K32, float(np.float32(oracle.YCBV_NEAR)), float(np.float32(oracle.YCBV_FAR)))
+        off = 0
+        for key, width in (("rgb_map", 3), ("disp_map", 1), ("acc_map", 1), ("rgb0", 3), ("disp0", 1), ("acc0", 1), ("z_std", 1)):
+            assert np.array_equal(got[off:off + width * n], cpu(want[key]).reshape(-1), equal_nan=True), (mlp, key)
+            off += width * n
+        m.close()

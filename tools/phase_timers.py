@@ -18,7 +18,9 @@ for _ in range(2):
     _lib.check(m.lib.nsr_render_views(m.h, _dev(c2w), 1, H, W, K9, S.YCBV_NEAR, S.YCBV_FAR, C.byref(ro), C.byref(dbg), _stream_ptr(m.device)))
     ms = m.last_kernel_ms()
 raw_t = t.cpu().numpy().astype(np.float64)
-tt = raw_t[:512 * 8].reshape(512, 8)
+x32 = (V == 32 or m.mlp != "fp32") and m.schedule != "phases"      # the x32-structured kernels: one workgroup per CU,
+G = torch.cuda.get_device_properties(m.device).multi_processor_count if x32 else 512   # [grid][8] totals + [grid][4] pass breakdown
+tt = raw_t[:G * 8].reshape(G, 8)
 tt = tt[tt.sum(1) > 0]
 print('variant', V, 'workgroups', len(tt))
 names = ["stage rays", "network passes", "coarse composite+out", "sample_pdf", "z_std+dbg", "merge sort", "fine composite+out", "-"]
@@ -29,9 +31,9 @@ print("kernel ms %.2f  total cycles/WG %.3e (100 MHz counter? ratio to ms: %.1f 
 for i, nm in enumerate(names):
     print("%-22s %6.2f %%   %.3e cycles/WG" % (nm, 100 * tt[:, i].mean() / tot, tt[:, i].mean()))
 
-if V == 32 and m.schedule != "phases":          # the x32-structured kernels also break the network passes down
-    g = len(tt)
-    tp = raw_t[g * 8:g * 8 + g * 4].reshape(g, 4)
+if x32:                                          # the x32-structured kernels also break the network passes down
+    tp = raw_t[G * 8:G * 8 + G * 4].reshape(G, 4)
+    tp = tp[tp.sum(1) > 0]
     ptot = tp.sum(1).mean()
     for i, nm in enumerate(["encodings", "GEMMs", "between GEMMs (epilogue, bias, first split)", "heads + output"]):
         print("  pass: %-44s %6.2f %% of the passes   %.3e cycles/WG" % (nm, 100 * tp[:, i].mean() / ptot, tp[:, i].mean()))
