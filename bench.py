@@ -64,6 +64,8 @@ METRIC = "Mray-samples/sec at 400x400, 64+128 samples, 8x256 MLP"
 MLP_MODES = ("fp32", "bf16x3", "f16x2")    # layer-GEMM arithmetics of the forward kernels (engine.NsrModel(mlp=...))
 # f16x2 (NSR_FLAG_MLP_F16X2): 3 piece products x the k16-padded layer shapes (csrc/nsr_h2.inc); fp16 MFMA peak = bf16's
 H2_ISSUED_FLOP_PER_POINT = 2 * 3 * (256 * 64 + 4 * 256 * 256 + 256 * (64 + 256) + 2 * 256 * 256 + 256 * 256 + 128 * 288)
+# ... and per transposed evaluation (2-block encoding GEMMs + 8-block GEMMs, csrc/nsr_h2_bwd.inc)
+H2_ISSUED_FLOP_PER_POINT_BWD = 2 * 3 * ((64 + 256) * 128 + 256 * 256 + 2 * 256 * 256 + (64 + 256) * 256 + 4 * 256 * 256 + 64 * 256)
 MLP_DTYPE = {"bf16x3": "bf16x3: fp32 operands as three bf16 pieces each, six piece products per fp32 product, fp32 accumulate",
              "f16x2": "f16x2: fp32 operands as two fp16 pieces each (power-of-two range management), three piece products per "
                       "fp32 product, fp32 accumulate"}
@@ -130,8 +132,7 @@ def alt_mlp_workload(mlp, sd_c, sd_f, device, c2w, ref, launches=3, sample=None)
                "rgb0_max_abs": float(d["rgb0"].max()),
                "rays_with_rgb_diff_above_1e-4": int((d["rgb_map"].max(-1).values > 1e-4).sum())},
            "how_to_enable": "NsrModel(..., mlp='%s') / NSR_MLP=%s / bench.py --mlp %s" % (mlp, mlp, mlp)}
-    if mlp != "f16x2":                       # an f16x2 handle's input gradients run on the fp32 kernels (the main line's)
-        res["roofline_vjp"] = vjp_roofline(m, c2w)
+    res["roofline_vjp"] = vjp_roofline(m, c2w)
     if sample is not None:                   # the same `parity` object as the main line's, against the same oracle output
         res["parity"] = parity_vs_oracle(m, sample)
     m.close()
@@ -423,14 +424,16 @@ def vjp_roofline(model, c2w, pmc_file=None):
     ach = H * W * FLOP_PER_RAY_VJP / (k_ms * 1e-3) / 1e12
     flop_note = ("per ray: 256 forward evaluations + 192 evaluations of the transposed fine network (input-side "
                  "VJP only: weights are constants) x 1 186 816 FLOP = 531.7 MFLOP")
-    if model.mlp == "bf16x3":
-        issued = H * W * (EVALS_PER_RAY * B3_ISSUED_FLOP_PER_POINT + 192 * B3_ISSUED_FLOP_PER_POINT_BWD) / (k_ms * 1e-3) / 1e12
+    if model.mlp in ("bf16x3", "f16x2"):
+        fwd, bwd = ((B3_ISSUED_FLOP_PER_POINT, B3_ISSUED_FLOP_PER_POINT_BWD) if model.mlp == "bf16x3" else
+                    (H2_ISSUED_FLOP_PER_POINT, H2_ISSUED_FLOP_PER_POINT_BWD))
+        issued = H * W * (EVALS_PER_RAY * fwd + 192 * bwd) / (k_ms * 1e-3) / 1e12
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "issued": round(issued, 1),
                 "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
                 "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": None,
-                "kernel": "nsr::k_render_vjp_b3", "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP,
-                "flop_note": flop_note}
+                "kernel": "nsr::k_render_vjp_b3" if model.mlp == "bf16x3" else "nsr::k_render_vjp_h2",
+                "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP, "flop_note": flop_note}
     traffic = None
     if pmc_file and os.path.exists(pmc_file) and model.variant != 32:
         prof = json.load(open(pmc_file))

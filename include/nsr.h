@@ -52,6 +52,7 @@ extern "C" {
 #define NSR_STREAM_SLABS_B3  219
 #define NSR_PACKED_B3_FLOATS (NSR_STREAM_SLABS_B3 * NSR_SLAB_FLOATS + NSR_AUX_FLOATS)
 #define NSR_STREAM_SLABS_B3_BWD 234            /* slabs of the transposed fine network in that layout */
+#define NSR_STREAM_SLABS_H2_BWD 146            /* ... and in the f16x2 layout (NSR_FLAG_MLP_F16X2)     */
 
 typedef struct nsr_handle_s* nsr_handle;
 
@@ -95,7 +96,9 @@ typedef struct NsrConfig {
                                    work of bf16x3.  Domain: a hidden activation whose scaled magnitude reaches 65504 makes
                                    that point's outputs NaN (loud, never a wrong number).  One workgroup per CU, 32 points
                                    per wave; needs nsr_upload_weights_h2.  Mutually exclusive with NSR_FLAG_MLP_BF16X3.
-                                   nsr_render_rays_vjp on such a handle runs the fp32 input-gradient kernels.           */
+                                   nsr_render_rays_vjp runs the same scheme (k_render_vjp_h2: forward and transposed GEMMs
+                                   on fp16 MFMAs, the gradients of every point normalised by a power of two on entry) once
+                                   nsr_upload_weights_bwd_h2 has been called; before that, the fp32 kernels of `variant`.  */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {
@@ -139,6 +142,10 @@ int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t 
  * fp16 pairs -- 2 pieces x 2 bytes = the fp32 stream's size -- the aux block holds the scaled biases / heads and the
  * activation scales).  Handles created with NSR_FLAG_MLP_F16X2. */
 int nsr_upload_weights_h2(nsr_handle h, int net_id, const float* packed, size_t n_floats);
+
+/* Transposed stream of the FINE network in the f16x2 layout (pack.py: pack_network_backward_h2; NSR_STREAM_SLABS_H2_BWD *
+ * NSR_SLAB_FLOATS floats; its multipliers live in the aux block nsr_upload_weights_h2 received for net_id 1). */
+int nsr_upload_weights_bwd_h2(nsr_handle h, const float* stream, size_t n_floats);
 
 /* Transposed stream of the FINE network in the bf16x3 layout (pack.py: pack_network_backward_b3;
  * NSR_STREAM_SLABS_B3_BWD * NSR_SLAB_FLOATS floats), for nsr_render_rays_vjp on an NSR_FLAG_MLP_BF16X3 handle. */

@@ -37,6 +37,7 @@ SIGNATURES = {
     "nsr_upload_weights_b3": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_bwd_b3": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_h2": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_size_t]),
+    "nsr_upload_weights_bwd_h2": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_bwd": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_weights_bwd16": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "nsr_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
@@ -75,7 +76,7 @@ SIGNATURES = {
 
 _lib = None
 
-KERNEL_SOURCES = ("nsr_device.h", "nsr_kernels.hip", "nsr_b3.inc", "nsr_h2.inc", "nsr_handoff.hip", "nsr_pose.hip", "nsr_api.hip")
+KERNEL_SOURCES = ("nsr_device.h", "nsr_kernels.hip", "nsr_b3.inc", "nsr_h2.inc", "nsr_h2_bwd.inc", "nsr_handoff.hip", "nsr_pose.hip", "nsr_api.hip")
 
 
 def kernel_source_hash():

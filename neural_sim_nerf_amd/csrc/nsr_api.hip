@@ -21,6 +21,7 @@ static_assert(NSR_STREAM_SLABS == nsr::kStreamSlabs, "header/kernels out of sync
 static_assert(NSR_AUX_FLOATS == nsr::kAuxFloats, "header/kernels out of sync");
 static_assert(NSR_STREAM_SLABS_B3 == nsr::kStreamSlabsB3, "header/kernels out of sync");
 static_assert(NSR_STREAM_SLABS_B3_BWD == nsr::kStreamSlabsB3Bwd, "header/kernels out of sync");
+static_assert(NSR_STREAM_SLABS_H2_BWD == nsr::kStreamSlabsH2Bwd, "header/kernels out of sync");
 
 namespace {
 
@@ -59,6 +60,9 @@ constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
 // bf16x3 images in d_nets_b3: coarse | fine | fine transposed, kB3Stride floats apart (the transposed stream is the longest)
 constexpr size_t kB3Stride = (size_t)NSR_STREAM_SLABS_B3_BWD * NSR_SLAB_FLOATS + NSR_AUX_FLOATS;
 static_assert(kB3Stride >= (size_t)NSR_PACKED_B3_FLOATS, "stride covers the forward images");
+// f16x2 images in d_nets_h2: coarse | fine | fine transposed, kH2Stride floats apart (the transposed stream is one slab longer)
+constexpr size_t kH2Stride = (size_t)NSR_STREAM_SLABS_H2_BWD * NSR_SLAB_FLOATS + NSR_AUX_FLOATS;
+static_assert(kH2Stride >= (size_t)NSR_PACKED_FLOATS, "stride covers the forward images");
 
 }  // namespace
 
@@ -73,8 +77,8 @@ struct nsr_handle_s {
   bool have_net16[3] = {false, false, false};
   float* d_nets_b3 = nullptr;                           // coarse | fine | fine transposed in the bf16x3 layout
   bool have_net_b3[3] = {false, false, false};          // (NSR_FLAG_MLP_BF16X3)
-  float* d_nets_h2 = nullptr;                           // coarse | fine in the f16x2 layout, NSR_PACKED_FLOATS apart
-  bool have_net_h2[2] = {false, false};                 // (NSR_FLAG_MLP_F16X2)
+  float* d_nets_h2 = nullptr;                           // coarse | fine | fine transposed in the f16x2 layout, kH2Stride apart
+  bool have_net_h2[3] = {false, false, false};          // (NSR_FLAG_MLP_F16X2)
   float* d_tables = nullptr;  // [64] + [128]
   bool have_tables = false;
   float* d_scratch = nullptr;  // selftest
@@ -134,8 +138,9 @@ static int allocate_handle(nsr_handle h) {
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   }
   if (cfg->flags & NSR_FLAG_MLP_F16X2) {
-    NSR_HIP(hipMalloc(&h->d_nets_h2, sizeof(float) * 2 * NSR_PACKED_FLOATS));
+    NSR_HIP(hipMalloc(&h->d_nets_h2, sizeof(float) * 3 * kH2Stride));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   }
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
@@ -290,8 +295,19 @@ int nsr_upload_weights_h2(nsr_handle h, int net_id, const float* packed, size_t 
   if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights_h2: net_id must be 0 (coarse) or 1 (fine)");
   if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights_h2: wrong packed size");
   NSR_DEVICE(h);
-  NSR_HIP(hipMemcpy(h->d_nets_h2 + (size_t)net_id * NSR_PACKED_FLOATS, packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  NSR_HIP(hipMemcpy(h->d_nets_h2 + (size_t)net_id * kH2Stride, packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   h->have_net_h2[net_id] = true;
+  return 0;
+}
+
+int nsr_upload_weights_bwd_h2(nsr_handle h, const float* stream, size_t n_floats) {
+  if (!h || !stream) return fail("nsr_upload_weights_bwd_h2: null argument");
+  if (!(h->cfg.flags & NSR_FLAG_MLP_F16X2)) return fail("nsr_upload_weights_bwd_h2: the handle was not created with NSR_FLAG_MLP_F16X2");
+  if (n_floats != (size_t)NSR_STREAM_SLABS_H2_BWD * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd_h2: wrong stream size");
+  NSR_DEVICE(h);
+  NSR_HIP(hipMemcpy(h->d_nets_h2 + 2 * kH2Stride, stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
+  if (int e = alloc_mask_scratch(h)) return e;
+  h->have_net_h2[2] = true;
   return 0;
 }
 
@@ -360,7 +376,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   if (a.n_rays <= 0) return 0;
   NSR_DEVICE(h);
   float* nets = h2 ? h->d_nets_h2 : (b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets));
-  const size_t net_floats = b3 ? kB3Stride : (size_t)NSR_PACKED_FLOATS;
+  const size_t net_floats = b3 ? kB3Stride : (h2 ? kH2Stride : (size_t)NSR_PACKED_FLOATS);
   const size_t stream_floats = (size_t)(b3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
   a.nets = nets;
   a.net_stride = (long long)sizeof(float) * (long long)net_floats;
@@ -466,12 +482,15 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
   if (int e = check_ready(h, true)) return e;
   const bool b3 = (h->cfg.flags & NSR_FLAG_MLP_BF16X3) != 0;
-  const bool x16 = use_x16(h) && !b3;
+  // an f16x2 handle runs its input gradients on fp16 MFMAs too once the transposed stream is there (nsr_upload_weights_bwd_h2);
+  // without it the fp32 kernels of `variant` serve (they need their own uploads)
+  const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) && h->have_net_h2[0] && h->have_net_h2[1] && h->have_net_h2[2];
+  const bool x16 = use_x16(h) && !b3 && !h2;
   if (b3 && !(h->have_net_b3[0] && h->have_net_b3[1] && h->have_net_b3[2]))
     return fail("nsr_render_rays_vjp: NSR_FLAG_MLP_BF16X3 needs nsr_upload_weights_b3 (both networks) and nsr_upload_weights_bwd_b3");
   if (x16 && !(h->have_net16[0] && h->have_net16[1] && h->have_net16[2]))
     return fail("nsr_render_rays_vjp: variant 16 needs nsr_upload_weights16 (both networks) and nsr_upload_weights_bwd16");
-  if (!x16 && !b3 && !h->have_net[2]) return fail("nsr_render_rays_vjp: backward stream not uploaded (nsr_upload_weights_bwd)");
+  if (!x16 && !b3 && !h2 && !h->have_net[2]) return fail("nsr_render_rays_vjp: backward stream not uploaded (nsr_upload_weights_bwd)");
   if (!d_rays_o || !d_rays_d || !d_grad_rgb || !d_grad_o || !d_grad_d) return fail("nsr_render_rays_vjp: null argument");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_render_rays_vjp: negative ray count");
   NSR_DEVICE(h);
@@ -492,8 +511,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   memset(&v, 0, sizeof(v));
   nsr::RenderArgs& a = v.r;
   a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.n_rays = n_rays; a.near_ = near_; a.far_ = far_; a.camera = 0;
-  float* nets = b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets);
-  const size_t net_floats = b3 ? kB3Stride : (size_t)NSR_PACKED_FLOATS;
+  float* nets = h2 ? h->d_nets_h2 : (b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets));
+  const size_t net_floats = b3 ? kB3Stride : (h2 ? kH2Stride : (size_t)NSR_PACKED_FLOATS);
   const size_t stream_floats = (size_t)(b3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
   a.nets = nets;
   a.net_stride = (long long)sizeof(float) * (long long)net_floats;
@@ -527,6 +546,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
     hipLaunchKernelGGL(nsr::k_render_vjp16, dim3((int)grid), dim3(256), kVjp16Lds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else if (b3)
     hipLaunchKernelGGL(nsr::k_render_vjp_b3, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  else if (h2)
+    hipLaunchKernelGGL(nsr::k_render_vjp_h2, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else
     hipLaunchKernelGGL(nsr::k_render_vjp, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   NSR_HIP(hipGetLastError());

@@ -27,6 +27,7 @@ constexpr int kAuxBRgb = 3073;       // 3
 constexpr int kAuxH2Scale = 3080;    // f16x2 layout only (nsr_h2.inc): the powers of two activations are multiplied with before
                                      // the fp16 split -- [0] encoding @ L0, [1..8] hidden input of L1..L7 / feature_linear,
                                      // [9] encoding @ L5, [10] feature @ views layer, [11] direction encoding @ views layer
+constexpr int kAuxH2Bwd = 3096;      // f16x2, transposed network (nsr_h2_bwd.inc): 14 power-of-two multipliers of the backward chain
 constexpr int kAuxFloats = 3328;     // padded to 13 KiB
 
 // LDS map of the fused kernel (bytes)

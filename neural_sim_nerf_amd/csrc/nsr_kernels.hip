@@ -1051,14 +1051,22 @@ __device__ __forceinline__ void embed_bwd(const float (&x)[3], const float* G /*
     }
 }
 
-// B3: the transposed GEMMs on bf16 MFMAs (nsr_b3.inc): every 9- or 10-block segment becomes an 8-block GEMM for the hidden
-// features plus a 4-block GEMM for the encoding rows (1 or 2 real blocks; the packer pads with zero weights).
-template <bool B3 = false>
+#include "nsr_h2_bwd.inc"
+
+// MODE kMlpB3: the transposed GEMMs on bf16 MFMAs (nsr_b3.inc): every 9- or 10-block segment becomes an 8-block GEMM for
+// the hidden features plus a 4-block GEMM for the encoding rows (1 or 2 real blocks; the packer pads with zero weights).
+// MODE kMlpH2: fp16 MFMAs, per-point normalised gradients (nsr_h2_bwd.inc).
+template <int MODE = kMlpF32>
 __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (&A0)[4], f32x4 (&A1)[4], int lane,
                                              const uint4* mask_src /* uniform */, int mask_tid, float g0, float g1,
                                              float g2, float gs, const float* ry /* LDS: the ray block */,
                                              const float* zrow /* LDS: z of this wave's 32 points */,
                                              float (&dp)[3], float (&dv)[3]) {
+  if constexpr (MODE == kMlpH2) {
+    mlp_bwd_pass_h2(rg, aux, A0, A1, lane, mask_src, mask_tid, g0, g1, g2, gs, ry, zrow, dp, dv);
+    return;
+  }
+  constexpr bool B3 = MODE == kMlpB3;
   const int h = lane >> 5;
   const int h4 = aux_half(lane);
   // rgb_linear^T (VALU) masked by the views layer's relu pattern
@@ -1259,8 +1267,9 @@ __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; *a.r.w
 //   pass 4-6    fine backward through the transposed network -> dL/d pts, dL/d viewdir per sample
 //   --          per-ray reduction: dL/d rays_o, dL/d rays_d
 // ------------------------------------------------------------------------------------------------------
-template <bool B3>
+template <int MODE>
 __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp, char* smem) {
+  constexpr bool B3 = MODE == kMlpB3;
   const VjpArgs& va_setup = *vp;
   const RenderArgs& a_setup = va_setup.r;
   const int tid0 = threadIdx.x;
@@ -1278,6 +1287,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
+  else if constexpr (MODE == kMlpH2) ring_start<kRingSlots, kStreamSlabs, kStreamSlabsH2Bwd>(rg, A0, lane);
   else ring_start(rg, A0, lane);
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
@@ -1343,7 +1353,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass<true, B3>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+      mlp_pass<true, MODE>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                          ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
     } else {
@@ -1354,7 +1364,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       const float* ry = st.ray[r];
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
-      mlp_bwd_pass<B3>(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
+      mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
                        ry, &st.zf[r][i - j], dp, dv);
       // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
       float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
@@ -1440,12 +1450,17 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
 
 __global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict__ vp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<false>(vp, smem);
+  render_vjp32_body<kMlpF32>(vp, smem);
 }
 // the same kernel with every GEMM, forward and transposed, on bf16 MFMAs with three-way split operands (nsr_b3.inc)
 __global__ void __launch_bounds__(256, 1) k_render_vjp_b3(const VjpArgs* __restrict__ vp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<true>(vp, smem);
+  render_vjp32_body<kMlpB3>(vp, smem);
+}
+// ... and on fp16 MFMAs with two-way split operands; the gradients are normalised per point (nsr_h2_bwd.inc)
+__global__ void __launch_bounds__(256, 1) k_render_vjp_h2(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<kMlpH2>(vp, smem);
 }
 
 // dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from .pack import (pack_network, pack_network16, pack_network_backward, pack_network_backward16, pack_network_b3,
-                   pack_network_backward_b3, pack_network_h2,
+                   pack_network_backward_b3, pack_network_h2, pack_network_backward_h2,
                    PACKED_FLOATS, PACKED_B3_FLOATS)
 
 N_SAMPLES = 64
@@ -58,8 +58,8 @@ class NsrModel:
         mlp: arithmetic of the layer GEMMs of the FORWARD render kernel: "fp32" (fp32 MFMAs) or "bf16x3" (bf16 MFMAs on
         fp32 operands split exactly into three bf16 pieces, NSR_FLAG_MLP_BF16X3: fp32-grade results, ~1.9x the MFMA
         rate) or "f16x2" (fp16 MFMAs on fp32 operands split into two fp16 pieces with power-of-two range management,
-        NSR_FLAG_MLP_F16X2: fp32-grade results at half of bf16x3's MFMA work; forward kernel only -- input gradients of
-        such a handle run on the fp32 kernels); None: "fp32" when `variant` (16 / 32) or `schedule` is given -- they name
+        NSR_FLAG_MLP_F16X2: fp32-grade results at half of bf16x3's MFMA work; the input-gradient kernel of such a handle
+        runs the same scheme with per-point normalised gradients); None: "fp32" when `variant` (16 / 32) or `schedule` is given -- they name
         fp32 forward kernels --, else $NSR_MLP, else DEFAULT_MLP."""
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
@@ -82,8 +82,8 @@ class NsrModel:
         if mlp not in MLP_MODES:
             raise ValueError("mlp must be one of %s" % (MLP_MODES,))
         self.mlp = mlp
-        # the x16 coarse+fine kernels only (an "f16x2" handle runs its input gradients on them; "bf16x3" never does)
-        phases = schedule == "phases" and variant != 32 and n_importance > 0 and mlp != "bf16x3"
+        # the x16 coarse+fine kernels only (the bf16x3 / f16x2 kernels take their items from the per-item queue)
+        phases = schedule == "phases" and variant != 32 and n_importance > 0 and mlp == "fp32"
         self.schedule = "phases" if phases else "queue"
         if n_importance not in (0, N_IMPORTANCE):
             raise NotImplementedError("N_importance must be 128 (or 0 for coarse-only); got %r" % (n_importance,))
@@ -210,6 +210,9 @@ class NsrModel:
             if self.mlp == "bf16x3":
                 b = pack_network_backward_b3(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd_b3(self.h, _fptr(b), b.size))
+            elif self.mlp == "f16x2":
+                b = pack_network_backward_h2(self._sd_fine_np)
+                _lib.check(self.lib.nsr_upload_weights_bwd_h2(self.h, _fptr(b), b.size))
             elif self.variant == 32:
                 b = pack_network_backward(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))

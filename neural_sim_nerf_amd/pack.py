@@ -446,6 +446,8 @@ def pack_network_backward_b3(sd):
 #   registers the NEXT layer reads carry it (P[l+1] = sw[l] + ca[l]); the multiplier applied before its split is
 #   2^(ca[l+1] - P[l+1]).  The two VALU heads read scaled registers too: their weights are stored times 2^-P.
 AUX_H2_SCALE = 3080
+AUX_H2_BWD = 3096
+STREAM_SLABS_H2_BWD = 146
 H2_WEIGHT_TOP_LOG2 = 15          # scaled weights stay below 2^15 (fp16 max is 65504 = 2^16 - 32)
 
 
@@ -493,7 +495,7 @@ def _pack_h2(W, cols, n_mo):
     n = 0
     for kb in range(n_kb):
         for st in range(n_mo // 2):                      # step st: hi pieces of blocks 2st, 2st+1, lo pieces of the partner pair
-            hb, lb = 2 * st, 2 * (st ^ 1)
+            hb, lb = 2 * st, (2 * (st ^ 1) if n_mo > 2 else 0)       # (a 2-block GEMM has one step: hi(0) hi(1) lo(0) lo(1))
             for piece, mo in ((hi, hb), (hi, hb + 1), (lo, lb), (lo, lb + 1)):
                 out[n] = piece[kb, mo]
                 n += 1
@@ -550,6 +552,47 @@ def pack_network_h2(sd, act_scale_log2=None):
     sc[10] = p2(ca[9] - P[9])                                           # feature @ views layer
     sc[11] = p2(ca[9])                                                  # direction encoding @ views layer
     aux[AUX_H2_SCALE:AUX_H2_SCALE + 16] = sc
+    # multipliers of the backward chain (csrc/nsr_h2_bwd.inc; gradients are normalised per point, their own scale cb = 0):
+    # the source of transposed layer j carries the weight scale of the GEMM before it (the rgb head's scaled weights first)
+    tb = np.zeros(16, np.float32)
+    tb[0] = p2(sw[9] + ca[9])                                           # views^T: gv was built from rgb weights x 2^-(sw9+ca9)
+    tb[1] = p2(-sw[9])                                                  # feature^T reads the output of views^T
+    for j, l in enumerate((8, 7, 6, 5, 4, 3, 2, 1)):                    # L7^T .. L1^T, L0^T read the output of layer l's transpose
+        tb[2 + j] = p2(-sw[l])
+    tb[10] = p2(sw[8] + P[8])                                           # alpha_linear^T: stored weights x 2^-P8, accumulator x 2^sw8
+    tb[11], tb[12], tb[13] = p2(-sw[9]), p2(-sw[5]), p2(-sw[0])         # encoding-gradient rows of views^T, L5^T, L0^T
+    aux[AUX_H2_BWD:AUX_H2_BWD + 16] = tb
     if not np.isfinite(aux).all():
         raise ValueError("pack_network_h2: a scaled bias / head weight left the fp32 range")
     return np.concatenate([stream.view(np.float32), aux]).astype(np.float32, copy=False)
+
+
+def pack_network_backward_h2(sd):
+    """Transposed stream of one network for k_render_vjp_h2, f16x2 layout, weights scaled like the forward stream (2^sw of
+    their layer).  The encoding rows of pack_network_backward's 9-, 10- and 2-block segments are 2-block GEMMs run BEFORE the
+    8-block GEMM of the same layer.  Order: views^T enc | views^T | feature^T | L7^T | L6^T | L5^T enc | L5^T | L4^T..L1^T |
+    L0^T enc.  Returns float32 [STREAM_SLABS_H2_BWD * SLAB_FLOATS] (packed fp16 pairs viewed as floats); the multipliers the
+    kernel needs are in the aux block of pack_network_h2."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    sw, _ = h2_scales(sd)
+    p2 = lambda e: np.float32(2.0) ** np.float32(e)
+    t128, t64 = np.arange(128), np.arange(64)
+    cols256 = np.stack([kappa(t128, 0), kappa(t128, 1)], 1)              # K = 256: 16 k16 blocks
+    cols128 = np.stack([kappa(t64, 0), kappa(t64, 1)], 1)                # K = 128 (views layer's outputs): 8 blocks
+    pad2 = lambda M: np.concatenate([M, np.zeros((64 - M.shape[0], M.shape[1]), np.float32)], 0)
+    segs = []
+    Wv = g("views_linears.0.weight") * p2(sw[9])                         # [128, 256 + 27]
+    segs.append(_pack_h2(pad2(_enc_rows_T(Wv[:, 256:], 4, 1)), cols128, 2))
+    segs.append(_pack_h2(np.ascontiguousarray(Wv[:, :256].T), cols128, 8))
+    segs.append(_pack_h2(np.ascontiguousarray(g("feature_linear.weight").T) * p2(sw[8]), cols256, 8))
+    for l in (7, 6):
+        segs.append(_pack_h2(np.ascontiguousarray(g("pts_linears.%d.weight" % l).T) * p2(sw[l]), cols256, 8))
+    W5 = g("pts_linears.5.weight") * p2(sw[5])                           # [256, 63 + 256], input columns first
+    segs.append(_pack_h2(pad2(_enc_rows_T(W5[:, :63], 10, 2)), cols256, 2))
+    segs.append(_pack_h2(np.ascontiguousarray(W5[:, 63:].T), cols256, 8))
+    for l in (4, 3, 2, 1):
+        segs.append(_pack_h2(np.ascontiguousarray(g("pts_linears.%d.weight" % l).T) * p2(sw[l]), cols256, 8))
+    segs.append(_pack_h2(pad2(_enc_rows_T(g("pts_linears.0.weight") * p2(sw[0]), 10, 2)), cols256, 2))
+    stream = np.concatenate([x.reshape(-1) for x in segs])
+    assert stream.size * 2 == STREAM_SLABS_H2_BWD * SLAB_FLOATS * 4
+    return stream.view(np.float32)

@@ -510,14 +510,16 @@ class StreamH2:
         self.pos = 0
         self.amax = np.zeros(64, np.float32)
 
-    def gemm(self, nmo, nkb, src, scale, acc):
-        """gemm_h2<NMO, NKB>: src(kb) -> [64, 8] fp32 (this lane's slots of k16 block kb), scale(kb) -> multiplier."""
+    def gemm(self, nmo, nkb, src, scale, acc, zero=False):
+        """gemm_h2<NMO, NKB, ZERO>: src(kb) -> [64, 8] fp32 (this lane's slots of k16 block kb), scale(kb) -> multiplier."""
+        if zero:
+            acc[:nmo] = 0
         for kb in range(nkb):
             t = (src(kb) * np.float32(scale(kb))).astype(np.float32)
             self.amax = np.maximum(self.amax, np.abs(t).max(1))
             hi, lo, _ = split_h2(src(kb), scale(kb))
             for st in range(nmo // 2):                               # one step: hi(HB), hi(HB+1), lo(LB), lo(LB+1)
-                hb, lb = 2 * st, 2 * (st ^ 1)
+                hb, lb = 2 * st, (2 * (st ^ 1) if nmo > 2 else 0)
                 A = [self.chunks[self.pos + c] for c in range(4)]
                 self.pos += 4
                 for a, bb, mo in ((A[0], lo, hb), (A[1], lo, hb + 1), (A[2], hi, lb), (A[3], hi, lb + 1),
@@ -578,3 +580,56 @@ def mlp_pass_h2(packed_h2, pts, dirs, masks=None):
         bias = aux[PK.AUX_B_RGB + c] if c < 3 else aux[PK.AUX_B_ALPHA]
         raw[:, c] = part[c][:32] + part[c][32:] + bias
     return raw
+
+
+def mlp_bwd_pass_h2(packed_h2_fwd, stream_bwd_h2, masks, pts, dirs, g_raw):
+    """One wave of mlp_bwd_pass_h2 (csrc/nsr_h2_bwd.inc): g_raw [32,4] -> (dL/dpts [32,3], dL/ddirs [32,3])."""
+    from neural_sim_nerf_amd import pack as PK
+    st = StreamH2(stream_bwd_h2)
+    aux = packed_h2_fwd[PK.STREAM_SLABS * PK.SLAB_FLOATS:]
+    tb = aux[PK.AUX_H2_BWD:PK.AUX_H2_BWD + 16]
+    h = LANE >> 5
+    P = np.concatenate([pts, pts], 0).astype(np.float32)
+    V = np.concatenate([dirs, dirs], 0).astype(np.float32)
+    G = np.concatenate([g_raw, g_raw], 0).astype(np.float32)
+    # per-point normalisation by a power of two (h2_norm_scale)
+    m = np.abs(G).max(1)
+    ef = (m.view(np.uint32) >> 23) & 0xff
+    ok = (ef >= 1) & (ef <= 253)
+    s = np.where(ok, ((254 - ef.astype(np.int64)) << 23).astype(np.uint32).view(np.float32), np.float32(1))
+    inv = np.where(ok, (ef.astype(np.uint32) << 23).view(np.float32), np.float32(1))
+    G = (G * s[:, None]).astype(np.float32)
+    gv = np.zeros((4, 64, 16), np.float32)
+    for mo in range(4):
+        for rq in range(4):
+            for ri in range(4):
+                idx = ((mo * 4 + rq) * 2 + h) * 4 + ri
+                v = (aux[PK.AUX_W_RGB + idx] * G[:, 0] + aux[PK.AUX_W_RGB + 128 + idx] * G[:, 1]
+                     + aux[PK.AUX_W_RGB + 256 + idx] * G[:, 2])
+                gv[mo][:, rq * 4 + ri] = np.where(masks[8][mo][:, rq * 4 + ri], v, 0)
+    frag_src = lambda arr: (lambda kb: arr[kb >> 1][:, 8 * (kb & 1):8 * (kb & 1) + 8])
+    ae = np.zeros((2, 64, 16), np.float32)
+    st.gemm(2, 8, frag_src(gv), lambda kb: tb[0], ae, zero=True)
+    dv = _embed_bwd(V, [ae[0][:, t] for t in range(16)], 4) * (tb[11] * inv)[:32, None]
+    acc = np.zeros((8, 64, 16), np.float32)
+    st.gemm(8, 8, frag_src(gv), lambda kb: tb[0], acc, zero=True)
+    gin = acc.copy()
+    dp5 = None
+    for idx in range(8):
+        mb = tb[1 + idx]
+        if idx == 3:
+            st.gemm(2, 16, frag_src(gin), lambda kb: mb, ae, zero=True)
+            dp5 = _embed_bwd(P, [ae[t >> 4][:, t & 15] for t in range(32)], 10) * tb[12]
+        st.gemm(8, 16, frag_src(gin), lambda kb: mb, acc, zero=True)
+        if idx == 0:
+            for tq in range(32):
+                for kk in range(4):
+                    t = 4 * tq + kk
+                    acc[t >> 4][:, t & 15] += aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk] * (G[:, 3] * tb[10])
+        gin = np.where(masks[7 - idx], acc, 0).astype(np.float32)
+    st.gemm(2, 16, frag_src(gin), lambda kb: tb[9], ae, zero=True)
+    assert st.pos == PK.STREAM_SLABS_H2_BWD * 16
+    dp = (_embed_bwd(P, [ae[t >> 4][:, t & 15] for t in range(32)], 10) * tb[13] + dp5) * inv[:32, None]
+    ov = np.where(st.amax > H2_MAX, np.float32(np.nan), np.float32(0))
+    ov = (ov[:32] + ov[32:])[:, None]
+    return dp + ov, dv + ov

@@ -29,7 +29,7 @@ def model(synth_nets):
     m.close()
 
 
-@pytest.fixture(scope="module", params=[(16, "phases"), (16, "queue"), (32, "queue"), ("b3", "queue")],
+@pytest.fixture(scope="module", params=[(16, "phases"), (16, "queue"), (32, "queue"), ("b3", "queue"), ("h2", "queue")],
                 ids=lambda p: "x%s-%s" % p)
 def vjp_model(request, synth_nets):
     """The input-gradient kernels: k_render_vjp16p (variant 16 + global phases = the default), k_render_vjp16 (variant
@@ -38,6 +38,8 @@ def vjp_model(request, synth_nets):
     from neural_sim_nerf_amd.engine import NsrModel
     if request.param[0] == "b3":
         m = NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3")
+    elif request.param[0] == "h2":          # k_render_vjp_h2: fp16 MFMAs, two-way split operands, per-point normalised gradients
+        m = NsrModel(synth_nets[0], synth_nets[1], mlp="f16x2")
     else:
         m = NsrModel(synth_nets[0], synth_nets[1], variant=request.param[0], schedule=request.param[1])
     yield m
@@ -220,10 +222,12 @@ def _mk(synth_nets, variant, **kw):
     from neural_sim_nerf_amd.engine import NsrModel
     if variant == "b3":
         return NsrModel(synth_nets[0], synth_nets[1], mlp="bf16x3", **kw)
+    if variant == "h2":
+        return NsrModel(synth_nets[0], synth_nets[1], mlp="f16x2", **kw)
     return NsrModel(synth_nets[0], synth_nets[1], variant=variant, **kw)
 
 
-@pytest.mark.parametrize("variant", [16, 32, "b3"])
+@pytest.mark.parametrize("variant", [16, 32, "b3", "h2"])
 def test_render_options_white_bkgd_lindisp(oracle, synth_nets, variant):
     """white_bkgd (RN:384-385) and lindisp (RN:443): forward stage-wise and against the reference (g11), the
     raw2outputs stage entry, and the VJP (the white background adds -sum(g) to dL/dw)."""
@@ -440,11 +444,13 @@ def test_pose_grad_kernel(model, oracle):
         assert np.allclose(got[p], want, rtol=1e-5, atol=1e-5)
 
 
-def test_render_api_autograd_and_render_path_grad(model16, oracle, synth_nets, tmp_path):
+def test_render_api_autograd_and_render_path_grad(oracle, synth_nets, tmp_path):
     """The reference-shaped API: render(rays=...) differentiable w.r.t. rays (RN:177), and render_path_grad's
-    per-patch dL/d psi (RN:179-190) against the same chain assembled from the oracle.  The API uses the library
-    default kernels (x16 forward and VJP), so the direct engine calls it is compared with do too."""
-    model = model16
+    per-patch dL/d psi (RN:179-190) against the same chain assembled from the oracle.  The API uses the engine's
+    default kernels (engine.DEFAULT_MLP: the f16x2 forward and VJP kernels), so the direct engine calls it is compared
+    with bit for bit do too."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    model = NsrModel(synth_nets[0], synth_nets[1])
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
     nets = []
@@ -808,6 +814,30 @@ def test_f16x2_stagewise_and_golden(model_h2, model, oracle, synth_nets):
     _stagewise(mo, oracle, synth_nets, ro, g11["rays_o"], g11["rays_d"], oracle.YCBV_NEAR, oracle.YCBV_FAR, white_bkgd=True, lindisp=True)
     _census(synth_nets, ro, g11["rays_o"], g11["rays_d"], oracle.YCBV_NEAR, oracle.YCBV_FAR, census_ref(g11), white_bkgd=True, lindisp=True)
     mo.close()
+
+
+def test_f16x2_vjp_over_twelve_orders_of_magnitude(model_h2, oracle, synth_nets):
+    """k_render_vjp_h2 normalises the gradients of every point by a power of two on entry (csrc/nsr_h2_bwd.inc): cotangents
+    of 1e-6 and 1e+6 per ray in ONE launch give gradients as accurate, ray by ray, as cotangents of order one; a zero
+    cotangent gives exactly zero; scaling a cotangent by a power of two scales the gradient exactly."""
+    g = load_golden("g8_backward")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays"][0], g["rays"][1]
+    n = ro.shape[0]
+    rng = np.random.RandomState(2)
+    amp = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), (n, 1))).astype(np.float32)
+    cot = (g["cot"] * amp).astype(np.float32)
+    cot[7] = 0.0
+    fwd = model_h2.render_rays(ro, rd, near, far, debug=True)
+    go, gd = model_h2.render_rays_vjp(ro, rd, near, far, cot)
+    want_o, want_d, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, near, far, cot, z_fine=cpu(fwd["z_fine"]))
+    for got, want in ((cpu(go), want_o), (cpu(gd), want_d)):
+        per_ray = np.linalg.norm(got - want, axis=1) / (np.linalg.norm(want, axis=1) + 1e-30)
+        keep = np.linalg.norm(want, axis=1) > 0
+        assert per_ray[keep].max() < 2e-3 and np.median(per_ray[keep]) < 2e-4, (per_ray[keep].max(), np.median(per_ray[keep]))
+        assert (got[7] == 0).all()
+    go4, gd4 = model_h2.render_rays_vjp(ro, rd, near, far, 4.0 * cot)
+    assert np.array_equal(cpu(go4), 4.0 * cpu(go)) and np.array_equal(cpu(gd4), 4.0 * cpu(gd))
 
 
 def test_f16x2_out_of_range_activation_is_nan(oracle, synth_nets):

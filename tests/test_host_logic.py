@@ -191,6 +191,19 @@ def test_packer_h2_through_kernel_emulation(oracle, synth_nets):
         m32 = {}
         E.mlp_pass(pack.pack_network(sd), pts, d, m32)
         assert all((masks[k] == m32[k]).mean() > 0.9999 for k in masks)               # same relu patterns (up to rounding at 0)
+        if ca is None:
+            # backward: the transposed stream (2-block encoding GEMMs ahead of the 8-block ones, per-point normalised
+            # gradients) against the oracle's VJP -- with cotangents spread over twelve orders of magnitude
+            b2 = pack.pack_network_backward_h2(sd)
+            assert b2.shape == (pack.STREAM_SLABS_H2_BWD * pack.SLAB_FLOATS,)
+            g = (rng.standard_normal((32, 4)) * np.exp(rng.uniform(-14, 14, (32, 1)))).astype(np.float32)
+            g[5] = 0.0
+            dp, dv = E.mlp_bwd_pass_h2(p2, b2, masks, pts, d, g)
+            rp, rv = oracle.network_vjp(sd, pts, d, g)
+            scale = np.abs(g).max(1, keepdims=True) + 1e-30
+            assert np.abs(dp - rp).max() / np.abs(rp).max() < 1e-5 and np.abs((dp - rp) / scale).max() < 2e-5 * np.abs(rp / scale).max()
+            assert np.abs(dv - rv).max() / np.abs(rv).max() < 1e-5 and np.abs((dv - rv) / scale).max() < 2e-5 * np.abs(rv / scale).max()
+            assert (dp[5] == 0).all() and (dv[5] == 0).all()
     # domain: a hidden activation whose scaled value leaves the fp16 range poisons that point, and only that point
     big = {k: v.copy() for k, v in sd.items()}
     big["pts_linears.0.bias"][7] = 7.0e4
