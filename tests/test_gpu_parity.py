@@ -816,10 +816,11 @@ def test_f16x2_stagewise_and_golden(model_h2, model, oracle, synth_nets):
     mo.close()
 
 
-def test_f16x2_vjp_over_twelve_orders_of_magnitude(model_h2, oracle, synth_nets):
+def test_f16x2_vjp_over_twelve_orders_of_magnitude(model_h2, model16, oracle, synth_nets):
     """k_render_vjp_h2 normalises the gradients of every point by a power of two on entry (csrc/nsr_h2_bwd.inc): cotangents
-    of 1e-6 and 1e+6 per ray in ONE launch give gradients as accurate, ray by ray, as cotangents of order one; a zero
-    cotangent gives exactly zero; scaling a cotangent by a power of two scales the gradient exactly."""
+    of 1e-6 and 1e+6 per ray in ONE launch give gradients as accurate, ray by ray, as the fp32-MFMA kernel's on the same
+    sample depths (both against the oracle's float64 backprop); a zero cotangent gives exactly zero; scaling a cotangent by
+    a power of two scales the gradient exactly."""
     g = load_golden("g8_backward")
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     ro, rd = g["rays"][0], g["rays"][1]
@@ -828,15 +829,23 @@ def test_f16x2_vjp_over_twelve_orders_of_magnitude(model_h2, oracle, synth_nets)
     amp = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), (n, 1))).astype(np.float32)
     cot = (g["cot"] * amp).astype(np.float32)
     cot[7] = 0.0
-    fwd = model_h2.render_rays(ro, rd, near, far, debug=True)
-    go, gd = model_h2.render_rays_vjp(ro, rd, near, far, cot)
-    want_o, want_d, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, near, far, cot, z_fine=cpu(fwd["z_fine"]))
-    for got, want in ((cpu(go), want_o), (cpu(gd), want_d)):
-        per_ray = np.linalg.norm(got - want, axis=1) / (np.linalg.norm(want, axis=1) + 1e-30)
-        keep = np.linalg.norm(want, axis=1) > 0
-        assert per_ray[keep].max() < 2e-3 and np.median(per_ray[keep]) < 2e-4, (per_ray[keep].max(), np.median(per_ray[keep]))
+    zf = cpu(model_h2.render_rays(ro, rd, near, far, debug=True)["z_fine"])
+    go, gd = model_h2.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    go32, gd32 = model16.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    want_o, want_d, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, near, far, cot, z_fine=zf)
+    for got, got32, want in ((cpu(go), cpu(go32), want_o), (cpu(gd), cpu(gd32), want_d)):
+        nrm = np.linalg.norm(want, axis=1)
+        keep = nrm > 0
+        e2 = (np.linalg.norm(got - want, axis=1) / (nrm + 1e-30))[keep]
+        e32 = (np.linalg.norm(got32 - want, axis=1) / (nrm + 1e-30))[keep]
+        print("per-ray relative VJP error: f16x2 max %.2e median %.2e | fp32 MFMA max %.2e median %.2e" % (e2.max(), np.median(e2), e32.max(), np.median(e32)))
+        # (the gradient is discontinuous in the relu patterns: a unit whose pre-activation is ~1e-6 can be "on" in one
+        # evaluation of the network and "off" in another -- fp64, fp32 MFMA, f16x2 -- and moves that ray by ~1/256 of its
+        # gradient; hence percentiles against the fp32 kernel and a loose bound on the single worst ray)
+        assert np.median(e2) < 2 * np.median(e32) + 1e-6 and np.percentile(e2, 95) < 3 * np.percentile(e32, 95) + 1e-5, (e2, e32)
+        assert e2.max() < 1e-2
         assert (got[7] == 0).all()
-    go4, gd4 = model_h2.render_rays_vjp(ro, rd, near, far, 4.0 * cot)
+    go4, gd4 = model_h2.render_rays_vjp(ro, rd, near, far, 4.0 * cot, z_fine=zf)
     assert np.array_equal(cpu(go4), 4.0 * cpu(go)) and np.array_equal(cpu(gd4), 4.0 * cpu(gd))
 
 
