@@ -532,6 +532,77 @@ def test_models_on_concurrent_streams(oracle):
         m.close()
 
 
+def test_config5_all_21_models_full_size(oracle):
+    """BASELINE configs[4] at FULL size on one GPU: 21 models (seeds 0..20 of the synthetic recipe), one native handle and
+    one HIP stream each, one 400x400 64+128 view per model.  Concurrent launches == the same launches one after the other,
+    bit for bit; two of the models are held to the oracle on a 1500-ray subset by the end-to-end census; the default
+    kernel of the engine is the one that runs.  (Across GPUs model m goes to rank m mod N: dist.shard_models, gloo tests.)"""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    K = oracle.YCBV_K
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    poses = np.asarray(oracle.sweep_poses(21, seed=3))
+    nets, models, streams = [], [], []
+    for m in range(21):
+        sd_c = oracle.synth_weights(m)
+        nets.append((sd_c, oracle.synth_weights(1000 + m, fine_of=sd_c)))
+        models.append(NsrModel(nets[m][0], nets[m][1]))
+        streams.append(torch.cuda.Stream())
+    outs = []
+    for m, st, p in zip(models, streams, poses):
+        with torch.cuda.stream(st):
+            outs.append(m.render_views(p, 400, 400, K, near, far))
+    torch.cuda.synchronize()
+    conc = [{k: cpu(o[k]) for k in ("rgb_map", "disp_map", "acc_map")} for o in outs]
+    for i, (m, p) in enumerate(zip(models, poses)):
+        o = m.render_views(p, 400, 400, K, near, far)
+        for k in conc[i]:
+            assert np.array_equal(cpu(o[k]), conc[i][k], equal_nan=True), (i, k)
+    assert not np.array_equal(conc[0]["rgb_map"], conc[1]["rgb_map"])            # the models really differ
+    sel = np.random.RandomState(0).choice(160000, 1500, replace=False)
+    for i in (4, 17):
+        ro, rd = oracle.get_rays(400, 400, K, poses[i][:3, :4])
+        ro, rd = ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]
+        sub = models[i].render_rays(ro, rd, near, far, debug=True)
+        assert np.array_equal(cpu(sub["rgb_map"]), conc[i]["rgb_map"][sel])      # ray independence
+        ref = oracle.render_rays(nets[i][0], nets[i][1], ro, rd, oracle.normalize_dirs(rd), near, far, extras=True)
+        c = _census(nets[i], sub, ro, rd, near, far, ref)
+        assert c["rays_above_tol"] <= 0.05 * c["rays"], c
+    for m in models:
+        m.close()
+
+
+def _bench_json(args, timeout=600):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                              # ONE JSON line on rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload", ["sweep100", "models21", "view400"])
+def test_bench_two_ranks_share_the_gpu(workload):
+    """`bench.py --gpus 2` end to end on a one-GPU box: the self-launch under torch.distributed.run, two ranks, the sharding
+    of views / models, the collectives at the outer-loop boundary (gloo stages them through the host: RCCL refuses two
+    ranks on one device) and the ONE JSON line -- for the three workloads of BASELINE configs[1], [2] and [4].  The number is
+    not a scaling result (the ranks share a GPU); `ranks_seen` is what says that both ranks really took part."""
+    args = ["--gpus", "2", "--backend", "gloo", "--share-gpu", "--workload", workload, "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-extras"] + (["--views", "4"] if workload == "sweep100" else [])
+    d = _bench_json(args)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["value"] > 0 and d["unit"] == "Mray-samples/s", d
+    assert d["steps"] == 1 and d["warmup"] == 1 and d["higher_is_better"] is True
+    if workload == "sweep100":
+        assert d["config"]["views"] == 4 and d["config"]["views_on_busiest_rank"] == 2 and d["scaling"] == "strong"
+        assert set(d["seconds_per_sweep_by_phase_max_over_ranks"]) == {"render", "gather_u8", "gather_f32", "png"}
+    if workload == "models21":
+        assert d["config"]["models"] == 21 and d["config"]["models_on_busiest_rank"] == 11
+
+
 def test_bilevel_gradient_end_to_end_vs_reference(synth_nets, oracle, tmp_path):
     """BASELINE config 4's render leg, end to end: psi -> poses (pose.py, LL:202-247) -> render_path_grad, against
     what the REFERENCE's sample_pose + render_path_grad returned for the same psi, noise log and cotangents
