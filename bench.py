@@ -463,9 +463,9 @@ def pmc_traffic(pmc_file, schedule="phases"):
     t = prof[key]["derived"]["hbm_traffic_bytes_per_launch"]
     return t, ("offline measurement: bytes/launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of "
                "this kernel and schedule (%s [%s], git blob %s, kernel sources sha256 %s... = this tree); FETCH_SIZE counts "
-               "L2 misses that Infinity Cache serves: re-streaming of the weight images (4.6 MiB of fp32 networks, 6.9 MiB "
-               "in the bf16x3 layout, vs 4 MiB L2 per XCD), not HBM reads; algorithmic HBM bytes are 7.0e6 per launch; the "
-               "x16 per-ray-queue schedule measures 2.1e10 to 8.8e10 depending on the run and is 0.4 %% faster (DESIGN.md 4)"
+               "L2 misses that Infinity Cache serves: re-streaming of the weight images (4.6 MiB per network pair in the fp32 "
+               "and f16x2 layouts, 6.9 MiB in the bf16x3 layout, vs 4 MiB L2 per XCD), not HBM reads; algorithmic HBM bytes "
+               "are 7.0e6 per launch (DESIGN.md 4)"
                % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
 
 
@@ -501,7 +501,7 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="validation only: ranks share the visible GPUs round-robin (e.g. --gpus 2 --backend gloo on a "
                          "1-GPU box exercises the N>1 code path end to end; the number is not a scaling result)")
-    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r02", "pmc_k_render.json"))
+    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r03", "pmc_k_render.json"))
     ap.add_argument("--mlp", choices=MLP_MODES, default=None,
                     help="layer-GEMM arithmetic of the forward kernel (default: the engine's, engine.DEFAULT_MLP / $NSR_MLP)")
     args = ap.parse_args()
@@ -603,7 +603,8 @@ def main():
             else:
                 traffic, traffic_note = pmc_traffic(args.pmc_file, model.schedule)
                 kernel_desc = "fp32, fused persistent kernel (x16: 2 workgroups per CU, %s schedule)" % model.schedule
-            roof.update({"traffic": traffic, "traffic_note": traffic_note})
+            roof.update({"traffic": traffic, "traffic_source": "offline rocprofv3 --pmc passes of this kernel, used only if their "
+                         "recorded kernel-source hash equals this tree's (else null)", "traffic_note": traffic_note})
             line.update({
                 "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "

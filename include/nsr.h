@@ -19,9 +19,15 @@
  *   - one handle per (model, stream): a handle owns one argument block, one work-queue head and its scratch
  *     buffers, so launches are ordered by the stream they are issued on; a launch on a DIFFERENT stream while the
  *     handle's previous launch is still running is refused with an error (never a silent race).  A handle is not
- *     thread-safe, distinct handles are;
- *   - the arithmetic is fp32 end to end (MFMA v_mfma_f32_32x32x2_f32 for the MLP GEMMs), fp64 only
- *     inside the two sequential scans where torch-CPU accumulates in fp64 (RN:376 cumprod, RH:203 cumsum).
+ *     thread-safe, distinct handles are.  The refusal covers EAGER launches: a launch that is being captured records
+ *     no completion event, so a graph replay still running on stream A is invisible to a later eager launch (or a
+ *     second replay) of the same handle on stream B -- order replays of one handle yourself (one stream, or events);
+ *   - the arithmetic is fp32 everywhere outside the layer GEMMs, fp64 inside the two sequential scans where
+ *     torch-CPU accumulates in fp64 (RN:376 cumprod, RH:203 cumsum).  The layer GEMMs run, per NsrConfig.flags, on
+ *     fp32 MFMAs (v_mfma_f32_16x16x4_f32 / 32x32x2: exact fp32 products), on bf16 MFMAs with every fp32 operand split
+ *     exactly into three bf16 pieces (NSR_FLAG_MLP_BF16X3) or on fp16 MFMAs with two fp16 pieces and power-of-two
+ *     range management (NSR_FLAG_MLP_F16X2): all three accumulate in fp32 and deliver fp32-grade results (error
+ *     against an fp64 evaluation within that of an fp32 GEMM chain: tests/test_host_logic.py, tests/test_gpu_parity.py).
  */
 #ifndef NSR_H_
 #define NSR_H_

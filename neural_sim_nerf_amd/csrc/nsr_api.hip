@@ -95,7 +95,6 @@ struct nsr_handle_s {
   size_t box_scratch_ints = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // kernel timing (eager launches only)
   hipEvent_t ev_busy = nullptr;              // completion of the last launch that used the per-handle scratch
-  unsigned epoch = 0;                        // global phases: launches so far, modulo 4094 (+1): tags the hand-off values
   hipStream_t last_stream = nullptr;
   bool launched = false;
   bool timed = false;
@@ -156,8 +155,8 @@ static int allocate_handle(nsr_handle h) {
     }
     zf_rays = (size_t)3 << kSuperLg;
     NSR_HIP(hipMalloc(&h->d_sched_flags, sizeof(unsigned) * 2 * zf_rays));
-    NSR_HIP(hipMalloc(&h->d_status, sizeof(unsigned)));
-    NSR_HIP(hipMemset(h->d_status, 0, sizeof(unsigned)));
+    NSR_HIP(hipMalloc(&h->d_status, 2 * sizeof(unsigned)));      // [0] recomputed rays, [1] launch epoch (device-side counter)
+    NSR_HIP(hipMemset(h->d_status, 0, 2 * sizeof(unsigned)));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
   }
@@ -409,7 +408,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     a.status = h->d_status;
     a.super_lg = kSuperLg;
     a.spin_max = h->cfg.chunk > 0 ? h->cfg.chunk - 1 : 64;   // looks at the ready flag before recomputing locally
-    a.epoch = h->epoch = h->epoch % 4094u + 1u;
+    a.epoch_counter = h->d_status + 1;                     // k_set_args advances it in stream order (also under graph replay)
     a.chunk = 1;
     NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
   } else if (x16) {
@@ -535,7 +534,7 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
     a.status = h->d_status;
     a.super_lg = kSuperLg;
     a.spin_max = h->cfg.chunk > 0 ? h->cfg.chunk - 1 : 64;
-    a.epoch = h->epoch = h->epoch % 4094u + 1u;
+    a.epoch_counter = h->d_status + 1;
     NSR_HIP(hipMemsetAsync(h->d_sched_flags, 0, sizeof(unsigned) * 2 * ((size_t)3 << kSuperLg), s));
   }
   hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, v, h->d_vjp_args);   // also zeroes the work counter

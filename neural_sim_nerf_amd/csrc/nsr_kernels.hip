@@ -789,7 +789,10 @@ struct RenderArgs {
   unsigned* status;         // k_render16p: number of fine tasks that recomputed their coarse pass (hand-off not there in time)
   int super_lg;             // k_render16p: log2 of the rays per super-chunk
   int spin_max;             // k_render16p: looks at the ready flag before a fine task recomputes locally
-  unsigned epoch;           // global phases: launch counter of the handle (1..4094), high bits of every generation tag
+  unsigned epoch;           // global phases: launch counter of the handle (1..4094), high bits of every generation tag;
+                            // advanced ON THE DEVICE by k_set_args (epoch_counter), so that every replay of a captured
+                            // launch gets a fresh one too
+  unsigned* epoch_counter;  // device word behind `epoch` (null: the schedule is not in use)
   unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays
 };
 
@@ -808,7 +811,11 @@ __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int ti
 // (stream-ordered, no host staging buffer to keep alive), and the render kernel reads its fields with scalar
 // loads at the point of use -- by-value kernel arguments were all preloaded into SGPRs and cost 70 more SGPR
 // spills inside the MFMA passes.
-__global__ void k_set_args(const RenderArgs a, RenderArgs* dst) { *dst = a; *a.work_counter = 0ull; }
+__global__ void k_set_args(const RenderArgs a, RenderArgs* dst) {
+  *dst = a;
+  *a.work_counter = 0ull;
+  if (a.epoch_counter) dst->epoch = *a.epoch_counter = *a.epoch_counter % 4094u + 1u;
+}
 
 #ifdef NSR_PHASE_TIMING      // diagnostic build: per-workgroup cycle totals of the item phases (thread 0), see tools
 #define NSR_T(i) do { if (threadIdx.x == 0) { const long long t_ = clock64(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
@@ -1023,8 +1030,9 @@ __global__ void __launch_bounds__(256, 1) k_render_h2(const RenderArgs* __restri
 //   G_in^T[K_in x 32pts] = W^T[K_in x K_out] * (G_out^T (.) relu')        (weights are constants: no dW)
 // The gradient fragment of layer l (C layout) is masked with the relu pattern captured in the forward pass
 // and is, register for register, the B operand of layer l-1's transposed GEMM.
-// Stream order: views^T 9 | feature^T 16 | L7^T 16 | L6^T 16 | L5^T 20 (8 blocks h4 + 2 blocks encoding) |
-//               L4^T..L1^T 64 | L0^T 4 (2 blocks encoding)  = 145 slabs.
+// Stream order: views^T 1 (encoding block) + 8 | feature^T 16 | L7^T 16 | L6^T 16 | L5^T 4 (2 encoding blocks) + 16 |
+//               L4^T..L1^T 64 | L0^T 4 (2 blocks encoding)  = 145 slabs.  The encoding rows are their own small segments, run
+//               BEFORE the 8-block GEMM of the same layer: 8 accumulator blocks instead of 10 (r02's 52 VGPR spills).
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x16 apply_mask(f32x16 x, unsigned word, int shift) {
   f32x16 r;
@@ -1091,7 +1099,7 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
   }
   // views^T: 256 feature rows (blocks 0-7) + 32 direction-encoding rows (block 8), K = 128
   f32x16 gin[8];
-  f32x16 acc[B3 ? 8 : 10];    // 0-7: gradient w.r.t. the 256 hidden features; fp32: 8-9 = gradient w.r.t. the 64 encoding registers
+  f32x16 acc[8];              // gradient w.r.t. the 256 hidden features (the encoding rows have their own small GEMMs)
   auto gv_src = [&](int kb, int i) { return gv[(kb >> 1) & 3][8 * (kb & 1) + i]; };
   auto gin_src = [&](int kb, int i) { return gin[(kb >> 1) & 7][8 * (kb & 1) + i]; };
   // B3: the encoding rows are their own 4-block GEMM, run BEFORE the 8-block one of the same layer so that its
@@ -1115,12 +1123,15 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
 #pragma unroll
       for (int mo = 0; mo < 8; ++mo) gin[mo] = acc[mo];          // feature_linear has no activation
     } else {
-      f32x16 accv[9];
-      seg<9, 16, kRingSlots, true>(rg, A0, A1, BRegs16<4>{gv}, accv, lane);
+      {                                                          // the 32 direction-encoding rows: their own 1-block segment,
+        f32x16 ae[1];                                            // run first (its accumulator is dead when the big one starts)
+        seg<1, 16, kRingSlots, true>(rg, A0, A1, BRegs16<4>{gv}, ae, lane);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) Gd[t] = accv[8][t];
+        for (int t = 0; t < 16; ++t) Gd[t] = ae[0][t];
+      }
+      seg<8, 16, kRingSlots, true>(rg, A0, A1, BRegs16<4>{gv}, acc, lane);
 #pragma unroll
-      for (int mo = 0; mo < 8; ++mo) gin[mo] = accv[mo];         // feature_linear has no activation
+      for (int mo = 0; mo < 8; ++mo) gin[mo] = acc[mo];          // feature_linear has no activation
     }
     const float v[3] = {ry[6], ry[7], ry[8]};              // re-read where needed: not kept alive across the GEMMs
     float part[3];
@@ -1146,8 +1157,17 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
       }
       gemm_b3<8, 8, true>(rg, A0, A1, gin_src, acc, lane);
     } else {
-      if (idx == 3) seg<10, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
-      else seg<8, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
+      if (idx == 3) {                                            // L5^T: its 64 encoding rows first (a 2-block segment)
+        f32x16 ae[2];
+        seg<2, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, ae, lane);
+        float Ge[32];
+#pragma unroll
+        for (int t = 0; t < 32; ++t) Ge[t] = ae[t >> 4][t & 15];
+        float p[3];
+        point(p);
+        embed_bwd<kMultires>(p, Ge, h, dp5);
+      }
+      seg<8, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, acc, lane);
     }
     if (idx == 0) {
       const float* wa = aux + kAuxWAlpha;                    // alpha_linear^T: rank-1 term w_alpha * dL/dsigma
@@ -1173,9 +1193,10 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
 #pragma unroll
       for (int t = 0; t < 32; ++t) Ge[t] = ae[t >> 4][t & 15];
     } else {
-      seg<2, 32>(rg, A0, A1, BRegs16<8>{gin}, *(f32x16(*)[2]) & acc[B3 ? 0 : 8], lane);
+      f32x16 ae[2];
+      seg<2, 32, kRingSlots, true>(rg, A0, A1, BRegs16<8>{gin}, ae, lane);
 #pragma unroll
-      for (int t = 0; t < 32; ++t) Ge[t] = acc[(B3 ? 0 : 8) + (t >> 4)][t & 15];
+      for (int t = 0; t < 32; ++t) Ge[t] = ae[t >> 4][t & 15];
     }
     float p[3];
     point(p);
@@ -1257,7 +1278,11 @@ struct VjpArgs {
                             // (z_samples is detached, RN:475: the depths are constants of the backward pass)
 };
 
-__global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) { *dst = a; *a.r.work_counter = 0ull; }
+__global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) {
+  *dst = a;
+  *a.r.work_counter = 0ull;
+  if (a.r.epoch_counter) dst->r.epoch = *a.r.epoch_counter = *a.r.epoch_counter % 4094u + 1u;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // Fused forward + input-gradient kernel (render_path_grad, RN:168-178).  Per item (2 rays):

@@ -172,18 +172,21 @@ def _enc_rows_T(W_cols, n_freq, n_blocks):
 
 
 def pack_network_backward(sd):
-    """Transposed stream of one network for the input-side VJP kernel (k_render_vjp).  Order:
-    views^T (9 blocks x 16 quads) | feature^T | L7^T | L6^T | L5^T (10 blocks) | L4^T..L1^T | L0^T (2 blocks).
-    Returns float32 [STREAM_SLABS * SLAB_FLOATS] (the aux block of pack_network is shared)."""
+    """Transposed stream of one network for the input-side VJP kernel (k_render_vjp).  Order: views^T encoding rows (1
+    block x 16 quads) | views^T (8 blocks) | feature^T | L7^T | L6^T | L5^T encoding rows (2 blocks) | L5^T (8 blocks) |
+    L4^T..L1^T | L0^T (2 encoding blocks): the encoding rows are their own segments, run before the 8-block GEMM of the same
+    layer.  Returns float32 [STREAM_SLABS * SLAB_FLOATS] (the aux block of pack_network is shared)."""
     g = lambda k: np.asarray(sd[k], dtype=np.float32)
     segs = []
     Wv = g("views_linears.0.weight")                                     # [128, 256 + 27]
-    segs.append(_pack_T(np.concatenate([Wv[:, :256].T, _enc_rows_T(Wv[:, 256:], 4, 1)], 0), 9, 16))
+    segs.append(_pack_T(_enc_rows_T(Wv[:, 256:], 4, 1), 1, 16))
+    segs.append(_pack_T(np.ascontiguousarray(Wv[:, :256].T), 8, 16))
     segs.append(_pack_T(g("feature_linear.weight").T, 8, 32))
     for l in (7, 6):
         segs.append(_pack_T(g("pts_linears.%d.weight" % l).T, 8, 32))
     W5 = g("pts_linears.5.weight")                                       # [256, 63 + 256], input columns first
-    segs.append(_pack_T(np.concatenate([W5[:, 63:].T, _enc_rows_T(W5[:, :63], 10, 2)], 0), 10, 32))
+    segs.append(_pack_T(_enc_rows_T(W5[:, :63], 10, 2), 2, 32))
+    segs.append(_pack_T(np.ascontiguousarray(W5[:, 63:].T), 8, 32))
     for l in (4, 3, 2, 1):
         segs.append(_pack_T(g("pts_linears.%d.weight" % l).T, 8, 32))
     segs.append(_pack_T(_enc_rows_T(g("pts_linears.0.weight"), 10, 2), 2, 32))

@@ -147,25 +147,30 @@ def mlp_bwd_pass(packed_fwd, stream_bwd, masks, pts, dirs, g_raw):
                 v = (aux[PK.AUX_W_RGB + idx] * G[:, 0] + aux[PK.AUX_W_RGB + 128 + idx] * G[:, 1]
                      + aux[PK.AUX_W_RGB + 256 + idx] * G[:, 2])
                 gv[mo][:, rq * 4 + ri] = np.where(masks[8][mo][:, rq * 4 + ri], v, 0)
-    accv = np.zeros((9, 64, 16), np.float32)
-    st.seg(9, 16, regs(gv), accv)
-    dv = _embed_bwd(V, [accv[8][:, t] for t in range(16)], 4)
-    gin = accv[:8].copy()
-    acc = np.zeros((10, 64, 16), np.float32)
+    ae = np.zeros((1, 64, 16), np.float32)
+    st.seg(1, 16, regs(gv), ae)                                    # the direction-encoding rows: their own 1-block segment
+    dv = _embed_bwd(V, [ae[0][:, t] for t in range(16)], 4)
+    acc = np.zeros((8, 64, 16), np.float32)
+    st.seg(8, 16, regs(gv), acc)
+    gin = acc.copy()
+    dp5 = None
     for idx in range(8):
+        if idx == 3:                                               # L5^T: its 64 encoding rows first
+            genc = np.zeros((2, 64, 16), np.float32)
+            st.seg(2, 32, regs(gin), genc)
+            dp5 = _embed_bwd(P, [genc[t >> 4][:, t & 15] for t in range(32)], 10)
+        acc[:] = 0
+        st.seg(8, 32, regs(gin), acc)
         if idx == 0:
             for tq in range(32):
                 for kk in range(4):
                     t = 4 * tq + kk
-                    acc[t >> 4][:, t & 15] = aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk] * G[:, 3]
-        else:
-            acc[:8] = 0
-        st.seg(10 if idx == 3 else 8, 32, regs(gin), acc)
-        gin = np.where(masks[7 - idx], acc[:8], 0).astype(np.float32)
-    genc = acc[8:]
+                    acc[t >> 4][:, t & 15] += aux[PK.AUX_W_ALPHA + (tq * 2 + h) * 4 + kk] * G[:, 3]
+        gin = np.where(masks[7 - idx], acc, 0).astype(np.float32)
+    genc = np.zeros((2, 64, 16), np.float32)
     st.seg(2, 32, regs(gin), genc)
     assert st.pos == 145 * 16
-    dp = _embed_bwd(P, [genc[t >> 4][:, t & 15] for t in range(32)], 10)
+    dp = _embed_bwd(P, [genc[t >> 4][:, t & 15] for t in range(32)], 10) + dp5
     return dp, dv
 
 

@@ -7,8 +7,10 @@ dst = os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r01"
 os.makedirs(dst, exist_ok=True)
 out = {}
 FLOP = {"x16": 160000 * 303824896, "x16q": 160000 * 303824896, "x32": 160000 * 303824896, "vjp": 160000 * 531693568,
-        "vjpq": 160000 * 531693568, "b3": 160000 * 303824896, "vjpb3": 160000 * 531693568}
-for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", "x16_queue_schedule", "k_render16("),
+        "vjpq": 160000 * 531693568, "b3": 160000 * 303824896, "vjpb3": 160000 * 531693568, "h2": 160000 * 303824896,
+        "vjph2": 160000 * 531693568}
+for tag, key, kname in (("h2", "f16x2", "k_render_h2"), ("vjph2", "vjp_f16x2", "k_render_vjp_h2"),
+                        ("x16", "x16_phases_schedule", "k_render16p"), ("x16q", "x16_queue_schedule", "k_render16("),
                         ("x32", "x32", "k_render("), ("b3", "bf16x3", "k_render_b3"), ("vjp", "vjp", "k_render_vjp16p"),
                         ("vjpq", "vjp_queue_schedule", "k_render_vjp16("), ("vjpb3", "vjp_bf16x3", "k_render_vjp_b3")):
     tot, disp, ns, first_id = {}, {}, None, {}
@@ -53,7 +55,7 @@ for tag, key, kname in (("x16", "x16_phases_schedule", "k_render16p"), ("x16q", 
 hf = os.path.join(src, "kernel_source_sha256.txt")
 out["kernel_source_sha256"] = open(hf).read().strip() if os.path.exists(hf) else None
 sched = {}
-for name in ("queue", "phases", "bf16x3", "x32"):
+for name in ("queue", "phases", "bf16x3", "x32", "f16x2", "fp32"):
     f = os.path.join(src, "schedule_%s.log" % name)
     if os.path.exists(f):
         ms = [float(l.split()[-1]) for l in open(f) if l.startswith("variant")]
@@ -62,7 +64,7 @@ for name in ("queue", "phases", "bf16x3", "x32"):
 if sched:
     out["schedule_timing_unprofiled"] = sched
 vj = {}
-for name in ("phases", "queue", "x32", "bf16x3"):
+for name in ("phases", "queue", "x32", "bf16x3", "f16x2", "fp32"):
     f = os.path.join(src, "vjp_%s.log" % name)
     if os.path.exists(f):
         for l in open(f):
@@ -76,6 +78,9 @@ if os.path.exists(pf):
                                "modes": "2 = fp32 x32 production segment, 12 = bf16x3 MFMAs only, 11 = bf16x3 production groups (tools/probe_bf16x3.py)"}
 json.dump(out, open(os.path.join(dst, "pmc_k_render.json"), "w"), indent=1)
 for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_b3", "kernel_stats_bench_bf16x3.csv"), ("stats_vjp", "kernel_stats_vjp.csv"),
+                  ("stats_f16x2", "kernel_stats_bench_steps3.csv"), ("stats_fp32", "kernel_stats_bench_fp32.csv"),
+                  ("stats_bf16x3", "kernel_stats_bench_bf16x3.csv"), ("stats_vjp_f16x2", "kernel_stats_vjp.csv"),
+                  ("stats_vjp_fp32", "kernel_stats_vjp_fp32.csv"), ("stats_vjp_bf16x3", "kernel_stats_vjp_bf16x3.csv"),
                   ("stats_handoff", "kernel_stats_handoff.csv")):
     for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
         rows = list(csv.reader(open(f)))          # keep our kernels + the top rows, drop torch's kilobyte-long template names
@@ -83,6 +88,10 @@ for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_b3", "kern
             w = csv.writer(g)
             for r in rows[:1] + [r for r in rows[1:] if r and (r[0].startswith("nsr::") or len(r[0]) < 120)]:
                 w.writerow(r)
+for extra in ("phase_timers.txt", "path_grad_f16x2.json"):
+    if os.path.exists(os.path.join(src, extra)):
+        os.makedirs(os.path.join(dst, "extra"), exist_ok=True)
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, "extra", extra))
 if os.path.exists(os.path.join(src, "bench.json")):
     lines = [l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")]
     if lines:
