@@ -1,1 +1,3 @@
-timeout 600 python -m pytest tests/ -q -m gpu -k "twelve_orders" -s 2>&1 | grep -E "per-ray|passed|failed|assert" | cut -c1-300
+# scratch command list for tools/gpu_session.sh (edited per GPU session)
+timeout 1800 python -m pytest tests/ -q -m gpu 2>&1 | tail -8
+bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -5 $O/collect.log
