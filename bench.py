@@ -91,6 +91,8 @@ def forward_roofline(model, k_ms, n_rays=H * W):
                                  (H2_ISSUED_FLOP_PER_POINT, "three", "fp16"))
         issued = n_rays * EVALS_PER_RAY * per_point / (k_ms * 1e-3) / 1e12
         r.update({"peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                  "frac_note": "frac = achieved (ALGORITHMIC fp32 FLOP/s) / peak of the datatype issued; issued_frac = the MFMA "
+                               "work actually issued (piece products) / the same peak",
                   "issued": round(issued, 1), "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
                   "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
                   "note": "`achieved` counts ALGORITHMIC fp32 FLOP (as for the fp32 kernels); the datatype issued is %s "

@@ -6,7 +6,7 @@ from neural_sim_nerf_amd.engine import NsrModel, _dev, _stream_ptr
 sd_c = S.synth_weights(0); sd_f = S.synth_weights(1000, fine_of=sd_c)
 import os
 V = int(os.environ.get('V', '32')); WG = int(os.environ.get('WG', '0'))
-m = NsrModel(sd_c, sd_f, variant=V, max_workgroups=WG)
+m = NsrModel(sd_c, sd_f, variant=V, max_workgroups=WG, mlp=os.environ.get('NSR_MLP', 'fp32'))   # V names the fp32 kernel; NSR_MLP the x32-structured bf16x3 / f16x2 ones
 H = W = 400
 c2w = torch.as_tensor(S.sweep_poses(1, 0)[0][:3, :4], device=m.device)[None].contiguous()
 n = H * W
@@ -22,7 +22,7 @@ x32 = (V == 32 or m.mlp != "fp32") and m.schedule != "phases"      # the x32-str
 G = torch.cuda.get_device_properties(m.device).multi_processor_count if x32 else 512   # [grid][8] totals + [grid][4] pass breakdown
 tt = raw_t[:G * 8].reshape(G, 8)
 tt = tt[tt.sum(1) > 0]
-print('variant', V, 'workgroups', len(tt))
+print('variant', V, 'mlp', m.mlp, 'workgroups', len(tt))
 names = ["stage rays", "network passes", "coarse composite+out", "sample_pdf", "z_std+dbg", "merge sort", "fine composite+out", "-"]
 if m.schedule == "phases":
     names = ["task start (wait, ray, z load)", "network passes", "coarse post-phase", "z publish", "fine post-phase", "queue pull", "-", "-"]
