@@ -292,7 +292,7 @@ def test_sort_merge_both_paths(model):
 
 
 @pytest.mark.timeout(120)
-@pytest.mark.parametrize("variant", [16, 32, "b3"])
+@pytest.mark.parametrize("variant", [16, 32, "b3", "h2"])
 def test_degenerate_rays_terminate_and_stay_local(oracle, synth_nets, variant):
     """NaN / inf / zero-length / far-away rays and near >= far: the kernels terminate, the bad rays come back NaN or
     finite garbage like any NaN input would in the reference, and the healthy rays next to them are untouched."""
@@ -920,6 +920,45 @@ def test_f16x2_vjp_over_twelve_orders_of_magnitude(model_h2, model16, oracle, sy
     assert np.array_equal(cpu(go4), 4.0 * cpu(go)) and np.array_equal(cpu(gd4), 4.0 * cpu(gd))
 
 
+@pytest.mark.parametrize("trunk_scale", [0.35, 1.0, 2.5])
+def test_f16x2_networks_of_other_scales(oracle, synth_nets, trunk_scale):
+    """The range management of the f16x2 kernels is per network (weights x 2^sw per layer) and per value (two fp16 pieces,
+    fp16 subnormals honoured): networks whose hidden activations are a hundred times smaller or larger than the synthetic
+    recipe's -- trunk weights x 0.35 (activations ~1e-3 by layer 7) and x 2.5 (~1e+3) -- and whose biases are ten times
+    larger still give the oracle's network outputs to the fp32 kernels' relative bound, forward and gradient."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g8_backward")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    nets = []
+    for sd in synth_nets:
+        t = {k: np.array(v, copy=True) for k, v in sd.items()}
+        for k in t:
+            if k.startswith("pts_linears") and k.endswith("weight"):
+                t[k] *= np.float32(trunk_scale)
+            if k.startswith("pts_linears") and k.endswith("bias"):
+                t[k] *= np.float32(10.0 if trunk_scale != 1.0 else 1.0)
+        nets.append(t)
+    ro, rd, cot = g["rays"][0][:48], g["rays"][1][:48], g["cot"][:48]
+    m = NsrModel(nets[0], nets[1], mlp="f16x2")
+    r = m.render_rays(ro, rd, near, far, debug=True)
+    zc = oracle.coarse_z(np.full(48, near, np.float32), np.full(48, far, np.float32))
+    pts = (ro[:, None] + rd[:, None] * zc[..., None]).astype(np.float32)
+    want = oracle.run_network(nets[0], pts, oracle.normalize_dirs(rd))
+    raw0 = cpu(r["raw0"])
+    assert np.isfinite(raw0).all()
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(raw0 - want).max() <= 5e-5 * scale, (trunk_scale, np.abs(raw0 - want).max(), scale)
+    zf = cpu(r["z_fine"])
+    ptf = (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32)
+    wantf = oracle.run_network(nets[1], ptf, oracle.normalize_dirs(rd))
+    assert np.abs(cpu(r["raw"]) - wantf).max() <= 5e-5 * max(1.0, float(np.abs(wantf).max()))
+    go, gd = m.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    want_o, want_d, _ = oracle.render_rays_vjp(nets[0], nets[1], ro, rd, near, far, cot, z_fine=zf)
+    if np.abs(want_d).max() > 0:
+        assert _relfro(cpu(go), want_o) < 5e-4 and _relfro(cpu(gd), want_d) < 5e-4, (_relfro(cpu(go), want_o), _relfro(cpu(gd), want_d))
+    m.close()
+
+
 def test_f16x2_out_of_range_activation_is_nan(oracle, synth_nets):
     """The domain of NSR_FLAG_MLP_F16X2 (include/nsr.h): a hidden activation whose scaled magnitude reaches the fp16
     maximum makes the point's outputs NaN -- loud -- and just below it the results are still the oracle's."""
@@ -1147,8 +1186,8 @@ g = np.load(%r)
 ro, rd = g["rays_o"].copy(), g["rays_d"].copy()
 ro[3] = np.nan; rd[5] = 0.0; rd[7] = np.inf; ro[9] = 1e30; rd[11] *= 1e-30
 out = {}
-for variant, schedule in ((16, "queue"), (16, "phases"), (32, "queue")):
-    m = NsrModel(sd_c, sd_f, variant=variant, schedule=schedule)
+for variant, schedule in ((16, "queue"), (16, "phases"), (32, "queue"), (0, "f16x2")):
+    m = NsrModel(sd_c, sd_f, mlp="f16x2") if schedule == "f16x2" else NsrModel(sd_c, sd_f, variant=variant, schedule=schedule)
     built, line = m.debug_bounds_status()
     r = m.render_rays(ro, rd, O.YCBV_NEAR, O.YCBV_FAR, debug=True)
     v = m.render_views(np.asarray(O.sweep_poses(2, seed=1)), 75, 75, O.scaled_K(400.0 / 75), O.YCBV_NEAR, O.YCBV_FAR)
@@ -1183,7 +1222,7 @@ def test_launch_is_graph_capturable_and_replays_bit_identically(synth_nets, orac
     g8 = load_golden("g8_backward")
     K = g["K32"].tolist() if "K32" in g else oracle.scaled_K(400.0 / 32)
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
-    for variant in (16, 32, "b3"):
+    for variant in (16, 32, "b3", "h2"):
         m = _mk(synth_nets, variant)
         poses = torch.as_tensor(np.asarray(oracle.sweep_poses(2, seed=11))[:, :3, :4], dtype=torch.float32, device=m.device)
         cam = poses[0:1].clone()
