@@ -47,7 +47,7 @@ sys.path.insert(0, ROOT)
 from neural_sim_nerf_amd import synthetic as S          # noqa: E402
 from neural_sim_nerf_amd import dist as D               # noqa: E402
 from neural_sim_nerf_amd import _lib                    # noqa: E402
-from neural_sim_nerf_amd.engine import NsrModel         # noqa: E402
+from neural_sim_nerf_amd.engine import NsrModel, DEFAULT_MLP         # noqa: E402
 
 H = W = 400
 SAMPLES_PER_RAY = 64 + 128                 # the metric's unit
@@ -753,9 +753,10 @@ def main():
             m.close()
 
     if rank == 0:
-        if args.workload != "view400" and (args.mlp or os.environ.get("NSR_MLP")) in MLP_DTYPE:
-            line["dtype"] = args.mlp or os.environ.get("NSR_MLP")
-            line["config"]["mlp"] = MLP_DTYPE[line["dtype"]]
+        eff_mlp = args.mlp or os.environ.get("NSR_MLP") or DEFAULT_MLP          # what NsrModel(mlp=args.mlp) resolved to
+        if args.workload != "view400" and eff_mlp in MLP_DTYPE:
+            line["dtype"] = eff_mlp
+            line["config"]["mlp"] = MLP_DTYPE[eff_mlp]
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,9 +1,8 @@
+# final collection of the round
+bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -3 $O/collect.log
 R=$PWD
-export NSR_MLP=f16x2
-for lib in neural_sim_nerf_amd/csrc/libnsr.so neural_sim_nerf_amd/csrc/ab/libnsr_v2.so neural_sim_nerf_amd/csrc/libnsr.so neural_sim_nerf_amd/csrc/ab/libnsr_v2.so; do
-  echo "== $lib"; NSR_LIB_PATH=$R/$lib timeout 120 python tools/one_view.py 0 0 "" 4 2>&1 | tail -3
-  NSR_LIB_PATH=$R/$lib timeout 120 python tools/bench_vjp.py 400 3 2>&1 | tail -1 | cut -c1-120
-done
-NSR_LIB_PATH=$R/neural_sim_nerf_amd/csrc/ab/libnsr_timing.so V=32 timeout 120 python tools/phase_timers.py 2>/dev/null | grep -E "kernel ms|GEMMs|between"
-unset NSR_MLP
-timeout 900 python -m pytest tests/ -q -m gpu -k "f16x2 and not full_size" 2>&1 | tail -3
+mkdir -p gpurun_out/prof/extra
+timeout 300 python bench.py --gpus 2 --backend gloo --share-gpu --workload sweep100 --views 12 --steps 1 --warmup 1 2>/dev/null | tail -1 > gpurun_out/prof/extra/bench_2ranks_shared_gpu_sweep12.json
+timeout 300 python bench.py --workload sweep100 --views 24 --steps 1 --warmup 1 2>/dev/null | tail -1 > gpurun_out/prof/extra/bench_sweep24.json
+timeout 300 python bench.py --workload models21 --steps 1 --warmup 1 2>/dev/null | tail -1 > gpurun_out/prof/extra/bench_models21.json
+for f in gpurun_out/prof/extra/*.json; do echo $f; cut -c1-400 $f; done
