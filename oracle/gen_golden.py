@@ -320,6 +320,82 @@ def main():
     g13.update(c1_sigma0_last=take_sig(fine=False)[0])
     save("g13_census", **g13)
 
+    # ---- G14 the stochastic options and the other ray set-ups of render() -----------------------
+    # (a) perturb > 0 (RN:447-459), sample_pdf with det=False (RH:211) and raw_noise_std > 0 (RN:365-374): the reference
+    #     draws from torch's global generator; torch.rand / torch.randn are wrapped to RECORD what it drew, in call order
+    #     (one chunk: t_rand [N,64], randn [N,64], u [N,128], randn [N,192]).  Forward and the gradient w.r.t. the rays.
+    # (b) c2w_staticcam (RN:91-96): rays of one camera, view directions of another.
+    # (c) ndc=True (RN:101-103, ndc_rays RH:168-186) on a forward-facing camera, near=0, far=1; forward and gradient.
+    drawn = []
+    orig_rand, orig_randn = torch.rand, torch.randn
+
+    def rec(fn):
+        def w(*a, **k):
+            out = fn(*a, **k)
+            drawn.append(out.detach().numpy().copy())
+            return out
+        return w
+    NOISE_STD = 0.7
+    sel = rng.choice(160000, size=96, replace=False)
+    ro14 = o32.reshape(-1, 3)[sel]
+    rd14 = d32.reshape(-1, 3)[sel]
+    kw14 = dict(kwargs, perturb=1.0, raw_noise_std=NOISE_STD)
+    rays = torch.stack([ro14, rd14], 0).clone().requires_grad_(True)
+    cot14 = torch.from_numpy(rng.standard_normal((96, 3)).astype(np.float32))
+    del sig_last[:]
+    z_seen = []
+    orig_r2o_b = RN.raw2outputs
+
+    def r2o_z(raw, z_vals, *a, **k):
+        z_seen.append(z_vals.detach().numpy().copy())
+        return orig_r2o_b(raw, z_vals, *a, **k)
+    RN.raw2outputs = r2o_z
+    torch.rand, torch.randn = rec(orig_rand), rec(orig_randn)
+    try:
+        with Capture(RN, RH) as cap:
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=96, rays=rays, retraw=True, **kw14)
+    finally:
+        torch.rand, torch.randn = orig_rand, orig_randn
+        RN.raw2outputs = orig_r2o_b
+    (g14g,) = torch.autograd.grad(rgb, rays, grad_outputs=cot14)
+    assert [d.shape for d in drawn] == [(96, 64), (96, 64), (96, 128), (96, 192)], [d.shape for d in drawn]
+    s0_14, s1_14 = take_sig()
+    g14 = dict(seed=np.int64(SEED), noise_std=np.float64(NOISE_STD), rays_o=ro14.numpy(), rays_d=rd14.numpy(),
+               t_rand=drawn[0], randn0=drawn[1], u=drawn[2], randn1=drawn[3], z_coarse=z_seen[0], z_fine=z_seen[1],
+               rgb=rgb.detach().numpy(), disp=disp.detach().numpy(), acc=acc.detach().numpy(),
+               rgb0=ex["rgb0"].detach().numpy(), disp0=ex["disp0"].detach().numpy(), acc0=ex["acc0"].detach().numpy(),
+               z_std=ex["z_std"].detach().numpy(), raw16=ex["raw"].detach().numpy()[:16], inds=cap.log[0]["inds"].astype(np.int8),
+               z_samples=cap.log[0]["samples"], pdf_weights=cap.log[0]["weights"], sigma0_last=s0_14, sigma_last=s1_14,
+               cot=cot14.numpy(), grad_rays=g14g.numpy())
+    # (b)
+    K16 = O.scaled_K(25.0)
+    with torch.no_grad():
+        rgb, disp, acc, ex = RN.render(16, 16, K16, chunk=512, c2w=torch.from_numpy(poses[0])[:3, :4],
+                                       c2w_staticcam=torch.from_numpy(poses[2])[:3, :4], **kwargs)
+    g14.update(sc_K=np.array(K16), sc_c2w=poses[0], sc_c2w_static=poses[2], sc_rgb=rgb.numpy(), sc_disp=disp.numpy(),
+               sc_acc=acc.numpy(), sc_rgb0=ex["rgb0"].numpy(), sc_z_std=ex["z_std"].numpy())
+    # (c) a forward-facing camera at the z = 0 plane (the LLFF set-up NDC is made for), looking down -z, slightly rotated
+    ang = 0.12
+    c2w_ndc = np.array([[np.cos(ang), 0.0, np.sin(ang), 0.15], [0.0, 1.0, 0.0, -0.1], [-np.sin(ang), 0.0, np.cos(ang), 0.05],
+                        [0.0, 0.0, 0.0, 1.0]], np.float32)
+    Hn, Wn, fn_ = 12, 16, 20.0
+    Kn = [[fn_, 0.0, Wn / 2.0], [0.0, fn_, Hn / 2.0], [0.0, 0.0, 1.0]]
+    ro_n, rd_n = RH.get_rays(Hn, Wn, Kn, torch.from_numpy(c2w_ndc)[:3, :4])
+    o_ndc, d_ndc = RH.ndc_rays(Hn, Wn, Kn[0][0], 1., ro_n, rd_n)
+    rays_n = torch.stack([ro_n.reshape(-1, 3), rd_n.reshape(-1, 3)], 0).clone().requires_grad_(True)
+    cot_n = torch.from_numpy(rng.standard_normal((Hn * Wn, 3)).astype(np.float32))
+    kwn = dict(kwargs, near=0.0, far=1.0, ndc=True)
+    with Capture(RN, RH) as cap:
+        rgb, disp, acc, ex = RN.render(Hn, Wn, Kn, chunk=512, rays=rays_n, **kwn)
+    (gn,) = torch.autograd.grad(rgb, rays_n, grad_outputs=cot_n)
+    g14.update(ndc_H=np.int64(Hn), ndc_W=np.int64(Wn), ndc_K=np.array(Kn), ndc_c2w=c2w_ndc, ndc_rays_o=ro_n.numpy(),
+               ndc_rays_d=rd_n.numpy(), ndc_o=o_ndc.numpy(), ndc_d=d_ndc.numpy(), ndc_rgb=rgb.detach().numpy(),
+               ndc_disp=disp.detach().numpy(), ndc_acc=acc.detach().numpy(), ndc_rgb0=ex["rgb0"].detach().numpy(),
+               ndc_z_std=ex["z_std"].detach().numpy(), ndc_z_samples=cap.log[0]["samples"], ndc_cot=cot_n.numpy(),
+               ndc_grad_rays=gn.numpy())
+    del sig_last[:]
+    save("g14_stochastic", **g14)
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

@@ -276,8 +276,9 @@ def run_network(sd, pts, viewdirs):
     return mlp(sd, np.concatenate([e, ed], -1)).reshape(N, S, 4)
 
 
-def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
-    """RN:343-387 with raw_noise_std=0.
+def raw2outputs(raw, z_vals, rays_d, white_bkgd=False, noise=None):
+    """RN:343-387.  noise [N,S] (or None): the term raw_noise_std * randn the reference adds to the density before the
+    relu (RN:365-374), drawn by the caller.
     Returns rgb_map [N,3], disp_map [N], acc_map [N], weights [N,S], depth_map [N]."""
     raw = raw.astype(f32)
     z = z_vals.astype(f32)
@@ -286,7 +287,8 @@ def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
     dists = (dists * dir_norm(rays_d)[:, None]).astype(f32)
     with np.errstate(over="ignore"):
         rgb = (f32(1) / (f32(1) + np.exp(-raw[..., :3]).astype(f32))).astype(f32)
-        sig = np.maximum(raw[..., 3], f32(0))
+        dens = raw[..., 3] if noise is None else _add(raw[..., 3], np.asarray(noise, f32))     # RN:374
+        sig = np.maximum(dens, f32(0))
         alpha = (f32(1) - np.exp((-sig * dists).astype(f32)).astype(f32)).astype(f32)
     one_minus = _add((f32(1) - alpha).astype(f32), f32(1e-10))
     T = _cumprod_f64(np.concatenate([np.ones((N, 1), f32), one_minus], -1))[:, :-1]
@@ -303,7 +305,8 @@ def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
 
 
 def sample_pdf(bins, weights, n_samples=N_IMPORTANCE, u=None):
-    """RH:199-243, deterministic branch (det=True because perturb==0, RN:474).
+    """RH:199-243.  u None: the deterministic branch (det=True because perturb==0, RN:474), u = linspace(0, 1, n);
+    u [n] or [N,n]: the uniforms of the det=False branch (RH:211), drawn by the caller.
     bins [N,63] (z mid-points), weights [N,62] (coarse weights[1:-1]).
     Returns samples [N,n], inds int64 [N,n] (searchsorted right=True), cdf [N,63]."""
     w = _add(weights.astype(f32), f32(1e-5))
@@ -311,8 +314,9 @@ def sample_pdf(bins, weights, n_samples=N_IMPORTANCE, u=None):
     cdf = np.concatenate([np.zeros((w.shape[0], 1), f32), _cumsum_f64(pdf)], -1)
     if u is None:
         u = torch_linspace01(n_samples)
+    u = np.broadcast_to(np.asarray(u, f32), (cdf.shape[0], np.shape(u)[-1]))
     nb = cdf.shape[-1]
-    inds = (cdf[:, None, :] <= u[None, :, None]).sum(-1).astype(np.int64)   # first idx with cdf > u
+    inds = (cdf[:, None, :] <= u[:, :, None]).sum(-1).astype(np.int64)      # first idx with cdf > u
     below = np.maximum(inds - 1, 0)
     above = np.minimum(inds, nb - 1)
     take = lambda a, i: np.take_along_axis(a, i, -1)
@@ -320,7 +324,7 @@ def sample_pdf(bins, weights, n_samples=N_IMPORTANCE, u=None):
     b0, b1 = take(bins.astype(f32), below), take(bins.astype(f32), above)
     denom = (c1 - c0).astype(f32)
     denom = np.where(denom < f32(1e-5), f32(1), denom)
-    t = ((u[None, :] - c0).astype(f32) / denom).astype(f32)
+    t = ((u - c0).astype(f32) / denom).astype(f32)
     samples = _add(b0, (t * (b1 - b0).astype(f32)).astype(f32))
     return samples, inds, cdf
 
@@ -337,53 +341,124 @@ def coarse_z(near, far, n=N_SAMPLES, lindisp=False):
     return _add((near * (f32(1) - t).astype(f32)).astype(f32), (far * t).astype(f32))
 
 
+def perturb_z(z, t_rand):
+    """RN:447-459: stratified samples, one per interval between the mid-points; t_rand [N,S] in [0, 1) from the caller."""
+    z = z.astype(f32)
+    mids = (f32(0.5) * _add(z[:, 1:], z[:, :-1])).astype(f32)
+    upper = np.concatenate([mids, z[:, -1:]], -1)
+    lower = np.concatenate([z[:, :1], mids], -1)
+    return _add(lower, ((upper - lower).astype(f32) * np.asarray(t_rand, f32)).astype(f32))
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """RH:168-186 in torch's fp32 arithmetic: python scalars (H, W, focal, near) combine in double and are rounded to
+    fp32 when they meet a tensor."""
+    o, d = rays_o.astype(f32), rays_d.astype(f32)
+    near32 = f32(near)
+    t = (-(_add(near32, o[..., 2])) / d[..., 2]).astype(f32)
+    o = _add(o, (t[..., None] * d).astype(f32))
+    cw = f32(-1.0 / (W / (2.0 * focal)))
+    ch = f32(-1.0 / (H / (2.0 * focal)))
+    two_near = f32(2.0 * near)
+    o0 = ((cw * o[..., 0]).astype(f32) / o[..., 2]).astype(f32)
+    o1 = ((ch * o[..., 1]).astype(f32) / o[..., 2]).astype(f32)
+    o2 = _add(f32(1), (two_near / o[..., 2]).astype(f32))
+    d0 = (cw * ((d[..., 0] / d[..., 2]).astype(f32) - (o[..., 0] / o[..., 2]).astype(f32)).astype(f32)).astype(f32)
+    d1 = (ch * ((d[..., 1] / d[..., 2]).astype(f32) - (o[..., 1] / o[..., 2]).astype(f32)).astype(f32)).astype(f32)
+    d2 = (f32(-2.0 * near) / o[..., 2]).astype(f32)
+    return np.stack([o0, o1, o2], -1), np.stack([d0, d1, d2], -1)
+
+
+def ndc_rays_vjp(H, W, focal, near, rays_o, rays_d, g_o, g_d):
+    """Input-side VJP of ndc_rays in float64: (dL/d o', dL/d d') -> (dL/d rays_o, dL/d rays_d)."""
+    o, d = rays_o.astype(f64), rays_d.astype(f64)
+    g_o, g_d = g_o.astype(f64), g_d.astype(f64)
+    cw, ch = -1.0 / (W / (2.0 * focal)), -1.0 / (H / (2.0 * focal))
+    t = -(near + o[..., 2]) / d[..., 2]
+    s = o + t[..., None] * d                                   # shifted origin
+    sx, sy, sz = s[..., 0], s[..., 1], s[..., 2]
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+    # outputs: o0 = cw sx/sz, o1 = ch sy/sz, o2 = 1 + 2 near/sz, d0 = cw (dx/dz - sx/sz), d1 = ch (dy/dz - sy/sz), d2 = -2 near/sz
+    gs = np.zeros_like(s)
+    gd = np.zeros_like(d)
+    gs[..., 0] = (g_o[..., 0] - g_d[..., 0]) * cw / sz
+    gs[..., 1] = (g_o[..., 1] - g_d[..., 1]) * ch / sz
+    gs[..., 2] = (-(g_o[..., 0] - g_d[..., 0]) * cw * sx - (g_o[..., 1] - g_d[..., 1]) * ch * sy
+                  - 2.0 * near * g_o[..., 2] + 2.0 * near * g_d[..., 2]) / (sz * sz)
+    gd[..., 0] = g_d[..., 0] * cw / dz
+    gd[..., 1] = g_d[..., 1] * ch / dz
+    gd[..., 2] = -(g_d[..., 0] * cw * dx + g_d[..., 1] * ch * dy) / (dz * dz)
+    # s = o + t d, t = -(near + oz)/dz
+    gt = (gs * d).sum(-1)
+    go = gs.copy()
+    go[..., 2] += gt * (-1.0 / dz)
+    gd = gd + gs * t[..., None]
+    gd[..., 2] += gt * (near + o[..., 2]) / (dz * dz)
+    return go.astype(f32), gd.astype(f32)
+
+
 def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
-                n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, extras=False, white_bkgd=False, lindisp=False):
-    """RN:390-501 with perturb=0, raw_noise_std=0.
+                n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, extras=False, white_bkgd=False, lindisp=False,
+                t_rand=None, u=None, noise0=None, noise1=None):
+    """RN:390-501.  The random draws of the stochastic options are the caller's: t_rand [N,S] (perturb > 0, RN:447-459),
+    u [N,n_importance] (sample_pdf with det=False, RH:211), noise0 [N,S] / noise1 [N,S+n_importance] (raw_noise_std *
+    randn of the coarse / fine raw2outputs, RN:365-372); None = the deterministic path (perturb=0, raw_noise_std=0).
     rays_o/rays_d/viewdirs [N,3], near/far scalars or [N]."""
     rays_o, rays_d, viewdirs = (a.astype(f32) for a in (rays_o, rays_d, viewdirs))
     N = rays_o.shape[0]
     near = np.broadcast_to(np.asarray(near, f32), (N,))
     far = np.broadcast_to(np.asarray(far, f32), (N,))
     z = coarse_z(near, far, n_samples, lindisp)
+    if t_rand is not None:
+        z = perturb_z(z, t_rand)
     pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32))
     raw = raw0 = run_network(sd_coarse, pts, viewdirs)
-    rgb_map, disp_map, acc_map, weights, _ = raw2outputs(raw, z, rays_d, white_bkgd)
+    rgb_map, disp_map, acc_map, weights, _ = raw2outputs(raw, z, rays_d, white_bkgd, noise0)
     ret = {}
     if n_importance > 0:
         ret.update(rgb0=rgb_map, disp0=disp_map, acc0=acc_map)
         z_mid = (f32(0.5) * _add(z[:, 1:], z[:, :-1])).astype(f32)
-        z_samples, inds, cdf = sample_pdf(z_mid, weights[:, 1:-1], n_importance)
+        z_samples, inds, cdf = sample_pdf(z_mid, weights[:, 1:-1], n_importance, u)
         z_fine = np.sort(np.concatenate([z, z_samples], -1), -1)
         pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z_fine[:, :, None]).astype(f32))
         raw = run_network(sd_fine if sd_fine is not None else sd_coarse, pts, viewdirs)
-        rgb_map, disp_map, acc_map, weights_f, _ = raw2outputs(raw, z_fine, rays_d, white_bkgd)
+        rgb_map, disp_map, acc_map, weights_f, _ = raw2outputs(raw, z_fine, rays_d, white_bkgd, noise1)
         ret["z_std"] = np.std(z_samples.astype(f64), -1).astype(f32)   # RN:495 (unbiased=False)
         if extras:
             ret.update(z_samples=z_samples, inds=inds, cdf=cdf, z_fine=z_fine, weights0=weights,
-                       weights=weights_f, raw=raw, raw0=raw0)
+                       weights=weights_f, raw=raw, raw0=raw0, z_coarse=z)
     elif extras:
-        ret.update(raw0=raw0, weights0=weights)
+        ret.update(raw0=raw0, weights0=weights, z_coarse=z)
     ret.update(rgb_map=rgb_map, disp_map=disp_map, acc_map=acc_map)
     return ret
 
 
 def render(sd_coarse, sd_fine, H, W, K, c2w=None, rays=None, near=0.0, far=1.0,
-           n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, chunk=4096, extras=False, white_bkgd=False, lindisp=False):
-    """RN:58-123 with use_viewdirs=True, ndc=False.  Returns dict of [H,W,...] (c2w form) or [N,...]."""
+           n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, chunk=4096, extras=False, white_bkgd=False, lindisp=False,
+           ndc=False, c2w_staticcam=None, randoms=None):
+    """RN:58-123 with use_viewdirs=True.  ndc: RN:101-103 (the caller passes near=0, far=1 as the reference's callers
+    do); c2w_staticcam: RN:91-96 (view directions from c2w, rays from the static camera); randoms: dict with any of
+    t_rand, u, noise0, noise1 for ALL rays (see render_rays), sliced per chunk here.
+    Returns dict of [H,W,...] (c2w form) or [N,...]."""
     if c2w is not None:
         rays_o, rays_d = get_rays(H, W, K, c2w)
     else:
         rays_o, rays_d = rays
+    viewdirs = normalize_dirs(rays_d.reshape(-1, 3).astype(f32))              # RN:89-98: from the rays BEFORE the next two
+    if c2w_staticcam is not None:
+        rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
     sh = rays_d.shape[:-1]
+    if ndc:
+        rays_o, rays_d = ndc_rays(H, W, K[0][0], 1.0, rays_o, rays_d)
     rays_o = rays_o.reshape(-1, 3).astype(f32)
     rays_d = rays_d.reshape(-1, 3).astype(f32)
-    viewdirs = normalize_dirs(rays_d)
+    randoms = randoms or {}
     outs = []
     for i in range(0, rays_o.shape[0], chunk):
         s = slice(i, i + chunk)
+        rnd = {k: np.asarray(v).reshape(rays_o.shape[0], -1)[s] for k, v in randoms.items() if v is not None}
         outs.append(render_rays(sd_coarse, sd_fine, rays_o[s], rays_d[s], viewdirs[s], near, far,
-                                n_samples, n_importance, extras, white_bkgd, lindisp))
+                                n_samples, n_importance, extras, white_bkgd, lindisp, **rnd))
     ret = {k: np.concatenate([o[k] for o in outs], 0) for k in outs[0]}
     return {k: v.reshape(sh + v.shape[1:]) for k, v in ret.items()}
 
@@ -487,20 +562,26 @@ def network_vjp(sd, pts, dirs, g_raw, fwd=None):
 # input-side VJP of the fine render (what render_path_grad needs, RN:168-178)
 # ----------------------------------------------------------------------------------------------
 def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
-                    n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, z_fine=None, white_bkgd=False, lindisp=False):
+                    n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, z_fine=None, white_bkgd=False, lindisp=False,
+                    viewdirs=None, noise1=None, randoms=None):
     """d(sum(rgb_map * grad_rgb)) / d(rays_o, rays_d), the quantity torch.autograd.grad(rgb_p, batch_rays,
     grad_outputs=patch_grad_E) returns at RN:177.  Network weights are constants and z_samples is detached
     (RN:475), so gradient reaches the rays only through the FINE pass: pts = o + d*z (RN:478), the view
     direction d/|d| (RN:97) and dists*|d| (RN:361).  Manual backprop in float64 on the fp32 forward's
-    activations pattern.  Returns grad_o [N,3], grad_d [N,3] (float32) and the forward rgb_map."""
+    activations pattern.  Returns grad_o [N,3], grad_d [N,3] (float32) and the forward rgb_map.
+    viewdirs [N,3]: view directions that are an input of their own (c2w_staticcam RN:91-96, ndc RN:101-103) -- the
+    return value then has a fourth entry, dL/d viewdirs, and grad_d holds no view-direction term.  noise1 [N,S]: the fine
+    pass's density noise (RN:365-374); randoms: the forward's draws when z_fine is to be recomputed here."""
     rays_o = rays_o.astype(f32)
     rays_d = rays_d.astype(f32)
     N = rays_o.shape[0]
     sd = sd_fine if sd_fine is not None else sd_coarse
-    vd = normalize_dirs(rays_d)
+    vd = normalize_dirs(rays_d) if viewdirs is None else viewdirs.astype(f32)
+    if randoms and noise1 is None:
+        noise1 = randoms.get("noise1")
     if z_fine is None:
         z_fine = render_rays(sd_coarse, sd_fine, rays_o, rays_d, vd, near, far, n_samples, n_importance,
-                             extras=True, white_bkgd=white_bkgd, lindisp=lindisp)["z_fine"]
+                             extras=True, white_bkgd=white_bkgd, lindisp=lindisp, **(randoms or {}))["z_fine"]
     S = z_fine.shape[1]
     z = z_fine.astype(f32)
     pts = _add(rays_o[:, None, :], (rays_d[:, None, :] * z[:, :, None]).astype(f32)).reshape(-1, 3)
@@ -510,6 +591,8 @@ def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
     sigma, rgb_raw = fwd["sigma"], fwd["rgb_raw"]
     # ---- compositing forward (float64) ----
     sigma = sigma.reshape(N, S)
+    if noise1 is not None:
+        sigma = _add(sigma.astype(f32), np.asarray(noise1, f32)).astype(f64)     # RN:374: the relu sees raw + noise
     c = 1.0 / (1.0 + np.exp(-rgb_raw.reshape(N, S, 3)))
     nrm = dir_norm(rays_d).astype(f64)
     dz = np.concatenate([np.diff(z.astype(f64), axis=1), np.full((N, 1), 1e10)], 1)
@@ -540,8 +623,10 @@ def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
     G_pts = G_pts.reshape(N, S, 3)
     G_v = G_dirs.reshape(N, S, 3).sum(1)
     grad_o = G_pts.sum(1)
-    v = vd.astype(f64)
+    v = normalize_dirs(rays_d).astype(f64)
     grad_d = (G_pts * z.astype(f64)[:, :, None]).sum(1)
-    grad_d += (G_v - v * (G_v * v).sum(-1, keepdims=True)) / nrm[:, None]        # d(d/|d|)
     grad_d += d_nrm[:, None] * v                                                 # d|d|/dd = d/|d|
+    if viewdirs is not None:
+        return grad_o.astype(f32), grad_d.astype(f32), rgb_map.astype(f32), G_v.astype(f32)
+    grad_d += (G_v - v * (G_v * v).sum(-1, keepdims=True)) / nrm[:, None]        # d(d/|d|)
     return grad_o.astype(f32), grad_d.astype(f32), rgb_map.astype(f32)

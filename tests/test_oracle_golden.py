@@ -127,6 +127,108 @@ def test_render_options_white_bkgd_lindisp(golden, oracle, synth_nets):
     assert np.abs(rgb - g["vjp_rgb"]).max() < 1e-5
 
 
+def _g14_randoms(g):
+    std = np.float32(float(g["noise_std"]))
+    return dict(t_rand=g["t_rand"], u=g["u"], noise0=(g["randn0"] * std).astype(np.float32),
+                noise1=(g["randn1"] * std).astype(np.float32))
+
+
+def test_stochastic_options_against_the_reference(golden, oracle, synth_nets):
+    """perturb > 0 (RN:447-459), sample_pdf det=False (RH:211), raw_noise_std > 0 (RN:365-374) against the reference run
+    with the SAME draws (g14: torch.rand / torch.randn recorded while the reference rendered).  Stage by stage: the
+    stratified depths bit for bit; coarse outputs 1e-5; the inverse-CDF on the reference's own coarse weights and uniforms
+    bit for bit (indices and samples, unsorted); the fine pass at the reference's own depths 1e-5; then end to end."""
+    g = golden("g14_stochastic")
+    sd_c, sd_f = synth_nets
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    rnd = _g14_randoms(g)
+    n = g["rays_o"].shape[0]
+    z = oracle.perturb_z(oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32)), g["t_rand"])
+    assert np.array_equal(z, g["z_coarse"])
+    vd = oracle.normalize_dirs(g["rays_d"])
+    r = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, extras=True, **rnd)
+    assert np.array_equal(r["z_coarse"], g["z_coarse"])
+    assert_close(r["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
+    assert_close(r["acc0"], g["acc0"], atol=1e-5, what="acc0")
+    # the noise really is in there: without it the coarse composite differs visibly
+    r_plain = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, t_rand=g["t_rand"], u=g["u"])
+    assert np.abs(r_plain["rgb0"] - g["rgb0"]).max() > 1e-3
+    z_mid = (np.float32(0.5) * (g["z_coarse"][:, 1:] + g["z_coarse"][:, :-1])).astype(np.float32)
+    s, inds, _ = oracle.sample_pdf(z_mid, g["pdf_weights"], 128, g["u"])
+    assert np.array_equal(inds, g["inds"].astype(np.int64)) and np.array_equal(s, g["z_samples"])
+    assert not np.all(np.diff(g["z_samples"], axis=1) >= 0)            # random uniforms: the samples arrive unsorted
+    assert np.array_equal(np.sort(np.concatenate([g["z_coarse"], g["z_samples"]], -1), -1), g["z_fine"])
+    # fine pass at the reference's depths
+    zf = g["z_fine"]
+    pts = (g["rays_o"][:, None, :] + (g["rays_d"][:, None, :] * zf[:, :, None]).astype(np.float32)).astype(np.float32)
+    raw = oracle.run_network(sd_f, pts, vd)
+    rgb, disp, acc, _, _ = oracle.raw2outputs(raw, zf, g["rays_d"], noise=rnd["noise1"])
+    # a density within float rounding of zero at the 1e10 last interval flips alpha between 0 and 1 (RN:358-359): those
+    # rays are excluded by the reference's own sigma_last + noise
+    last = g["sigma_last"] + rnd["noise1"][:, -1]
+    ok = np.abs(last) > 1e-4
+    assert ok.sum() >= 0.95 * n
+    assert_close(rgb[ok], g["rgb"][ok], atol=2e-5, what="fine rgb at the reference's depths")
+    assert_close(acc[ok], g["acc"][ok], atol=2e-5, what="fine acc at the reference's depths")
+    assert_close(raw[:16], g["raw16"], atol=2e-5, rtol=1e-5, what="raw (returned WITHOUT the noise, RN:493)")
+    # end to end (the resampling is ill-conditioned, see test_render_rays_end_to_end)
+    far_off = np.abs(r["rgb_map"] - g["rgb"]).max(-1) > 1e-4
+    assert far_off.mean() <= 0.08 and np.abs(r["rgb_map"] - g["rgb"]).mean() < 2e-4
+    assert_close(r["z_std"], g["z_std"], atol=2e-3, what="z_std")
+    # gradient w.r.t. the rays at the reference's depths and draws
+    go, gd, rgb_v = oracle.render_rays_vjp(sd_c, sd_f, g["rays_o"], g["rays_d"], near, far, g["cot"], z_fine=zf,
+                                           noise1=rnd["noise1"])
+    # per ray: a unit whose pre-activation (or a density + noise) is within rounding of zero has a different relu'
+    # in fp32 and fp64 -- one such ray in these 96 (1e-2 of its gradient) -- hence a percentile and a loose overall bound
+    for a, b in ((go, g["grad_rays"][0]), (gd, g["grad_rays"][1])):
+        e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+        assert np.percentile(e[ok], 95) < 1e-4 and np.linalg.norm(a[ok] - b[ok]) / np.linalg.norm(b[ok]) < 1e-2, e.max()
+
+
+def test_c2w_staticcam_against_the_reference(golden, oracle, synth_nets):
+    """RN:91-96: rays of the static camera, view directions of the other one."""
+    g = golden("g14_stochastic")
+    sd_c, sd_f = synth_nets
+    r = oracle.render(sd_c, sd_f, 16, 16, g["sc_K"].tolist(), c2w=g["sc_c2w"][:3, :4], c2w_staticcam=g["sc_c2w_static"][:3, :4],
+                      near=oracle.YCBV_NEAR, far=oracle.YCBV_FAR)
+    assert_close(r["rgb0"], g["sc_rgb0"], atol=1e-5, what="rgb0")
+    d = np.abs(r["rgb_map"] - g["sc_rgb"]).max(-1)
+    assert (d > 1e-4).mean() <= 0.05 and d.mean() < 1e-4
+    # and it is not the plain render of either camera
+    for c in (g["sc_c2w"], g["sc_c2w_static"]):
+        p = oracle.render(sd_c, sd_f, 16, 16, g["sc_K"].tolist(), c2w=c[:3, :4], near=oracle.YCBV_NEAR, far=oracle.YCBV_FAR)
+        assert np.abs(p["rgb0"] - g["sc_rgb0"]).max() > 1e-3
+
+
+def test_ndc_against_the_reference(golden, oracle, synth_nets):
+    """ndc_rays (RH:168-186) bit for bit; render(ndc=True, near=0, far=1) (RN:101-103) and its gradient w.r.t. the rays."""
+    g = golden("g14_stochastic")
+    sd_c, sd_f = synth_nets
+    H, W, K = int(g["ndc_H"]), int(g["ndc_W"]), g["ndc_K"].tolist()
+    o, d = oracle.ndc_rays(H, W, K[0][0], 1.0, g["ndc_rays_o"], g["ndc_rays_d"])
+    assert np.array_equal(o, g["ndc_o"]) and np.array_equal(d, g["ndc_d"])
+    assert np.abs(o[..., :2]).max() < 1.5 and np.all(d[..., 2] > 0)              # a sane NDC frustum: the test camera is forward facing
+    rays = (g["ndc_rays_o"].reshape(-1, 3), g["ndc_rays_d"].reshape(-1, 3))
+    r = oracle.render(sd_c, sd_f, H, W, K, rays=rays, near=0.0, far=1.0, ndc=True, extras=True)
+    assert_close(r["rgb0"], g["ndc_rgb0"], atol=1e-5, what="rgb0")
+    dd = np.abs(r["rgb_map"] - g["ndc_rgb"]).max(-1)
+    assert (dd > 1e-4).mean() <= 0.05 and dd.mean() < 1e-4
+    # gradient: fine pass at the reference's samples, view directions from the rays BEFORE the projection (RN:89-98)
+    n = H * W
+    ro, rd = g["ndc_rays_o"].reshape(n, 3), g["ndc_rays_d"].reshape(n, 3)
+    on, dn = o.reshape(n, 3), d.reshape(n, 3)
+    vd = oracle.normalize_dirs(rd)
+    z = oracle.coarse_z(np.zeros(n, np.float32), np.ones(n, np.float32))
+    zf = np.sort(np.concatenate([z, g["ndc_z_samples"]], -1), -1)
+    g_on, g_dn, _, g_v = oracle.render_rays_vjp(sd_c, sd_f, on, dn, 0.0, 1.0, g["ndc_cot"], z_fine=zf, viewdirs=vd)
+    go, gd = oracle.ndc_rays_vjp(H, W, K[0][0], 1.0, ro, rd, g_on, g_dn)
+    nrm = np.linalg.norm(rd.astype(np.float64), axis=-1, keepdims=True)
+    v = vd.astype(np.float64)
+    gd = gd + ((g_v - v * (g_v * v).sum(-1, keepdims=True)) / nrm).astype(np.float32)     # d(d/|d|), RN:97
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(go, g["ndc_grad_rays"][0]) < 1e-4 and rel(gd, g["ndc_grad_rays"][1]) < 1e-4
+
+
 def test_render_image(golden, oracle, synth_nets):
     g = golden("g7_render")
     sd_c, sd_f = synth_nets
