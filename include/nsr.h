@@ -169,11 +169,39 @@ int nsr_upload_weights_bwd16(nsr_handle h, const float* stream, size_t n_floats)
  * (RN:439 t_vals[64], RH:208 u[128]); host buffers. */
 int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine);
 
-/* render(rays=...) -> batchify_rays -> render_rays (RN:58-123, RN:43-55, RN:390-501), use_viewdirs=True,
- * ndc=False, perturb=0, raw_noise_std=0, white_bkgd=False, lindisp=False.
+/* render(rays=...) -> batchify_rays -> render_rays (RN:58-123, RN:43-55, RN:390-501), use_viewdirs=True, on the
+ * deterministic test-time path (ndc=False, perturb=0, raw_noise_std=0; white_bkgd / lindisp per the handle's flags).
  * d_rays_o, d_rays_d: [N,3].  viewdirs = rays_d/|rays_d| are computed in-kernel (RN:97). */
 int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays,
                     float near_, float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream);
+
+/* The per-ray inputs of the options render() / render_rays() have beyond that path.  Every pointer is nullable (NULL =
+ * the option is off) and addresses caller-owned DEVICE memory.  The random draws are the CALLER's (the reference takes
+ * them from torch's global generator inside render_rays, once per 'chunk' of rays and in the order t_rand, noise0, u,
+ * noise1): the library adds no generator of its own, so a caller that hands over the draws the reference made gets the
+ * reference's render (tests/golden/g14_stochastic.npz), and one that draws [N, .] arrays in the same order reproduces the
+ * reference's stream whenever N <= chunk.
+ *   d_viewdirs [N,3]  view directions to use instead of rays_d/|rays_d|: render(c2w_staticcam=...) takes the rays of the
+ *                     static camera and the view directions of c2w (RN:91-96); render(ndc=True) takes them from the
+ *                     rays BEFORE ndc_rays (RN:89-103, nsr_ndc_rays below)
+ *   d_t_rand  [N,64]  perturb > 0: stratified jitter in [0,1), z = lower + (upper - lower) * t_rand (RN:447-459)
+ *   d_u       [N,128] sample_pdf with det=False (perturb > 0, RN:474): the uniforms of RH:211; the importance samples then
+ *                     arrive unsorted and the merged depths are fully sorted (RN:477)
+ *   d_noise0  [N,64]  raw_noise_std > 0: raw_noise_std * randn added to the coarse densities before the relu (RN:365-374)
+ *   d_noise1  [N,192] ... to the fine densities (the raw returned through NsrDebugOut stays the network's output)
+ * Served by the x32-structured kernels: an fp32 handle of any `variant` runs k_render / k_render_vjp for such a call
+ * (the VJP then needs nsr_upload_weights_bwd), bf16x3 / f16x2 handles run their usual kernels. */
+typedef struct NsrRayExtras {
+  const float* d_viewdirs;
+  const float* d_t_rand;
+  const float* d_u;
+  const float* d_noise0;
+  const float* d_noise1;
+} NsrRayExtras;
+
+/* nsr_render_rays with the extras above (ex may be NULL: identical to nsr_render_rays). */
+int nsr_render_rays_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                       float far_, const NsrRayExtras* ex, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream);
 
 /* render(c2w=...) for a batch of views (RN:84-86 get_rays + the above; render_path's loop RN:229-235 is
  * folded into one launch).  d_c2w: [n_views,3,4] row-major; K9: HOST 3x3 intrinsics (row-major, as the
@@ -193,6 +221,24 @@ int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W
 int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                         float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
                         const float* d_z_fine, const NsrRenderOut* out, void* stream);
+
+/* nsr_render_rays_vjp with the extras: the forward half of the launch repeats the render with the same draws (or takes
+ * d_z_fine), the backward half sees the noisy fine densities (the relu' of RN:374).  With ex->d_viewdirs the view
+ * directions are an input of their own: d_grad_viewdirs [N,3] (nullable) receives dL/d viewdirs and d_grad_d holds only
+ * the paths through the points and through dists * |rays_d| (RN:361); without it d_grad_viewdirs must be NULL. */
+int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                           float far_, const NsrRayExtras* ex, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
+                           float* d_grad_viewdirs, const float* d_z_fine, const NsrRenderOut* out, void* stream);
+
+/* ndc_rays (RH:168-186), the projection render(ndc=True) applies to the rays of forward-facing scenes before rendering
+ * them with near=0, far=1 (RN:101-103): [N,3] x 2 -> [N,3] x 2 in torch's fp32 op order (bit-exact against the reference,
+ * tests/golden/g14_stochastic.npz).  focal = K[0][0]; near_ = 1.0 at the reference's call site.  _vjp: (dL/d o', dL/d d')
+ * -> (dL/d rays_o, dL/d rays_d), the link autograd adds between the rays and nsr_render_rays_vjp_ex. */
+int nsr_ndc_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, int H, int W, double focal,
+                 double near_, float* d_o_out, float* d_d_out, void* stream);
+int nsr_ndc_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, int H, int W, double focal,
+                     double near_, const float* d_grad_o_ndc, const float* d_grad_d_ndc, float* d_grad_o, float* d_grad_d,
+                     void* stream);
 
 /* Chain rule through get_rays (RH:160-164, linear in c2w): per patch of `patch` consecutive pixels (row-major,
  * the order of RN:150-157), d_out[p] = dL/d c2w[3][4] given dL/d rays.  n_patches = ceil(H*W / patch). */

@@ -26,6 +26,11 @@ class NsrRenderOut(C.Structure):
                 ("d_disp0", C.c_void_p), ("d_acc0", C.c_void_p), ("d_z_std", C.c_void_p)]
 
 
+class NsrRayExtras(C.Structure):
+    _fields_ = [("d_viewdirs", C.c_void_p), ("d_t_rand", C.c_void_p), ("d_u", C.c_void_p), ("d_noise0", C.c_void_p),
+                ("d_noise1", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/nsr.h declares
 SIGNATURES = {
     "nsr_last_error": (C.c_char_p, []),
@@ -43,6 +48,15 @@ SIGNATURES = {
     "nsr_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
     "nsr_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                   C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut), C.c_void_p]),
+    "nsr_render_rays_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                     C.POINTER(NsrRayExtras), C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut), C.c_void_p]),
+    "nsr_render_rays_vjp_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                         C.POINTER(NsrRayExtras), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(NsrRenderOut), C.c_void_p]),
+    "nsr_ndc_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nsr_ndc_rays_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_render_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
                                    C.c_float, C.c_float, C.POINTER(NsrRenderOut), C.POINTER(NsrDebugOut),
                                    C.c_void_p]),

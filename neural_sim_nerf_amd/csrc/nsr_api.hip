@@ -363,7 +363,10 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   const bool fine = h->cfg.n_importance > 0;
   const bool b3 = (h->cfg.flags & NSR_FLAG_MLP_BF16X3) != 0;
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) != 0;
-  const bool x16 = use_x16(h) && !b3 && !h2;
+  // the per-ray extras (NsrRayExtras) are read by the x32-structured kernels: an fp32 handle serves them with k_render
+  // (its x32 stream is always uploaded, see check_ready) whatever its `variant`
+  const bool extras = a.viewdirs || a.t_rand || a.u_rays || a.noise0 || a.noise1;
+  const bool x16 = use_x16(h) && !b3 && !h2 && !extras;
   if (int e = check_ready(h, fine)) return e;
   if (h2 && (!h->have_net_h2[0] || (fine && !h->have_net_h2[1])))
     return fail("NSR_FLAG_MLP_F16X2 needs nsr_upload_weights_h2 for every network");
@@ -449,15 +452,28 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   return 0;
 }
 
-int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
-                    float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
+static void set_extras(nsr::RenderArgs& a, const NsrRayExtras* ex) {
+  if (!ex) return;
+  a.viewdirs = ex->d_viewdirs; a.t_rand = ex->d_t_rand; a.u_rays = ex->d_u; a.noise0 = ex->d_noise0; a.noise1 = ex->d_noise1;
+}
+
+int nsr_render_rays_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                       float far_, const NsrRayExtras* ex, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!d_rays_o || !d_rays_d) return fail("nsr_render_rays: null rays");
   if (n_rays < 0) return fail("nsr_render_rays: negative ray count");
+  if (h && ex && h->cfg.n_importance == 0 && (ex->d_u || ex->d_noise1))
+    return fail("nsr_render_rays_ex: d_u / d_noise1 belong to the fine pass (this handle is coarse only)");
   nsr::RenderArgs a;
   memset(&a, 0, sizeof(a));
   a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.n_rays = n_rays; a.near_ = near_; a.far_ = far_; a.camera = 0;
+  set_extras(a, ex);
   return launch_render(h, a, out, dbg, stream);
+}
+
+int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                    float far_, const NsrRenderOut* out, const NsrDebugOut* dbg, void* stream) {
+  return nsr_render_rays_ex(h, d_rays_o, d_rays_d, n_rays, near_, far_, nullptr, out, dbg, stream);
 }
 
 int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9, float near_,
@@ -476,6 +492,13 @@ int nsr_render_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W
 int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                         float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
                         const float* d_z_fine, const NsrRenderOut* out, void* stream) {
+  return nsr_render_rays_vjp_ex(h, d_rays_o, d_rays_d, n_rays, near_, far_, nullptr, d_grad_rgb, d_grad_o, d_grad_d, nullptr,
+                                d_z_fine, out, stream);
+}
+
+int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                           float far_, const NsrRayExtras* ex, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
+                           float* d_grad_viewdirs, const float* d_z_fine, const NsrRenderOut* out, void* stream) {
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h) return fail("nsr_render_rays_vjp: null handle");
   if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
@@ -484,7 +507,11 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   // an f16x2 handle runs its input gradients on fp16 MFMAs too once the transposed stream is there (nsr_upload_weights_bwd_h2);
   // without it the fp32 kernels of `variant` serve (they need their own uploads)
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) && h->have_net_h2[0] && h->have_net_h2[1] && h->have_net_h2[2];
-  const bool x16 = use_x16(h) && !b3 && !h2;
+  const bool extras = ex && (ex->d_viewdirs || ex->d_t_rand || ex->d_u || ex->d_noise0 || ex->d_noise1);
+  if (d_grad_viewdirs && !(ex && ex->d_viewdirs))
+    return fail("nsr_render_rays_vjp_ex: d_grad_viewdirs without d_viewdirs (the view directions are rays_d / |rays_d| then, "
+                "and their gradient is part of d_grad_d)");
+  const bool x16 = use_x16(h) && !b3 && !h2 && !extras;      // the extras are read by the x32-structured kernels
   if (b3 && !(h->have_net_b3[0] && h->have_net_b3[1] && h->have_net_b3[2]))
     return fail("nsr_render_rays_vjp: NSR_FLAG_MLP_BF16X3 needs nsr_upload_weights_b3 (both networks) and nsr_upload_weights_bwd_b3");
   if (x16 && !(h->have_net16[0] && h->have_net16[1] && h->have_net16[2]))
@@ -510,6 +537,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
   memset(&v, 0, sizeof(v));
   nsr::RenderArgs& a = v.r;
   a.rays_o = d_rays_o; a.rays_d = d_rays_d; a.n_rays = n_rays; a.near_ = near_; a.far_ = far_; a.camera = 0;
+  set_extras(a, ex);
+  v.grad_viewdirs = d_grad_viewdirs;
   float* nets = h2 ? h->d_nets_h2 : (b3 ? h->d_nets_b3 : (x16 ? h->d_nets16 : h->d_nets));
   const size_t net_floats = b3 ? kB3Stride : (h2 ? kH2Stride : (size_t)NSR_PACKED_FLOATS);
   const size_t stream_floats = (size_t)(b3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
@@ -579,6 +608,35 @@ int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K
   const int n = H * W;
   hipLaunchKernelGGL(nsr::k_get_rays, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_c2w, (float)K9[0],
                      (float)K9[4], (float)K9[2], (float)K9[5], H, W, d_rays_o, d_rays_d);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_ndc_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, int H, int W, double focal,
+                 double near_, float* d_o_out, float* d_d_out, void* stream) {
+  if (h && n_rays == 0) return 0;
+  if (!h || !d_rays_o || !d_rays_d || !d_o_out || !d_d_out) return fail("nsr_ndc_rays: null argument");
+  if (n_rays < 0 || H <= 0 || W <= 0 || !(focal > 0.0)) return fail("nsr_ndc_rays: bad geometry");
+  NSR_DEVICE(h);
+  hipLaunchKernelGGL(nsr::k_ndc_rays, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_rays_o,
+                     d_rays_d, (long long)n_rays, (float)near_, (float)(-1.0 / (W / (2.0 * focal))),
+                     (float)(-1.0 / (H / (2.0 * focal))), (float)(2.0 * near_), (float)(-2.0 * near_), d_o_out, d_d_out);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsr_ndc_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, int H, int W, double focal,
+                     double near_, const float* d_grad_o_ndc, const float* d_grad_d_ndc, float* d_grad_o, float* d_grad_d,
+                     void* stream) {
+  if (h && n_rays == 0) return 0;
+  if (!h || !d_rays_o || !d_rays_d || !d_grad_o_ndc || !d_grad_d_ndc || !d_grad_o || !d_grad_d)
+    return fail("nsr_ndc_rays_vjp: null argument");
+  if (n_rays < 0 || H <= 0 || W <= 0 || !(focal > 0.0)) return fail("nsr_ndc_rays_vjp: bad geometry");
+  NSR_DEVICE(h);
+  hipLaunchKernelGGL(nsr::k_ndc_rays_vjp, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_rays_o, d_rays_d, (long long)n_rays, (float)near_, (float)(-1.0 / (W / (2.0 * focal))),
+                     (float)(-1.0 / (H / (2.0 * focal))), (float)(2.0 * near_), d_grad_o_ndc, d_grad_d_ndc, d_grad_o,
+                     d_grad_d);
   NSR_HIP(hipGetLastError());
   return 0;
 }

@@ -520,7 +520,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // (RN:376), one lane per ray, 8 factors per LDS round trip; (3) weights and the five weighted sums, one wave per
 // ray (lane l owns samples l, l+64, l+128), xor-shuffle tree.
 template <int S, int R = 2, typename ST>
-__device__ __forceinline__ void composite(ST& st, const float* z, float* raw, float* wout, float* tout, int tid) {
+__device__ __forceinline__ void composite(ST& st, const float* z, float* raw, float* wout, float* tout, int tid,
+                                          const float* noise = nullptr /* global [rays][S]: RN:365-374 */,
+                                          long long row0 = 0, int valid = R) {
   static_assert(S % 8 == 0, "scan is unrolled by 8");
   for (int idx = tid; idx < R * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
@@ -528,6 +530,7 @@ __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, fl
     float dist = (i < S - 1) ? (zr[i + 1] - zr[i]) : 1e10f;   // RN:358-359
     dist = dist * st.ray[r][11];                               // RN:361
     float* q = raw + (r * S + i) * 4;
+    if (noise) q[3] = q[3] + noise[(row0 + (r < valid ? r : 0)) * S + i];   // RN:374 (kept: the backward's relu' sees it too)
     const float sigma = fmaxf(q[3], 0.0f);
     const float a = 1.0f - expf(-sigma * dist);                // RN:356
     st.alpha[r][i] = a;
@@ -595,7 +598,8 @@ template <int R = 2, typename ST, typename BinsFn>
 __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[128], LDS or global*/,
                                                 const float* w /*[R][stride]*/, int wstride, BinsFn bins,
                                                 int64_t* inds_out /*[R][128] or null*/, int64_t inds_stride, int tid,
-                                                int valid_rays) {
+                                                int valid_rays, const float* u_rays = nullptr /* global [rays][128]: RH:211 */,
+                                                long long row0 = 0) {
   // (1) x = w + 1e-5 and the 8 vector-lane partial sums of ATen's cascade, 8 lanes per ray
   if (tid < 64 * R && (tid & 63) < 62) {
     const int r = tid >> 6, i = tid & 63;
@@ -644,7 +648,7 @@ __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[12
   __syncthreads();
   if (tid < 128 * R) {
     const int r = tid >> 7, k = tid & 127;
-    const float u = ufine[k];
+    const float u = u_rays ? u_rays[(row0 + (r < valid_rays ? r : 0)) * 128 + k] : ufine[k];
     const float* cdf = st.cdf[r];
     // searchsorted(cdf, u, right=True): number of entries <= u among 63 (RH:227)
     int lo = 0, hi = 63;
@@ -750,6 +754,23 @@ __device__ __forceinline__ float coarse_z(float near_, float far_, float t, int 
   return (near_ * (1.0f - t)) + (far_ * t);
 }
 
+// RN:447-459 (perturb > 0): one stratified sample per interval between the mid-points of the coarse depths of both rays of
+// an item; t_rand [rays][64] are the caller's draws.  Called by the whole workgroup once st.zc is complete.
+template <typename ST>
+__device__ __forceinline__ void perturb_coarse_z(ST& st, const float* t_rand, long long row0, int valid, int tid) {
+  const int r = (tid >> 6) & 1, i = tid & 63;
+  float zn = 0.0f;
+  if (tid < 128) {
+    const float* zr = st.zc[r];
+    const float lower = i > 0 ? 0.5f * (zr[i] + zr[i - 1]) : zr[0];
+    const float upper = i < 63 ? 0.5f * (zr[i + 1] + zr[i]) : zr[63];
+    zn = lower + (upper - lower) * t_rand[(row0 + (r < valid ? r : 0)) * 64 + i];
+  }
+  __syncthreads();
+  if (tid < 128) st.zc[r][i] = zn;
+  __syncthreads();
+}
+
 // get_rays RH:156-165 for pixel (row, col); cam = {c2w[12], fx, fy, cx, cy}
 __device__ __forceinline__ void gen_ray(const float* __restrict__ c2w, float fx, float fy, float cx, float cy,
                                         int row, int col, float (&o)[3], float (&d)[3]) {
@@ -793,7 +814,14 @@ struct RenderArgs {
                             // advanced ON THE DEVICE by k_set_args (epoch_counter), so that every replay of a captured
                             // launch gets a fresh one too
   unsigned* epoch_counter;  // device word behind `epoch` (null: the schedule is not in use)
-  unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays
+  unsigned long long* work_counter;   // head of the work queue (chunks / items), zeroed by k_set_args; 64-bit: no wrap for any n_rays  // per-ray inputs of the options the reference's render() has beyond the deterministic test-time path; all nullable and
+  // all read by the x32-structured kernels only (k_render / _b3 / _h2 and their VJPs) -- the launcher routes accordingly
+  const float* viewdirs;    // [N,3] (RAYS mode): view directions given by the caller instead of rays_d / |rays_d| -- they are
+                            // another camera's (c2w_staticcam, RN:91-96) or those of the rays before ndc_rays (RN:89-103)
+  const float* t_rand;      // [N,64]  perturb > 0: stratified jitter in [0, 1) per coarse sample (RN:447-459)
+  const float* u_rays;      // [N,128] sample_pdf with det=False: the uniforms (RH:211)
+  const float* noise0;      // [N,64]  raw_noise_std * randn added to the coarse densities before the relu (RN:365-374)
+  const float* noise1;      // [N,192] ... to the fine densities
 };
 
 __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
@@ -892,8 +920,12 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
           for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
         }
         const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));   // torch.norm RN:97, RN:361
+        const float* vd = a.camera ? nullptr : a.viewdirs;                           // given view directions: RN:91-103
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c]; st.ray[tid][6 + c] = d[c] / nrm; }
+        for (int c = 0; c < 3; ++c) {
+          st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c];
+          st.ray[tid][6 + c] = vd ? vd[rr * 3 + c] : d[c] / nrm;
+        }
         st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
@@ -903,6 +935,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         st.zc[r][i] = coarse_z(near_, far_, t, a.lindisp);
       }
       __syncthreads();
+      if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);
       NSR_T(0);
     }
 
@@ -938,7 +971,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         for (int idx = tid; idx < valid * 256; idx += 256) a.dbg_raw0[ray0 * 256 + idx] = (&st.rawc[0][0][0])[idx];
         __syncthreads();
       }
-      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
+      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
       if (tid < valid * 8) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -963,7 +996,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 #endif
       sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
-                      inds ? inds + ray0 * 128 : nullptr, 128, tid, valid);
+                      inds ? inds + ray0 * 128 : nullptr, 128, tid, valid, a.u_rays, ray0);
       NSR_T(3);
       if (wave < 2) {
         const float sd = zstd_wave(st, wave, lane);
@@ -985,7 +1018,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         for (int idx = tid; idx < valid * 768; idx += 256) a.dbg_raw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
         __syncthreads();
       }
-      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid);
+      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
       if (tid < valid * 8) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1276,6 +1309,7 @@ struct VjpArgs {
   uint4* mask_scratch;      // [gridDim][3 passes][9 layers][256 threads]
   const float* z_fine;      // optional [N,192]: sorted fine sample depths to use instead of the kernel's own resampling
                             // (z_samples is detached, RN:475: the depths are constants of the backward pass)
+  float* grad_viewdirs;     // optional [N,3]: dL/d viewdirs when r.viewdirs is given (x32-structured kernels)
 };
 
 __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) {
@@ -1349,8 +1383,12 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
 #pragma unroll
         for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[rr * 3 + c]; d[c] = a.rays_d[rr * 3 + c]; }
         const float nrm = sqrtf(((d[0] * d[0]) + (d[1] * d[1])) + (d[2] * d[2]));
+        const float* vd = a.viewdirs;                                                // given view directions: RN:91-103
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c]; st.ray[tid][6 + c] = d[c] / nrm; }
+        for (int c = 0; c < 3; ++c) {
+          st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c];
+          st.ray[tid][6 + c] = vd ? vd[rr * 3 + c] : d[c] / nrm;
+        }
         st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
@@ -1360,6 +1398,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         st.zc[r][i] = coarse_z(near_, far_, t, a.lindisp);
       }
       __syncthreads();
+      if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);
     }
 
     if (pass <= 3) {
@@ -1407,10 +1446,11 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
     const int tid = opaque_v(tid0);
     if (pass == 0) {
       __syncthreads();
-      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid);
+      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
       int64_t* none = nullptr;
       sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
-                      [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid);
+                      [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid,
+                      a.u_rays, ray0);
       merge_sort_item(st, tid);
       if (va.z_fine) {                                       // caller-supplied depths replace the resampled ones
         for (int idx = tid; idx < 2 * 192; idx += 256) {
@@ -1424,7 +1464,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       ++pass;
     } else if (pass == 3) {
       __syncthreads();
-      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid);
+      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
       if (tid < valid * 8) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1457,12 +1497,22 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
           }
         const float* ry = st.ray[r];
         const float nrm = ry[11];
-        const float vdot = (sv[0] * ry[6] + sv[1] * ry[7]) + sv[2] * ry[8];
+        if (a.viewdirs) {          // view directions given by the caller: their gradient is an output of its own, and
+                                   // rays_d is reached through the points and through dists * |d| only (RN:361)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float v = ry[6 + c];
-          va.grad_o[(ray0 + r) * 3 + c] = so[c];
-          va.grad_d[(ray0 + r) * 3 + c] = sd[c] + (sv[c] - v * vdot) / nrm + st.gnorm[r] * v;   // RN:97, RN:361
+          for (int c = 0; c < 3; ++c) {
+            va.grad_o[(ray0 + r) * 3 + c] = so[c];
+            va.grad_d[(ray0 + r) * 3 + c] = sd[c] + st.gnorm[r] * (ry[3 + c] / nrm);
+            if (va.grad_viewdirs) va.grad_viewdirs[(ray0 + r) * 3 + c] = sv[c];
+          }
+        } else {
+          const float vdot = (sv[0] * ry[6] + sv[1] * ry[7]) + sv[2] * ry[8];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float v = ry[6 + c];
+            va.grad_o[(ray0 + r) * 3 + c] = so[c];
+            va.grad_d[(ray0 + r) * 3 + c] = sd[c] + (sv[c] - v * vdot) / nrm + st.gnorm[r] * v;   // RN:97, RN:361
+          }
         }
       }
       __syncthreads();
@@ -2720,6 +2770,49 @@ __global__ void k_get_rays(const float* __restrict__ c2w, float fx, float fy, fl
   gen_ray(c2w, fx, fy, cx, cy, pix / W, pix % W, o, d);
 #pragma unroll
   for (int c = 0; c < 3; ++c) { rays_o[pix * 3 + c] = o[c]; rays_d[pix * 3 + c] = d[c]; }
+}
+
+// ndc_rays (RH:168-186) in torch's fp32 op order: the python scalars -1/(W/(2 focal)), -1/(H/(2 focal)), 2 near, -2 near
+// are formed in double by the caller and reach the tensors as fp32 (cw, ch, two_near, m2near).
+__global__ void k_ndc_rays(const float* __restrict__ ro, const float* __restrict__ rd, long long n, float near_, float cw,
+                           float ch, float two_near, float m2near, float* __restrict__ oo, float* __restrict__ od) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2];
+  const float dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+  const float t = -(near_ + oz) / dz;                                  // RH:170
+  const float sx = ox + t * dx, sy = oy + t * dy, sz = oz + t * dz;    // RH:171
+  oo[i * 3 + 0] = (cw * sx) / sz;                                      // RH:174-176
+  oo[i * 3 + 1] = (ch * sy) / sz;
+  oo[i * 3 + 2] = 1.0f + two_near / sz;
+  od[i * 3 + 0] = cw * (dx / dz - sx / sz);                            // RH:178-180
+  od[i * 3 + 1] = ch * (dy / dz - sy / sz);
+  od[i * 3 + 2] = m2near / sz;
+}
+
+// input-side VJP of the above: (dL/d o', dL/d d') -> (dL/d rays_o, dL/d rays_d), what autograd gives the reference's
+// render(rays=..., ndc=True) under torch.autograd.grad (RN:101-103 sits between the rays and the renderer)
+__global__ void k_ndc_rays_vjp(const float* __restrict__ ro, const float* __restrict__ rd, long long n, float near_,
+                               float cw, float ch, float two_near, const float* __restrict__ g_o,
+                               const float* __restrict__ g_d, float* __restrict__ go, float* __restrict__ gd) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float ox = ro[i * 3], oy = ro[i * 3 + 1], oz = ro[i * 3 + 2];
+  const float dx = rd[i * 3], dy = rd[i * 3 + 1], dz = rd[i * 3 + 2];
+  const float t = -(near_ + oz) / dz;
+  const float sx = ox + t * dx, sy = oy + t * dy, sz = oz + t * dz;
+  const float a0 = g_o[i * 3] - g_d[i * 3], a1 = g_o[i * 3 + 1] - g_d[i * 3 + 1];     // o0 and d0 hold -+ cw sx / sz
+  const float gsx = a0 * cw / sz, gsy = a1 * ch / sz;
+  const float gsz = ((-a0 * cw * sx - a1 * ch * sy) - two_near * g_o[i * 3 + 2] + two_near * g_d[i * 3 + 2]) / (sz * sz);
+  float gdx = g_d[i * 3] * cw / dz, gdy = g_d[i * 3 + 1] * ch / dz;
+  float gdz = -(g_d[i * 3] * cw * dx + g_d[i * 3 + 1] * ch * dy) / (dz * dz);
+  const float gt = (gsx * dx + gsy * dy) + gsz * dz;                                   // s = o + t d, t = -(near + oz) / dz
+  go[i * 3 + 0] = gsx;
+  go[i * 3 + 1] = gsy;
+  go[i * 3 + 2] = gsz - gt / dz;
+  gd[i * 3 + 0] = gdx + gsx * t;
+  gd[i * 3 + 1] = gdy + gsy * t;
+  gd[i * 3 + 2] = (gdz + gsz * t) + gt * (near_ + oz) / (dz * dz);
 }
 
 // Embedder.embed (RH:39-48): [n,3] -> [n, 3 + 6 L] = [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]

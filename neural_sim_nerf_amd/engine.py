@@ -176,15 +176,53 @@ class NsrModel:
         return o, ro, dbg
 
     # ---- the path -----------------------------------------------------------------------------------
-    def render_rays(self, rays_o, rays_d, near, far, debug=False):
-        """render(rays=...) (RN:58-123): rays_o, rays_d [N,3] -> dict of [N,...] tensors on the device."""
+    EXTRA_WIDTHS = dict(viewdirs=3, t_rand=64, u=128, noise0=64, noise1=192)
+
+    def _extras(self, extras, n):
+        """dict with any of viewdirs [N,3], t_rand [N,64], u [N,128], noise0 [N,64], noise1 [N,192] (include/nsr.h:
+        NsrRayExtras) -> (struct, tensors kept alive) or (None, None)."""
+        if not extras or all(v is None for v in extras.values()):
+            return None, None
+        unknown = set(extras) - set(self.EXTRA_WIDTHS)
+        if unknown:
+            raise ValueError("unknown ray extras: %s" % sorted(unknown))
+        keep = {k: self._f32(v, (n, self.EXTRA_WIDTHS[k])) for k, v in extras.items() if v is not None}
+        ex = _lib.NsrRayExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "t_rand", "u", "noise0", "noise1")])
+        return ex, keep
+
+    def render_rays(self, rays_o, rays_d, near, far, debug=False, extras=None):
+        """render(rays=...) (RN:58-123): rays_o, rays_d [N,3] -> dict of [N,...] tensors on the device.
+        extras: the per-ray inputs of the stochastic options / given view directions (see _extras); the draws are the
+        caller's."""
         rays_o = self._f32(rays_o, (-1, 3))
         rays_d = self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
         o, ro, dbg = self._outs(n, debug)
-        _lib.check(self.lib.nsr_render_rays(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
-                                            C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
+        ex, keep = self._extras(extras, n)
+        _lib.check(self.lib.nsr_render_rays_ex(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
+                                               C.byref(ex) if ex else None, C.byref(ro), C.byref(dbg) if dbg else None,
+                                               _stream_ptr(self.device)))
         return o
+
+    def ndc_rays(self, rays_o, rays_d, H, W, focal, near=1.0):
+        """ndc_rays (RH:168-186) on the device: [..,3] x 2 -> [..,3] x 2."""
+        shape = tuple(torch.as_tensor(rays_o).shape)
+        ro, rd = self._f32(rays_o, (-1, 3)), self._f32(rays_d, (-1, 3))
+        n = ro.shape[0]
+        o, d = self._new(n, 3), self._new(n, 3)
+        _lib.check(self.lib.nsr_ndc_rays(self.h, _dev(ro), _dev(rd), n, int(H), int(W), float(focal), float(near), _dev(o),
+                                         _dev(d), _stream_ptr(self.device)))
+        return o.reshape(shape), d.reshape(shape)
+
+    def ndc_rays_vjp(self, rays_o, rays_d, H, W, focal, grad_o_ndc, grad_d_ndc, near=1.0):
+        """(dL/d o', dL/d d') of ndc_rays -> (dL/d rays_o, dL/d rays_d), [N,3] each."""
+        ro, rd = self._f32(rays_o, (-1, 3)), self._f32(rays_d, (-1, 3))
+        n = ro.shape[0]
+        g0, g1 = self._f32(grad_o_ndc, (n, 3)), self._f32(grad_d_ndc, (n, 3))
+        go, gd = self._new(n, 3), self._new(n, 3)
+        _lib.check(self.lib.nsr_ndc_rays_vjp(self.h, _dev(ro), _dev(rd), n, int(H), int(W), float(focal), float(near),
+                                             _dev(g0), _dev(g1), _dev(go), _dev(gd), _stream_ptr(self.device)))
+        return go, gd
 
     def render_views(self, c2w, H, W, K, near, far, debug=False):
         """render(c2w=...) for V views in one launch: c2w [V,3,4] (or [3,4]) -> dict of [V*H*W,...] tensors."""
@@ -200,12 +238,20 @@ class NsrModel:
                                              C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
         return o
 
-    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None):
+    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None, extras=None):
         """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each.
         z_fine (optional [N,192]): sorted fine sample depths to differentiate at, instead of the kernel's own
-        resampling (they are constants of the backward, RN:475)."""
+        resampling (they are constants of the backward, RN:475).
+        extras: as for render_rays; with extras["viewdirs"] the view directions are an input of their own and the result
+        gains dL/d viewdirs: (grad_o, grad_d, grad_viewdirs[, forward])."""
         if self.n_importance == 0:
             raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
+        has_extras = bool(extras) and any(v is not None for v in extras.values())
+        if has_extras and self.mlp == "fp32" and self.variant != 32 and not getattr(self, "_bwd32_ready", False):
+            # the extras are read by the x32-structured kernels: an fp32 handle of another variant runs k_render_vjp for them
+            b = pack_network_backward(self._sd_fine_np)
+            _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
+            self._bwd32_ready = True
         if not self._bwd_ready:                      # the transposed stream is packed on first use only
             if self.mlp == "bf16x3":
                 b = pack_network_backward_b3(self._sd_fine_np)
@@ -231,10 +277,13 @@ class NsrModel:
             fwd = dict(rgb_map=self._new(n, 3), disp_map=self._new(n), acc_map=self._new(n))
             ro = _lib.NsrRenderOut(_dev(fwd["rgb_map"]), _dev(fwd["disp_map"]), _dev(fwd["acc_map"]), None, None,
                                    None, None)
-        _lib.check(self.lib.nsr_render_rays_vjp(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
-                                                _dev(g), _dev(go), _dev(gd), _dev(zf), C.byref(ro) if ro else None,
-                                                _stream_ptr(self.device)))
-        return (go, gd, fwd) if with_forward else (go, gd)
+        ex, keep = self._extras(extras, n)
+        gv = self._new(n, 3) if (keep and "viewdirs" in keep) else None
+        _lib.check(self.lib.nsr_render_rays_vjp_ex(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
+                                                   C.byref(ex) if ex else None, _dev(g), _dev(go), _dev(gd), _dev(gv),
+                                                   _dev(zf), C.byref(ro) if ro else None, _stream_ptr(self.device)))
+        res = (go, gd) if gv is None else (go, gd, gv)
+        return res + (fwd,) if with_forward else res
 
     def pose_grad(self, grad_o, grad_d, H, W, K, patch):
         """dL/d c2w[3,4] per patch of `patch` consecutive pixels, given dL/d rays of a full H x W image."""

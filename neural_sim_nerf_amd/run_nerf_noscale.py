@@ -134,6 +134,72 @@ class _RenderRays(torch.autograd.Function):
         return go, gd, None, None, None, None
 
 
+class _RenderRaysEx(torch.autograd.Function):
+    """render_rays with the per-ray extras of the options beyond the deterministic test-time path (include/nsr.h:
+    NsrRayExtras): given view directions (c2w_staticcam RN:91-96, ndc RN:101-103) -- a differentiable input of their own
+    -- and the draws of perturb / raw_noise_std (constants of the backward pass)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, viewdirs, model, near, far, want_raw, draws):
+        ex = dict(draws or {})
+        if viewdirs is not None:
+            ex["viewdirs"] = viewdirs.detach()
+        out = model.render_rays(rays_o.detach(), rays_d.detach(), near, far, debug=want_raw, extras=ex)
+        ctx.save_for_backward(rays_o.detach(), rays_d.detach())
+        ctx.cfg = (model, near, far, ex)
+        fine = model.n_importance > 0
+        keys = ["rgb_map", "disp_map", "acc_map"] + (["rgb0", "disp0", "acc0", "z_std"] if fine else [])
+        if want_raw:
+            keys.append("raw" if fine else "raw0")
+        ctx.mark_non_differentiable(*[out[k] for k in keys[1:]])
+        return tuple(out[k] for k in keys)
+
+    @staticmethod
+    def backward(ctx, g_rgb, *others):
+        model, near, far, ex = ctx.cfg
+        rays_o, rays_d = ctx.saved_tensors
+        res = model.render_rays_vjp(rays_o, rays_d, near, far, g_rgb, extras=ex)
+        gv = res[2] if "viewdirs" in ex else None
+        return res[0], res[1], gv, None, None, None, None, None
+
+
+class _NdcRays(torch.autograd.Function):
+    """ndc_rays (RH:168-186) on the device, with its input-side VJP."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, model, H, W, focal):
+        ctx.save_for_backward(rays_o.detach(), rays_d.detach())
+        ctx.cfg = (model, H, W, focal)
+        return model.ndc_rays(rays_o.detach(), rays_d.detach(), H, W, focal, 1.0)
+
+    @staticmethod
+    def backward(ctx, g_o, g_d):
+        model, H, W, focal = ctx.cfg
+        rays_o, rays_d = ctx.saved_tensors
+        go, gd = model.ndc_rays_vjp(rays_o, rays_d, H, W, focal, g_o.contiguous(), g_d.contiguous(), 1.0)
+        return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None
+
+
+def _draws(kw, n, n_importance, dev):
+    """The random draws of the stochastic options, in the reference's order within one chunk of rays: t_rand (RN:451),
+    the coarse density noise (RN:368), the resampling uniforms (RH:211), the fine density noise.  From torch's generator
+    of the render device: the reference's stream is reproduced when it, too, renders all N rays as ONE chunk on that
+    device; for pinned comparisons hand the reference's own draws to NsrModel.render_rays(extras=...)."""
+    perturb = kw.get("perturb", 0.)
+    std = float(kw.get("raw_noise_std", 0.) or 0.)
+    d = {}
+    if perturb not in (0, 0., False) and perturb > 0.:
+        d["t_rand"] = torch.rand(n, 64, device=dev)
+    if std > 0.:
+        d["noise0"] = torch.randn(n, 64, device=dev) * std
+    if n_importance > 0:
+        if "t_rand" in d:                                   # det = (perturb == 0.), RN:474
+            d["u"] = torch.rand(n, 128, device=dev)
+        if std > 0.:
+            d["noise1"] = torch.randn(n, 192, device=dev) * std
+    return d
+
+
 # ------------------------------------------------------------------------------------------------------
 # the reference API
 # ------------------------------------------------------------------------------------------------------
@@ -161,10 +227,6 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
 
 def _check_kwargs(kw):
     bad = []
-    if kw.get("perturb", 0.) not in (0, 0., False):
-        bad.append("perturb>0 (stratified jitter)")
-    if kw.get("raw_noise_std", 0.) not in (0, 0.):
-        bad.append("raw_noise_std>0")
     if kw.get("N_samples", 64) != 64:
         bad.append("N_samples=%r (kernel is specialised to 64)" % kw.get("N_samples"))
     if kw.get("N_importance", 0) not in (0, 128):
@@ -178,13 +240,11 @@ def _check_kwargs(kw):
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
     """RN:58-123.  Returns [rgb_map, disp_map, acc_map, extras] with the reference's shapes: [H,W,...] when
-    c2w is given, rays_d.shape[:-1] + ... for the rays form.  `chunk` is accepted and ignored."""
-    if ndc:
-        raise NotImplementedError("render: ndc=True (LLFF forward-facing scenes) is not supported")
+    c2w is given, rays_d.shape[:-1] + ... for the rays form.  `chunk` is accepted and ignored.
+    ndc (RN:101-103), c2w_staticcam (RN:91-96), perturb > 0 (RN:447-459, RH:211) and raw_noise_std > 0 (RN:365-374) go
+    through the per-ray extras of the native renderer (include/nsr.h: NsrRayExtras); see _draws for the random stream."""
     if not use_viewdirs:
         raise NotImplementedError("render: use_viewdirs=False is not supported")
-    if c2w_staticcam is not None:
-        raise NotImplementedError("render: c2w_staticcam is not supported")
     if not (np.isscalar(near) and np.isscalar(far)):
         raise NotImplementedError("render: near/far must be python scalars (per-ray bounds are not supported)")
     _check_kwargs(kwargs)
@@ -192,10 +252,11 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
+    special = bool(ndc) or c2w_staticcam is not None or _stochastic(kwargs)
 
     if c2w is not None:
         c2w = torch.as_tensor(c2w, dtype=torch.float32)
-        if not c2w.requires_grad:
+        if not c2w.requires_grad and not special:
             out = model.render_views(c2w.to(model.device), H, W, K, near, far, debug=retraw)
             sh = (int(H), int(W))
             ret = {k: v.reshape(sh + tuple(v.shape[1:])) for k, v in out.items()
@@ -209,15 +270,32 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
         rays_o, rays_d = rays
     rays_o = torch.as_tensor(rays_o, dtype=torch.float32)
     rays_d = torch.as_tensor(rays_d, dtype=torch.float32)
+    viewdirs = None
+    if ndc or c2w_staticcam is not None:                    # RN:89-98: view directions from the rays BEFORE the next two
+        v = rays_d.reshape(-1, 3).to(model.device)
+        viewdirs = v / torch.norm(v, dim=-1, keepdim=True)
+    if c2w_staticcam is not None:                           # RN:91-96
+        rays_o, rays_d = _get_rays_autograd(H, W, K, c2w_staticcam)
     sh = tuple(rays_d.shape[:-1])
     ro = rays_o.reshape(-1, 3).to(model.device)
     rd = rays_d.reshape(-1, 3).to(model.device)
-    outs = _RenderRays.apply(ro, rd, model, float(near), float(far), retraw)
+    if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
+        ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]))
+    if special:
+        outs = _RenderRaysEx.apply(ro, rd, viewdirs, model, float(near), float(far), retraw,
+                                   _draws(kwargs, ro.shape[0], n_imp, model.device))
+    else:
+        outs = _RenderRays.apply(ro, rd, model, float(near), float(far), retraw)
     keys = ["rgb_map", "disp_map", "acc_map"] + (["rgb0", "disp0", "acc0", "z_std"] if fine else [])
     if retraw:
         keys.append("raw")
     ret = {k: v.reshape(sh + tuple(v.shape[1:])) for k, v in zip(keys, outs)}
     return _pack_ret(ret)
+
+
+def _stochastic(kw):
+    perturb = kw.get("perturb", 0.)
+    return (perturb not in (0, 0., False) and perturb > 0.) or float(kw.get("raw_noise_std", 0.) or 0.) > 0.
 
 
 def _pack_ret(ret):
@@ -232,12 +310,16 @@ def _scaled_hw(hwf, render_factor):
     return int(H), int(W), focal
 
 
-def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False):
+def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False, general_ok=False):
     H, W, _ = _scaled_hw(hwf, render_factor)
     kw = dict(render_kwargs)
     near, far = kw.pop("near", 0.), kw.pop("far", 1.)
-    if kw.pop("ndc", True):
-        raise NotImplementedError("%s: ndc=True is not supported" % name)
+    if kw.pop("ndc", True) or _stochastic(kw):
+        if not general_ok:
+            raise NotImplementedError("%s: ndc=True / perturb>0 / raw_noise_std>0 are served by render() only" % name)
+        general = True
+    else:
+        general = False
     if not kw.pop("use_viewdirs", False):
         raise NotImplementedError("%s: use_viewdirs=False is not supported" % name)
     _check_kwargs(kw)
@@ -245,6 +327,8 @@ def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False):
     if need_fine and n_imp != 128:
         raise NotImplementedError("%s needs the coarse+fine configuration (N_importance=128)" % name)
     model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
+    if general_ok:
+        return H, W, near, far, model, general
     return H, W, near, far, model
 
 
@@ -259,7 +343,7 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
     poses, the images are all-gathered (RCCL) and EVERY rank returns all K views in pose order -- the call site
     NM:128 needs no change.  NSR_AUTO_SHARD=0 disables it."""
     from . import dist as D
-    H, W, near, far, model = _path_setup("render_path", hwf, render_factor, render_kwargs)
+    H, W, near, far, model, general = _path_setup("render_path", hwf, render_factor, render_kwargs, general_ok=True)
     if savedir is not None:
         os.makedirs(os.path.join(savedir, str(object_id)), exist_ok=True)
     poses = torch.as_tensor(render_poses, dtype=torch.float32).detach()
@@ -267,6 +351,9 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
     def render_fn(p):
         if p.shape[0] == 0:
             return (torch.zeros((0, H, W, 3), device=model.device), torch.zeros((0, H, W), device=model.device))
+        if general:               # ndc / stochastic options: pose by pose through render(), as the reference does (RN:229-235)
+            r = [render(H, W, K, chunk=chunk, c2w=c[:3, :4], **render_kwargs)[:2] for c in p]
+            return torch.stack([x[0] for x in r]), torch.stack([x[1] for x in r])
         out = model.render_views(p[:, :3, :4].to(model.device), H, W, K, near, far)
         return out["rgb_map"].reshape(-1, H, W, 3), out["disp_map"].reshape(-1, H, W)
 
