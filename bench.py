@@ -292,6 +292,34 @@ def api_overhead_workload(sd_c, sd_f, device, reps=60):
             "weights_version_ms_per_network": round(fp, 4)}
 
 
+def render_options_workload(sd_c, sd_f, c2w, device):
+    """One 400x400 view through render(rays=...) with ALL the stochastic options on (perturb > 0: stratified depths and random
+    resampling uniforms, raw_noise_std > 0: density noise in both passes -- RN:447-459, RH:211, RN:365-374) next to the same
+    rays on the deterministic path: the per-ray extras cost 448 more floats of HBM reads per ray and a full sort of the
+    unsorted importance samples, nothing inside the network passes."""
+    eng = NsrModel(sd_c, sd_f, device=device)
+    ro, rd = eng.get_rays(400, 400, S.YCBV_K, torch.as_tensor(c2w[:3, :4]))
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    n = ro.shape[0]
+    dev = torch.device("cuda", device)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    ex = dict(t_rand=torch.rand(n, 64, device=dev, generator=gen), noise0=torch.randn(n, 64, device=dev, generator=gen),
+              u=torch.rand(n, 128, device=dev, generator=gen), noise1=torch.randn(n, 192, device=dev, generator=gen))
+
+    def ms(extras):
+        eng.render_rays(ro, rd, S.YCBV_NEAR, S.YCBV_FAR, extras=extras)
+        t = []
+        for _ in range(3):
+            eng.render_rays(ro, rd, S.YCBV_NEAR, S.YCBV_FAR, extras=extras)
+            t.append(eng.last_kernel_ms())
+        return float(np.mean(t))
+    plain, stoch = ms(None), ms(ex)
+    eng.close()
+    return {"workload": "400x400 rays, 64+128 samples, perturb + raw_noise_std via NsrRayExtras (kernel ms, HIP events)",
+            "deterministic_ms": round(plain, 3), "stochastic_ms": round(stoch, 3), "ratio": round(stoch / plain, 4),
+            "extra_hbm_bytes_per_ray": 448 * 4}
+
+
 def config1_workload(sd_c, c2w, device, cpu_setting):
     """BASELINE configs[0]: 64x64 view, 64 coarse samples only.  GPU: 50 launches, HIP-event mean.
     CPU: the oracle on the same view at the reference's chunk (512, CF:25) and at 4096."""
@@ -632,7 +660,8 @@ def main():
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),
                                            "handoff": handoff_workload(model, not args.no_cpu_baseline),
-                                           "api_overhead": api_overhead_workload(sd_c, sd_f, local)}
+                                           "api_overhead": api_overhead_workload(sd_c, sd_f, local),
+                                           "render_options": render_options_workload(sd_c, sd_f, poses[0], local)}
                 ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
                 for mlp in MLP_MODES:
                     if mlp != model.mlp:

@@ -189,6 +189,8 @@ int nsr_render_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, 
  *                     arrive unsorted and the merged depths are fully sorted (RN:477)
  *   d_noise0  [N,64]  raw_noise_std > 0: raw_noise_std * randn added to the coarse densities before the relu (RN:365-374)
  *   d_noise1  [N,192] ... to the fine densities (the raw returned through NsrDebugOut stays the network's output)
+ *   d_near, d_far [N] per-ray bounds: render()'s near / far may be arrays (RN:106-108); both or neither, they replace
+ *                     the call's scalars
  * Served by the x32-structured kernels: an fp32 handle of any `variant` runs k_render / k_render_vjp for such a call
  * (the VJP then needs nsr_upload_weights_bwd), bf16x3 / f16x2 handles run their usual kernels. */
 typedef struct NsrRayExtras {
@@ -197,6 +199,8 @@ typedef struct NsrRayExtras {
   const float* d_u;
   const float* d_noise0;
   const float* d_noise1;
+  const float* d_near;
+  const float* d_far;
 } NsrRayExtras;
 
 /* nsr_render_rays with the extras above (ex may be NULL: identical to nsr_render_rays). */

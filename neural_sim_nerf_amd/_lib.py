@@ -28,7 +28,7 @@ class NsrRenderOut(C.Structure):
 
 class NsrRayExtras(C.Structure):
     _fields_ = [("d_viewdirs", C.c_void_p), ("d_t_rand", C.c_void_p), ("d_u", C.c_void_p), ("d_noise0", C.c_void_p),
-                ("d_noise1", C.c_void_p)]
+                ("d_noise1", C.c_void_p), ("d_near", C.c_void_p), ("d_far", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/nsr.h declares

@@ -365,7 +365,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) != 0;
   // the per-ray extras (NsrRayExtras) are read by the x32-structured kernels: an fp32 handle serves them with k_render
   // (its x32 stream is always uploaded, see check_ready) whatever its `variant`
-  const bool extras = a.viewdirs || a.t_rand || a.u_rays || a.noise0 || a.noise1;
+  const bool extras = a.viewdirs || a.t_rand || a.u_rays || a.noise0 || a.noise1 || a.near_rays;
   const bool x16 = use_x16(h) && !b3 && !h2 && !extras;
   if (int e = check_ready(h, fine)) return e;
   if (h2 && (!h->have_net_h2[0] || (fine && !h->have_net_h2[1])))
@@ -455,6 +455,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
 static void set_extras(nsr::RenderArgs& a, const NsrRayExtras* ex) {
   if (!ex) return;
   a.viewdirs = ex->d_viewdirs; a.t_rand = ex->d_t_rand; a.u_rays = ex->d_u; a.noise0 = ex->d_noise0; a.noise1 = ex->d_noise1;
+  a.near_rays = ex->d_near; a.far_rays = ex->d_far;
 }
 
 int nsr_render_rays_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
@@ -462,6 +463,7 @@ int nsr_render_rays_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!d_rays_o || !d_rays_d) return fail("nsr_render_rays: null rays");
   if (n_rays < 0) return fail("nsr_render_rays: negative ray count");
+  if (ex && ((ex->d_near == nullptr) != (ex->d_far == nullptr))) return fail("nsr_render_rays_ex: d_near and d_far come together");
   if (h && ex && h->cfg.n_importance == 0 && (ex->d_u || ex->d_noise1))
     return fail("nsr_render_rays_ex: d_u / d_noise1 belong to the fine pass (this handle is coarse only)");
   nsr::RenderArgs a;
@@ -507,7 +509,8 @@ int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_r
   // an f16x2 handle runs its input gradients on fp16 MFMAs too once the transposed stream is there (nsr_upload_weights_bwd_h2);
   // without it the fp32 kernels of `variant` serve (they need their own uploads)
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) && h->have_net_h2[0] && h->have_net_h2[1] && h->have_net_h2[2];
-  const bool extras = ex && (ex->d_viewdirs || ex->d_t_rand || ex->d_u || ex->d_noise0 || ex->d_noise1);
+  const bool extras = ex && (ex->d_viewdirs || ex->d_t_rand || ex->d_u || ex->d_noise0 || ex->d_noise1 || ex->d_near);
+  if (ex && ((ex->d_near == nullptr) != (ex->d_far == nullptr))) return fail("nsr_render_rays_vjp_ex: d_near and d_far come together");
   if (d_grad_viewdirs && !(ex && ex->d_viewdirs))
     return fail("nsr_render_rays_vjp_ex: d_grad_viewdirs without d_viewdirs (the view directions are rays_d / |rays_d| then, "
                 "and their gradient is part of d_grad_d)");

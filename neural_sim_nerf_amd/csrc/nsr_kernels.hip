@@ -822,6 +822,8 @@ struct RenderArgs {
   const float* u_rays;      // [N,128] sample_pdf with det=False: the uniforms (RH:211)
   const float* noise0;      // [N,64]  raw_noise_std * randn added to the coarse densities before the relu (RN:365-374)
   const float* noise1;      // [N,192] ... to the fine densities
+  const float* near_rays;   // [N] per-ray bounds (RN:106-108: near / far may be arrays); both or neither
+  const float* far_rays;
 };
 
 __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
@@ -926,13 +928,16 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
           st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c];
           st.ray[tid][6 + c] = vd ? vd[rr * 3 + c] : d[c] / nrm;
         }
-        st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
+        st.ray[tid][9] = a.near_rays ? a.near_rays[rr] : near_;       // per-ray bounds (RN:106-108) or the call's scalars
+        st.ray[tid][10] = a.near_rays ? a.far_rays[rr] : far_;
+        st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
-        st.zc[r][i] = coarse_z(near_, far_, t, a.lindisp);
+        const long long rb = ray0 + (r < valid ? r : 0);
+        st.zc[r][i] = coarse_z(a.near_rays ? a.near_rays[rb] : near_, a.near_rays ? a.far_rays[rb] : far_, t, a.lindisp);
       }
       __syncthreads();
       if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);
@@ -1389,13 +1394,16 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
           st.ray[tid][c] = o[c]; st.ray[tid][3 + c] = d[c];
           st.ray[tid][6 + c] = vd ? vd[rr * 3 + c] : d[c] / nrm;
         }
-        st.ray[tid][9] = near_; st.ray[tid][10] = far_; st.ray[tid][11] = nrm;
+        st.ray[tid][9] = a.near_rays ? a.near_rays[rr] : near_;       // per-ray bounds (RN:106-108) or the call's scalars
+        st.ray[tid][10] = a.near_rays ? a.far_rays[rr] : far_;
+        st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
-        st.zc[r][i] = coarse_z(near_, far_, t, a.lindisp);
+        const long long rb = ray0 + (r < valid ? r : 0);
+        st.zc[r][i] = coarse_z(a.near_rays ? a.near_rays[rb] : near_, a.near_rays ? a.far_rays[rb] : far_, t, a.lindisp);
       }
       __syncthreads();
       if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);

@@ -176,18 +176,20 @@ class NsrModel:
         return o, ro, dbg
 
     # ---- the path -----------------------------------------------------------------------------------
-    EXTRA_WIDTHS = dict(viewdirs=3, t_rand=64, u=128, noise0=64, noise1=192)
+    EXTRA_WIDTHS = dict(viewdirs=3, t_rand=64, u=128, noise0=64, noise1=192, near=1, far=1)
 
     def _extras(self, extras, n):
-        """dict with any of viewdirs [N,3], t_rand [N,64], u [N,128], noise0 [N,64], noise1 [N,192] (include/nsr.h:
-        NsrRayExtras) -> (struct, tensors kept alive) or (None, None)."""
+        """dict with any of viewdirs [N,3], t_rand [N,64], u [N,128], noise0 [N,64], noise1 [N,192], near + far [N]
+        (include/nsr.h: NsrRayExtras) -> (struct, tensors kept alive) or (None, None)."""
         if not extras or all(v is None for v in extras.values()):
             return None, None
         unknown = set(extras) - set(self.EXTRA_WIDTHS)
         if unknown:
             raise ValueError("unknown ray extras: %s" % sorted(unknown))
         keep = {k: self._f32(v, (n, self.EXTRA_WIDTHS[k])) for k, v in extras.items() if v is not None}
-        ex = _lib.NsrRayExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "t_rand", "u", "noise0", "noise1")])
+        if ("near" in keep) != ("far" in keep):
+            raise ValueError("per-ray bounds: near and far come together")
+        ex = _lib.NsrRayExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "t_rand", "u", "noise0", "noise1", "near", "far")])
         return ex, keep
 
     def render_rays(self, rays_o, rays_d, near, far, debug=False, extras=None):

@@ -7,9 +7,9 @@ Embedder, the 8x256 MLP -- is ONE persistent gfx950 kernel (csrc/nsr_kernels.hip
 of include/nsr.h.  This file is host glue: argument checking, handle caching, reshapes, PNG side effects.
 
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
-different path is worse): ndc=True, perturb>0, raw_noise_std>0, c2w_staticcam,
-use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, per-ray near/far arrays.  white_bkgd (RN:384-385)
-and lindisp (RN:443) are supported (one native handle per option pair).
+different path is worse): use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, pytest=True.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
+ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and raw_noise_std>0 (RN:365-374) reach the
+same kernels as per-ray extras (include/nsr.h: NsrRayExtras) -- see _draws for where the random numbers come from.
 
 `create_nerf` deliberately restates RN:258-340 statement by statement: the args it reads, the kwargs keys, the
 checkpoint keys and the returned 5-tuple ARE the drop-in contract, so there is nothing to redesign there."""
@@ -245,14 +245,13 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     through the per-ray extras of the native renderer (include/nsr.h: NsrRayExtras); see _draws for the random stream."""
     if not use_viewdirs:
         raise NotImplementedError("render: use_viewdirs=False is not supported")
-    if not (np.isscalar(near) and np.isscalar(far)):
-        raise NotImplementedError("render: near/far must be python scalars (per-ray bounds are not supported)")
+    per_ray_bounds = not (np.isscalar(near) and np.isscalar(far))          # RN:106-108: near / far may be arrays
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
     model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
-    special = bool(ndc) or c2w_staticcam is not None or _stochastic(kwargs)
+    special = bool(ndc) or c2w_staticcam is not None or _stochastic(kwargs) or per_ray_bounds
 
     if c2w is not None:
         c2w = torch.as_tensor(c2w, dtype=torch.float32)
@@ -282,8 +281,15 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
         ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]))
     if special:
-        outs = _RenderRaysEx.apply(ro, rd, viewdirs, model, float(near), float(far), retraw,
-                                   _draws(kwargs, ro.shape[0], n_imp, model.device))
+        ex = _draws(kwargs, ro.shape[0], n_imp, model.device)
+        if per_ray_bounds:                                  # one bound per ray (the reference multiplies them into [N,1])
+            for k, v in (("near", near), ("far", far)):
+                t = torch.as_tensor(v, dtype=torch.float32).to(model.device).reshape(-1)
+                if t.numel() not in (1, ro.shape[0]):
+                    raise ValueError("render: %s has %d entries for %d rays" % (k, t.numel(), ro.shape[0]))
+                ex[k] = t.expand(ro.shape[0]).contiguous()
+            near = far = 0.0
+        outs = _RenderRaysEx.apply(ro, rd, viewdirs, model, float(near), float(far), retraw, ex)
     else:
         outs = _RenderRays.apply(ro, rd, model, float(near), float(far), retraw)
     keys = ["rgb_map", "disp_map", "acc_map"] + (["rgb0", "disp0", "acc0", "z_std"] if fine else [])

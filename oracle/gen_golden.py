@@ -393,6 +393,15 @@ def main():
                ndc_disp=disp.detach().numpy(), ndc_acc=acc.detach().numpy(), ndc_rgb0=ex["rgb0"].detach().numpy(),
                ndc_z_std=ex["z_std"].detach().numpy(), ndc_z_samples=cap.log[0]["samples"], ndc_cot=cot_n.numpy(),
                ndc_grad_rays=gn.numpy())
+    # (d) near / far as per-ray arrays (RN:106-108 multiplies them into [N,1])
+    nb = (O.YCBV_NEAR + rng.uniform(0.0, 0.3, (96, 1))).astype(np.float32)
+    fb = (O.YCBV_FAR - rng.uniform(0.0, 0.3, (96, 1))).astype(np.float32)
+    with torch.no_grad():
+        with Capture(RN, RH) as cap:
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=96, rays=torch.stack([ro14, rd14], 0),
+                                           **dict(kwargs, near=torch.from_numpy(nb), far=torch.from_numpy(fb)))
+    g14.update(nf_near=nb[:, 0], nf_far=fb[:, 0], nf_rgb=rgb.numpy(), nf_disp=disp.numpy(), nf_acc=acc.numpy(),
+               nf_rgb0=ex["rgb0"].numpy(), nf_z_std=ex["z_std"].numpy(), nf_z_samples=cap.log[0]["samples"])
     del sig_last[:]
     save("g14_stochastic", **g14)
 

@@ -312,6 +312,66 @@ def test_given_view_directions_and_ndc_rays(oracle, synth_nets):
         m.close()
 
 
+def test_per_ray_bounds_and_coarse_only_extras(oracle, synth_nets):
+    """near / far as per-ray arrays (RN:106-108) against the oracle stage by stage and against the reference (g14), their
+    VJP, the same through render(); and the coarse-only configuration with stratified depths and density noise."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g14_stochastic")
+    ro, rd = g["rays_o"], g["rays_d"]
+    nb, fb = g["nf_near"], g["nf_far"]
+    m = NsrModel(synth_nets[0], synth_nets[1])
+    try:
+        r = m.render_rays(ro, rd, 0.0, 0.0, debug=True, extras=dict(near=nb, far=fb))
+        _stagewise(m, oracle, synth_nets, r, ro, rd, nb, fb)
+        assert_close(cpu(r["rgb0"]), g["nf_rgb0"], atol=1e-5, what="rgb0 vs reference")
+        d = np.abs(cpu(r["rgb_map"]) - g["nf_rgb"]).max(-1)
+        assert (d > 1e-4).mean() <= 0.06 and d.mean() < 1e-4
+        # a constant array is the scalar call, bit for bit
+        near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+        n = ro.shape[0]
+        a = m.render_rays(ro, rd, 0.0, 0.0, extras=dict(near=np.full(n, near, np.float32), far=np.full(n, far, np.float32)))
+        b = m.render_rays(ro, rd, near, far)
+        assert np.array_equal(cpu(a["rgb_map"]), cpu(b["rgb_map"]), equal_nan=True)
+        cot = np.random.RandomState(8).standard_normal((n, 3)).astype(np.float32)
+        go, gd = m.render_rays_vjp(ro, rd, 0.0, 0.0, cot, z_fine=cpu(r["z_fine"]), extras=dict(near=nb, far=fb))
+        wo, wd, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, nb, fb, cot, z_fine=cpu(r["z_fine"]))
+        for x, y in ((cpu(go), wo), (cpu(gd), wd)):
+            e = np.linalg.norm(x - y, axis=1) / (np.linalg.norm(y, axis=1) + 1e-12)
+            assert np.percentile(e, 90) < 3e-4, np.percentile(e, 90)
+        with pytest.raises(ValueError, match="come together"):
+            m.render_rays(ro, rd, 0.0, 0.0, extras=dict(near=nb))
+    finally:
+        m.close()
+    # through the reference-shaped API ([N,1] tensors, as RN:106-108 needs them)
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    nets = []
+    for sd in synth_nets:
+        nn_ = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        nn_.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(nn_.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False)
+    rgb = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), near=torch.tensor(nb)[:, None],
+                   far=torch.tensor(fb)[:, None], **kw)[0]
+    assert np.array_equal(cpu(rgb), cpu(r["rgb_map"]), equal_nan=True)
+    # coarse only (config 1's shape) with stratified depths and density noise
+    std = np.float32(float(g["noise_std"]))
+    rnd = dict(t_rand=g["t_rand"], noise0=(g["randn0"] * std).astype(np.float32))
+    mc = NsrModel(synth_nets[0], None, n_importance=0)
+    try:
+        rc = mc.render_rays(ro, rd, oracle.YCBV_NEAR, oracle.YCBV_FAR, debug=True, extras=rnd)
+        want = oracle.render_rays(synth_nets[0], None, ro, rd, oracle.normalize_dirs(rd), oracle.YCBV_NEAR, oracle.YCBV_FAR,
+                                  n_importance=0, extras=True, **rnd)
+        assert_close(cpu(rc["raw0"]), want["raw0"], atol=5e-5, rtol=5e-5, what="coarse-only raw")
+        assert_close(cpu(rc["rgb_map"]), g["rgb0"], atol=1e-5, what="coarse-only rgb vs the reference's coarse image")
+        from neural_sim_nerf_amd import _lib
+        with pytest.raises(_lib.NsrError, match="fine pass"):
+            mc.render_rays(ro, rd, 0.3, 1.9, extras=dict(u=g["u"]))
+    finally:
+        mc.close()
+
+
 def test_render_api_ndc_staticcam_and_stochastic_options(oracle, synth_nets, tmp_path):
     """The reference-shaped API with the options round 2 refused: render(ndc=True) with its gradient w.r.t. the rays against
     the reference's autograd (g14), render(c2w_staticcam=...) against the reference's image, render(perturb=1,

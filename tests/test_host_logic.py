@@ -380,10 +380,9 @@ def test_api_rejects_unsupported_configurations():
     K = [[100., 0, 4], [0, 100., 4], [0, 0, 1]]
     base = dict(H=8, W=8, K=K, c2w=np.eye(4, dtype=np.float32)[:3], ndc=False, use_viewdirs=True,
                 network_fn=None, N_samples=64, N_importance=128)
-    # (ndc, c2w_staticcam, perturb and raw_noise_std are served since round 3: tests/test_gpu_parity.py, g14)
+    # (ndc, c2w_staticcam, perturb, raw_noise_std and per-ray near / far are served since round 3: tests/test_gpu_parity.py, g14)
     for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=32), "N_samples"),
-                     (dict(N_importance=64), "N_importance"), (dict(near=np.zeros(3)), "near/far"),
-                     (dict(pytest=True), "pytest")):
+                     (dict(N_importance=64), "N_importance"), (dict(pytest=True), "pytest")):
         kw = dict(base)
         kw.update(bad)
         with pytest.raises(NotImplementedError, match=pat):

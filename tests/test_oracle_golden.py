@@ -200,6 +200,19 @@ def test_c2w_staticcam_against_the_reference(golden, oracle, synth_nets):
         assert np.abs(p["rgb0"] - g["sc_rgb0"]).max() > 1e-3
 
 
+def test_per_ray_bounds_against_the_reference(golden, oracle, synth_nets):
+    """near / far as per-ray arrays (RN:106-108)."""
+    g = golden("g14_stochastic")
+    sd_c, sd_f = synth_nets
+    vd = oracle.normalize_dirs(g["rays_d"])
+    r = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, g["nf_near"], g["nf_far"], extras=True)
+    assert_close(r["rgb0"], g["nf_rgb0"], atol=1e-5, what="rgb0")
+    d = np.abs(r["rgb_map"] - g["nf_rgb"]).max(-1)
+    assert (d > 1e-4).mean() <= 0.06 and d.mean() < 1e-4
+    assert (np.abs(r["z_samples"] - g["nf_z_samples"]) > 1e-4).mean() < 0.02
+    assert np.all(r["z_coarse"][:, 0] == g["nf_near"]) and np.abs(r["z_coarse"][:, -1] - g["nf_far"]).max() < 1e-6
+
+
 def test_ndc_against_the_reference(golden, oracle, synth_nets):
     """ndc_rays (RH:168-186) bit for bit; render(ndc=True, near=0, far=1) (RN:101-103) and its gradient w.r.t. the rays."""
     g = golden("g14_stochastic")
