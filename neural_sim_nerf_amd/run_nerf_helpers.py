@@ -49,22 +49,38 @@ class NeRF(nn.Module):
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super().__init__()
-        if (D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs)) != (8, 256, 63, 27, [4], True):
+        ok_views = (bool(use_viewdirs) and input_ch_views == 27) or (not use_viewdirs and output_ch in (4, 5))
+        if (D, W, input_ch, list(skips)) != (8, 256, 63, [4]) or not ok_views:
             raise NotImplementedError(
-                "the gfx950 kernel is specialised to D=8, W=256, input_ch=63, input_ch_views=27, skips=[4], "
-                "use_viewdirs=True (configs/nerf_param_ycbv_general.txt); got D=%r W=%r input_ch=%r "
-                "input_ch_views=%r skips=%r use_viewdirs=%r" % (D, W, input_ch, input_ch_views, skips, use_viewdirs))
+                "the gfx950 kernel is specialised to D=8, W=256, input_ch=63, skips=[4] with use_viewdirs=True, "
+                "input_ch_views=27 (configs/nerf_param_ycbv_general.txt) or use_viewdirs=False, output_ch 4 / 5; got D=%r "
+                "W=%r input_ch=%r input_ch_views=%r skips=%r use_viewdirs=%r output_ch=%r"
+                % (D, W, input_ch, input_ch_views, skips, use_viewdirs, output_ch))
         self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
-        self.skips, self.use_viewdirs = skips, use_viewdirs
+        self.skips, self.use_viewdirs = skips, bool(use_viewdirs)
         self.pts_linears = nn.ModuleList(
             [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in skips else nn.Linear(W + input_ch, W)
                                         for i in range(D - 1)])
-        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
-        self.feature_linear = nn.Linear(W, W)
-        self.alpha_linear = nn.Linear(W, 1)
-        self.rgb_linear = nn.Linear(W // 2, 3)
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])      # RH:86 (unused without viewdirs)
+        if use_viewdirs:
+            self.feature_linear = nn.Linear(W, W)
+            self.alpha_linear = nn.Linear(W, 1)
+            self.rgb_linear = nn.Linear(W // 2, 3)
+        else:
+            self.output_linear = nn.Linear(W, output_ch)                                 # RH:95-96
         self._native = None
         self._native_key = None
+
+    def native_state_dict(self):
+        """The weights in the architecture the kernels are built for (use_viewdirs=True, RH:92-94).  A use_viewdirs=False
+        network (outputs = output_linear(h), RH:119-120) is EXACTLY such a network with particular weights: feature_linear
+        = identity, alpha_linear = the density row, a view layer that computes +y and -y for the three colour rows y =
+        W_rgb h + b (direction columns zero) and an rgb_linear that takes relu(y) - relu(-y) = y.  The same fused kernels
+        then serve it, forward and input gradients, at the price of the two layers it does not need (17 % of a pass)."""
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        if self.use_viewdirs:
+            return sd
+        return noviews_as_viewdirs(sd)
 
     @staticmethod
     def weights_version_of(*nets):
@@ -139,7 +155,7 @@ class NeRF(nn.Module):
             if self._native is not None:
                 self._native.close()
             p0 = next(self.parameters())
-            self._native = NsrModel(self.state_dict(), None, n_importance=0, mlp="fp32",       # k_run_network (stage kernel)
+            self._native = NsrModel(self.native_state_dict(), None, n_importance=0, mlp="fp32",       # k_run_network (stage kernel)
                                     device=p0.device.index if p0.is_cuda else None)     # the module's device, not the current one
             self._native_key = key
         return self._native
@@ -153,7 +169,32 @@ class NeRF(nn.Module):
         """The reference's signature: x = cat([embedded points (63), embedded directions (27)]) [P,90].  Only the raw
         coordinates (columns 0:3 and 63:66, the include_input part of each encoding) are read."""
         x = x.reshape(-1, x.shape[-1])
+        if not self.use_viewdirs:                           # [P,63]: no direction columns; any unit vector will do
+            d = torch.zeros_like(x[:, :3])
+            d[:, 2] = 1.0
+            return self.evaluate(x[:, :3], d)
         return self.evaluate(x[:, :3], x[:, self.input_ch:self.input_ch + 3])
+
+
+def noviews_as_viewdirs(sd):
+    """State dict of a use_viewdirs=False NeRF (pts_linears.*, output_linear [4 or 5, 256]) -> the equal-valued
+    use_viewdirs=True state dict (see NeRF.native_state_dict).  Works on torch tensors or numpy arrays."""
+    is_t = torch.is_tensor(next(iter(sd.values())))
+    as_np = lambda v: v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+    w_out, b_out = as_np(sd["output_linear.weight"]).astype(np.float32), as_np(sd["output_linear.bias"]).astype(np.float32)
+    out = {k: as_np(v).astype(np.float32) for k, v in sd.items() if k.startswith("pts_linears")}
+    W = w_out.shape[1]
+    out["feature_linear.weight"], out["feature_linear.bias"] = np.eye(W, dtype=np.float32), np.zeros(W, np.float32)
+    out["alpha_linear.weight"], out["alpha_linear.bias"] = w_out[3:4].copy(), b_out[3:4].copy()
+    wv, bv = np.zeros((W // 2, W + 27), np.float32), np.zeros(W // 2, np.float32)
+    wv[0:3, :W], bv[0:3] = w_out[0:3], b_out[0:3]
+    wv[3:6, :W], bv[3:6] = -w_out[0:3], -b_out[0:3]
+    out["views_linears.0.weight"], out["views_linears.0.bias"] = wv, bv
+    wr = np.zeros((3, W // 2), np.float32)
+    wr[np.arange(3), np.arange(3)] = 1.0
+    wr[np.arange(3), 3 + np.arange(3)] = -1.0
+    out["rgb_linear.weight"], out["rgb_linear.bias"] = wr, np.zeros(3, np.float32)
+    return {k: torch.from_numpy(v) for k, v in out.items()} if is_t else out
 
 
 def get_rays(H, W, K, c2w):
@@ -162,9 +203,14 @@ def get_rays(H, W, K, c2w):
     return _get_rays_autograd(H, W, K, c2w)
 
 
-def ndc_rays(*a, **k):
-    raise NotImplementedError("NDC rays (forward-facing LLFF scenes, RH:178) are outside this path: "
-                              "LINEMOD/YCB-V uses ndc=False (RN:331-334)")
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    """RH:168-186 on the device (nsr_ndc_rays; bit-exact against the reference, tests/golden/g14_stochastic.npz);
+    differentiable w.r.t. the rays (nsr_ndc_rays_vjp)."""
+    from .run_nerf_noscale import _NdcRays, _util_model
+    rays_o = torch.as_tensor(rays_o, dtype=torch.float32)
+    rays_d = torch.as_tensor(rays_d, dtype=torch.float32)
+    m = _util_model(rays_o.device if rays_o.is_cuda else None)
+    return _NdcRays.apply(rays_o.to(m.device), rays_d.to(m.device), m, int(H), int(W), float(focal), float(near))
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False):

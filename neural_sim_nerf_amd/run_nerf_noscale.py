@@ -7,7 +7,8 @@ Embedder, the 8x256 MLP -- is ONE persistent gfx950 kernel (csrc/nsr_kernels.hip
 of include/nsr.h.  This file is host glue: argument checking, handle caching, reshapes, PNG side effects.
 
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
-different path is worse): use_viewdirs=False, N_samples != 64, N_importance not in {0,128}, pytest=True.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
+different path is worse): network shapes other than 8x256 with skip 4, N_samples != 64, N_importance not in {0,128},
+pytest=True.  use_viewdirs=False networks (RH:95-96) run on the same kernels through NeRF.native_state_dict.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
 ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and raw_noise_std>0 (RN:365-374) reach the
 same kernels as per-ray extras (include/nsr.h: NsrRayExtras) -- see _draws for where the random numbers come from.
 
@@ -31,6 +32,11 @@ DEBUG = False
 # ------------------------------------------------------------------------------------------------------
 _UTIL = {}
 _MAX_HANDLES_PER_MODULE = 8        # (render options, device, stream) handles kept per network pair, least recently used out
+
+
+def _native_sd(net):
+    """State dict in the architecture the kernels are built for (a use_viewdirs=False module maps itself onto it)."""
+    return net.native_state_dict() if hasattr(net, "native_state_dict") else net.state_dict()
 
 
 def _util_model(dev=None):
@@ -70,7 +76,7 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
         if cache.get("model") is not None:
             cache["model"].close()
         with torch.cuda.device(dev):
-            cache["model"] = NsrModel(network_fn.state_dict(), network_fine.state_dict() if network_fine is not None
+            cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
                                       else None, device=dev, n_importance=n_importance, white_bkgd=white,
                                       lindisp=lindisp)
         cache["key"] = key
@@ -167,17 +173,17 @@ class _NdcRays(torch.autograd.Function):
     """ndc_rays (RH:168-186) on the device, with its input-side VJP."""
 
     @staticmethod
-    def forward(ctx, rays_o, rays_d, model, H, W, focal):
+    def forward(ctx, rays_o, rays_d, model, H, W, focal, near):
         ctx.save_for_backward(rays_o.detach(), rays_d.detach())
-        ctx.cfg = (model, H, W, focal)
-        return model.ndc_rays(rays_o.detach(), rays_d.detach(), H, W, focal, 1.0)
+        ctx.cfg = (model, H, W, focal, near)
+        return model.ndc_rays(rays_o.detach(), rays_d.detach(), H, W, focal, near)
 
     @staticmethod
     def backward(ctx, g_o, g_d):
-        model, H, W, focal = ctx.cfg
+        model, H, W, focal, near = ctx.cfg
         rays_o, rays_d = ctx.saved_tensors
-        go, gd = model.ndc_rays_vjp(rays_o, rays_d, H, W, focal, g_o.contiguous(), g_d.contiguous(), 1.0)
-        return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None
+        go, gd = model.ndc_rays_vjp(rays_o, rays_d, H, W, focal, g_o.contiguous(), g_d.contiguous(), near)
+        return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None, None
 
 
 def _draws(kw, n, n_importance, dev):
@@ -211,10 +217,14 @@ def batchify(fn, chunk):
 
 def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk=1024 * 64):
     """RN:26-40: inputs [..., 3] points, viewdirs [N, 3] -> [..., 4], evaluated natively (encoding fused)."""
-    if viewdirs is None:
-        raise NotImplementedError("use_viewdirs=False is not supported")
     flat = inputs.reshape(-1, 3)
-    dirs = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
+    if viewdirs is None:                                    # use_viewdirs=False (RN:31): the network ignores directions
+        if not (isinstance(fn, NeRF) and not fn.use_viewdirs):
+            raise NotImplementedError("run_network: viewdirs=None needs a use_viewdirs=False NeRF module")
+        dirs = torch.zeros_like(flat)
+        dirs[:, 2] = 1.0
+    else:
+        dirs = viewdirs[:, None].expand(inputs.shape).reshape(-1, 3)
     if isinstance(fn, NeRF):
         out = fn.evaluate(flat, dirs)                       # straight to the native kernel: no [P,90] staging tensor
     else:                                                   # any other callable gets the reference's [P,90] layout
@@ -223,6 +233,17 @@ def run_network(inputs, viewdirs, fn, embed_fn=None, embeddirs_fn=None, netchunk
         x[:, 63:66] = dirs
         out = fn(x)
     return out.reshape(list(inputs.shape[:-1]) + [out.shape[-1]])
+
+
+def _check_viewdirs(name, use_viewdirs, kw):
+    """use_viewdirs must say what the networks are (RN:60 / RH:92-96): a use_viewdirs=False network has no direction
+    input at all -- it is served by the same kernels through NeRF.native_state_dict -- and a use_viewdirs=True network
+    rendered without directions has no meaning."""
+    for key in ("network_fn", "network_fine"):
+        net = kw.get(key)
+        if net is not None and bool(getattr(net, "use_viewdirs", True)) != bool(use_viewdirs):
+            raise NotImplementedError("%s: use_viewdirs=%r with a %s built for use_viewdirs=%r"
+                                      % (name, use_viewdirs, key, getattr(net, "use_viewdirs", True)))
 
 
 def _check_kwargs(kw):
@@ -243,8 +264,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     c2w is given, rays_d.shape[:-1] + ... for the rays form.  `chunk` is accepted and ignored.
     ndc (RN:101-103), c2w_staticcam (RN:91-96), perturb > 0 (RN:447-459, RH:211) and raw_noise_std > 0 (RN:365-374) go
     through the per-ray extras of the native renderer (include/nsr.h: NsrRayExtras); see _draws for the random stream."""
-    if not use_viewdirs:
-        raise NotImplementedError("render: use_viewdirs=False is not supported")
+    _check_viewdirs("render", use_viewdirs, kwargs)
     per_ray_bounds = not (np.isscalar(near) and np.isscalar(far))          # RN:106-108: near / far may be arrays
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
@@ -279,7 +299,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     ro = rays_o.reshape(-1, 3).to(model.device)
     rd = rays_d.reshape(-1, 3).to(model.device)
     if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
-        ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]))
+        ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]), 1.0)
     if special:
         ex = _draws(kwargs, ro.shape[0], n_imp, model.device)
         if per_ray_bounds:                                  # one bound per ray (the reference multiplies them into [N,1])
@@ -326,8 +346,7 @@ def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False, genera
         general = True
     else:
         general = False
-    if not kw.pop("use_viewdirs", False):
-        raise NotImplementedError("%s: use_viewdirs=False is not supported" % name)
+    _check_viewdirs(name, kw.pop("use_viewdirs", False), kw)
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
     if need_fine and n_imp != 128:
@@ -452,9 +471,10 @@ def create_nerf(args):
     """RN:258-340: builds the coarse/fine networks, loads `args.ft_path` (or the newest .tar under
     basedir/expname) and returns (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer)."""
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed)
-    if not args.use_viewdirs:
-        raise NotImplementedError("create_nerf: use_viewdirs=False is not supported")
-    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
+    input_ch_views = 0
+    embeddirs_fn = None
+    if args.use_viewdirs:
+        embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed)
     output_ch = 5 if args.N_importance > 0 else 4
     skips = [4]
     model = NeRF(D=args.netdepth, W=args.netwidth, input_ch=input_ch, output_ch=output_ch, skips=skips,

@@ -405,6 +405,30 @@ def main():
     del sig_last[:]
     save("g14_stochastic", **g14)
 
+    # ---- G15 the use_viewdirs=False network (RH:95-96, RH:119-120; create_nerf RN:262-267: output_ch = 5) ------------
+    sd_nc = O.synth_weights_noviews(SEED)
+    sd_nf = O.synth_weights_noviews(SEED + 1000, fine_of=sd_nc)
+    nv = []
+    for sd in (sd_nc, sd_nf):
+        net = RH.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=0, use_viewdirs=False)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nv.append(net)
+    q_nv = lambda inputs, viewdirs, fn: RN.run_network(inputs, viewdirs, fn, embed_fn=embed_fn, embeddirs_fn=None,
+                                                      netchunk=65536)
+    kw15 = dict(kwargs, network_query_fn=q_nv, network_fn=nv[0], network_fine=nv[1], use_viewdirs=False)
+    sel = rng.choice(160000, size=64, replace=False)
+    ro15, rd15 = o32.reshape(-1, 3)[sel], d32.reshape(-1, 3)[sel]
+    rays = torch.stack([ro15, rd15], 0).clone().requires_grad_(True)
+    cot15 = torch.from_numpy(rng.standard_normal((64, 3)).astype(np.float32))
+    with Capture(RN, RH) as cap:
+        rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=64, rays=rays, retraw=True, **kw15)
+    (g15g,) = torch.autograd.grad(rgb, rays, grad_outputs=cot15)
+    del sig_last[:]
+    save("g15_noviewdirs", seed=np.int64(SEED), rays_o=ro15.numpy(), rays_d=rd15.numpy(), rgb=rgb.detach().numpy(),
+         disp=disp.detach().numpy(), acc=acc.detach().numpy(), rgb0=ex["rgb0"].detach().numpy(),
+         acc0=ex["acc0"].detach().numpy(), z_std=ex["z_std"].detach().numpy(), raw16=ex["raw"].detach().numpy()[:16],
+         z_samples=cap.log[0]["samples"], cot=cot15.numpy(), grad_rays=g15g.numpy())
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

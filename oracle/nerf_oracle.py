@@ -167,6 +167,26 @@ def synth_weights(seed, fine_of=None):
     return sd
 
 
+def synth_weights_noviews(seed, fine_of=None, output_ch=5):
+    """The use_viewdirs=False network of RH:70-122 (create_nerf RN:267: output_ch = 5 with a fine pass) from the recipe
+    above: the same trunk, `output_linear` = three colour rows + the density row of synth_weights (+ an unused fifth
+    row), and the reference's unused `views_linears.0` of shape [128, 0 + 256]."""
+    if fine_of is not None:
+        rng = np.random.RandomState(seed)
+        return {k: (v * (1.0 + 0.05 * rng.standard_normal(v.shape))).astype(f32) for k, v in fine_of.items()}
+    base = synth_weights(seed)
+    rng = np.random.RandomState(seed + 77)
+    sd = {k: v for k, v in base.items() if k.startswith("pts_linears")}
+    bound = 1.0 / np.sqrt(NET_WIDTH)
+    w = rng.uniform(-bound, bound, size=(output_ch, NET_WIDTH)) * 4.0
+    b = rng.uniform(-bound, bound, size=(output_ch,))
+    w[3], b[3] = base["alpha_linear.weight"][0], base["alpha_linear.bias"][0]
+    sd["output_linear.weight"], sd["output_linear.bias"] = w.astype(f32), b.astype(f32)
+    sd["views_linears.0.weight"] = rng.uniform(-bound, bound, size=(NET_WIDTH // 2, NET_WIDTH)).astype(f32)
+    sd["views_linears.0.bias"] = rng.uniform(-bound, bound, size=(NET_WIDTH // 2,)).astype(f32)
+    return sd
+
+
 # ----------------------------------------------------------------------------------------------
 # the path
 # ----------------------------------------------------------------------------------------------
@@ -212,7 +232,8 @@ def embed(x, n_freqs):
 
 
 def mlp(sd, x_embedded, keep=None):
-    """RH:99-122 (use_viewdirs=True).  x_embedded [P, 90] -> [P, 4] = (rgb logits, sigma)."""
+    """RH:99-122.  x_embedded [P, 90] -> [P, 4] = (rgb logits, sigma).  A state dict with `output_linear` is the
+    use_viewdirs=False network (RH:95-96, RH:119-120): the direction columns are ignored, the outputs are output_linear(h)."""
     lin = lambda name, h: (h @ sd[name + ".weight"].T + sd[name + ".bias"]).astype(f32)
     pts, views = x_embedded[:, :IN_CH], x_embedded[:, IN_CH:]
     h = pts
@@ -222,6 +243,8 @@ def mlp(sd, x_embedded, keep=None):
             keep["h%d" % i] = h
         if i == SKIP_AT:
             h = np.concatenate([pts, h], -1)
+    if "output_linear.weight" in sd:                    # use_viewdirs=False (RH:119-120): 4 (or 5, RN:267) outputs of h
+        return lin("output_linear", h)[:, :4]
     alpha = lin("alpha_linear", h)
     feature = lin("feature_linear", h)
     hv = np.maximum(lin("views_linears.0", np.concatenate([feature, views], -1)), f32(0))
@@ -519,6 +542,9 @@ def _network_forward64(sd, pts, dirs):
         h = np.maximum(a, 0)
         if i == SKIP_AT:
             h = np.concatenate([e_p, h], -1)
+    if "output_linear.weight" in sd:                    # use_viewdirs=False (RH:119-120)
+        out = h @ W("output_linear").T + B("output_linear")
+        return dict(pre=pre, av=None, sigma=out[:, 3], rgb_raw=out[:, :3])
     sigma = (h @ W("alpha_linear").T + B("alpha_linear"))[:, 0]
     feat = h @ W("feature_linear").T + B("feature_linear")
     av = np.concatenate([feat, e_d], -1) @ W("views_linears.0").T + B("views_linears.0")
@@ -544,10 +570,14 @@ def network_vjp(sd, pts, dirs, g_raw, fwd=None):
         fwd = _network_forward64(sd, pts, dirs)
     pre, av = fwd["pre"], fwd["av"]
     g_raw = g_raw.astype(f64)
-    G_av = (g_raw[:, :3] @ W("rgb_linear")) * (av > 0)
-    G_cat = G_av @ W("views_linears.0")
-    G_feat, G_ed = G_cat[:, :NET_WIDTH], G_cat[:, NET_WIDTH:]
-    G_h = G_feat @ W("feature_linear") + g_raw[:, 3:4] @ W("alpha_linear")
+    if av is None:                                      # use_viewdirs=False: outputs = output_linear(h)
+        G_h = g_raw @ W("output_linear")[:4]
+        G_ed = np.zeros((pts.shape[0], IN_CH_VIEWS), f64)
+    else:
+        G_av = (g_raw[:, :3] @ W("rgb_linear")) * (av > 0)
+        G_cat = G_av @ W("views_linears.0")
+        G_feat, G_ed = G_cat[:, :NET_WIDTH], G_cat[:, NET_WIDTH:]
+        G_h = G_feat @ W("feature_linear") + g_raw[:, 3:4] @ W("alpha_linear")
     G_ep = np.zeros((pts.shape[0], IN_CH), f64)
     for i in reversed(range(NET_DEPTH)):
         if i == SKIP_AT:

@@ -301,6 +301,15 @@ def test_given_view_directions_and_ndc_rays(oracle, synth_nets):
         wo, wd = oracle.ndc_rays_vjp(H, W, Kn[0][0], 1.0, g["ndc_rays_o"].reshape(n, 3), g["ndc_rays_d"].reshape(n, 3), g0, g1)
         assert_close(cpu(go), wo, atol=1e-5, rtol=1e-5, what="ndc vjp rays_o")
         assert_close(cpu(gd), wd, atol=1e-5, rtol=1e-5, what="ndc vjp rays_d")
+        # the reference's helper name, with gradient
+        import torch
+        import neural_sim_nerf_amd.run_nerf_helpers as RHn
+        tro = torch.tensor(g["ndc_rays_o"], device=m.device, requires_grad=True)
+        o2, d2 = RHn.ndc_rays(H, W, Kn[0][0], 1., tro, torch.tensor(g["ndc_rays_d"], device=m.device))
+        assert np.array_equal(cpu(o2), g["ndc_o"]) and np.array_equal(cpu(d2), g["ndc_d"])
+        (gg,) = torch.autograd.grad(o2, tro, grad_outputs=torch.tensor(g0.reshape(H, W, 3), device=m.device))
+        wo0, _ = oracle.ndc_rays_vjp(H, W, Kn[0][0], 1.0, g["ndc_rays_o"].reshape(n, 3), g["ndc_rays_d"].reshape(n, 3), g0, 0 * g1)
+        assert_close(cpu(gg).reshape(n, 3), wo0, atol=1e-5, rtol=1e-5, what="helpers.ndc_rays autograd")
         # grad_viewdirs without viewdirs is refused
         from neural_sim_nerf_amd import _lib
         import ctypes as C
@@ -370,6 +379,66 @@ def test_per_ray_bounds_and_coarse_only_extras(oracle, synth_nets):
             mc.render_rays(ro, rd, 0.3, 1.9, extras=dict(u=g["u"]))
     finally:
         mc.close()
+
+
+@pytest.mark.parametrize("mlp", ["f16x2", "fp32"])
+def test_noviewdirs_network(mlp, oracle):
+    """use_viewdirs=False networks (RH:95-96, RH:119-120) on the kernels built for the use_viewdirs=True architecture
+    (run_nerf_helpers.noviews_as_viewdirs: identity feature layer, +-y through the view layer's relu): stage by stage
+    against the oracle's DIRECT restatement of the smaller network, against the reference (g15) forward and gradient, and
+    through the reference-shaped API with use_viewdirs=False."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    from neural_sim_nerf_amd.run_nerf_helpers import noviews_as_viewdirs
+    g = load_golden("g15_noviewdirs")
+    seed = int(g["seed"])
+    sd_c = oracle.synth_weights_noviews(seed)
+    sd_f = oracle.synth_weights_noviews(seed + 1000, fine_of=sd_c)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"], g["rays_d"]
+    m = NsrModel(noviews_as_viewdirs(sd_c), noviews_as_viewdirs(sd_f), mlp=mlp)
+    try:
+        r = m.render_rays(ro, rd, near, far, debug=True)
+        _stagewise(m, oracle, (sd_c, sd_f), r, ro, rd, near, far)
+        assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+        d = np.abs(cpu(r["rgb_map"]) - g["rgb"]).max(-1)
+        assert (d > 1e-4).mean() <= 0.08 and d.mean() < 2e-4
+        z = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
+        zf = np.sort(np.concatenate([z, g["z_samples"]], -1), -1)
+        go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf)
+        for a, b in ((cpu(go), g["grad_rays"][0]), (cpu(gd), g["grad_rays"][1])):
+            e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+            assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (np.percentile(e, 90), e.max())
+        want = cpu(r["rgb_map"])
+    finally:
+        m.close()
+    if mlp != "f16x2":
+        return
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    nets = []
+    for sd in (sd_c, sd_f):
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=0, use_viewdirs=False)
+        assert set(n.state_dict()) == set(sd)                         # the reference's parameter names (RH:82-96)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=False, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=near, far=far)
+    rays = torch.tensor(np.stack([ro, rd]), device=R.device, requires_grad=True)
+    rgb, disp, acc, ex = R.render(400, 400, oracle.YCBV_K, rays=rays, **kw)
+    assert np.array_equal(cpu(rgb), want, equal_nan=True)
+    (gr,) = torch.autograd.grad(rgb, rays, grad_outputs=torch.tensor(g["cot"], device=R.device))
+    assert np.isfinite(cpu(gr)).all()
+    # run_network without directions and a module that takes [P,63]
+    pts = torch.tensor(ro[:8, None, :] + rd[:8, None, :] * 1.0, device=R.device)
+    out = R.run_network(pts, None, nets[0])
+    e = oracle.embed(cpu(pts).reshape(-1, 3), 10)
+    assert_close(cpu(out).reshape(-1, 4), oracle.mlp(sd_c, np.concatenate([e, np.zeros((8, 27), np.float32)], -1)), atol=5e-5,
+                 rtol=5e-5, what="run_network(viewdirs=None)")
+    with pytest.raises(NotImplementedError, match="use_viewdirs"):
+        R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, use_viewdirs=True))
+    for n in nets:
+        n.invalidate()
 
 
 def test_render_api_ndc_staticcam_and_stochastic_options(oracle, synth_nets, tmp_path):

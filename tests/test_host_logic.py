@@ -380,13 +380,19 @@ def test_api_rejects_unsupported_configurations():
     K = [[100., 0, 4], [0, 100., 4], [0, 0, 1]]
     base = dict(H=8, W=8, K=K, c2w=np.eye(4, dtype=np.float32)[:3], ndc=False, use_viewdirs=True,
                 network_fn=None, N_samples=64, N_importance=128)
-    # (ndc, c2w_staticcam, perturb, raw_noise_std and per-ray near / far are served since round 3: tests/test_gpu_parity.py, g14)
+    # (ndc, c2w_staticcam, perturb, raw_noise_std, per-ray near / far and use_viewdirs=False NETWORKS are served since
+    # round 3: tests/test_gpu_parity.py, g14, g15)
+    net = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+    base["network_fn"] = net
     for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=32), "N_samples"),
                      (dict(N_importance=64), "N_importance"), (dict(pytest=True), "pytest")):
         kw = dict(base)
         kw.update(bad)
         with pytest.raises(NotImplementedError, match=pat):
             R.render(**kw)
+    nv = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=0, use_viewdirs=False)
+    assert "output_linear.weight" in nv.state_dict() and "alpha_linear.weight" not in nv.state_dict()
+    assert set(nv.native_state_dict()) == set(net.state_dict())
     with pytest.raises(NotImplementedError, match="specialised"):
         R.NeRF(D=4, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
     with pytest.raises(NotImplementedError):
