@@ -42,20 +42,20 @@ def get_embedder(multires, i=0):
 
 
 class NeRF(nn.Module):
-    """RH:70-122: weight container with the reference's parameter names, so the reference's checkpoints
-    (`network_fn_state_dict` / `network_fine_state_dict`, RN:296-314) load with load_state_dict unchanged.
+    """RH:70-122: weight container with the reference's parameter names and shapes for the given D / W / input sizes /
+    skips / use_viewdirs, so the reference's checkpoints (`network_fn_state_dict` / `network_fine_state_dict`, RN:296-314)
+    load with load_state_dict unchanged.  Shapes that cannot be expressed as the kernels' network are refused (fits_kernel).
     forward() evaluates the network natively; its input is the reference's [P, 90] embedded tensor, of which
     only the raw position (columns 0:3) and direction (63:66) are read -- the kernel re-derives the rest."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super().__init__()
-        ok_views = (bool(use_viewdirs) and input_ch_views == 27) or (not use_viewdirs and output_ch in (4, 5))
-        if (D, W, input_ch, list(skips)) != (8, 256, 63, [4]) or not ok_views:
+        why = fits_kernel(D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs), output_ch)
+        if why:
             raise NotImplementedError(
-                "the gfx950 kernel is specialised to D=8, W=256, input_ch=63, skips=[4] with use_viewdirs=True, "
-                "input_ch_views=27 (configs/nerf_param_ycbv_general.txt) or use_viewdirs=False, output_ch 4 / 5; got D=%r "
-                "W=%r input_ch=%r input_ch_views=%r skips=%r use_viewdirs=%r output_ch=%r"
-                % (D, W, input_ch, input_ch_views, skips, use_viewdirs, output_ch))
+                "the gfx950 kernel is specialised to the 8 x 256 network of configs/nerf_param_ycbv_general.txt (63 + 27 "
+                "inputs, skip after layer 4, use_viewdirs=True) and to the networks that can be written as one exactly "
+                "(run_nerf_helpers.as_kernel_network); this one cannot: " + why)
         self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
         self.skips, self.use_viewdirs = skips, bool(use_viewdirs)
         self.pts_linears = nn.ModuleList(
@@ -72,15 +72,15 @@ class NeRF(nn.Module):
         self._native_key = None
 
     def native_state_dict(self):
-        """The weights in the architecture the kernels are built for (use_viewdirs=True, RH:92-94).  A use_viewdirs=False
-        network (outputs = output_linear(h), RH:119-120) is EXACTLY such a network with particular weights: feature_linear
-        = identity, alpha_linear = the density row, a view layer that computes +y and -y for the three colour rows y =
-        W_rgb h + b (direction columns zero) and an rgb_linear that takes relu(y) - relu(-y) = y.  The same fused kernels
-        then serve it, forward and input gradients, at the price of the two layers it does not need (17 % of a pass)."""
+        """The weights in the architecture the kernels are built for (as_kernel_network): this module's own state dict
+        when it IS that architecture, else the equal-valued 8 x 256 network (narrower / shallower networks, fewer
+        encoding frequencies, another skip position, use_viewdirs=False) -- the same fused kernels then serve it, forward
+        and input gradients, at the full network's price."""
         sd = {k: v.detach() for k, v in self.state_dict().items()}
-        if self.use_viewdirs:
+        if (self.D, self.W, self.input_ch, self.input_ch_views, list(self.skips), self.use_viewdirs) == \
+                (KERNEL_D, KERNEL_W, KERNEL_IN, KERNEL_IN_VIEWS, [KERNEL_SKIP], True):
             return sd
-        return noviews_as_viewdirs(sd)
+        return as_kernel_network(sd)
 
     @staticmethod
     def weights_version_of(*nets):
@@ -176,25 +176,115 @@ class NeRF(nn.Module):
         return self.evaluate(x[:, :3], x[:, self.input_ch:self.input_ch + 3])
 
 
-def noviews_as_viewdirs(sd):
-    """State dict of a use_viewdirs=False NeRF (pts_linears.*, output_linear [4 or 5, 256]) -> the equal-valued
-    use_viewdirs=True state dict (see NeRF.native_state_dict).  Works on torch tensors or numpy arrays."""
+KERNEL_D, KERNEL_W, KERNEL_IN, KERNEL_IN_VIEWS, KERNEL_SKIP = 8, 256, 63, 27, 4
+
+
+def _shape_of(sd):
+    D = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("pts_linears."))
+    W, input_ch = tuple(sd["pts_linears.0.weight"].shape)
+    skips = [i for i in range(D - 1) if sd["pts_linears.%d.weight" % (i + 1)].shape[1] == W + input_ch]
+    use_viewdirs = "output_linear.weight" not in sd
+    input_ch_views = sd["views_linears.0.weight"].shape[1] - W
+    return D, W, input_ch, input_ch_views, skips, use_viewdirs
+
+
+def fits_kernel(D, W, input_ch, input_ch_views, skips, use_viewdirs, output_ch=4):
+    """None if a NeRF of this shape (RH:70-97) can be expressed EXACTLY as the 8 x 256 / skip-after-layer-4 / 63 + 27 input
+    network the kernels are built for (see as_kernel_network), else the reason why not."""
+    if W > KERNEL_W or W % 2:
+        return "netwidth %r (an even width <= %d)" % (W, KERNEL_W)
+    if input_ch > KERNEL_IN or (input_ch - 3) % 6:
+        return "input_ch %r (3 + 6 L with L <= 10 frequencies)" % (input_ch,)
+    if use_viewdirs and (input_ch_views > KERNEL_IN_VIEWS or (input_ch_views - 3) % 6 or input_ch_views < 3):
+        return "input_ch_views %r (3 + 6 L with L <= 4 frequencies)" % (input_ch_views,)
+    if not use_viewdirs and output_ch not in (4, 5):
+        return "output_ch %r (4 or 5)" % (output_ch,)
+    eff = [s for s in skips if s < D - 1]                   # a skip after the last layer breaks the reference itself (RH:109)
+    if len(eff) > 1:
+        return "skips %r (at most one)" % (skips,)
+    if not eff:
+        return None if D <= KERNEL_D else "netdepth %r (<= %d)" % (D, KERNEL_D)
+    s = eff[0]
+    if s > KERNEL_SKIP or D - s - 2 > KERNEL_D - KERNEL_SKIP - 2:
+        return "netdepth %r with the skip after layer %r (needs skip <= %d and at most %d layers after it)" % (
+            D, s, KERNEL_SKIP, KERNEL_D - KERNEL_SKIP - 1)
+    return None
+
+
+def as_kernel_network(sd):
+    """State dict of ANY NeRF that fits (fits_kernel) -> the equal-valued state dict of the kernel's network (D = 8,
+    W = 256, inputs 63 + 27, skip after layer 4, use_viewdirs=True), exact up to fp32 rounding of sums of exact zeros:
+      * narrower layers are zero-padded (a padded unit is relu(0) = 0 and feeds zero weights);
+      * fewer encoding frequencies: the encoder emits its bands in increasing order (RH:35-48), so a network built for L
+        frequencies reads the leading 3 + 6 L columns and the rest get zero weights;
+      * fewer layers / another skip position: IDENTITY layers (h >= 0 after a relu, so relu(I h + 0) = h) fill the gap
+        between the network's skip and the kernel's, and the tail;
+      * use_viewdirs=False (outputs = output_linear(h), RH:119-120): identity feature_linear, the density row as
+        alpha_linear, a view layer computing +y and -y for the three colour rows y = W_rgb h + b (direction columns
+        zero) and an rgb_linear taking relu(y) - relu(-y) = y.
+    Works on torch tensors or numpy arrays (returns the same kind)."""
     is_t = torch.is_tensor(next(iter(sd.values())))
-    as_np = lambda v: v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
-    w_out, b_out = as_np(sd["output_linear.weight"]).astype(np.float32), as_np(sd["output_linear.bias"]).astype(np.float32)
-    out = {k: as_np(v).astype(np.float32) for k, v in sd.items() if k.startswith("pts_linears")}
-    W = w_out.shape[1]
-    out["feature_linear.weight"], out["feature_linear.bias"] = np.eye(W, dtype=np.float32), np.zeros(W, np.float32)
-    out["alpha_linear.weight"], out["alpha_linear.bias"] = w_out[3:4].copy(), b_out[3:4].copy()
-    wv, bv = np.zeros((W // 2, W + 27), np.float32), np.zeros(W // 2, np.float32)
-    wv[0:3, :W], bv[0:3] = w_out[0:3], b_out[0:3]
-    wv[3:6, :W], bv[3:6] = -w_out[0:3], -b_out[0:3]
-    out["views_linears.0.weight"], out["views_linears.0.bias"] = wv, bv
-    wr = np.zeros((3, W // 2), np.float32)
-    wr[np.arange(3), np.arange(3)] = 1.0
-    wr[np.arange(3), 3 + np.arange(3)] = -1.0
-    out["rgb_linear.weight"], out["rgb_linear.bias"] = wr, np.zeros(3, np.float32)
+    a = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32) for k, v in sd.items()}
+    D, W, in_ch, in_v, skips, use_viewdirs = _shape_of(a)
+    why = fits_kernel(D, W, in_ch, in_v, skips, use_viewdirs, a["output_linear.weight"].shape[0] if not use_viewdirs else 4)
+    if why:
+        raise NotImplementedError("this network does not fit the gfx950 kernel's 8x256 architecture: " + why)
+    KW, KI = KERNEL_W, KERNEL_IN
+    eff = [s for s in skips if s < D - 1]
+    s = eff[0] if eff else None
+    # which source layer sits in which kernel layer (None = identity)
+    if s is None:
+        place = list(range(D)) + [None] * (KERNEL_D - D)
+    else:
+        place = list(range(s + 1)) + [None] * (KERNEL_SKIP - s) + list(range(s + 1, D))
+        place += [None] * (KERNEL_D - len(place))
+    out = {}
+    for kl, src in enumerate(place):
+        takes_pts = kl == 0 or kl == KERNEL_SKIP + 1
+        cols = KI if kl == 0 else (KI + KW if takes_pts else KW)
+        w, b = np.zeros((KW, cols), np.float32), np.zeros(KW, np.float32)
+        hcol = 0 if kl == 0 else (KI if takes_pts else 0)    # first column of the hidden part
+        if src is None:
+            w[np.arange(KW), hcol + np.arange(KW)] = 1.0
+        else:
+            sw, sb = a["pts_linears.%d.weight" % src], a["pts_linears.%d.bias" % src]
+            b[:W] = sb
+            if src == 0:
+                w[:W, :in_ch] = sw
+            elif src - 1 in eff:                             # the layer after the skip: [pts | h] -> [pts(63) | h(256)]
+                w[:W, :in_ch] = sw[:, :in_ch]
+                w[:W, KI:KI + W] = sw[:, in_ch:]
+            else:
+                w[:W, hcol:hcol + W] = sw
+        out["pts_linears.%d.weight" % kl], out["pts_linears.%d.bias" % kl] = w, b
+    wv, bv = np.zeros((KW // 2, KW + KERNEL_IN_VIEWS), np.float32), np.zeros(KW // 2, np.float32)
+    wr, br = np.zeros((3, KW // 2), np.float32), np.zeros(3, np.float32)
+    wf, bf = np.zeros((KW, KW), np.float32), np.zeros(KW, np.float32)
+    wa, ba = np.zeros((1, KW), np.float32), np.zeros(1, np.float32)
+    if use_viewdirs:
+        wf[:W, :W], bf[:W] = a["feature_linear.weight"], a["feature_linear.bias"]
+        wa[:, :W], ba[:] = a["alpha_linear.weight"], a["alpha_linear.bias"]
+        sv = a["views_linears.0.weight"]
+        wv[:W // 2, :W] = sv[:, :W]
+        wv[:W // 2, KW:KW + in_v] = sv[:, W:]
+        bv[:W // 2] = a["views_linears.0.bias"]
+        wr[:, :W // 2], br[:] = a["rgb_linear.weight"], a["rgb_linear.bias"]
+    else:
+        w_out, b_out = a["output_linear.weight"], a["output_linear.bias"]
+        wf[np.arange(KW), np.arange(KW)] = 1.0
+        wa[:, :W], ba[:] = w_out[3:4], b_out[3:4]
+        wv[0:3, :W], bv[0:3] = w_out[0:3], b_out[0:3]
+        wv[3:6, :W], bv[3:6] = -w_out[0:3], -b_out[0:3]
+        wr[np.arange(3), np.arange(3)] = 1.0
+        wr[np.arange(3), 3 + np.arange(3)] = -1.0
+    out.update({"feature_linear.weight": wf, "feature_linear.bias": bf, "alpha_linear.weight": wa, "alpha_linear.bias": ba,
+                "views_linears.0.weight": wv, "views_linears.0.bias": bv, "rgb_linear.weight": wr, "rgb_linear.bias": br})
     return {k: torch.from_numpy(v) for k, v in out.items()} if is_t else out
+
+
+def noviews_as_viewdirs(sd):
+    """The use_viewdirs=False case of as_kernel_network under its first name."""
+    return as_kernel_network(sd)
 
 
 def get_rays(H, W, K, c2w):

@@ -7,8 +7,9 @@ Embedder, the 8x256 MLP -- is ONE persistent gfx950 kernel (csrc/nsr_kernels.hip
 of include/nsr.h.  This file is host glue: argument checking, handle caching, reshapes, PNG side effects.
 
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
-different path is worse): network shapes other than 8x256 with skip 4, N_samples != 64, N_importance not in {0,128},
-pytest=True.  use_viewdirs=False networks (RH:95-96) run on the same kernels through NeRF.native_state_dict.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
+different path is worse): networks that cannot be written as the kernels' 8x256 network (run_nerf_helpers.fits_kernel),
+N_samples != 64, N_importance not in {0,128}, pytest=True.  Smaller networks and use_viewdirs=False networks (RH:95-96) run
+on the same kernels through NeRF.native_state_dict.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
 ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and raw_noise_std>0 (RN:365-374) reach the
 same kernels as per-ray extras (include/nsr.h: NsrRayExtras) -- see _draws for where the random numbers come from.
 

@@ -429,6 +429,43 @@ def main():
          acc0=ex["acc0"].detach().numpy(), z_std=ex["z_std"].detach().numpy(), raw16=ex["raw"].detach().numpy()[:16],
          z_samples=cap.log[0]["samples"], cot=cot15.numpy(), grad_rays=g15g.numpy())
 
+    # ---- G16 networks of other shapes (create_nerf reads netdepth / netwidth / multires / multires_views, RN:260-278) ----
+    g16 = dict(seed=np.int64(SEED))
+    sel = rng.choice(160000, size=48, replace=False)
+    ro16, rd16 = o32.reshape(-1, 3)[sel], d32.reshape(-1, 3)[sel]
+    cot16 = torch.from_numpy(rng.standard_normal((48, 3)).astype(np.float32))
+    pts16 = rng.uniform(-1.5, 1.5, (128, 3)).astype(np.float32)
+    dir16 = rng.standard_normal((128, 3)).astype(np.float32)
+    dir16 /= np.linalg.norm(dir16, axis=-1, keepdims=True)
+    g16.update(rays_o=ro16.numpy(), rays_d=rd16.numpy(), cot=cot16.numpy(), pts=pts16, dirs=dir16)
+    for tag, (D, Wd, L, Lv, skips, uv) in (("a", (6, 128, 6, 2, [2], True)), ("b", (4, 64, 10, 4, [4], False))):
+        sdc = O.synth_weights_shape(SEED + 31, D, Wd, L, Lv, skips, uv)
+        sdf = {k: (v * (1.0 + 0.05 * np.random.RandomState(SEED + 32).standard_normal(v.shape))).astype(np.float32)
+               for k, v in sdc.items()}
+        ef, in_ch = RH.get_embedder(L, 0)
+        edf, in_v = RH.get_embedder(Lv, 0) if uv else (None, 0)
+        nn_ = []
+        for sd in (sdc, sdf):
+            net = RH.NeRF(D=D, W=Wd, input_ch=in_ch, output_ch=5, skips=skips, input_ch_views=in_v, use_viewdirs=uv)
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            nn_.append(net)
+        q = lambda inputs, viewdirs, fn, ef=ef, edf=edf: RN.run_network(inputs, viewdirs, fn, embed_fn=ef, embeddirs_fn=edf,
+                                                                        netchunk=65536)
+        kw16 = dict(kwargs, network_query_fn=q, network_fn=nn_[0], network_fine=nn_[1], use_viewdirs=uv)
+        with torch.no_grad():
+            net_out = q(torch.from_numpy(pts16)[:, None, :], torch.from_numpy(dir16) if uv else None, nn_[0])[:, 0]
+        rays = torch.stack([ro16, rd16], 0).clone().requires_grad_(True)
+        with Capture(RN, RH) as cap:
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=48, rays=rays, **kw16)
+        (gg,) = torch.autograd.grad(rgb, rays, grad_outputs=cot16)
+        g16.update({tag + "_shape": np.array([D, Wd, L, Lv, skips[0], int(uv)]), tag + "_net_out": net_out.numpy(),
+                    tag + "_rgb": rgb.detach().numpy(), tag + "_acc": acc.detach().numpy(),
+                    tag + "_disp": disp.detach().numpy(), tag + "_rgb0": ex["rgb0"].detach().numpy(),
+                    tag + "_acc0": ex["acc0"].detach().numpy(), tag + "_z_samples": cap.log[0]["samples"],
+                    tag + "_grad_rays": gg.numpy()})
+    del sig_last[:]
+    save("g16_other_shapes", **g16)
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

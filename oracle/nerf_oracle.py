@@ -231,25 +231,67 @@ def embed(x, n_freqs):
     return np.concatenate(out, -1)
 
 
+def net_shape(sd):
+    """(D, W, input_ch, input_ch_views, skips, use_viewdirs) of a state dict with the parameter names of RH:70-97, read off
+    the weight shapes: layer i + 1 takes W + input_ch inputs exactly when i is a skip (RH:82-83)."""
+    D = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("pts_linears."))
+    W, input_ch = sd["pts_linears.0.weight"].shape
+    skips = [i for i in range(D - 1) if sd["pts_linears.%d.weight" % (i + 1)].shape[1] == W + input_ch]
+    use_viewdirs = "output_linear.weight" not in sd
+    input_ch_views = sd["views_linears.0.weight"].shape[1] - W
+    return D, W, input_ch, input_ch_views, skips, use_viewdirs
+
+
 def mlp(sd, x_embedded, keep=None):
-    """RH:99-122.  x_embedded [P, 90] -> [P, 4] = (rgb logits, sigma).  A state dict with `output_linear` is the
-    use_viewdirs=False network (RH:95-96, RH:119-120): the direction columns are ignored, the outputs are output_linear(h)."""
+    """RH:99-122 for the network the state dict describes (net_shape): x_embedded [P, 63 + 27] = the FULL encodings
+    (10 / 4 frequencies) -> [P, 4] = (rgb logits, sigma).  A network built for fewer frequencies reads the leading
+    3 + 6 L columns of each (the encoder emits its bands in increasing order, RH:35-48); a state dict with `output_linear`
+    is the use_viewdirs=False network (RH:95-96, RH:119-120): outputs = output_linear(h), directions ignored."""
     lin = lambda name, h: (h @ sd[name + ".weight"].T + sd[name + ".bias"]).astype(f32)
-    pts, views = x_embedded[:, :IN_CH], x_embedded[:, IN_CH:]
+    D, W, input_ch, input_ch_views, skips, use_viewdirs = net_shape(sd)
+    pts, views = x_embedded[:, :input_ch], x_embedded[:, IN_CH:IN_CH + max(input_ch_views, 0)]
     h = pts
-    for i in range(NET_DEPTH):
+    for i in range(D):
         h = np.maximum(lin("pts_linears.%d" % i, h), f32(0))
         if keep is not None:
             keep["h%d" % i] = h
-        if i == SKIP_AT:
+        if i in skips:
             h = np.concatenate([pts, h], -1)
-    if "output_linear.weight" in sd:                    # use_viewdirs=False (RH:119-120): 4 (or 5, RN:267) outputs of h
+    if not use_viewdirs:
         return lin("output_linear", h)[:, :4]
     alpha = lin("alpha_linear", h)
     feature = lin("feature_linear", h)
     hv = np.maximum(lin("views_linears.0", np.concatenate([feature, views], -1)), f32(0))
     rgb = lin("rgb_linear", hv)
     return np.concatenate([rgb, alpha], -1)
+
+
+def synth_weights_shape(seed, D, W, L, Lv, skips, use_viewdirs=True, output_ch=5):
+    """Seeded weights for a NeRF of another shape (RH:70-97) in the spirit of synth_weights: nn.Linear-style init, trunk
+    x 1.6 * sqrt(256 / W) (keeps the activations of a narrower net alive), density row x 50 * 256 / W, density bias -0.5."""
+    rng = np.random.RandomState(seed)
+    in_ch, in_v = 3 + 6 * L, (3 + 6 * Lv if use_viewdirs else 0)
+    sd = {}
+
+    def lin(name, o, i, scale=1.0):
+        bound = 1.0 / np.sqrt(i)
+        sd[name + ".weight"] = (rng.uniform(-bound, bound, size=(o, i)) * scale).astype(f32)
+        sd[name + ".bias"] = rng.uniform(-bound, bound, size=(o,)).astype(f32)
+    g = 1.6 * np.sqrt(256.0 / W)
+    lin("pts_linears.0", W, in_ch, g)
+    for i in range(D - 1):
+        lin("pts_linears.%d" % (i + 1), W, W + in_ch if i in skips else W, g)
+    lin("views_linears.0", W // 2, in_v + W)
+    if use_viewdirs:
+        lin("feature_linear", W, W)
+        lin("alpha_linear", 1, W, 50.0 * 256.0 / W)
+        sd["alpha_linear.bias"] = np.full(1, -0.5, f32)
+        lin("rgb_linear", 3, W // 2)
+    else:
+        lin("output_linear", output_ch, W, 4.0)
+        sd["output_linear.weight"][3] *= f32(12.5 * 256.0 / W)
+        sd["output_linear.bias"][3] = f32(-0.5)
+    return sd
 
 
 _BACKEND = "numpy"

@@ -394,7 +394,9 @@ def test_api_rejects_unsupported_configurations():
     assert "output_linear.weight" in nv.state_dict() and "alpha_linear.weight" not in nv.state_dict()
     assert set(nv.native_state_dict()) == set(net.state_dict())
     with pytest.raises(NotImplementedError, match="specialised"):
-        R.NeRF(D=4, W=128, input_ch=63, input_ch_views=27, use_viewdirs=True)
+        R.NeRF(D=9, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    small = R.NeRF(D=4, W=128, input_ch=39, input_ch_views=15, use_viewdirs=True)       # fits: served as an 8 x 256 network
+    assert {k: tuple(v.shape) for k, v in small.native_state_dict().items()} == {k: tuple(v.shape) for k, v in net.state_dict().items()}
     with pytest.raises(NotImplementedError):
         R.get_embedder(10, -1)
     assert R.get_embedder(10, 0)[1] == 63 and R.get_embedder(4, 0)[1] == 27

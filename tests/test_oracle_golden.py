@@ -5,6 +5,7 @@ Tolerances: bit-exact wherever the arithmetic is IEEE add/mul/div/sqrt/compare (
 cdf, searchsorted indices, inverse-CDF samples); ~1 ulp-level tolerances downstream of sin/cos/exp,
 which numpy's libm and torch's Sleef round differently."""
 import numpy as np
+import pytest
 
 from conftest import assert_close, census_ref
 
@@ -274,6 +275,53 @@ def test_noviewdirs_network_against_the_reference(golden, oracle):
         assert set(m) == set(oracle.synth_weights(0))
         x = np.concatenate([oracle.embed(pts.reshape(-1, 3)[:500], 10), oracle.embed(np.repeat(vd[:16], 192, 0)[:500], 4)], -1)
         assert_close(oracle.mlp(m, x), oracle.mlp(sd, x), atol=3e-6, rtol=1e-6, what="mapped network")
+
+
+def _g16_nets(oracle, g, tag):
+    D, W, L, Lv, s, uv = (int(v) for v in g[tag + "_shape"])
+    seed = int(g["seed"])
+    sd_c = oracle.synth_weights_shape(seed + 31, D, W, L, Lv, [s], bool(uv))
+    sd_f = {k: (v * (1.0 + 0.05 * np.random.RandomState(seed + 32).standard_normal(v.shape))).astype(np.float32)
+            for k, v in sd_c.items()}
+    return sd_c, sd_f
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_networks_of_other_shapes_against_the_reference(tag, golden, oracle):
+    """Networks of another depth / width / skip position / number of encoding frequencies, with and without view
+    directions (create_nerf RN:260-278 builds whatever the arguments say): the oracle's shape-driven mlp against the
+    reference's own such networks (g16: a = 6 x 128, 6 + 2 frequencies, skip after layer 2; b = 4 x 64, no effective skip,
+    use_viewdirs=False) -- raw outputs, a render, and the product's exact re-expression of each as the 8 x 256 network of
+    the kernels (run_nerf_helpers.as_kernel_network) through the oracle."""
+    from neural_sim_nerf_amd.run_nerf_helpers import as_kernel_network, fits_kernel
+    g = golden("g16_other_shapes")
+    sd_c, sd_f = _g16_nets(oracle, g, tag)
+    assert fits_kernel(*oracle.net_shape(sd_c)) is None
+    x = np.concatenate([oracle.embed(g["pts"], 10), oracle.embed(g["dirs"], 4)], -1)
+    want = g[tag + "_net_out"][:, :4]
+    assert_close(oracle.mlp(sd_c, x), want, atol=1e-5 + 2e-6 * np.abs(want).max(), rtol=2e-6, what="network outputs")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    vd = oracle.normalize_dirs(g["rays_d"])
+    r = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, extras=True)
+    assert_close(r["rgb0"], g[tag + "_rgb0"], atol=1e-5, what="rgb0")
+    assert_close(r["acc0"], g[tag + "_acc0"], atol=1e-5, what="acc0")
+    d = np.abs(r["rgb_map"] - g[tag + "_rgb"]).max(-1)
+    assert (d > 1e-4).mean() <= 0.1 and d.mean() < 2e-4, ((d > 1e-4).mean(), d.mean())
+    for sd in (sd_c, sd_f):
+        m = as_kernel_network(sd)
+        assert oracle.net_shape(m) == (8, 256, 63, 27, [4], True)
+        a, b = oracle.mlp(m, x), oracle.mlp(sd, x)
+        assert_close(a, b, atol=1e-6 * max(1.0, np.abs(b).max()), what="the same function as an 8 x 256 network")
+
+
+def test_networks_that_do_not_fit_are_refused():
+    from neural_sim_nerf_amd.run_nerf_helpers import fits_kernel
+    assert fits_kernel(8, 256, 63, 27, [4], True) is None and fits_kernel(8, 256, 63, 0, [4], False, 5) is None
+    assert fits_kernel(5, 256, 63, 27, [1], True) is None and fits_kernel(8, 256, 63, 27, [], True) is None
+    for bad in ((9, 256, 63, 27, [4], True), (8, 512, 63, 27, [4], True), (8, 256, 63, 27, [6], True),
+                (8, 256, 75, 27, [4], True), (8, 256, 63, 33, [4], True), (8, 256, 63, 27, [1, 4], True),
+                (8, 255, 63, 27, [4], True), (6, 256, 63, 27, [0], True)):
+        assert fits_kernel(*bad), bad
 
 
 def test_render_image(golden, oracle, synth_nets):
