@@ -104,7 +104,7 @@ def forward_roofline(model, k_ms, n_rays=H * W):
     return r
 
 
-def alt_mlp_workload(mlp, sd_c, sd_f, device, c2w, ref, launches=3, sample=None):
+def alt_mlp_workload(mlp, sd_c, sd_f, device, c2w, ref, launches=3, sample=None, pmc_file=None):
     """extra_workloads.<mlp>: the SAME 400x400 view through a forward kernel with another layer-GEMM arithmetic --
     "bf16x3" (k_render_b3: bf16 MFMAs, fp32 operands split exactly into three bf16 pieces), "f16x2" (k_render_h2: fp16
     MFMAs, two fp16 pieces, power-of-two range management) or "fp32" (k_render16p, when the main line is one of the
@@ -134,7 +134,7 @@ def alt_mlp_workload(mlp, sd_c, sd_f, device, c2w, ref, launches=3, sample=None)
                "rgb0_max_abs": float(d["rgb0"].max()),
                "rays_with_rgb_diff_above_1e-4": int((d["rgb_map"].max(-1).values > 1e-4).sum())},
            "how_to_enable": "NsrModel(..., mlp='%s') / NSR_MLP=%s / bench.py --mlp %s" % (mlp, mlp, mlp)}
-    res["roofline_vjp"] = vjp_roofline(m, c2w)
+    res["roofline_vjp"] = vjp_roofline(m, c2w, pmc_file)
     if sample is not None:                   # the same `parity` object as the main line's, against the same oracle output
         res["parity"] = parity_vs_oracle(m, sample)
     m.close()
@@ -458,10 +458,15 @@ def vjp_roofline(model, c2w, pmc_file=None):
         fwd, bwd = ((B3_ISSUED_FLOP_PER_POINT, B3_ISSUED_FLOP_PER_POINT_BWD) if model.mlp == "bf16x3" else
                     (H2_ISSUED_FLOP_PER_POINT, H2_ISSUED_FLOP_PER_POINT_BWD))
         issued = H * W * (EVALS_PER_RAY * fwd + 192 * bwd) / (k_ms * 1e-3) / 1e12
+        traffic, key = None, "vjp_" + model.mlp
+        if pmc_file and os.path.exists(pmc_file):
+            prof = json.load(open(pmc_file))
+            if prof.get("kernel_source_sha256") == _lib.kernel_source_hash() and key in prof:
+                traffic = prof[key]["derived"].get("hbm_traffic_bytes_per_launch")   # same hash rule as roofline.traffic
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "issued": round(issued, 1),
                 "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
-                "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": None,
+                "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
                 "kernel": "nsr::k_render_vjp_b3" if model.mlp == "bf16x3" else "nsr::k_render_vjp_h2",
                 "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP, "flop_note": flop_note}
     traffic = None
@@ -666,7 +671,7 @@ def main():
                 for mlp in MLP_MODES:
                     if mlp != model.mlp:
                         line["extra_workloads"][mlp] = alt_mlp_workload(mlp, sd_c, sd_f, local, poses[args.warmup], ref,
-                                                                        sample=cpu_sample)
+                                                                        sample=cpu_sample, pmc_file=args.pmc_file)
         model.close()
 
     # ------------------------------------------------------------------------------------------------------------
