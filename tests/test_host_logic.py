@@ -402,6 +402,27 @@ def test_api_rejects_unsupported_configurations():
     assert R.get_embedder(10, 0)[1] == 63 and R.get_embedder(4, 0)[1] == 27
 
 
+def test_random_draws_follow_the_references_order():
+    """run_nerf_noscale._draws: what is drawn for which option, in the order the reference draws inside one chunk
+    (t_rand RN:451, coarse noise RN:368, u RH:211, fine noise) -- and nothing for the deterministic path."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    cpu = torch.device("cpu")
+    assert R._draws(dict(perturb=False, raw_noise_std=0.), 5, 128, cpu) == {}
+    assert not R._stochastic(dict(perturb=0., raw_noise_std=0.)) and R._stochastic(dict(perturb=1.)) and R._stochastic(dict(raw_noise_std=.1))
+    d = R._draws(dict(perturb=1.0, raw_noise_std=2.0), 5, 128, cpu)
+    assert list(d) == ["t_rand", "noise0", "u", "noise1"]
+    assert [tuple(v.shape) for v in d.values()] == [(5, 64), (5, 64), (5, 128), (5, 192)]
+    assert 0 <= float(d["t_rand"].min()) and float(d["t_rand"].max()) < 1 and 0 <= float(d["u"].min()) and float(d["u"].max()) < 1
+    assert list(R._draws(dict(perturb=1.0), 3, 0, cpu)) == ["t_rand"]                      # coarse only: no resampling
+    assert list(R._draws(dict(raw_noise_std=0.5), 3, 128, cpu)) == ["noise0", "noise1"]   # det resampling stays (RN:474)
+    torch.manual_seed(4)
+    a = R._draws(dict(perturb=1.0, raw_noise_std=2.0), 7, 128, cpu)
+    torch.manual_seed(4)
+    t = torch.rand(7, 64); n0 = torch.randn(7, 64) * 2.0; u = torch.rand(7, 128); n1 = torch.randn(7, 192) * 2.0
+    assert all(torch.equal(x, y) for x, y in zip(a.values(), (t, n0, u, n1)))
+
+
 def test_nerf_module_has_reference_parameter_names(synth_nets):
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
