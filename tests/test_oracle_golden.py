@@ -314,6 +314,30 @@ def test_networks_of_other_shapes_against_the_reference(tag, golden, oracle):
         assert_close(a, b, atol=1e-6 * max(1.0, np.abs(b).max()), what="the same function as an 8 x 256 network")
 
 
+@pytest.mark.parametrize("shape", [(8, 256, 10, 4, 4, True), (8, 256, 10, 4, 7, True), (8, 254, 9, 3, 4, True),
+                                   (7, 192, 8, 3, 3, True), (6, 128, 6, 2, 2, True), (5, 256, 10, 4, 1, True),
+                                   (4, 96, 5, 1, 0, True), (2, 16, 1, 1, 1, True), (1, 8, 0, 0, 0, True),
+                                   (8, 256, 10, 0, 4, False), (6, 64, 4, 0, 3, False), (3, 32, 4, 0, 0, False)])
+def test_every_fitting_shape_is_the_same_function_as_an_8x256_network(shape, oracle):
+    """as_kernel_network over depth, width, number of frequencies, skip position (incl. none: a skip index >= D - 1 never
+    takes effect) and use_viewdirs: the re-expressed network has the kernel's shape and the oracle evaluates both to the
+    same outputs to fp32 rounding."""
+    from neural_sim_nerf_amd.run_nerf_helpers import as_kernel_network
+    D, W, L, Lv, s, uv = shape
+    sd = oracle.synth_weights_shape(11 + D + W, D, W, L, Lv, [s], uv)
+    rng = np.random.RandomState(D * 1000 + W)
+    pts = rng.uniform(-1.2, 1.2, (96, 3)).astype(np.float32)
+    d = rng.standard_normal((96, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.concatenate([oracle.embed(pts, 10), oracle.embed(d, 4)], -1)
+    m = as_kernel_network(sd)
+    assert oracle.net_shape(m) == (8, 256, 63, 27, [4], True)
+    a, b = oracle.mlp(m, x), oracle.mlp(sd, x)
+    assert np.isfinite(b).all() and np.abs(b).max() > 1e-3
+    # (zero padding changes the blocking of the host BLAS sums, so equal means to fp32 rounding, not bit for bit)
+    assert_close(a, b, atol=2e-6 * max(1.0, np.abs(b).max()), what="mapped network")
+
+
 def test_networks_that_do_not_fit_are_refused():
     from neural_sim_nerf_amd.run_nerf_helpers import fits_kernel
     assert fits_kernel(8, 256, 63, 27, [4], True) is None and fits_kernel(8, 256, 63, 0, [4], False, 5) is None
