@@ -1,7 +1,5 @@
-timeout 1800 python -m pytest tests/ -q -m gpu 2>&1 | tail -4
-timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; python - <<'P'
-import json, os
-d = json.load(open(os.environ['O'] + '/bench.json'))
-print({k: d[k] for k in ('value', 'ms_per_step', 'dtype')}); print('traffic', d['roofline'].get('traffic'), d['roofline_vjp'].get('traffic'), d['extra_workloads']['bf16x3']['roofline_vjp'].get('traffic')); print('cpu', d['cpu_baseline']['value'])
-P
+mkdir -p $O/extra
+timeout 300 python bench.py --workload sweep100 --views 24 --steps 1 --warmup 0 > $O/extra/bench_sweep24.json 2> $O/extra/sweep.err; tail -c 300 $O/extra/bench_sweep24.json; echo
+timeout 300 python bench.py --workload models21 --steps 1 --warmup 1 > $O/extra/bench_models21.json 2> $O/extra/models.err; tail -c 300 $O/extra/bench_models21.json; echo
+NSR_DIST_TIMING=1 timeout 400 python bench.py --gpus 2 --backend gloo --share-gpu --workload sweep100 --views 12 --steps 1 --warmup 0 > $O/extra/bench_2ranks_shared_gpu_sweep12.json 2> $O/extra/ranks.err; tail -c 400 $O/extra/bench_2ranks_shared_gpu_sweep12.json; echo
+NSR_MLP=f16x2 timeout 200 python tools/bench_path_grad.py > $O/extra/path_grad_f16x2.json 2> /dev/null; cat $O/extra/path_grad_f16x2.json | head -3
