@@ -12,6 +12,10 @@ import torch
 import torch.distributed as dist
 
 LAST_TIMINGS = {}          # per-phase seconds of the last render_path_distributed call (max over ranks) when NSR_DIST_TIMING=1
+# NSR_DIST_FORCE_COLLECTIVES=1: issue every collective also when the group has ONE rank (where each is the identity).  A
+# one-GPU box can then run this module's RCCL calls for real -- dtypes, devices, contiguity -- instead of skipping them
+# (tests/test_gpu_parity.py::test_collective_wrappers_over_rccl_with_one_rank).
+_FORCE = os.environ.get("NSR_DIST_FORCE_COLLECTIVES", "0") == "1"
 
 
 def world_info(group=None):
@@ -75,7 +79,7 @@ def check_same_poses(poses, group=None, tol=1e-6):
     """Sharding by index only makes sense if every rank holds the SAME pose list.  The reference seeds its pose
     sampler from the wall clock (LL:273), so ranks of an unchanged script can disagree: fail loudly then."""
     world, rank = world_info(group)
-    if world == 1:
+    if world == 1 and not _FORCE:
         return
     dev = _comm_device(group)
     p0 = torch.as_tensor(poses, dtype=torch.float32).detach().to(dev).contiguous().clone()
@@ -93,7 +97,7 @@ def gather_views(local, n_total, group=None):
     """local: [k_local, ...] tensor of this rank's views (in shard order).  Returns [n_total, ...] in global view
     order on every rank.  Ranks hold ceil or floor(n_total/world) views; shorter ranks pad to the maximum."""
     world, rank = world_info(group)
-    if world == 1:
+    if world == 1 and not _FORCE:
         return local
     k_max = (n_total + world - 1) // world
     if local.device != _comm_device(group):
@@ -157,12 +161,12 @@ def render_path_distributed(render_fn, render_poses, savedir=None, object_id=2, 
     t0 = mark("gather_rgb", t0)
     disps = gather_views(disp, n, group).cpu().numpy() if gather_disp else None
     t0 = mark("gather_disp", t0)
-    if savedir is not None and world > 1:
+    if savedir is not None and (world > 1 or _FORCE):
         dist.barrier(group=group)                # the files of all ranks exist when any rank returns
     if timing:
         names = ("render", "png", "gather_rgb", "gather_disp")
         buf = torch.tensor([marks.get(k, 0.0) for k in names], dtype=torch.float64, device=_comm_device(group))
-        if world > 1:
+        if world > 1 or _FORCE:
             dist.all_reduce(buf, op=dist.ReduceOp.MAX, group=group)
         LAST_TIMINGS.clear()
         LAST_TIMINGS.update({k: float(v) for k, v in zip(names, buf.cpu().tolist())}, views=n, ranks=world)
@@ -198,7 +202,7 @@ def mean_psi_grad(local_dLdpsis, group=None):
     if s is not None:
         buf[:n_cat] = s
         buf[n_cat] = len(local_dLdpsis)
-    if world > 1:
+    if world > 1 or _FORCE:
         buf = buf.to(_comm_device(group))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf = buf.cpu()

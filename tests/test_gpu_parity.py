@@ -969,6 +969,41 @@ def test_bench_two_ranks_share_the_gpu(workload):
         assert d["config"]["models"] == 21 and d["config"]["models_on_busiest_rank"] == 11
 
 
+def _launch(argv, extra_env=None, timeout=600):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 400)] + argv
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def test_collective_wrappers_over_rccl_with_one_rank():
+    """The first thing an 8-GPU run does that a one-GPU box never did is call RCCL.  With NSR_DIST_FORCE_COLLECTIVES=1 the
+    wrappers of dist.py issue their collectives for a group of ONE rank too (each is then the identity): backend "nccl",
+    device buffers, uint8 / fp32 / int32 payloads, all_gather_into_tensor, broadcast, all_reduce, and render_path over the
+    group with the real renderer -- tests/rccl_one_rank_script.py under torch.distributed.run."""
+    r = _launch([os.path.join(ROOT, "tests", "rccl_one_rank_script.py")], {"NSR_DIST_FORCE_COLLECTIVES": "1"})
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("workload", ["view400", "sweep100", "models21"])
+def test_bench_one_rank_under_the_launcher_uses_rccl(workload):
+    """bench.py exactly as the driver starts it for N > 1 (torch.distributed.run, backend nccl = RCCL), with the one rank a
+    one-GPU box allows: process-group init on the device, the barriers, the max / sum all-reduces and the all-gather of the
+    per-rank kernel times all go through RCCL; ONE JSON line comes out."""
+    import json
+    args = [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", workload, "--steps", "1", "--warmup", "1",
+            "--no-cpu-baseline", "--no-extras"] + (["--views", "3"] if workload == "sweep100" else [])
+    r = _launch(args)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 0 and d["unit"] == "Mray-samples/s", d
+
+
 def test_bilevel_gradient_end_to_end_vs_reference(synth_nets, oracle, tmp_path):
     """BASELINE config 4's render leg, end to end: psi -> poses (pose.py, LL:202-247) -> render_path_grad, against
     what the REFERENCE's sample_pose + render_path_grad returned for the same psi, noise log and cotangents
