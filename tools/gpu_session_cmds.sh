@@ -1,1 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "rccl" 2>&1 | tail -25
+timeout 1800 python -m pytest tests/ -q -m gpu 2>&1 | tail -4
+timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
