@@ -525,6 +525,31 @@ def test_create_nerf_loads_reference_checkpoints(tmp_path, synth_nets):
         assert all(np.array_equal(got[k].cpu().numpy(), sd[k]) for k in sd)
 
 
+def test_create_nerf_builds_whatever_the_arguments_say(tmp_path, oracle):
+    """RN:260-278: netdepth / netwidth / multires / multires_views / use_viewdirs decide the networks.  Shapes that can be
+    written as the kernels' 8 x 256 network are built with the reference's parameter names and shapes (so its checkpoints
+    load) and re-express themselves for the kernels; the others are refused with the reason."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    a = _args(tmp_path, None)
+    a.netdepth, a.netwidth, a.netdepth_fine, a.netwidth_fine, a.multires, a.multires_views = 6, 128, 4, 64, 6, 2
+    train, test, start, grad_vars, _ = R.create_nerf(a)
+    c, f = test["network_fn"], test["network_fine"]
+    assert c.pts_linears[0].weight.shape == (128, 39) and c.views_linears[0].weight.shape == (64, 128 + 15)
+    assert f.pts_linears[0].weight.shape == (64, 39) and len(f.pts_linears) == 4 and start == 0
+    sd = {k: v.detach().numpy() for k, v in c.state_dict().items()}
+    assert oracle.net_shape(sd) == (6, 128, 39, 15, [4], True)
+    assert oracle.net_shape({k: v.numpy() for k, v in c.native_state_dict().items()}) == (8, 256, 63, 27, [4], True)
+    a.use_viewdirs = False
+    _, test, _, _, _ = R.create_nerf(a)
+    n = test["network_fn"]
+    assert not n.use_viewdirs and n.output_linear.weight.shape == (5, 128) and test["use_viewdirs"] is False
+    assert n.views_linears[0].weight.shape == (64, 128) and not hasattr(n, "alpha_linear")            # RH:86, RH:95-96
+    a.netwidth = 512
+    with pytest.raises(NotImplementedError, match="netwidth 512"):
+        R.create_nerf(a)
+
+
 def test_bench_self_launch_fails_only_on_device_count():
     """`python bench.py --gpus N` outside a launcher re-execs itself under torch.distributed.run; with fewer than N
     devices the ONLY failure is the device count, stated as such (no 'use torchrun' error)."""
