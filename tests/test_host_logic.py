@@ -46,6 +46,29 @@ def test_probe_and_debug_libraries_export_their_headers():
             assert hasattr(lib, name), (so, name)
 
 
+def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
+    """The library as built (no compiler run, no GPU): its only offload target is gfx950, and the fused render kernels --
+    forward and input-gradient, all three arithmetics, both structures -- keep every value in registers (no VGPR spill, no
+    scratch).  The one exception is stated, not hidden: the x32 fp32 input-gradient kernel k_render_vjp (not a default;
+    it serves the per-ray extras of fp32 handles) spills 4 registers.  Figures from the code object's metadata
+    (tools/kernel_resources.py)."""
+    import sys
+    lib = os.path.join(ROOT, "neural_sim_nerf_amd", "csrc", "libnsr.so")
+    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_resources import kernel_resources
+    res, targets = kernel_resources(lib)
+    assert targets == ["hipv4-amdgcn-amd-amdhsa--gfx950"], targets
+    fused = ["k_render_h2", "k_render_vjp_h2", "k_render_b3", "k_render_vjp_b3", "k_render16p", "k_render16", "k_render",
+             "k_render_vjp16p", "k_render_vjp16", "k_run_network"]
+    for k in fused:
+        assert res[k]["vgpr_spill_count"] == 0 and res[k]["private_segment_fixed_size"] == 0, (k, res[k])
+    assert res["k_render_vjp"]["vgpr_spill_count"] <= 4 and res["k_render_vjp"]["private_segment_fixed_size"] <= 20, res["k_render_vjp"]
+    # the x32-structured kernels own a whole SIMD's register file (one workgroup per CU); the x16 ones share it two ways
+    assert res["k_render_h2"]["vgpr_count"] > 256 and res["k_render16p"]["vgpr_count"] <= 256
+
+
 def test_header_constants_match_packer():
     from neural_sim_nerf_amd import pack
     hdr = open(os.path.join(ROOT, "include", "nsr.h")).read()
