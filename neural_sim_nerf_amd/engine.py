@@ -28,11 +28,22 @@ DEFAULT_MLP = "f16x2"
 MLP_MODES = ("fp32", "bf16x3", "f16x2")
 
 
-def _host_tables():
+def _host_tables(n_importance=N_IMPORTANCE):
     """The reference builds both linspace tables on the HOST and moves them (RN:439, RH:208); torch's CPU
-    linspace is not bit-equal to numpy's, so the same call is made here."""
-    return (torch.linspace(0., 1., steps=N_SAMPLES).numpy().astype(np.float32),
-            torch.linspace(0., 1., steps=N_IMPORTANCE).numpy().astype(np.float32))
+    linspace is not bit-equal to numpy's, so the same call is made here.
+    n_importance < 128 (a divisor of 128): the kernels always draw 128 importance samples, from the 128 uniforms of this
+    table -- filled with the reference's linspace(0, 1, n_importance), every value 128 / n_importance times.  The extra
+    samples are exact duplicates: a duplicated depth is a zero-length interval (alpha = 1 - exp(0) = 0: no weight, and the
+    transmittance moves by the 1e-10 of RN:376 only), and every value being repeated equally often leaves
+    std(z_samples) (RN:495) what it was.  The render is the reference's N_importance = n render to 2.4e-7
+    (tests/test_oracle_golden.py::test_fewer_importance_samples_by_duplicated_uniforms), at the price of all 192 fine
+    evaluations."""
+    n = n_importance if n_importance else N_IMPORTANCE
+    u = torch.linspace(0., 1., steps=n).repeat_interleave(N_IMPORTANCE // n)
+    return torch.linspace(0., 1., steps=N_SAMPLES).numpy().astype(np.float32), u.numpy().astype(np.float32)
+
+
+IMPORTANCE_COUNTS = (0, 1, 2, 4, 8, 16, 32, 64, 128)       # 0 = coarse only; the divisors of the kernels' 128
 
 
 def _fptr(a):
@@ -85,8 +96,9 @@ class NsrModel:
         # the x16 coarse+fine kernels only (the bf16x3 / f16x2 kernels take their items from the per-item queue)
         phases = schedule == "phases" and variant != 32 and n_importance > 0 and mlp == "fp32"
         self.schedule = "phases" if phases else "queue"
-        if n_importance not in (0, N_IMPORTANCE):
-            raise NotImplementedError("N_importance must be 128 (or 0 for coarse-only); got %r" % (n_importance,))
+        if n_importance not in IMPORTANCE_COUNTS:
+            raise NotImplementedError("N_importance must be 128, 0 (coarse only) or a divisor of 128 (rendered with duplicated "
+                                      "importance samples, see _host_tables); got %r" % (n_importance,))
         if n_importance > 0 and sd_fine is None:
             sd_fine = sd_coarse          # RN:482: run_fn = network_fn if network_fine is None
         self.n_importance = n_importance
@@ -94,7 +106,7 @@ class NsrModel:
             raise NotImplementedError("variant must be 0 (library default), 16 or 32")
         self.variant = variant
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
-        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, n_importance, max_workgroups, variant,
+        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, N_IMPORTANCE if n_importance else 0, max_workgroups, variant,
                              (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0)
                              | (8 if mlp == "bf16x3" else 0) | (16 if mlp == "f16x2" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
@@ -102,7 +114,7 @@ class NsrModel:
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.upload(sd_coarse, sd_fine)
-        t, u = _host_tables()
+        t, u = _host_tables(n_importance)
         _lib.check(self.lib.nsr_upload_tables(self.h, _fptr(t), 64, _fptr(u), 128))
 
     def upload(self, sd_coarse, sd_fine=None):

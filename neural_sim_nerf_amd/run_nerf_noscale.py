@@ -8,7 +8,7 @@ of include/nsr.h.  This file is host glue: argument checking, handle caching, re
 
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
 different path is worse): networks that cannot be written as the kernels' 8x256 network (run_nerf_helpers.fits_kernel),
-N_samples != 64, N_importance not in {0,128}, pytest=True.  Smaller networks and use_viewdirs=False networks (RH:95-96) run
+N_samples != 64, N_importance other than 0, 128 or a divisor of 128 (engine._host_tables), pytest=True.  Smaller networks and use_viewdirs=False networks (RH:95-96) run
 on the same kernels through NeRF.native_state_dict.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
 ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and raw_noise_std>0 (RN:365-374) reach the
 same kernels as per-ray extras (include/nsr.h: NsrRayExtras) -- see _draws for where the random numbers come from.
@@ -200,8 +200,8 @@ def _draws(kw, n, n_importance, dev):
     if std > 0.:
         d["noise0"] = torch.randn(n, 64, device=dev) * std
     if n_importance > 0:
-        if "t_rand" in d:                                   # det = (perturb == 0.), RN:474
-            d["u"] = torch.rand(n, 128, device=dev)
+        if "t_rand" in d:                                   # det = (perturb == 0.), RN:474; fewer than 128: duplicated, as
+            d["u"] = torch.rand(n, n_importance, device=dev).repeat_interleave(128 // n_importance, dim=1)   # engine._host_tables
         if std > 0.:
             d["noise1"] = torch.randn(n, 192, device=dev) * std
     return d
@@ -251,8 +251,12 @@ def _check_kwargs(kw):
     bad = []
     if kw.get("N_samples", 64) != 64:
         bad.append("N_samples=%r (kernel is specialised to 64)" % kw.get("N_samples"))
-    if kw.get("N_importance", 0) not in (0, 128):
-        bad.append("N_importance=%r (0 or 128)" % kw.get("N_importance"))
+    from .engine import IMPORTANCE_COUNTS
+    if kw.get("N_importance", 0) not in IMPORTANCE_COUNTS:
+        bad.append("N_importance=%r (128, 0, or a divisor of 128)" % kw.get("N_importance"))
+    if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128):
+        bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4])"
+                   % kw.get("N_importance"))
     if kw.get("pytest", False):
         bad.append("pytest=True")
     if bad:
@@ -350,8 +354,8 @@ def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False, genera
     _check_viewdirs(name, kw.pop("use_viewdirs", False), kw)
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
-    if need_fine and n_imp != 128:
-        raise NotImplementedError("%s needs the coarse+fine configuration (N_importance=128)" % name)
+    if need_fine and n_imp == 0:
+        raise NotImplementedError("%s needs the coarse+fine configuration (N_importance > 0)" % name)
     model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
     if general_ok:
         return H, W, near, far, model, general

@@ -466,6 +466,21 @@ def main():
     del sig_last[:]
     save("g16_other_shapes", **g16)
 
+    # ---- G17 fewer importance samples (N_importance = 64, NM:1260 is an argument) --------------------------------
+    sel = rng.choice(160000, size=48, replace=False)
+    ro17, rd17 = o32.reshape(-1, 3)[sel], d32.reshape(-1, 3)[sel]
+    kw17 = dict(kwargs, N_importance=64)
+    rays = torch.stack([ro17, rd17], 0).clone().requires_grad_(True)
+    cot17 = torch.from_numpy(rng.standard_normal((48, 3)).astype(np.float32))
+    with Capture(RN, RH) as cap:
+        rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=48, rays=rays, **kw17)
+    (g17g,) = torch.autograd.grad(rgb, rays, grad_outputs=cot17)
+    del sig_last[:]
+    save("g17_importance64", seed=np.int64(SEED), rays_o=ro17.numpy(), rays_d=rd17.numpy(), rgb=rgb.detach().numpy(),
+         disp=disp.detach().numpy(), acc=acc.detach().numpy(), rgb0=ex["rgb0"].detach().numpy(),
+         z_std=ex["z_std"].detach().numpy(), z_samples=cap.log[0]["samples"], inds=cap.log[0]["inds"].astype(np.int8),
+         pdf_weights=cap.log[0]["weights"], cot=cot17.numpy(), grad_rays=g17g.numpy())
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

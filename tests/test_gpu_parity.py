@@ -495,6 +495,67 @@ def test_networks_of_other_shapes(tag, oracle):
         n.invalidate()
 
 
+def test_fewer_importance_samples(oracle, synth_nets):
+    """N_importance = 64 (and 32) on kernels that always draw 128: the uniforms table holds the reference's linspace with
+    every value repeated (engine._host_tables), the duplicated samples carry no weight.  Against the oracle's 64-sample
+    render stage-wise (the distinct samples bit for bit), against the reference (g17) forward and gradient, and through
+    render(N_importance=64)."""
+    import torch
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g17_importance64")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"], g["rays_d"]
+    vd = oracle.normalize_dirs(rd)
+    for ni, mlp in ((64, "f16x2"), (32, "fp32")):
+        m = NsrModel(synth_nets[0], synth_nets[1], n_importance=ni, mlp=mlp)
+        try:
+            r = m.render_rays(ro, rd, near, far, debug=True)
+            zs = cpu(r["z_samples"])
+            assert np.array_equal(zs[:, ::128 // ni], zs[:, 128 // ni - 1::128 // ni])           # exact duplicates
+            z = oracle.coarse_z(np.full(len(ro), near, np.float32), np.full(len(ro), far, np.float32))
+            z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+            s, inds, _ = oracle.sample_pdf(z_mid, cpu(r["weights0"])[:, 1:-1], ni)
+            assert np.array_equal(zs[:, ::128 // ni], s) and np.array_equal(cpu(r["inds"])[:, ::128 // ni], inds)
+            # the oracle's ni-sample fine pass at the kernel's distinct depths
+            zf = np.sort(np.concatenate([z, s], -1), -1)
+            pts = (ro[:, None, :] + rd[:, None, :] * zf[:, :, None]).astype(np.float32)
+            rgb, disp, acc, _, _ = oracle.raw2outputs(oracle.run_network(synth_nets[1], pts, vd), zf, rd)
+            assert_close(cpu(r["rgb_map"]), rgb, atol=2e-5, what="rgb vs the %d-sample composite" % ni)
+            assert_close(cpu(r["acc_map"]), acc, atol=2e-5, what="acc")
+            assert_close(cpu(r["z_std"]), np.std(s.astype(np.float64), -1), atol=1e-6, what="z_std")
+            if ni == 64:
+                assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+                d = np.abs(cpu(r["rgb_map"]) - g["rgb"]).max(-1)
+                assert (d > 1e-4).mean() <= 0.08 and d.mean() < 2e-4
+                assert_close(cpu(r["z_std"]), g["z_std"], atol=2e-3, what="z_std vs reference")
+                # gradient at the reference's depths: its 128 sorted depths with the 64 samples doubled
+                zf_ref = np.sort(np.concatenate([z, g["z_samples"], g["z_samples"]], -1), -1)
+                go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf_ref)
+                for a, b in ((cpu(go), g["grad_rays"][0]), (cpu(gd), g["grad_rays"][1])):
+                    e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+                    assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (np.percentile(e, 90), e.max())
+                want = cpu(r["rgb_map"])
+        finally:
+            m.close()
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    nets = []
+    for sd in synth_nets:
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=64, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=near, far=far)
+    rgb = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), **kw)[0]
+    assert np.array_equal(cpu(rgb), want, equal_nan=True)
+    with pytest.raises(NotImplementedError, match="retraw"):
+        R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **kw)
+    with pytest.raises(NotImplementedError, match="N_importance"):
+        R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), **dict(kw, N_importance=100))
+    for n in nets:
+        n.invalidate()
+
+
 def test_render_api_ndc_staticcam_and_stochastic_options(oracle, synth_nets, tmp_path):
     """The reference-shaped API with the options round 2 refused: render(ndc=True) with its gradient w.r.t. the rays against
     the reference's autograd (g14), render(c2w_staticcam=...) against the reference's image, render(perturb=1,

@@ -408,7 +408,8 @@ def test_api_rejects_unsupported_configurations():
     net = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     base["network_fn"] = net
     for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=32), "N_samples"),
-                     (dict(N_importance=64), "N_importance"), (dict(pytest=True), "pytest")):
+                     (dict(N_importance=100), "N_importance"), (dict(pytest=True), "pytest"),
+                     (dict(N_importance=64, retraw=True), "retraw")):
         kw = dict(base)
         kw.update(bad)
         with pytest.raises(NotImplementedError, match=pat):

@@ -348,6 +348,37 @@ def test_networks_that_do_not_fit_are_refused():
         assert fits_kernel(*bad), bad
 
 
+def test_fewer_importance_samples_by_duplicated_uniforms(golden, oracle, synth_nets):
+    """N_importance = 64 (NM:1260 is an argument): the oracle's 64-sample path against the reference (g17: the inverse CDF
+    on the reference's own weights bit for bit, the render end to end), and the way the product renders it -- 128 samples
+    drawn from linspace(0, 1, 64) with every value twice (engine._host_tables): exact duplicates carry no weight, so the
+    192-sample render IS the 128-sample one (2.4e-7), z_std included."""
+    from neural_sim_nerf_amd.engine import _host_tables
+    g = golden("g17_importance64")
+    sd_c, sd_f = synth_nets
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    n = g["rays_o"].shape[0]
+    z = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32))
+    z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    s, inds, _ = oracle.sample_pdf(z_mid, g["pdf_weights"], 64)
+    assert s.shape == (n, 64) and np.array_equal(inds, g["inds"].astype(np.int64)) and np.array_equal(s, g["z_samples"])
+    vd = oracle.normalize_dirs(g["rays_d"])
+    ref = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, n_importance=64, extras=True)
+    assert_close(ref["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
+    d = np.abs(ref["rgb_map"] - g["rgb"]).max(-1)
+    assert (d > 1e-4).mean() <= 0.08 and d.mean() < 2e-4
+    assert_close(ref["z_std"], g["z_std"], atol=2e-3, what="z_std")
+    for ni in (64, 32, 1):
+        t, u = _host_tables(ni)
+        assert u.shape == (128,) and np.array_equal(u[::128 // ni], oracle.torch_linspace01(ni)) and np.all(np.diff(u) >= 0)
+        want = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, n_importance=ni, extras=True)
+        emu = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, n_importance=128, extras=True, u=u)
+        assert np.array_equal(emu["z_samples"][:, ::128 // ni], want["z_samples"])
+        for k in ("rgb_map", "acc_map", "disp_map", "z_std"):
+            assert_close(emu[k], want[k], atol=5e-7, rtol=5e-7, what="%s with %d importance samples" % (k, ni))
+    assert np.array_equal(_host_tables(128)[1], oracle.torch_linspace01(128)) and np.array_equal(_host_tables(0)[0], oracle.torch_linspace01(64))
+
+
 def test_render_image(golden, oracle, synth_nets):
     g = golden("g7_render")
     sd_c, sd_f = synth_nets
