@@ -8,7 +8,7 @@ of include/nsr.h.  This file is host glue: argument checking, handle caching, re
 
 Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
 different path is worse): networks that cannot be written as the kernels' 8x256 network (run_nerf_helpers.fits_kernel),
-N_samples != 64, N_importance other than 0, 128 or a divisor of 128 (engine._host_tables), pytest=True.  Smaller networks and use_viewdirs=False networks (RH:95-96) run
+N_samples != 64, N_importance other than 0, 128 or a divisor of 128 (engine._host_tables).  Smaller networks and use_viewdirs=False networks (RH:95-96) run
 on the same kernels through NeRF.native_state_dict.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
 ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and raw_noise_std>0 (RN:365-374) reach the
 same kernels as per-ray extras (include/nsr.h: NsrRayExtras) -- see _draws for where the random numbers come from.
@@ -187,15 +187,40 @@ class _NdcRays(torch.autograd.Function):
         return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None, None
 
 
-def _draws(kw, n, n_importance, dev):
+def _draws(kw, n, n_importance, dev, chunk=None):
     """The random draws of the stochastic options, in the reference's order within one chunk of rays: t_rand (RN:451),
     the coarse density noise (RN:368), the resampling uniforms (RH:211), the fine density noise.  From torch's generator
     of the render device: the reference's stream is reproduced when it, too, renders all N rays as ONE chunk on that
-    device; for pinned comparisons hand the reference's own draws to NsrModel.render_rays(extras=...)."""
+    device; for pinned comparisons hand the reference's own draws to NsrModel.render_rays(extras=...).
+    pytest=True (the reference's test hook, RN:454-457, RH:214-222): every draw site reseeds numpy's GLOBAL generator
+    with 0 and takes its numbers from it -- once per `chunk` of rays, so ray i gets row i mod chunk -- and the
+    deterministic resampling uses NUMPY's linspace (a few ulp from torch's); reproduced exactly, side effect included."""
     perturb = kw.get("perturb", 0.)
+    perturbed = perturb not in (0, 0., False) and perturb > 0.
     std = float(kw.get("raw_noise_std", 0.) or 0.)
     d = {}
-    if perturb not in (0, 0., False) and perturb > 0.:
+    if kw.get("pytest", False):
+        if std > 0.:
+            raise NotImplementedError("render: pytest=True with raw_noise_std > 0 -- the reference itself fails there (RN:371 "
+                                      "calls .cuda() on a numpy array)")
+        c = n if not chunk else max(1, min(int(chunk), n))
+        rows = torch.arange(n) % c
+        rep = 128 // n_importance if n_importance else 1
+
+        def seeded(width):
+            np.random.seed(0)
+            return torch.Tensor(np.random.rand(c, width))[rows]
+        if perturbed:
+            d["t_rand"] = seeded(64).to(dev)
+        if n_importance > 0:
+            if perturbed:
+                d["u"] = seeded(n_importance).repeat_interleave(rep, dim=1).to(dev)
+            else:
+                np.random.seed(0)                           # RH:216 reseeds on the deterministic branch too
+                u = torch.Tensor(np.linspace(0., 1., n_importance)).repeat_interleave(rep)
+                d["u"] = u[None].expand(n, 128).contiguous().to(dev)
+        return d
+    if perturbed:
         d["t_rand"] = torch.rand(n, 64, device=dev)
     if std > 0.:
         d["noise0"] = torch.randn(n, 64, device=dev) * std
@@ -257,8 +282,6 @@ def _check_kwargs(kw):
     if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128):
         bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4])"
                    % kw.get("N_importance"))
-    if kw.get("pytest", False):
-        bad.append("pytest=True")
     if bad:
         raise NotImplementedError("render: unsupported option(s): " + ", ".join(bad))
 
@@ -306,7 +329,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
         ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]), 1.0)
     if special:
-        ex = _draws(kwargs, ro.shape[0], n_imp, model.device)
+        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk)
         if per_ray_bounds:                                  # one bound per ray (the reference multiplies them into [N,1])
             for k, v in (("near", near), ("far", far)):
                 t = torch.as_tensor(v, dtype=torch.float32).to(model.device).reshape(-1)
@@ -326,7 +349,8 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
 
 def _stochastic(kw):
     perturb = kw.get("perturb", 0.)
-    return (perturb not in (0, 0., False) and perturb > 0.) or float(kw.get("raw_noise_std", 0.) or 0.) > 0.
+    return ((perturb not in (0, 0., False) and perturb > 0.) or float(kw.get("raw_noise_std", 0.) or 0.) > 0.
+            or bool(kw.get("pytest", False)))
 
 
 def _pack_ret(ret):

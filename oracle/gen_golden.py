@@ -481,6 +481,24 @@ def main():
          z_std=ex["z_std"].detach().numpy(), z_samples=cap.log[0]["samples"], inds=cap.log[0]["inds"].astype(np.int8),
          pdf_weights=cap.log[0]["weights"], cot=cot17.numpy(), grad_rays=g17g.numpy())
 
+    # ---- G18 the reference's pytest hook (RN:454-457, RH:214-222): numpy's global generator reseeded with 0 at every
+    # draw site and once per chunk; 80 rays in chunks of 32; stratified (perturb=1) and deterministic (perturb=0) ---------
+    sel = rng.choice(160000, size=80, replace=False)
+    ro18, rd18 = o32.reshape(-1, 3)[sel], d32.reshape(-1, 3)[sel]
+    g18 = dict(seed=np.int64(SEED), rays_o=ro18.numpy(), rays_d=rd18.numpy(), chunk=np.int64(32))
+    state = np.random.get_state()
+    for tag, pert in (("p", 1.0), ("d", 0.0)):
+        with torch.no_grad():
+            with Capture(RN, RH) as cap:
+                rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=32, rays=torch.stack([ro18, rd18], 0),
+                                               **dict(kwargs, perturb=pert, pytest=True))
+        g18.update({tag + "_rgb": rgb.numpy(), tag + "_acc": acc.numpy(), tag + "_rgb0": ex["rgb0"].numpy(),
+                    tag + "_z_std": ex["z_std"].numpy(), tag + "_u": np.concatenate([c["u"] for c in cap.log], 0),
+                    tag + "_z_samples": np.concatenate([c["samples"] for c in cap.log], 0)})
+    np.random.set_state(state)
+    del sig_last[:]
+    save("g18_pytest_hook", **g18)
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

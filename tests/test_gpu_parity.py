@@ -614,6 +614,15 @@ def test_render_api_ndc_staticcam_and_stochastic_options(oracle, synth_nets, tmp
     same = m.render_rays(ro, rd, near, far, extras=dr)
     assert np.array_equal(cpu(same["rgb_map"]), cpu(a1[0]))
     m.close()
+    # the reference's pytest hook: numpy's generator reseeded per draw site and per chunk (g18: 80 rays, chunk 32)
+    g18 = load_golden("g18_pytest_hook")
+    r18 = (torch.tensor(g18["rays_o"], device=R.device), torch.tensor(g18["rays_d"], device=R.device))
+    for tag, pert in (("p", 1.0), ("d", 0.0)):
+        rgb, _, _, ex = R.render(400, 400, oracle.YCBV_K, chunk=int(g18["chunk"]), rays=r18, **dict(kw, perturb=pert, pytest=True))
+        assert_close(cpu(ex["rgb0"]), g18[tag + "_rgb0"], atol=1e-5, what="pytest hook rgb0 (%s)" % tag)
+        dd = np.abs(cpu(rgb) - g18[tag + "_rgb"]).max(-1)
+        assert (dd > 1e-4).mean() <= 0.08 and dd.mean() < 2e-4, (tag, (dd > 1e-4).mean())
+        assert_close(cpu(ex["z_std"]), g18[tag + "_z_std"], atol=2e-3, what="z_std")
     # render_path with such kwargs: pose by pose through render()
     poses = torch.tensor(load_golden("g9_pose")["c2w"][:2])
     torch.manual_seed(3)

@@ -408,7 +408,7 @@ def test_api_rejects_unsupported_configurations():
     net = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     base["network_fn"] = net
     for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=32), "N_samples"),
-                     (dict(N_importance=100), "N_importance"), (dict(pytest=True), "pytest"),
+                     (dict(N_importance=100), "N_importance"),
                      (dict(N_importance=64, retraw=True), "retraw")):
         kw = dict(base)
         kw.update(bad)
@@ -445,6 +445,35 @@ def test_random_draws_follow_the_references_order():
     torch.manual_seed(4)
     t = torch.rand(7, 64); n0 = torch.randn(7, 64) * 2.0; u = torch.rand(7, 128); n1 = torch.randn(7, 192) * 2.0
     assert all(torch.equal(x, y) for x, y in zip(a.values(), (t, n0, u, n1)))
+
+
+def test_pytest_hook_draws_are_the_references(oracle, synth_nets):
+    """pytest=True (RN:454-457, RH:214-222): numpy's global generator reseeded with 0 at every draw site and once per chunk
+    of rays; the deterministic resampling takes NUMPY's linspace.  run_nerf_noscale._draws against what the reference's
+    sample_pdf saw (g18: 80 rays in chunks of 32), and the oracle's render with these draws against the reference's."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g18_pytest_hook.npz"))
+    cpu = torch.device("cpu")
+    chunk = int(g["chunk"])
+    p = R._draws(dict(perturb=1.0, pytest=True), 80, 128, cpu, chunk)
+    d = R._draws(dict(perturb=0.0, pytest=True), 80, 128, cpu, chunk)
+    assert list(p) == ["t_rand", "u"] and list(d) == ["u"]
+    assert np.array_equal(p["u"].numpy(), g["p_u"]) and np.array_equal(d["u"].numpy(), g["d_u"])
+    assert np.array_equal(p["u"].numpy()[:32], p["u"].numpy()[32:64]) and np.array_equal(p["u"].numpy()[:16], p["u"].numpy()[64:])
+    assert not np.array_equal(d["u"].numpy()[0], oracle.torch_linspace01(128))            # numpy's linspace, not torch's
+    assert R._stochastic(dict(pytest=True))
+    with pytest.raises(NotImplementedError, match="reference itself fails"):
+        R._draws(dict(raw_noise_std=1.0, pytest=True), 8, 128, cpu, 8)
+    sd_c, sd_f = synth_nets
+    vd = oracle.normalize_dirs(g["rays_d"])
+    for tag, dr in (("p", p), ("d", d)):
+        rnd = {k: v.numpy() for k, v in dr.items()}
+        r = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, oracle.YCBV_NEAR, oracle.YCBV_FAR, extras=True, **rnd)
+        assert np.abs(r["rgb0"] - g[tag + "_rgb0"]).max() < 1e-5
+        dd = np.abs(r["rgb_map"] - g[tag + "_rgb"]).max(-1)
+        assert (dd > 1e-4).mean() <= 0.08 and dd.mean() < 2e-4, (tag, (dd > 1e-4).mean())
+        assert (np.abs(r["z_samples"] - g[tag + "_z_samples"]) > 1e-4).mean() < 0.03
 
 
 def test_nerf_module_has_reference_parameter_names(synth_nets):
