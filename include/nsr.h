@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NSR_ABI_VERSION 2
+#define NSR_ABI_VERSION 3
 
 /* Fixed architecture of the path (configs/nerf_param_ycbv_general.txt:12-13; NM:1232-1272). */
 #define NSR_N_SAMPLES     64   /* N_samples    (coarse, RN:439)          */
@@ -104,7 +104,17 @@ typedef struct NsrConfig {
                                    per wave; needs nsr_upload_weights_h2.  Mutually exclusive with NSR_FLAG_MLP_BF16X3.
                                    nsr_render_rays_vjp runs the same scheme (k_render_vjp_h2: forward and transposed GEMMs
                                    on fp16 MFMAs, the gradients of every point normalised by a power of two on entry) once
-                                   nsr_upload_weights_bwd_h2 has been called; before that, the fp32 kernels of `variant`.  */
+                                   nsr_upload_weights_bwd_h2 has been called; before that, the fp32 kernels of `variant`.
+                                   RANGE SAFETY NET (ABI 3): a NaN never reaches the caller because of the fp16 range.  The
+                                   f16x2 kernels append every item (2 consecutive rays) with a NaN network output or
+                                   gradient to a device-side list, and the same launch call enqueues the fp32 kernel of the
+                                   same template (k_render / k_render_vjp, RH:99-118 has no range limit) over exactly that
+                                   list -- list and length stay on the device, no host round trip; with an empty list every
+                                   workgroup of the second launch returns at once (~10 us).  The reported items then hold
+                                   the fp32 kernel's results (a NaN the fp32 arithmetic itself produces -- NaN inputs, the
+                                   encoder's domain -- stays a NaN).  nsr_range_status counts what happened.  The input-
+                                   gradient launch needs nsr_upload_weights_bwd (fp32 transposed stream) for its fallback;
+                                   without it the affected rays keep their NaN gradients and are counted as dropped.       */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
 typedef struct NsrDebugOut {
@@ -226,6 +236,25 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
                         float far_, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
                         const float* d_z_fine, const NsrRenderOut* out, void* stream);
 
+/* Debug taps of the input-gradient launch (x32-structured kernels: f16x2, bf16x3 and fp32 `variant` 32 handles; an fp32
+ * handle of another variant runs k_render_vjp for a call with taps, like for the extras).  All pointers nullable.
+ *   d_relu_masks [ceil(N/2)][3][9][256][4] uint32: the relu patterns the backward pass applied, as captured by the
+ *       forward passes of the same launch -- item t = rays 2t, 2t+1; fine pass p of the item covers the 128 points
+ *       q = 128 p + 32 w + j (wave w = thread / 64, j = thread % 32) = sample q % 192 of ray 2t + q / 192; layer 0..7 =
+ *       pts_linears, 8 = views_linears.0; thread (w, lane) holds, for its point, the units
+ *       32 mo + (r & 3) + 8 (r >> 2) + 4 (lane >> 5) in bit 31 - (16 (mo & 1) + r) of word mo >> 1, SET = unit OFF
+ *       (pre-activation <= 0)
+ *   d_grad_raw  [N,192,4]  dL/d raw of the fine samples (rgb logits, sigma): what the compositing backward hands to the
+ *       network backward
+ *   d_grad_pts  [N,192,6]  per fine sample: dL/d pts (3) and dL/d viewdirs (3), the results of the network backward
+ * oracle/vjp_census.py replays the oracle's fp64 backprop with these to attribute a ray's gradient error to relu units
+ * whose pre-activation sits at the discontinuity. */
+typedef struct NsrVjpDebugOut {
+  uint32_t* d_relu_masks;
+  float*    d_grad_raw;
+  float*    d_grad_pts;
+} NsrVjpDebugOut;
+
 /* nsr_render_rays_vjp with the extras: the forward half of the launch repeats the render with the same draws (or takes
  * d_z_fine), the backward half sees the noisy fine densities (the relu' of RN:374).  With ex->d_viewdirs the view
  * directions are an input of their own: d_grad_viewdirs [N,3] (nullable) receives dL/d viewdirs and d_grad_d holds only
@@ -233,6 +262,12 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
 int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                            float far_, const NsrRayExtras* ex, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
                            float* d_grad_viewdirs, const float* d_z_fine, const NsrRenderOut* out, void* stream);
+
+/* ... and with the debug taps (dbg may be NULL: identical to nsr_render_rays_vjp_ex). */
+int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                            float far_, const NsrRayExtras* ex, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
+                            float* d_grad_viewdirs, const float* d_z_fine, const NsrRenderOut* out,
+                            const NsrVjpDebugOut* dbg, void* stream);
 
 /* ndc_rays (RH:168-186), the projection render(ndc=True) applies to the rays of forward-facing scenes before rendering
  * them with near=0, far=1 (RN:101-103): [N,3] x 2 -> [N,3] x 2 in torch's fp32 op order (bit-exact against the reference,
@@ -326,6 +361,13 @@ int nsr_selftest(nsr_handle h, void* stream);
  * pass because the handed-over depths were not there in time -- 0 in normal operation, > 0 when the GPU is shared with
  * other work; never an error.  0 for handles without NSR_FLAG_SCHED_PHASES.  Synchronises the device. */
 int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays);
+
+/* f16x2 range safety net (NSR_FLAG_MLP_F16X2): what the handle's launches reported so far.  *last_items = items (2 rays)
+ * the LAST launch handed to its fp32 fallback; cumulative over the handle's life: *points = network evaluations whose
+ * outputs / gradients were NaN, *rays = rays rendered again by the fp32 kernel, *dropped_items = items that could not be
+ * (beyond the list's capacity of 2^17 items per launch, or an input-gradient launch without nsr_upload_weights_bwd): those
+ * kept their NaN.  Any pointer may be NULL.  All zero for other handles.  Synchronises the device. */
+int nsr_range_status(nsr_handle h, unsigned* last_items, unsigned* points, unsigned* rays, unsigned* dropped_items);
 
 /* Debug build (`make -C neural_sim_nerf_amd/csrc debug` -> libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent
  * LDS / scratch index of the kernels (searchsorted results, merge ranks, hand-off slots) is range-checked; a violation

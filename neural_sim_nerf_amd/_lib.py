@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "csrc", "libnsr.so"))   # override: A/B builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 PACKED_FLOATS = 145 * 4096 + 3328
 
 
@@ -29,6 +29,10 @@ class NsrRenderOut(C.Structure):
 class NsrRayExtras(C.Structure):
     _fields_ = [("d_viewdirs", C.c_void_p), ("d_t_rand", C.c_void_p), ("d_u", C.c_void_p), ("d_noise0", C.c_void_p),
                 ("d_noise1", C.c_void_p), ("d_near", C.c_void_p), ("d_far", C.c_void_p)]
+
+
+class NsrVjpDebugOut(C.Structure):
+    _fields_ = [("d_relu_masks", C.c_void_p), ("d_grad_raw", C.c_void_p), ("d_grad_pts", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol include/nsr.h declares
@@ -53,6 +57,11 @@ SIGNATURES = {
     "nsr_render_rays_vjp_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
                                          C.POINTER(NsrRayExtras), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.POINTER(NsrRenderOut), C.c_void_p]),
+    "nsr_render_rays_vjp_dbg": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                          C.POINTER(NsrRayExtras), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(NsrRenderOut), C.POINTER(NsrVjpDebugOut), C.c_void_p]),
+    "nsr_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint),
+                                   C.POINTER(C.c_uint)]),
     "nsr_ndc_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_ndc_rays_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,

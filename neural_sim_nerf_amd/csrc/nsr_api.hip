@@ -51,6 +51,7 @@ struct DeviceGuard {
 };
 #define NSR_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSR_HIP(guard_.err)
 
+constexpr unsigned kOvfCap = 1u << 17;      // items (2 rays each) one launch can hand to its fp32 fallback: 1 MiB per handle
 static int kSuperLg = 12;              // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
@@ -86,7 +87,11 @@ struct nsr_handle_s {
   nsr::VjpArgs* d_vjp_args = nullptr;
   uint4* d_mask_scratch = nullptr;    // relu patterns of the fine forward passes: x32 [n_cu][3][9][256] uint4 = x16
   int mask_grid = 0;                  // [2 n_cu][3][9][256] uint2 (same bytes); allocated by nsr_upload_weights_bwd*
-  unsigned long long* d_work_counter = nullptr;  // work-queue head
+  unsigned long long* d_work_counter = nullptr;  // work-queue heads: [0] the launch, [1] its fp32 fallback launch (f16x2)
+  nsr::RenderArgs* d_args_fb = nullptr;          // f16x2 range safety net: argument blocks of the fallback launches,
+  nsr::VjpArgs* d_vjp_args_fb = nullptr;
+  unsigned long long* d_ovf_items = nullptr;     // ... the items (2 rays) the f16x2 kernel reported, [kOvfCap]
+  unsigned* d_ovf_stat = nullptr;                // ... [0] items of the last launch, [1] points, [2] rays, [3] items beyond the cap
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
   int zf_grid = 0;
   unsigned* d_sched_flags = nullptr;  // global phases: ready / taken generations of the 3 * 2^kSuperLg hand-off slots
@@ -138,13 +143,18 @@ static int allocate_handle(nsr_handle h) {
   }
   if (cfg->flags & NSR_FLAG_MLP_F16X2) {
     NSR_HIP(hipMalloc(&h->d_nets_h2, sizeof(float) * 3 * kH2Stride));
+    NSR_HIP(hipMalloc(&h->d_args_fb, sizeof(nsr::RenderArgs)));
+    NSR_HIP(hipMalloc(&h->d_vjp_args_fb, sizeof(nsr::VjpArgs)));
+    NSR_HIP(hipMalloc(&h->d_ovf_items, sizeof(unsigned long long) * kOvfCap));
+    NSR_HIP(hipMalloc(&h->d_ovf_stat, 4 * sizeof(unsigned)));
+    NSR_HIP(hipMemset(h->d_ovf_stat, 0, 4 * sizeof(unsigned)));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
   }
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
-  NSR_HIP(hipMalloc(&h->d_work_counter, sizeof(unsigned long long)));
+  NSR_HIP(hipMalloc(&h->d_work_counter, 2 * sizeof(unsigned long long)));
   // k_render16's inter-phase scratch: bounded by the grid (2 workgroups per CU, or max_workgroups) x chunk
   h->zf_grid = cfg->max_workgroups > 0 ? cfg->max_workgroups : 2 * h->n_cu;
   size_t zf_rays = (size_t)h->zf_grid * h->chunk;
@@ -230,6 +240,10 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_box_scratch);
   hipFree(h->d_zf_scratch);
   hipFree(h->d_work_counter);
+  hipFree(h->d_args_fb);
+  hipFree(h->d_vjp_args_fb);
+  hipFree(h->d_ovf_items);
+  hipFree(h->d_ovf_stat);
   hipFree(h->d_sched_flags);
   hipFree(h->d_status);
   if (h->ev0) hipEventDestroy(h->ev0);
@@ -430,6 +444,10 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     g = grid_for(h, (a.n_rays + 1) / 2);
   }
   a.work_counter = h->d_work_counter;
+  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = kOvfCap; }
+#ifdef NSR_EXP_SAMENET       // timing experiment: every pass streams the SAME weight image (L2-resident); results are wrong
+  a.net_stride = 0;
+#endif
   hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, a, h->d_args);     // also zeroes the work counter
   if (!capturing) NSR_HIP(hipEventRecord(h->ev0, s));
   if (phases)
@@ -442,6 +460,23 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     hipLaunchKernelGGL(nsr::k_render_h2, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   else
     hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
+#ifndef NSR_EXP_NO_RANGE
+  if (h2) {
+    // f16x2 range safety net: the items k_render_h2 reported (a NaN network output: a scaled activation beyond the fp16
+    // range) are rendered again by the fp32 kernel of the same template, which overwrites their outputs.  The list and
+    // its length stay on the device; with an empty list every workgroup of this launch returns at once.
+    nsr::RenderArgs f = a;
+    f.nets = h->d_nets;
+    f.net_stride = (long long)sizeof(float) * (long long)NSR_PACKED_FLOATS;
+    f.aux[0] = h->d_nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+    f.aux[1] = h->d_nets + (fine ? (size_t)NSR_PACKED_FLOATS : 0) + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+    f.ovf_items = nullptr; f.ovf_stat = nullptr; f.ovf_cap = 0;
+    f.item_list = h->d_ovf_items; f.item_count = h->d_ovf_stat; f.item_cap = kOvfCap;
+    f.work_counter = h->d_work_counter + 1;
+    hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, f, h->d_args_fb);
+    hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args_fb);
+  }
+#endif
   NSR_HIP(hipGetLastError());
   if (!capturing) {
     NSR_HIP(hipEventRecord(h->ev1, s));
@@ -501,6 +536,14 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
 int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
                            float far_, const NsrRayExtras* ex, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
                            float* d_grad_viewdirs, const float* d_z_fine, const NsrRenderOut* out, void* stream) {
+  return nsr_render_rays_vjp_dbg(h, d_rays_o, d_rays_d, n_rays, near_, far_, ex, d_grad_rgb, d_grad_o, d_grad_d,
+                                 d_grad_viewdirs, d_z_fine, out, nullptr, stream);
+}
+
+int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_,
+                            float far_, const NsrRayExtras* ex, const float* d_grad_rgb, float* d_grad_o, float* d_grad_d,
+                            float* d_grad_viewdirs, const float* d_z_fine, const NsrRenderOut* out,
+                            const NsrVjpDebugOut* dbg, void* stream) {
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h) return fail("nsr_render_rays_vjp: null handle");
   if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
@@ -514,7 +557,8 @@ int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_r
   if (d_grad_viewdirs && !(ex && ex->d_viewdirs))
     return fail("nsr_render_rays_vjp_ex: d_grad_viewdirs without d_viewdirs (the view directions are rays_d / |rays_d| then, "
                 "and their gradient is part of d_grad_d)");
-  const bool x16 = use_x16(h) && !b3 && !h2 && !extras;      // the extras are read by the x32-structured kernels
+  const bool taps = dbg && (dbg->d_relu_masks || dbg->d_grad_raw || dbg->d_grad_pts);
+  const bool x16 = use_x16(h) && !b3 && !h2 && !extras && !taps;   // extras and debug taps: the x32-structured kernels
   if (b3 && !(h->have_net_b3[0] && h->have_net_b3[1] && h->have_net_b3[2]))
     return fail("nsr_render_rays_vjp: NSR_FLAG_MLP_BF16X3 needs nsr_upload_weights_b3 (both networks) and nsr_upload_weights_bwd_b3");
   if (x16 && !(h->have_net16[0] && h->have_net16[1] && h->have_net16[2]))
@@ -558,6 +602,10 @@ int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_r
   if (out) { a.rgb = out->d_rgb; a.disp = out->d_disp; a.acc = out->d_acc; }
   v.grad_rgb = d_grad_rgb; v.grad_o = d_grad_o; v.grad_d = d_grad_d; v.mask_scratch = h->d_mask_scratch;
   v.z_fine = d_z_fine;
+  if (dbg) { v.dbg_masks = (uint4*)dbg->d_relu_masks; v.dbg_graw = dbg->d_grad_raw; v.dbg_gpts = dbg->d_grad_pts; }
+  // f16x2 range safety net (see launch_render): needs the fp32 transposed stream (nsr_upload_weights_bwd) for its fallback
+  const bool fallback = h2 && h->have_net[2];
+  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = fallback ? kOvfCap : 0u; }
   // global-phases schedule (k_render_vjp16p) unless the caller supplies the depths itself (then nothing is handed over)
   const bool phases = x16 && (h->cfg.flags & NSR_FLAG_SCHED_PHASES) && !d_z_fine;
   if (phases) {
@@ -581,6 +629,19 @@ int nsr_render_rays_vjp_ex(nsr_handle h, const float* d_rays_o, const float* d_r
     hipLaunchKernelGGL(nsr::k_render_vjp_h2, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else
     hipLaunchKernelGGL(nsr::k_render_vjp, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  if (fallback) {          // the reported items again, forward and backward, on the fp32 kernel of the same template
+    nsr::VjpArgs f = v;
+    nsr::RenderArgs& fa = f.r;
+    fa.nets = h->d_nets;
+    fa.net_stride = (long long)sizeof(float) * (long long)NSR_PACKED_FLOATS;
+    fa.aux[0] = h->d_nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+    fa.aux[1] = h->d_nets + (size_t)NSR_PACKED_FLOATS + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+    fa.ovf_items = nullptr; fa.ovf_stat = nullptr; fa.ovf_cap = 0;
+    fa.item_list = h->d_ovf_items; fa.item_count = h->d_ovf_stat; fa.item_cap = kOvfCap;
+    fa.work_counter = h->d_work_counter + 1;
+    hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, f, h->d_vjp_args_fb);
+    hipLaunchKernelGGL(nsr::k_render_vjp, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
+  }
   NSR_HIP(hipGetLastError());
   if (!capturing) {
     NSR_HIP(hipEventRecord(h->ev1, s));
@@ -860,6 +921,21 @@ int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays) {
   NSR_DEVICE(h);
   NSR_HIP(hipDeviceSynchronize());
   NSR_HIP(hipMemcpy(recomputed_rays, h->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsr_range_status(nsr_handle h, unsigned* last_items, unsigned* points, unsigned* rays, unsigned* dropped_items) {
+  if (!h) return fail("nsr_range_status: null handle");
+  unsigned st[4] = {0u, 0u, 0u, 0u};
+  if (h->d_ovf_stat) {                                     // handles without NSR_FLAG_MLP_F16X2 have nothing to report
+    NSR_DEVICE(h);
+    NSR_HIP(hipDeviceSynchronize());
+    NSR_HIP(hipMemcpy(st, h->d_ovf_stat, sizeof(st), hipMemcpyDeviceToHost));
+  }
+  if (last_items) *last_items = st[0];
+  if (points) *points = st[1];
+  if (rays) *rays = st[2];
+  if (dropped_items) *dropped_items = st[3];
   return 0;
 }
 

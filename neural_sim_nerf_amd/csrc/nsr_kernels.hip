@@ -824,6 +824,17 @@ struct RenderArgs {
   const float* noise1;      // [N,192] ... to the fine densities
   const float* near_rays;   // [N] per-ray bounds (RN:106-108: near / far may be arrays); both or neither
   const float* far_rays;
+  // f16x2 range safety net (x32-structured kernels).  The f16x2 kernels REPORT: an item (2 rays) in which any network
+  // output came out NaN -- a scaled activation / gradient beyond the fp16 range, nsr_h2.inc -- is appended to ovf_items
+  // (ovf_stat[0] = items appended by this launch, zeroed by k_set_args; [1] points, [2] rays, [3] items beyond ovf_cap:
+  // cumulative).  The launcher then runs the fp32 kernel of the same template over exactly that list (item_list /
+  // item_count, read on the device: no host round trip), which overwrites the items' outputs.
+  unsigned long long* ovf_items;
+  unsigned* ovf_stat;
+  unsigned ovf_cap;
+  const unsigned long long* item_list;   // fallback launch: the items to render instead of 0 .. ceil(n_rays / 2) - 1
+  const unsigned* item_count;            // ... how many (device word written by the launch before)
+  unsigned item_cap;
 };
 
 __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int tid) {
@@ -844,7 +855,43 @@ __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int ti
 __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) {
   *dst = a;
   *a.work_counter = 0ull;
+  if (a.ovf_stat) a.ovf_stat[0] = 0u;
   if (a.epoch_counter) dst->epoch = *a.epoch_counter = *a.epoch_counter % 4094u + 1u;
+}
+
+// Work queue of the x32-structured kernels: the next item (2 rays) of this launch, or -1 when there is none left.  A
+// fallback launch (item_list) hands out the items the f16x2 kernel reported.  Thread 0 only.
+__device__ __forceinline__ long long queue_next_item(const RenderArgs& q) {
+  const unsigned long long v = atomicAdd(q.work_counter, 1ull);
+  if (q.item_list) {
+    unsigned n = *q.item_count;
+    n = n < q.item_cap ? n : q.item_cap;
+    return v < (unsigned long long)n ? (long long)q.item_list[v] : -1ll;
+  }
+  return v < (unsigned long long)((q.n_rays + 1) >> 1) ? (long long)v : -1ll;
+}
+__device__ __forceinline__ long long queue_items(const RenderArgs& q) {
+  if (q.item_list) { const unsigned n = *q.item_count; return (long long)(n < q.item_cap ? n : q.item_cap); }
+  return (q.n_rays + 1) >> 1;
+}
+// f16x2: a NaN network output marks the item (LDS counter of the item's affected points)
+__device__ __forceinline__ void range_mark(int* ovf, float chk, int lane) {
+#ifndef NSR_EXP_NO_RANGE     // (timing experiment: the kernels without the safety net)
+  if (chk != chk && lane < 32) atomicAdd(ovf, 1);
+#endif
+}
+// ... and the item is reported once it is complete (thread 0)
+__device__ __forceinline__ void range_report(const RenderArgs& a, int* ovf, long long item, int valid) {
+#ifdef NSR_EXP_NO_RANGE
+  return;
+#endif
+  const int pts = *ovf;
+  if (pts != 0 && a.ovf_stat) {
+    const unsigned n = atomicAdd(a.ovf_stat, 1u);
+    atomicAdd(a.ovf_stat + 1, (unsigned)pts);
+    if (n < a.ovf_cap) { a.ovf_items[n] = (unsigned long long)item; atomicAdd(a.ovf_stat + 2, (unsigned)valid); }
+    else atomicAdd(a.ovf_stat + 3, 1u);
+  }
 }
 
 #ifdef NSR_PHASE_TIMING      // diagnostic build: per-workgroup cycle totals of the item phases (thread 0), see tools
@@ -872,9 +919,9 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   ItemState& st = *(ItemState*)(smem + kLdsState);
 
   const long long n_rays = a_setup.n_rays;
-  const long long n_items = (n_rays + 1) >> 1;
-  if ((long long)blockIdx.x >= n_items) return;
+  if ((long long)blockIdx.x >= queue_items(a_setup)) return;
   const int fine = a_setup.fine;
+  int* ovf = (int*)&st.ray[1][14];                       // f16x2: points of the current item with NaN network outputs
 
   Ring rg;
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 4 : 1, wave, lane);
@@ -892,7 +939,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   // items come from a global counter: nothing forces the workgroups to progress at the same rate
   long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
   auto next_item = [&]() -> long long {
-    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(ap)->work_counter, 1ull);
+    if (opaque_v(tid0) == 0) *item_slot = queue_next_item(*opaque_s(ap));
     __syncthreads();
     const long long v = uniform64(*item_slot);
     __syncthreads();
@@ -901,7 +948,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   long long item = next_item();
   int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current item
 #pragma unroll 1
-  while (item < n_items) {
+  while (item >= 0) {
     const long long ray0 = item * 2;
     const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
     if (pass == 0) {
@@ -933,6 +980,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
+      if (MODE == kMlpH2 && tid == 64) *ovf = 0;
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
@@ -965,6 +1013,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       mlp_pass<false, MODE>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, nullptr, 0, NSR_TPASS);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
+      if constexpr (MODE == kMlpH2) range_mark(ovf, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
     }
     NSR_T(1);
 
@@ -990,7 +1039,10 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       }
       if (a.dbg_w0)
         for (int idx = tid; idx < valid * 64; idx += 256) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
-      if (!fine) { __syncthreads(); item = next_item(); continue; }
+      if (!fine) {
+        if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
+        __syncthreads(); item = next_item(); continue;
+      }
       NSR_T(2);
 
       // ---- hierarchical resampling ----------------------------------------------------------------
@@ -1032,6 +1084,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         else if (c == 3) { if (a.disp) a.disp[rr] = v; }
         else if (c == 4) { if (a.acc) a.acc[rr] = v; }
       }
+      if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
       __syncthreads();
       NSR_T(6);
       pass = 0;
@@ -1315,11 +1368,16 @@ struct VjpArgs {
   const float* z_fine;      // optional [N,192]: sorted fine sample depths to use instead of the kernel's own resampling
                             // (z_samples is detached, RN:475: the depths are constants of the backward pass)
   float* grad_viewdirs;     // optional [N,3]: dL/d viewdirs when r.viewdirs is given (x32-structured kernels)
+  // debug taps of the x32-structured kernels (include/nsr.h: NsrVjpDebugOut), all nullable
+  uint4* dbg_masks;         // [ceil(N/2) items][3 fine passes][9 layers][256 threads]: the relu patterns the backward applied
+  float* dbg_graw;          // [N,192,4] dL/d raw of the fine samples (output of the compositing backward)
+  float* dbg_gpts;          // [N,192,6] per sample: dL/d pts, dL/d viewdirs (output of the network backward)
 };
 
 __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) {
   *dst = a;
   *a.r.work_counter = 0ull;
+  if (a.r.ovf_stat) a.r.ovf_stat[0] = 0u;
   if (a.r.epoch_counter) dst->r.epoch = *a.r.epoch_counter = *a.r.epoch_counter % 4094u + 1u;
 }
 
@@ -1343,8 +1401,8 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
   ItemState& st = *(ItemState*)(smem + kLdsState);
 
   const long long n_rays = a_setup.n_rays;
-  const long long n_items = (n_rays + 1) >> 1;
-  if ((long long)blockIdx.x >= n_items) return;
+  if ((long long)blockIdx.x >= queue_items(a_setup)) return;
+  int* ovf = (int*)&st.ray[1][14];                       // f16x2: points of the current item with NaN outputs / gradients
 
   Ring rg;
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);
@@ -1366,7 +1424,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
 
   long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
   auto next_item = [&]() -> long long {
-    if (opaque_v(tid0) == 0) *item_slot = (long long)atomicAdd(opaque_s(vp)->r.work_counter, 1ull);
+    if (opaque_v(tid0) == 0) *item_slot = queue_next_item(opaque_s(vp)->r);
     __syncthreads();
     const long long v = uniform64(*item_slot);
     __syncthreads();
@@ -1375,7 +1433,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
   long long item = next_item();
   int pass = 0;
 #pragma unroll 1
-  while (item < n_items) {
+  while (item >= 0) {
     const long long ray0 = item * 2;
     const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
     if (pass == 0) {
@@ -1399,6 +1457,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
+      if (MODE == kMlpH2 && tid == 64) *ovf = 0;
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
@@ -1428,6 +1487,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       mlp_pass<true, MODE>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                          ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
+      if constexpr (MODE == kMlpH2) range_mark(ovf, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
     } else {
       // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
       const int q0 = 128 * (pass - 4) + 32 * wave;
@@ -1438,6 +1498,13 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       float dp[3], dv[3];
       mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
                        ry, &st.zf[r][i - j], dp, dv);
+      if constexpr (MODE == kMlpH2) range_mark(ovf, dp[0] + dv[0], lane);
+      if (float* gp = opaque_s(vp)->dbg_gpts) {            // debug tap: the per-sample results of the network backward
+        if (lane < 32 && r < valid) {
+          float* q = gp + ((ray0 + r) * 192 + i) * 6;
+          q[0] = dp[0]; q[1] = dp[1]; q[2] = dp[2]; q[3] = dv[0]; q[4] = dv[1]; q[5] = dv[2];
+        }
+      }
       // reduce the 32 points of this wave (all on ray r): sum dp, sum z*dp, sum dv
       float red[9] = {dp[0], dp[1], dp[2], z * dp[0], z * dp[1], z * dp[2], dv[0], dv[1], dv[2]};
 #pragma unroll
@@ -1488,6 +1555,8 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       }
       __syncthreads();
       composite_bwd(st, grgb, tid);
+      if (va.dbg_graw)                                     // debug tap: dL/d raw as the network backward receives it
+        for (int idx = tid; idx < valid * 768; idx += 256) va.dbg_graw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
       pass = 4;
     } else if (pass < 6) {
       ++pass;
@@ -1523,6 +1592,9 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
           }
         }
       }
+      if (va.dbg_masks)                                    // debug tap: the relu patterns of this item's three fine passes
+        for (int k = 0; k < 27; ++k) va.dbg_masks[((size_t)item * 27 + k) * 256 + tid] = my_masks[k * 256 + tid];
+      if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
       __syncthreads();
       pass = 0;
       item = next_item();

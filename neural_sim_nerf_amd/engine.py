@@ -110,6 +110,7 @@ class NsrModel:
                              (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0)
                              | (8 if mlp == "bf16x3" else 0) | (16 if mlp == "f16x2" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
+        self._bwd_ready = self._bwd32_ready = False
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -133,7 +134,7 @@ class NsrModel:
             p = pack_network_h2(sd_c)
             _lib.check(self.lib.nsr_upload_weights_h2(self.h, 0, _fptr(p), PACKED_FLOATS))
         self._sd_fine_np = None
-        self._bwd_ready = False
+        self._bwd_ready = self._bwd32_ready = False     # both transposed streams belong to the previous fine network
         if sd_fine is not None:
             self._sd_fine_np = to_np(sd_fine)
             p = pack_network(self._sd_fine_np)
@@ -252,17 +253,22 @@ class NsrModel:
                                              C.byref(ro), C.byref(dbg) if dbg else None, _stream_ptr(self.device)))
         return o
 
-    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None, extras=None):
+    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None, extras=None,
+                        debug=False):
         """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each.
         z_fine (optional [N,192]): sorted fine sample depths to differentiate at, instead of the kernel's own
         resampling (they are constants of the backward, RN:475).
         extras: as for render_rays; with extras["viewdirs"] the view directions are an input of their own and the result
-        gains dL/d viewdirs: (grad_o, grad_d, grad_viewdirs[, forward])."""
+        gains dL/d viewdirs: (grad_o, grad_d, grad_viewdirs[, forward]).
+        debug: append a dict with the taps of include/nsr.h: NsrVjpDebugOut (relu_masks uint32 [ceil(N/2),3,9,256,4],
+        grad_raw [N,192,4], grad_pts [N,192,6]) -- served by the x32-structured kernels."""
         if self.n_importance == 0:
             raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
         has_extras = bool(extras) and any(v is not None for v in extras.values())
-        if has_extras and self.mlp == "fp32" and self.variant != 32 and not getattr(self, "_bwd32_ready", False):
-            # the extras are read by the x32-structured kernels: an fp32 handle of another variant runs k_render_vjp for them
+        need32 = ((has_extras or debug) and self.mlp == "fp32" and self.variant != 32) or self.mlp == "f16x2"
+        if need32 and not self._bwd32_ready:
+            # the fp32 x32 transposed stream: the extras and the debug taps are served by the x32-structured kernels (an fp32
+            # handle of another variant runs k_render_vjp for them), and it is the fallback of an f16x2 handle's range safety net
             b = pack_network_backward(self._sd_fine_np)
             _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
             self._bwd32_ready = True
@@ -293,11 +299,19 @@ class NsrModel:
                                    None, None)
         ex, keep = self._extras(extras, n)
         gv = self._new(n, 3) if (keep and "viewdirs" in keep) else None
-        _lib.check(self.lib.nsr_render_rays_vjp_ex(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
-                                                   C.byref(ex) if ex else None, _dev(g), _dev(go), _dev(gd), _dev(gv),
-                                                   _dev(zf), C.byref(ro) if ro else None, _stream_ptr(self.device)))
+        taps, dbg = None, None
+        if debug:
+            taps = dict(relu_masks=torch.zeros(((n + 1) // 2, 3, 9, 256, 4), dtype=torch.int32, device=self.device),
+                        grad_raw=self._new(n, 192, 4), grad_pts=self._new(n, 192, 6))
+            dbg = _lib.NsrVjpDebugOut(_dev(taps["relu_masks"]), _dev(taps["grad_raw"]), _dev(taps["grad_pts"]))
+        _lib.check(self.lib.nsr_render_rays_vjp_dbg(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
+                                                    C.byref(ex) if ex else None, _dev(g), _dev(go), _dev(gd), _dev(gv),
+                                                    _dev(zf), C.byref(ro) if ro else None, C.byref(dbg) if dbg else None,
+                                                    _stream_ptr(self.device)))
         res = (go, gd) if gv is None else (go, gd, gv)
-        return res + (fwd,) if with_forward else res
+        if with_forward:
+            res = res + (fwd,)
+        return res + (taps,) if debug else res
 
     def pose_grad(self, grad_o, grad_d, H, W, K, patch):
         """dL/d c2w[3,4] per patch of `patch` consecutive pixels, given dL/d rays of a full H x W image."""
@@ -437,6 +451,14 @@ class NsrModel:
         n = C.c_uint()
         _lib.check(self.lib.nsr_schedule_stats(self.h, C.byref(n)))
         return int(n.value)
+
+    def range_status(self):
+        """f16x2 range safety net (include/nsr.h: nsr_range_status): dict(last_items, points, rays, dropped_items) --
+        items (2 rays) the last launch handed to its fp32 fallback; cumulative network evaluations with NaN outputs /
+        gradients, rays re-rendered by the fp32 kernel, items that could not be.  Synchronises the device."""
+        v = [C.c_uint() for _ in range(4)]
+        _lib.check(self.lib.nsr_range_status(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("last_items", "points", "rays", "dropped_items"), (int(x.value) for x in v)))
 
     def debug_bounds_status(self):
         """(built_with_checks, first_bad_source_line): see nsr_debug_bounds_status / `make debug`."""

@@ -58,6 +58,7 @@ class NeRF(nn.Module):
                 "(run_nerf_helpers.as_kernel_network); this one cannot: " + why)
         self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
         self.skips, self.use_viewdirs = skips, bool(use_viewdirs)
+        self.output_ch = int(output_ch)
         self.pts_linears = nn.ModuleList(
             [nn.Linear(input_ch, W)] + [nn.Linear(W, W) if i not in skips else nn.Linear(W + input_ch, W)
                                         for i in range(D - 1)])
@@ -70,6 +71,7 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(W, output_ch)                                 # RH:95-96
         self._native = None
         self._native_key = None
+        self._native5 = None                                 # use_viewdirs=False with output_ch = 5: see evaluate()
 
     def native_state_dict(self):
         """The weights in the architecture the kernels are built for (as_kernel_network): this module's own state dict
@@ -143,7 +145,9 @@ class NeRF(nn.Module):
             cache.clear()
         if self._native is not None:
             self._native.close()
-        self._native = None
+        if self._native5 is not None:
+            self._native5.close()
+        self._native = self._native5 = None
         self._native_key = None
 
     def _native_handle(self):
@@ -154,16 +158,30 @@ class NeRF(nn.Module):
         if self._native is None or self._native_key != key:
             if self._native is not None:
                 self._native.close()
+            if self._native5 is not None:
+                self._native5.close()
+            self._native5 = None
             p0 = next(self.parameters())
-            self._native = NsrModel(self.native_state_dict(), None, n_importance=0, mlp="fp32",       # k_run_network (stage kernel)
-                                    device=p0.device.index if p0.is_cuda else None)     # the module's device, not the current one
+            dev = p0.device.index if p0.is_cuda else None     # the module's device, not the current one
+            self._native = NsrModel(self.native_state_dict(), None, n_importance=0, mlp="fp32", device=dev)   # k_run_network (stage kernel)
+            if not self.use_viewdirs and self.output_ch == 5:
+                # RH:95-96 + RN:267: output_linear has FIVE rows when N_importance > 0; render_rays reads rows 0..3, but the
+                # module's forward returns all five.  The fifth row runs through the same kernel as the density row of a
+                # second re-expression of the network.
+                sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
+                sd["output_linear.weight"][3], sd["output_linear.bias"][3] = sd["output_linear.weight"][4], sd["output_linear.bias"][4]
+                self._native5 = NsrModel(as_kernel_network(sd), None, n_importance=0, mlp="fp32", device=dev)
             self._native_key = key
         return self._native
 
     def evaluate(self, pts, viewdirs):
         """run_network's arithmetic (RN:26-40 = Embedder RH:18-48 + the MLP RH:99-122) on raw points [P,3] and unit
-        directions [P,3] -> [P,4]; the encodings are fused into the kernel, nothing is materialised."""
-        return self._native_handle().run_network(pts, viewdirs, 0)
+        directions [P,3] -> [P, 4] ([P, output_ch] for a use_viewdirs=False module, RH:119-120: 5 when N_importance > 0);
+        the encodings are fused into the kernel, nothing is materialised."""
+        out = self._native_handle().run_network(pts, viewdirs, 0)
+        if self._native5 is not None:
+            out = torch.cat([out, self._native5.run_network(pts, viewdirs, 0)[:, 3:4]], -1)
+        return out
 
     def forward(self, x):
         """The reference's signature: x = cat([embedded points (63), embedded directions (27)]) [P,90].  Only the raw

@@ -69,19 +69,35 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     cache = pair.pop(slot, None) or {}
     pair[slot] = cache                                    # most recently used last
     while len(pair) > _MAX_HANDLES_PER_MODULE:            # each handle holds 3 x 2 packed networks + ~19 MB of scratch
-        _, old = next(iter(pair.items()))
-        if old.get("model") is not None:
-            old["model"].close()
+        # dropped, not closed: an autograd graph of an earlier render() may still hold the handle (ctx.cfg of _RenderRays /
+        # _RenderRaysEx) for its backward; NsrModel.__del__ frees the native side with the last reference
         del pair[next(iter(pair))]
     if cache.get("key") != key:
-        if cache.get("model") is not None:
-            cache["model"].close()
+        cache.pop("model", None)                          # same: released when no graph refers to it any more
         with torch.cuda.device(dev):
             cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
                                       else None, device=dev, n_importance=n_importance, white_bkgd=white,
                                       lindisp=lindisp)
         cache["key"] = key
     return cache["model"]
+
+
+_RANGE_WARNED = set()
+
+
+def _note_range(model):
+    """f16x2 range safety net (include/nsr.h: NSR_FLAG_MLP_F16X2): called where the API has synchronised anyway.  Rays whose
+    network evaluation left the fp16 range were rendered again by the fp32 kernel inside the same launch call -- the
+    results are the fp32 kernel's -- so this only says so, once per handle."""
+    if getattr(model, "mlp", None) != "f16x2" or id(model) in _RANGE_WARNED:
+        return
+    st = model.range_status()
+    if st["points"]:
+        import warnings
+        _RANGE_WARNED.add(id(model))
+        warnings.warn("neural_sim_nerf_amd: %d network evaluations left the fp16 range of the f16x2 kernels; %d rays were "
+                      "rendered again by the fp32 kernel (%d items could not be and hold NaN).  NSR_MLP=fp32 selects the fp32 "
+                      "kernels for this network outright." % (st["points"], st["rays"], st["dropped_items"]), RuntimeWarning)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -282,6 +298,11 @@ def _check_kwargs(kw):
     if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128):
         bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4])"
                    % kw.get("N_importance"))
+    net = kw.get("network_fine") if kw.get("N_importance", 0) > 0 and kw.get("network_fine") is not None else kw.get("network_fn")
+    if kw.get("retraw", False) and not getattr(net, "use_viewdirs", True) and getattr(net, "output_ch", 4) != 4:
+        bad.append("retraw with a use_viewdirs=False network of output_ch=%r (the reference's raw is [N,S,%r]: RN:267, RH:119-120; "
+                   "the fused kernels tap the four channels render_rays reads -- NeRF.evaluate / run_network return all of them)"
+                   % (net.output_ch, net.output_ch))
     if bad:
         raise NotImplementedError("render: unsupported option(s): " + ", ".join(bad))
 
@@ -289,7 +310,9 @@ def _check_kwargs(kw):
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
            c2w_staticcam=None, **kwargs):
     """RN:58-123.  Returns [rgb_map, disp_map, acc_map, extras] with the reference's shapes: [H,W,...] when
-    c2w is given, rays_d.shape[:-1] + ... for the rays form.  `chunk` is accepted and ignored.
+    c2w is given, rays_d.shape[:-1] + ... for the rays form.  `chunk` does not change the deterministic render (RN:67-68; one
+    persistent launch covers all rays); it only decides how the random draws of the stochastic options are laid out (_draws:
+    the reference draws once per chunk of rays, and with pytest=True ray i gets row i mod chunk).
     ndc (RN:101-103), c2w_staticcam (RN:91-96), perturb > 0 (RN:447-459, RH:211) and raw_noise_std > 0 (RN:365-374) go
     through the per-ray extras of the native renderer (include/nsr.h: NsrRayExtras); see _draws for the random stream."""
     _check_viewdirs("render", use_viewdirs, kwargs)
@@ -299,7 +322,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
-    special = bool(ndc) or c2w_staticcam is not None or _stochastic(kwargs) or per_ray_bounds
+    special = bool(ndc) or (c2w_staticcam is not None and use_viewdirs) or _stochastic(kwargs) or per_ray_bounds
 
     if c2w is not None:
         c2w = torch.as_tensor(c2w, dtype=torch.float32)
@@ -318,7 +341,9 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     rays_o = torch.as_tensor(rays_o, dtype=torch.float32)
     rays_d = torch.as_tensor(rays_d, dtype=torch.float32)
     viewdirs = None
-    if ndc or c2w_staticcam is not None:                    # RN:89-98: view directions from the rays BEFORE the next two
+    if not use_viewdirs:
+        c2w_staticcam = None                                # RN:91-96 sits inside `if use_viewdirs:`: ignored without it
+    if use_viewdirs and (ndc or c2w_staticcam is not None):     # RN:89-98: view directions from the rays BEFORE the next two
         v = rays_d.reshape(-1, 3).to(model.device)
         viewdirs = v / torch.norm(v, dim=-1, keepdim=True)
     if c2w_staticcam is not None:                           # RN:91-96
@@ -419,6 +444,7 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
             return rgbs, disps
         rgb, disp = render_fn(poses)
         rgbs, disps = rgb.cpu().numpy(), disp.cpu().numpy()
+        _note_range(model)
     print("rendered %d views in %.3f s" % (rgbs.shape[0], time.time() - t))
     if savedir is not None:
         png.imwrite_many([os.path.join(savedir, str(object_id), "{:03d}.png".format(i)) for i in range(rgbs.shape[0])],
@@ -492,6 +518,7 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
         grads = D.gather_patch_grads(grads, n_poses).cpu()
         if savedir is not None:
             torch.distributed.barrier()
+    _note_range(model)
     dLdpsis = [grads[i, p] for i in range(grads.shape[0]) for p in range(n_patches)]         # RN:190 order
     return rgbs.numpy(), dLdpsis
 

@@ -604,19 +604,22 @@ def _embed_bwd(x, G, n_freqs):
     return out
 
 
-def network_vjp(sd, pts, dirs, g_raw, fwd=None):
+def network_vjp(sd, pts, dirs, g_raw, fwd=None, relu_on=None):
     """Input-side VJP of run_network: g_raw [P,4] = dL/d(rgb logits, sigma) -> dL/d pts [P,3], dL/d dirs [P,3]
-    (weights are constants).  Manual backprop of RH:99-122 in float64."""
+    (weights are constants).  Manual backprop of RH:99-122 in float64.
+    relu_on (counterfactual replay, oracle/vjp_census.py): dict(pre=[8 x [P,256] bool], av=[P,128] bool) -- the relu
+    patterns to apply INSTEAD of the forward's own (pre > 0), i.e. relu' as another evaluation of the forward saw it."""
     W = lambda k: sd[k + ".weight"].astype(f64)
     if fwd is None:
         fwd = _network_forward64(sd, pts, dirs)
     pre, av = fwd["pre"], fwd["av"]
+    on = [p > 0 for p in pre] if relu_on is None else relu_on["pre"]
     g_raw = g_raw.astype(f64)
     if av is None:                                      # use_viewdirs=False: outputs = output_linear(h)
         G_h = g_raw @ W("output_linear")[:4]
         G_ed = np.zeros((pts.shape[0], IN_CH_VIEWS), f64)
     else:
-        G_av = (g_raw[:, :3] @ W("rgb_linear")) * (av > 0)
+        G_av = (g_raw[:, :3] @ W("rgb_linear")) * ((av > 0) if relu_on is None else relu_on["av"])
         G_cat = G_av @ W("views_linears.0")
         G_feat, G_ed = G_cat[:, :NET_WIDTH], G_cat[:, NET_WIDTH:]
         G_h = G_feat @ W("feature_linear") + g_raw[:, 3:4] @ W("alpha_linear")
@@ -625,7 +628,7 @@ def network_vjp(sd, pts, dirs, g_raw, fwd=None):
         if i == SKIP_AT:
             G_ep += G_h[:, :IN_CH]
             G_h = G_h[:, IN_CH:]
-        G_h = (G_h * (pre[i] > 0)) @ W("pts_linears.%d" % i)
+        G_h = (G_h * on[i]) @ W("pts_linears.%d" % i)
     G_ep += G_h
     return _embed_bwd(pts, G_ep, MULTIRES), _embed_bwd(dirs, G_ed, MULTIRES_VIEWS)
 
@@ -635,7 +638,7 @@ def network_vjp(sd, pts, dirs, g_raw, fwd=None):
 # ----------------------------------------------------------------------------------------------
 def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
                     n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, z_fine=None, white_bkgd=False, lindisp=False,
-                    viewdirs=None, noise1=None, randoms=None):
+                    viewdirs=None, noise1=None, randoms=None, relu_on=None, sigma_on=None, parts=None):
     """d(sum(rgb_map * grad_rgb)) / d(rays_o, rays_d), the quantity torch.autograd.grad(rgb_p, batch_rays,
     grad_outputs=patch_grad_E) returns at RN:177.  Network weights are constants and z_samples is detached
     (RN:475), so gradient reaches the rays only through the FINE pass: pts = o + d*z (RN:478), the view
@@ -685,13 +688,16 @@ def render_rays_vjp(sd_coarse, sd_fine, rays_o, rays_d, near, far, grad_rgb,
     Aw = A * w
     suffix = np.concatenate([np.cumsum(Aw[:, ::-1], 1)[:, ::-1][:, 1:], np.zeros((N, 1))], 1)   # sum_{k>i}
     d_alpha = A * T - suffix / om
-    d_sigma = d_alpha * delta * (1.0 - alpha) * (sigma > 0)
+    d_sigma = d_alpha * delta * (1.0 - alpha) * ((sigma > 0) if sigma_on is None else sigma_on)
     d_delta = d_alpha * rs * (1.0 - alpha)
     d_nrm = (d_delta * dz).sum(1)
     d_rgb_raw = (w[..., None] * g[:, None, :]) * c * (1.0 - c)
     # ---- network backward (inputs only) ----
-    G_pts, G_dirs = network_vjp(sd, pts, dirs, np.concatenate([d_rgb_raw.reshape(-1, 3),
-                                                                d_sigma.reshape(-1, 1)], -1), fwd)
+    g_raw = np.concatenate([d_rgb_raw.reshape(-1, 3), d_sigma.reshape(-1, 1)], -1)
+    G_pts, G_dirs = network_vjp(sd, pts, dirs, g_raw, fwd, relu_on)
+    if parts is not None:                               # the intermediates oracle/vjp_census.py attributes with
+        parts.update(fwd=fwd, pts=pts, dirs=dirs, g_raw=g_raw.reshape(N, S, 4), sigma=sigma,
+                     g_pts=G_pts.reshape(N, S, 3), g_dirs=G_dirs.reshape(N, S, 3))
     G_pts = G_pts.reshape(N, S, 3)
     G_v = G_dirs.reshape(N, S, 3).sum(1)
     grad_o = G_pts.sum(1)

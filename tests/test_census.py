@@ -116,3 +116,24 @@ def test_coarse_only_census(oracle, synth_nets):
     c = C.census((synth_nets[0], None), ro, rd, oracle.YCBV_NEAR, oracle.YCBV_FAR, a, b, coarse_only=True)
     assert c["rays_above_tol"] == 1 and c["cliff_rays"] == 1 and c["unattributed"] == 0
     assert c["psnr_delta_db"] > c["psnr_delta_db_excluding_attributed"] == 0.0
+
+
+def test_perturbed_coarse_weights_do_not_pass(oracle, synth_nets, pair):
+    """VERDICT r03 #4 / ADVICE r03: the discontinuities of sample_pdf may only be blamed when what went INTO sample_pdf
+    agrees with the reference's to rounding.  A render whose coarse weights are off by 1e-4 -- it resamples from them, flips
+    indices, moves pixels -- is not attributed, and passes() refuses it even if no pixel happened to move."""
+    import census as C
+    ro, rd, ref, _ = pair
+    rng = np.random.RandomState(7)
+    w_bad = (ref["weights0"] + 1e-4 * rng.uniform(0.5, 1.0, ref["weights0"].shape)).astype(np.float32)
+    zc = ref["z_coarse"]
+    z_mid = (np.float32(0.5) * (zc[:, 1:] + zc[:, :-1])).astype(np.float32)
+    zs, inds, _ = oracle.sample_pdf(z_mid, w_bad[:, 1:-1])
+    zf = np.sort(np.concatenate([zc, zs], -1), -1)
+    pts = (ro[:, None, :] + rd[:, None, :] * zf[:, :, None]).astype(np.float32)
+    raw = oracle.run_network(synth_nets[1], pts, oracle.normalize_dirs(rd))
+    rgb, disp, acc, _, _ = oracle.raw2outputs(raw, zf, rd)
+    bad = dict(ref, weights0=w_bad, z_samples=zs, inds=inds, z_fine=zf, raw=raw, rgb_map=rgb, disp_map=disp, acc_map=acc)
+    c = C.census(synth_nets, ro, rd, oracle.YCBV_NEAR, oracle.YCBV_FAR, bad, ref)
+    assert c["max_abs_dweights0"] > 5e-5 and not C.passes(c), c
+    assert c["rays_above_tol"] == 0 or c["unattributed"] > 0, c          # a moved pixel of such a render is NOT attributed

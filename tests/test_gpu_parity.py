@@ -1372,21 +1372,28 @@ def test_f16x2_vjp_over_twelve_orders_of_magnitude(model_h2, model16, oracle, sy
     cot = (g["cot"] * amp).astype(np.float32)
     cot[7] = 0.0
     zf = cpu(model_h2.render_rays(ro, rd, near, far, debug=True)["z_fine"])
-    go, gd = model_h2.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    go, gd, taps = model_h2.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf, debug=True)
     go32, gd32 = model16.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
     want_o, want_d, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, near, far, cot, z_fine=zf)
+    worst32 = 0.0
     for got, got32, want in ((cpu(go), cpu(go32), want_o), (cpu(gd), cpu(gd32), want_d)):
         nrm = np.linalg.norm(want, axis=1)
         keep = nrm > 0
         e2 = (np.linalg.norm(got - want, axis=1) / (nrm + 1e-30))[keep]
         e32 = (np.linalg.norm(got32 - want, axis=1) / (nrm + 1e-30))[keep]
         print("per-ray relative VJP error: f16x2 max %.2e median %.2e | fp32 MFMA max %.2e median %.2e" % (e2.max(), np.median(e2), e32.max(), np.median(e32)))
-        # (the gradient is discontinuous in the relu patterns: a unit whose pre-activation is ~1e-6 can be "on" in one
-        # evaluation of the network and "off" in another -- fp64, fp32 MFMA, f16x2 -- and moves that ray by ~1/256 of its
-        # gradient; hence percentiles against the fp32 kernel and a loose bound on the single worst ray)
         assert np.median(e2) < 2 * np.median(e32) + 1e-6 and np.percentile(e2, 95) < 3 * np.percentile(e32, 95) + 1e-5, (e2, e32)
-        assert e2.max() < 1e-2
         assert (got[7] == 0).all()
+        worst32 = max(worst32, float(e32.max()))
+    # the worst ray (r04; r03 had loosened this to a flat 1e-2): within 3x the fp32 kernel's worst ray -- or ATTRIBUTED by
+    # the relu-flip census (oracle/vjp_census.py) to units whose pre-activation sits at the relu discontinuity, with the
+    # oracle's backprop replayed under the kernel's own relu patterns reproducing the kernel's gradient
+    import vjp_census as V
+    c = V.census(synth_nets, ro, rd, near, far, cot, zf,
+                 dict(grad_o=cpu(go), grad_d=cpu(gd), relu_masks=cpu(taps["relu_masks"]), grad_raw=cpu(taps["grad_raw"]),
+                      grad_pts=cpu(taps["grad_pts"])), thr=3.0 * worst32 + 1e-5)
+    print("f16x2 VJP, cotangents over twelve orders of magnitude:", c)
+    assert c["unattributed"] == 0 and c["max_err_unflagged"] <= 3.0 * worst32 + 1e-5, c
     go4, gd4 = model_h2.render_rays_vjp(ro, rd, near, far, 4.0 * cot, z_fine=zf)
     assert np.array_equal(cpu(go4), 4.0 * cpu(go)) and np.array_equal(cpu(gd4), 4.0 * cpu(gd))
 
@@ -1430,26 +1437,28 @@ def test_f16x2_networks_of_other_scales(oracle, synth_nets, trunk_scale):
     m.close()
 
 
-def test_f16x2_out_of_range_activation_is_nan(oracle, synth_nets):
-    """The domain of NSR_FLAG_MLP_F16X2 (include/nsr.h): a hidden activation whose scaled magnitude reaches the fp16
-    maximum makes the point's outputs NaN -- loud -- and just below it the results are still the oracle's."""
+def test_f16x2_out_of_range_activation_goes_to_the_fp32_kernel(oracle, synth_nets):
+    """The fp16 range of NSR_FLAG_MLP_F16X2 (include/nsr.h): just below a scaled hidden activation of 65504 the results are
+    still f16x2's own and the oracle's; at it the point's outputs are NaN inside k_render_h2 -- and the range safety net
+    renders the item again on the fp32 kernel within the same launch call (r03 returned the NaN), so the caller sees the
+    oracle's numbers either way and nsr_range_status says which route they took."""
     from neural_sim_nerf_amd.engine import NsrModel
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
     ro, rd = g["rays_o"][:64], g["rays_d"][:64]
-    for bias, finite in ((6.0e4, True), (7.0e4, False)):
+    for bias, inside in ((6.0e4, True), (7.0e4, False)):
         big = {k: np.array(v, copy=True) for k, v in synth_nets[0].items()}
         big["pts_linears.0.bias"][7] = bias
         m = NsrModel(big, None, n_importance=0, mlp="f16x2")
         r = m.render_rays(ro, rd, near, far, debug=True)
         raw0 = cpu(r["raw0"])
-        if finite:
-            zc = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
-            want = oracle.run_network(big, (ro[:, None] + rd[:, None] * zc[..., None]).astype(np.float32), oracle.normalize_dirs(rd))
-            assert np.isfinite(raw0).all()
-            assert_close(raw0, want, atol=5e-5 * max(1.0, np.abs(want).max()), rtol=5e-5, what="just inside the fp16 range")
-        else:
-            assert np.isnan(raw0).all() and np.isnan(cpu(r["rgb_map"])).all()
+        zc = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
+        want = oracle.run_network(big, (ro[:, None] + rd[:, None] * zc[..., None]).astype(np.float32), oracle.normalize_dirs(rd))
+        assert np.isfinite(raw0).all() and np.isfinite(cpu(r["rgb_map"])).all()
+        assert_close(raw0, want, atol=5e-5 * max(1.0, np.abs(want).max()), rtol=5e-5, what="bias %g" % bias)
+        st = m.range_status()
+        assert (st["rays"] == 0 and st["points"] == 0) if inside else (st["rays"] == 64 and st["points"] == 64 * 64), st
+        assert st["dropped_items"] == 0
         m.close()
 
 

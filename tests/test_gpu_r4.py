@@ -1,0 +1,376 @@
+"""GPU tests added in round 4 (run with -m gpu on an MI355X), through the C ABI like tests/test_gpu_parity.py:
+  * the relu-flip census of the input-gradient kernels (oracle/vjp_census.py) on the kernels' own debug taps;
+  * the f16x2 range safety net: a point that leaves the fp16 range is rendered again by the fp32 kernel inside the same
+    launch call -- no NaN reaches the caller that the fp32 kernel would not produce;
+  * the DEFAULT (f16x2) kernels at full size: size-independent properties forward and VJP, and render_path_grad on a
+    400x400 pose with 313 patches (BASELINE configs[3]'s render leg at its real size)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _rel_rows(a, b):
+    return np.linalg.norm(a.astype(np.float64) - b, axis=1) / (np.linalg.norm(b.astype(np.float64), axis=1) + 1e-300)
+
+
+def _mk(nets, kind, **kw):
+    from neural_sim_nerf_amd.engine import NsrModel
+    if kind == "x32":
+        return NsrModel(nets[0], nets[1], variant=32, **kw)
+    if kind == "x16p":
+        return NsrModel(nets[0], nets[1], mlp="fp32", **kw)
+    return NsrModel(nets[0], nets[1], mlp=kind, **kw)
+
+
+def _vjp_with_taps(m, ro, rd, near, far, cot, zf):
+    go, gd, taps = m.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf, debug=True)
+    return dict(grad_o=cpu(go), grad_d=cpu(gd), relu_masks=cpu(taps["relu_masks"]), grad_raw=cpu(taps["grad_raw"]),
+                grad_pts=cpu(taps["grad_pts"]))
+
+
+def _census_chunked(V, nets, ro, rd, near, far, cot, zf, got, thr, chunk=256):
+    """oracle/vjp_census.py over chunks of rays (its float64 forward keeps every pre-activation), counts summed"""
+    tot = None
+    for i in range(0, ro.shape[0], chunk):
+        s = slice(i, i + chunk)
+        s2 = slice(i // 2, (i + chunk) // 2) if chunk % 2 == 0 else None
+        g = dict(grad_o=got["grad_o"][s], grad_d=got["grad_d"][s], relu_masks=got["relu_masks"][s2],
+                 grad_raw=got["grad_raw"][s], grad_pts=got["grad_pts"][s])
+        c = V.census(nets, ro[s], rd[s], near, far, cot[s], zf[s], g, thr)
+        p = V.per_point(nets, ro[s], rd[s], zf[s], g)
+        c["per_point_max"], c["per_point_p99"] = p["max"], p["p99"]
+        if tot is None:
+            tot = c
+        else:
+            for k in ("rays", "rays_above_thr", "attributed", "unattributed", "rays_with_flips", "flipped_units_total",
+                      "flagged_without_flips", "sigma_flips_total"):
+                tot[k] += c[k]
+            for k in ("worst_flip_margin", "err_max", "replay_max", "max_err_unflagged", "per_point_max", "per_point_p99"):
+                tot[k] = max(tot[k], c[k])
+            tot["worst"] = sorted(tot["worst"] + [dict(w, ray=w["ray"] + i) for w in c["worst"]], key=lambda w: -w["err"])[:8]
+    return tot
+
+
+@pytest.fixture(scope="module")
+def fp32_errors(oracle, synth_nets):
+    """per-ray relative error of the default fp32 input-gradient kernel (k_render_vjp16p / 16) on g8 -- the yardstick"""
+    g = load_golden("g8_backward")
+    m = _mk(synth_nets, "x16p")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd, cot = g["rays"][0], g["rays"][1], g["cot"]
+    zf = cpu(m.render_rays(ro, rd, near, far, debug=True)["z_fine"])
+    go, gd = m.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    wo, wd, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, near, far, cot, z_fine=zf)
+    e = _rel_rows(np.concatenate([cpu(go), cpu(gd)], 1), np.concatenate([wo, wd], 1))
+    m.close()
+    return dict(zf=zf, p95=float(np.percentile(e, 95)), max=float(e.max()), p50=float(np.median(e)))
+
+
+@pytest.mark.parametrize("kind", ["f16x2", "bf16x3", "x32"])
+def test_vjp_relu_flip_census(kind, oracle, synth_nets, fp32_errors):
+    """every ray of g8 whose gradient differs from the oracle's float64 backprop (same depths) by more than
+    10 x the fp32 kernel's 95th percentile is ATTRIBUTED: the units whose on/off state differs from the float64 forward sit
+    at the relu discontinuity, and the oracle's backprop replayed with the kernel's own relu patterns reproduces the
+    kernel's gradient to that tolerance.  None unattributed.  The network backward alone (kernel's dL/d raw and patterns in,
+    per-sample gradients out; flips excluded by construction) is held to fp32 grade per sample."""
+    import vjp_census as V
+    g = load_golden("g8_backward")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd, cot = g["rays"][0], g["rays"][1], g["cot"]
+    zf = fp32_errors["zf"]
+    thr = max(10.0 * fp32_errors["p95"], 2e-5)
+    m = _mk(synth_nets, kind)
+    got = _vjp_with_taps(m, ro, rd, near, far, cot, zf)
+    go, gd = m.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)                  # the taps change nothing
+    assert np.array_equal(cpu(go), got["grad_o"]) and np.array_equal(cpu(gd), got["grad_d"])
+    c = _census_chunked(V, synth_nets, ro, rd, near, far, cot, zf, got, thr)
+    print("vjp census %s (fp32 kernel: p50 %.2e p95 %.2e max %.2e): %s" % (kind, fp32_errors["p50"], fp32_errors["p95"],
+                                                                           fp32_errors["max"], c))
+    assert c["unattributed"] == 0, c
+    assert c["worst_flip_margin"] <= V.MARGIN, c
+    assert c["replay_max"] <= thr and c["per_point_max"] <= 2e-5, c
+    m.close()
+
+
+def test_f16x2_vjp_census_wide_cotangents_and_full_view(oracle, synth_nets, fp32_errors):
+    """... the same on cotangents spread over twelve orders of magnitude (1e-6 .. 1e+6 per ray, one launch: the per-point
+    gradient normalisation of csrc/nsr_h2_bwd.inc) and on 2000 rays of a full 400x400 view."""
+    import vjp_census as V
+    g = load_golden("g8_backward")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays"][0], g["rays"][1]
+    rng = np.random.RandomState(2)
+    amp = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), (ro.shape[0], 1))).astype(np.float32)
+    cot = (g["cot"] * amp).astype(np.float32)
+    thr = max(10.0 * fp32_errors["p95"], 2e-5)
+    m = _mk(synth_nets, "f16x2")
+    got = _vjp_with_taps(m, ro, rd, near, far, cot, fp32_errors["zf"])
+    c = _census_chunked(V, synth_nets, ro, rd, near, far, cot, fp32_errors["zf"], got, thr)
+    print("vjp census f16x2, cotangents 1e-6..1e+6:", c)
+    assert c["unattributed"] == 0 and c["per_point_max"] <= 2e-5, c
+    # 2000 rays of a BASELINE configs[1] view, at the kernel's own depths
+    K = oracle.YCBV_K
+    c2w = np.asarray(oracle.sweep_poses(1, seed=21))[0]
+    fo, fd = m.get_rays(400, 400, K, c2w)
+    sel = np.random.RandomState(4).choice(160000, 2000, replace=False)
+    fo, fd = cpu(fo).reshape(-1, 3)[sel], cpu(fd).reshape(-1, 3)[sel]
+    cotv = np.random.RandomState(1).standard_normal((2000, 3)).astype(np.float32)
+    zf = cpu(m.render_rays(fo, fd, near, far, debug=True)["z_fine"])
+    got = _vjp_with_taps(m, fo, fd, near, far, cotv, zf)
+    c = _census_chunked(V, synth_nets, fo, fd, near, far, cotv, zf, got, thr)
+    print("vjp census f16x2, 2000 rays of a 400x400 view:", c)
+    assert c["unattributed"] == 0 and c["per_point_max"] <= 2e-5, c
+    m.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# range safety net
+# ------------------------------------------------------------------------------------------------------------------
+def _scaled_nets(nets, **scale):
+    """trained-NeRF-like statistics the synthetic recipe does not reach"""
+    out = []
+    for sd in nets:
+        t = {k: np.array(v, copy=True) for k, v in sd.items()}
+        for k in t:
+            if k.startswith("pts_linears") and k.endswith("weight"):
+                t[k] *= np.float32(scale.get("trunk", 1.0))
+            if k.endswith("bias") and not k.startswith("alpha"):
+                t[k] *= np.float32(scale.get("bias", 1.0))
+        t["alpha_linear.weight"] = t["alpha_linear.weight"] * np.float32(scale.get("alpha", 1.0))
+        if scale.get("outlier"):
+            t["pts_linears.3.weight"][11] *= np.float32(scale["outlier"])
+        out.append(t)
+    return out
+
+
+SAFETY_CASES = {"trunk x10": dict(trunk=10.0), "trunk x30": dict(trunk=30.0), "alpha x500": dict(alpha=500.0 / 50.0),
+                "biases x100": dict(bias=100.0), "outlier row 1e3": dict(outlier=1e3),
+                "trunk x4, biases x100": dict(trunk=4.0, bias=100.0)}
+
+
+@pytest.mark.parametrize("case", list(SAFETY_CASES))
+def test_f16x2_never_returns_a_nan_the_fp32_kernel_would_not(case, oracle, synth_nets):
+    """on networks far outside the synthetic recipe the default (f16x2) handle returns, ray for ray, either
+    its own result (nothing left the fp16 range: network outputs at the fp32 kernels' relative bound) or the fp32 kernel's
+    (bit for bit: the range safety net re-rendered that item inside the same launch call).  NaN patterns agree with the
+    fp32 handle everywhere, forward and input gradient."""
+    nets = _scaled_nets(synth_nets, **SAFETY_CASES[case])
+    g = load_golden("g8_backward")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd, cot = g["rays"][0][:96], g["rays"][1][:96], g["cot"][:96]
+    mh, m32 = _mk(nets, "f16x2"), _mk(nets, "x32")
+    a = mh.render_rays(ro, rd, near, far, debug=True)
+    st = mh.range_status()
+    b = m32.render_rays(ro, rd, near, far, debug=True)
+    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+    for k in keys:
+        assert np.array_equal(np.isnan(cpu(a[k])), np.isnan(cpu(b[k]))), (case, k)
+    print("%s: range status after the forward launch %s" % (case, st))
+    assert st["dropped_items"] == 0
+    raw, raw32 = cpu(a["raw"]), cpu(b["raw"])
+    assert np.array_equal(np.isnan(raw), np.isnan(raw32))
+    if st["last_items"] == 0:                       # nothing left the range: f16x2's own numbers, at the fp32 kernels' bound
+        zf = cpu(a["z_fine"])
+        want = oracle.run_network(nets[1], (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), oracle.normalize_dirs(rd))
+        assert np.abs(raw - want).max() <= 5e-5 * max(1.0, float(np.abs(want).max())), (case, np.abs(raw - want).max())
+    else:                                           # re-rendered items hold the fp32 kernel's bits
+        diff = np.array([not np.array_equal(cpu(a["rgb_map"])[i], cpu(b["rgb_map"])[i], equal_nan=True) for i in range(96)])
+        assert st["rays"] >= 2 * st["last_items"] - 1 and st["points"] > 0
+        assert (~diff).sum() >= st["rays"], (case, (~diff).sum(), st)      # at least the re-rendered rays are bit-equal
+    # input gradients: finite wherever the fp32 kernel's are
+    zf = cpu(b["z_fine"])
+    go, gd = mh.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    go32, gd32 = m32.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+    assert np.array_equal(np.isfinite(cpu(go)), np.isfinite(cpu(go32))), case
+    assert np.array_equal(np.isfinite(cpu(gd)), np.isfinite(cpu(gd32))), case
+    st2 = mh.range_status()
+    print("%s: range status after the VJP launch %s" % (case, st2))
+    assert st2["dropped_items"] == 0
+    fin = np.isfinite(cpu(gd32)).all(1) & (np.linalg.norm(cpu(gd32), axis=1) > 0)
+    if fin.any():
+        e = _rel_rows(cpu(gd)[fin], cpu(gd32)[fin].astype(np.float64))
+        assert np.median(e) < 1e-4, (case, np.median(e))
+    mh.close(); m32.close()
+
+
+def test_f16x2_out_of_range_items_are_the_fp32_kernels(oracle, synth_nets):
+    """A hidden bias of 7e4 puts every point outside the fp16 range (r03: every output NaN).  Now every item goes through
+    the fallback: outputs, debug taps and input gradients are the fp32 x32 kernel's, bit for bit; the status counts them."""
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    ro, rd = g["rays_o"][:65], g["rays_d"][:65]                       # an odd count: the last item holds one ray
+    big = [{k: np.array(v, copy=True) for k, v in sd.items()} for sd in synth_nets]
+    big[0]["pts_linears.0.bias"][7] = 7.0e4
+    big[1]["pts_linears.0.bias"][7] = 7.0e4
+    mh, m32 = _mk(big, "f16x2"), _mk(big, "x32")
+    a = mh.render_rays(ro, rd, near, far, debug=True)
+    b = m32.render_rays(ro, rd, near, far, debug=True)
+    for k in a:
+        assert np.array_equal(cpu(a[k]), cpu(b[k]), equal_nan=True), k
+    assert np.isfinite(cpu(a["rgb_map"])).all()
+    st = mh.range_status()
+    assert st["last_items"] == 33 and st["rays"] == 65 and st["dropped_items"] == 0 and st["points"] >= 65 * 64, st
+    cot = np.random.RandomState(0).standard_normal((65, 3)).astype(np.float32)
+    ga = mh.render_rays_vjp(ro, rd, near, far, cot)
+    gb = m32.render_rays_vjp(ro, rd, near, far, cot)
+    assert np.array_equal(cpu(ga[0]), cpu(gb[0])) and np.array_equal(cpu(ga[1]), cpu(gb[1]))
+    assert mh.range_status()["rays"] == 130
+    # coarse-only handles and the view form take the same route
+    mc, mc32 = _mk([big[0], None], "f16x2", n_importance=0), _mk([big[0], None], "x32", n_importance=0)
+    K = oracle.scaled_K(50.0)
+    c2w = np.asarray(oracle.sweep_poses(1, seed=3))[0]
+    va, vb = mc.render_views(c2w, 8, 8, K, near, far), mc32.render_views(c2w, 8, 8, K, near, far)
+    for k in va:
+        assert np.array_equal(cpu(va[k]), cpu(vb[k]), equal_nan=True), k
+    assert mc.range_status()["rays"] == 64
+    # a network inside the range reports nothing
+    mok = _mk(synth_nets, "f16x2")
+    mok.render_rays(ro, rd, near, far)
+    assert mok.range_status() == dict(last_items=0, points=0, rays=0, dropped_items=0)
+    for m in (mh, m32, mc, mc32, mok):
+        m.close()
+
+
+def test_dropin_api_warns_once_about_the_range(oracle, synth_nets, tmp_path):
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    nets = []
+    for sd in synth_nets:
+        t = {k: np.array(v, copy=True) for k, v in sd.items()}
+        t["pts_linears.0.bias"][7] = 7.0e4
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in t.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=oracle.YCBV_NEAR, far=oracle.YCBV_FAR)
+    K = oracle.scaled_K(50.0)
+    poses = torch.tensor(np.asarray(oracle.sweep_poses(2, seed=3)))
+    with pytest.warns(RuntimeWarning, match="left the fp16 range"):
+        rgbs, _ = R.render_path(None, poses, [8, 8, K[0][0]], K, 512, kw, savedir=str(tmp_path))
+    assert np.isfinite(rgbs).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the default kernels at full size
+# ------------------------------------------------------------------------------------------------------------------
+def test_f16x2_full_size_view_properties(synth_nets, oracle):
+    """what test_full_size_view_properties holds the fp32 kernels to, for the DEFAULT kernels (k_render_h2,
+    k_render_vjp_h2) on BASELINE configs[1] at full size: determinism; multi-view launch == single views; a 20 000-ray subset
+    rendered alone == those pixels of the full view, forward AND input gradient; range invariants; nothing reported by the
+    range safety net; the oracle on 384 rays."""
+    from neural_sim_nerf_amd.engine import NsrModel, DEFAULT_MLP
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.YCBV_K
+    poses = np.asarray(oracle.sweep_poses(3, seed=21))
+    m = NsrModel(synth_nets[0], synth_nets[1])
+    assert m.mlp == DEFAULT_MLP == "f16x2"
+    full = m.render_views(poses[0], 400, 400, K, near, far)
+    again = m.render_views(poses[0], 400, 400, K, near, far)
+    keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
+    for k in keys:
+        assert np.array_equal(cpu(full[k]), cpu(again[k]), equal_nan=True), k
+    rgb, acc = cpu(full["rgb_map"]), cpu(full["acc_map"])
+    assert np.isfinite(rgb).all() and rgb.min() >= 0.0 and rgb.max() <= 1.0 + 1e-5
+    assert acc.min() >= 0.0 and acc.max() <= 1.0 + 1e-5 and (cpu(full["z_std"]) >= 0).all()
+    three = m.render_views(poses, 400, 400, K, near, far)
+    assert np.array_equal(cpu(three["rgb_map"])[:160000], rgb)
+    one = m.render_views(poses[2], 400, 400, K, near, far)
+    for k in keys:
+        assert np.array_equal(cpu(three[k])[320000:], cpu(one[k]), equal_nan=True), k
+    ro, rd = m.get_rays(400, 400, K, poses[0])
+    ro, rd = cpu(ro).reshape(-1, 3), cpu(rd).reshape(-1, 3)
+    sel = np.random.RandomState(0).choice(160000, 20000, replace=False)
+    sub = m.render_rays(ro[sel], rd[sel], near, far, debug=True)
+    for k in keys:
+        assert np.array_equal(cpu(sub[k]), cpu(full[k])[sel], equal_nan=True), k
+    zf = cpu(sub["z_fine"])
+    assert (np.diff(zf, axis=1) >= 0).all() and zf.min() >= near * (1 - 1e-6) and zf.max() <= far * (1 + 1e-6)
+    sm = sel[:384]
+    ref = oracle.render(synth_nets[0], synth_nets[1], 400, 400, K, rays=(ro[sm], rd[sm]), near=near, far=far)
+    assert_close(cpu(full["rgb0"])[sm], ref["rgb0"], atol=1e-5, what="coarse rgb vs oracle at full size")
+    assert oracle.psnr(rgb[sm], ref["rgb_map"]) > 55.0
+    cot = np.random.RandomState(1).standard_normal((160000, 3)).astype(np.float32)
+    go, gd, fwd = m.render_rays_vjp(ro, rd, near, far, cot, with_forward=True)
+    assert np.array_equal(cpu(fwd["rgb_map"]), rgb)                                # the VJP launch's forward == the forward kernel
+    so, sd = m.render_rays_vjp(ro[sel], rd[sel], near, far, cot[sel])
+    assert np.array_equal(cpu(so), cpu(go)[sel]) and np.array_equal(cpu(sd), cpu(gd)[sel])
+    assert np.isfinite(cpu(go)).all() and np.isfinite(cpu(gd)).all()
+    go2, gd2 = m.render_rays_vjp(ro, rd, near, far, cot)
+    assert np.array_equal(cpu(go2), cpu(go)) and np.array_equal(cpu(gd2), cpu(gd))      # deterministic
+    assert m.range_status() == dict(last_items=0, points=0, rays=0, dropped_items=0)
+    m.close()
+
+
+def test_render_path_grad_full_size(synth_nets, oracle, tmp_path):
+    """BASELINE configs[3]'s render leg at its real size: ONE 400x400 pose, chunk = 512 -> 313 patches, through the drop-in
+    render_path_grad with the default kernels (RN:126-210, CF:25).  Checked against (i) the engine's single-launch input
+    gradient contracted on the host, 8 random patches; (ii) the oracle's chain on 2 patches: float64 backprop at the
+    kernel's own depths, contracted with d rays / d c2w and the pose's Jacobian."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd.engine import NsrModel
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    H = W = 400
+    K = oracle.YCBV_K
+    nets = []
+    for sd in synth_nets:
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64,
+              network_fn=nets[0], use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False,
+              near=near, far=far)
+    base = torch.tensor(np.asarray(oracle.sweep_poses(1, seed=21))[0])
+    D = torch.tensor(np.random.RandomState(3).standard_normal((8, 4, 4)).astype(np.float32) * 0.02)
+    D[:, 3] = 0
+    prob = torch.full((8,), 0.125, requires_grad=True)
+    pose = base + (prob[:, None, None] * D).sum(0)
+    cotv = np.random.RandomState(9).standard_normal((3, H, W)).astype(np.float32)
+    grad_E = [{"grad_E": [torch.tensor(cotv)]}]
+    rgbs, dl = R.render_path_grad(prob, pose[None], [H, W, K[0][0]], K, 512, grad_E, kw, savedir=str(tmp_path), object_id=2)
+    assert rgbs.shape == (1, H, W, 3) and len(dl) == 313 and dl[0].shape == (8,)
+    assert (tmp_path / "2" / "withgrad" / "000.png").exists()
+    got = np.stack([d.numpy() for d in dl])
+    assert np.isfinite(got).all()
+    # (i) the engine's own single-launch gradient, contracted on the host in float64
+    m = NsrModel(synth_nets[0], synth_nets[1])
+    c2w = pose.detach().numpy()
+    ro, rd = m.get_rays(H, W, K, c2w[:3, :4])
+    ro, rd = cpu(ro).reshape(-1, 3), cpu(rd).reshape(-1, 3)
+    cot = cotv.transpose(1, 2, 0).reshape(-1, 3)
+    go, gd, fwd = m.render_rays_vjp(ro, rd, near, far, cot, with_forward=True)
+    go, gd = cpu(go).astype(np.float64), cpu(gd).astype(np.float64)
+    assert np.array_equal(rgbs[0].reshape(-1, 3), cpu(fwd["rgb_map"]))
+    col = np.tile(np.arange(W, dtype=np.float64), H)
+    row = np.repeat(np.arange(H, dtype=np.float64), W)
+    dirs = np.stack([(col - K[0][2]) / K[0][0], -((row - K[1][2]) / K[1][1]), -np.ones_like(col)], -1)
+    Dn = D.numpy().astype(np.float64)
+
+    def contract(wo, wd, s):
+        gpose = np.concatenate([wd.T @ dirs[s], wo.sum(0)[:, None]], 1)
+        return np.array([(gpose * Dn[k][:3, :4]).sum() for k in range(8)])
+    patches = np.random.RandomState(5).choice(313, 8, replace=False)
+    for p in list(patches) + [312]:                                               # 312: the short last patch (256 rays)
+        s = slice(512 * p, min(512 * (p + 1), H * W))
+        want = contract(go[s], gd[s], s)
+        assert np.abs(got[p] - want).max() <= 1e-4 * np.abs(want).max() + 1e-6, (p, got[p], want)
+    # (ii) the oracle's chain on 2 patches
+    for p in patches[:2]:
+        s = slice(512 * p, 512 * (p + 1))
+        zf = cpu(m.render_rays(ro[s], rd[s], near, far, debug=True)["z_fine"])
+        wo, wd, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro[s], rd[s], near, far, cot[s], z_fine=zf)
+        want = contract(wo.astype(np.float64), wd.astype(np.float64), s)
+        # 512-ray patch sums cancel: bound by the largest component (VJP itself: 2e-4 relative Frobenius)
+        assert np.abs(got[p] - want).max() < 2e-3 * np.abs(want).max(), (p, got[p], want)
+    m.close()
