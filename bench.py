@@ -94,6 +94,9 @@ def forward_roofline(model, k_ms, n_rays=H * W):
                   "frac_note": "frac = achieved (ALGORITHMIC fp32 FLOP/s) / peak of the datatype issued; issued_frac = the MFMA "
                                "work actually issued (piece products) / the same peak",
                   "issued": round(issued, 1), "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                  # a scheme of n piece products per fp32 product cannot deliver more than 1/n of the piece datatype's peak
+                  "attainable_frac": round(1.0 / (6 if model.mlp == "bf16x3" else 3), 4),
+                  "frac_of_attainable": round(ach / PEAK_BF16_MFMA_TFLOPS * (6 if model.mlp == "bf16x3" else 3), 4),
                   "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3),
                   "note": "`achieved` counts ALGORITHMIC fp32 FLOP (as for the fp32 kernels); the datatype issued is %s "
                           "(peak 2.5 PFLOP/s dense): every fp32 product costs %s %s piece products, so the kernel "
@@ -504,6 +507,72 @@ def pmc_traffic(pmc_file, schedule="phases"):
                % (os.path.relpath(pmc_file, ROOT), key, blob[:12], here[:12]))
 
 
+_KNAME = {"f16x2": "k_render_h2", "bf16x3": "k_render_b3", "fp32": "k_render16p"}
+
+
+def live_traffic(mlp):
+    """HBM-side bytes of ONE launch of the forward kernel, measured NOW: two extra launches of the same view in child
+    processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters + kernel trace only, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per that guide's gfx950 correction), when
+    rocprofv3 is on the box.  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found on this box"
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="nsr_pmc_")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "one_view.py"), "0"], cwd=tmp, capture_output=True, text=True,
+                               timeout=240, env=dict(os.environ, NSR_MLP=mlp, TMPDIR=tmp))
+            files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, (r.stderr or r.stdout)[-200:])
+            first = None
+            for row in csv.DictReader(open(files[0])):
+                if _KNAME[mlp] in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    first = first or row["Dispatch_Id"]
+                    if row["Dispatch_Id"] == first:
+                        tot[ctr] = tot.get(ctr, 0.0) + float(row["Counter_Value"])
+            if ctr not in tot:
+                return None, "rocprofv3 --pmc %s: no %s dispatch in the counter file" % (ctr, _KNAME[mlp])
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
+        return None, "live PMC pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, (
+        "measured in THIS run: one extra launch of the same view per counter under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in "
+        "separate passes, summed over the XCDs); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; L2 misses served by Infinity Cache "
+        "(weight re-streaming), not HBM reads -- algorithmic HBM bytes are 7.0e6 per launch (DESIGN.md 4)")
+
+
+def strict_fp32_line(sd_c, sd_f, device, c2w, launches=3):
+    """The same view on the strict-fp32 kernel (k_render16p: fp32-input MFMAs, exact fp32 products), in the same run: what a
+    reader who wants BASELINE configs[1]'s "fp32" taken literally should look at next to a split-arithmetic headline."""
+    m = NsrModel(sd_c, sd_f, device=device, mlp="fp32")
+    pose = torch.as_tensor(c2w[:3, :4], device=m.device)
+    m.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+    torch.cuda.synchronize()
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        m.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+        ms.append(m.last_kernel_ms())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    k_ms = float(np.mean(ms))
+    r = {"value": round(launches * H * W * SAMPLES_PER_RAY / dt / 1e6, 3), "unit": "Mray-samples/s", "kernel": forward_kernel_name(m),
+         "kernel_ms": round(k_ms, 3), "frac": round(H * W * FLOP_PER_RAY / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+         "peak": PEAK_F32_MFMA_TFLOPS}
+    m.close()
+    return r
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside a launcher: re-exec under torch.distributed.run, one rank per GPU."""
     n_dev = torch.cuda.device_count()
@@ -536,7 +605,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="validation only: ranks share the visible GPUs round-robin (e.g. --gpus 2 --backend gloo on a "
                          "1-GPU box exercises the N>1 code path end to end; the number is not a scaling result)")
-    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "r03", "pmc_k_render.json"))
+    ap.add_argument("--pmc-file", default=next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_k_render.json") for r in ("r04", "r03"))
+                                                 if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04", "pmc_k_render.json")))
     ap.add_argument("--mlp", choices=MLP_MODES, default=None,
                     help="layer-GEMM arithmetic of the forward kernel (default: the engine's, engine.DEFAULT_MLP / $NSR_MLP)")
     args = ap.parse_args()
@@ -638,8 +708,18 @@ def main():
             else:
                 traffic, traffic_note = pmc_traffic(args.pmc_file, model.schedule)
                 kernel_desc = "fp32, fused persistent kernel (x16: 2 workgroups per CU, %s schedule)" % model.schedule
-            roof.update({"traffic": traffic, "traffic_source": "offline rocprofv3 --pmc passes of this kernel, used only if their "
-                         "recorded kernel-source hash equals this tree's (else null)", "traffic_note": traffic_note})
+            traffic_source = ("offline rocprofv3 --pmc passes of this kernel, used only if their recorded kernel-source hash "
+                              "equals this tree's (else null)")
+            if world == 1 and not args.no_extras:            # measured in this run when rocprofv3 is on the box
+                live, live_note = live_traffic(model.mlp)
+                if live is not None:
+                    traffic, traffic_note, traffic_source = live, live_note, "live"
+                else:
+                    traffic_note = "%s | live pass: %s" % (traffic_note, live_note)
+            roof.update({"traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note})
+            if world == 1 and model.mlp != "fp32":
+                roof["strict_fp32"] = strict_fp32_line(sd_c, sd_f, local, poses[args.warmup])
+            line["range_status"] = model.range_status()      # f16x2 range safety net: all zero = nothing left the fp16 range
             line.update({
                 "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "config": {"workload": "YCB-V object-2 camera, 400x400 view per step per GPU, 64 coarse + 128 fine "
@@ -661,6 +741,9 @@ def main():
                                                                             side=args.cpu_sample_side)
                 line["cpu_baseline"] = cpu
                 line["parity"] = par
+                line["parity_summary"] = {"rays": par["census"]["rays"], "rays_above_tol": par["census"]["rays_above_tol"],
+                                          "unattributed": par["census"]["unattributed"], "psnr_delta_db": par["psnr_delta_db"],
+                                          "inds_exact": par["inds_exact_match_rate"], "passes": par["passes"]}
             if world == 1 and not args.no_extras:
                 line["roofline_vjp"] = vjp_roofline(model, poses[args.warmup], args.pmc_file)
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),

@@ -189,21 +189,34 @@ def gather_patch_grads(local, n_poses, group=None):
     return gather_views(local, n_poses, group)
 
 
-def mean_psi_grad(local_dLdpsis, group=None):
+def mean_psi_grad(local_dLdpsis, group=None, n_cat=None):
     """torch.mean(torch.stack(dLdpsis), 0) (NM:191) when the per-patch gradients are spread over ranks:
-    all-reduce(sum) of [sum of local [n_cat] vectors | local count]."""
+    all-reduce(sum) of [sum of local [n_cat] vectors | local count].  n_cat (the length of psi; 8 in the reference,
+    NM:1164) is taken from the local gradients; a rank that holds none (fewer poses than ranks) learns it from the others
+    through one all-reduce(max) -- or from the argument."""
     world, _ = world_info(group)
     if len(local_dLdpsis):
         s = torch.stack([torch.as_tensor(g, dtype=torch.float64) for g in local_dLdpsis]).sum(0)
     else:
         s = None
-    n_cat = s.numel() if s is not None else 8
-    buf = torch.zeros(n_cat + 1, dtype=torch.float64)
+    mine = s.numel() if s is not None else (int(n_cat) if n_cat else 0)
+    if n_cat is not None and mine != int(n_cat):
+        raise ValueError("mean_psi_grad: local gradients have %d entries, n_cat=%d" % (mine, int(n_cat)))
+    if world > 1 or _FORCE:
+        t = torch.tensor([mine], dtype=torch.int64, device=_comm_device(group))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        agreed = int(t.item())
+        if mine and mine != agreed:
+            raise ValueError("mean_psi_grad: this rank's gradients have %d entries, another rank's %d" % (mine, agreed))
+        mine = agreed
+    if mine == 0:
+        raise ValueError("mean_psi_grad: no rank holds a gradient")
+    buf = torch.zeros(mine + 1, dtype=torch.float64)
     if s is not None:
-        buf[:n_cat] = s
-        buf[n_cat] = len(local_dLdpsis)
+        buf[:mine] = s
+        buf[mine] = len(local_dLdpsis)
     if world > 1 or _FORCE:
         buf = buf.to(_comm_device(group))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf = buf.cpu()
-    return (buf[:n_cat] / buf[n_cat]).to(torch.float32)
+    return (buf[:mine] / buf[mine]).to(torch.float32)

@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 from .pack import (pack_network, pack_network16, pack_network_backward, pack_network_backward16, pack_network_b3,
-                   pack_network_backward_b3, pack_network_h2, pack_network_backward_h2,
+                   pack_network_backward_b3, pack_network_h2, pack_network_backward_h2, h2_report,
                    PACKED_FLOATS, PACKED_B3_FLOATS)
 
 N_SAMPLES = 64
@@ -111,6 +111,8 @@ class NsrModel:
                              | (8 if mlp == "bf16x3" else 0) | (16 if mlp == "f16x2" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
         self._bwd_ready = self._bwd32_ready = False
+        self.rays_launched = 0                       # rays handed to the render / input-gradient launches so far (host count)
+        self.h2_range = None                         # f16x2: pack.h2_report of (coarse, fine) -- pack-time range report
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -133,6 +135,7 @@ class NsrModel:
         if self.mlp == "f16x2":
             p = pack_network_h2(sd_c)
             _lib.check(self.lib.nsr_upload_weights_h2(self.h, 0, _fptr(p), PACKED_FLOATS))
+            self.h2_range = (h2_report(sd_c), None)
         self._sd_fine_np = None
         self._bwd_ready = self._bwd32_ready = False     # both transposed streams belong to the previous fine network
         if sd_fine is not None:
@@ -148,6 +151,7 @@ class NsrModel:
             if self.mlp == "f16x2":
                 p = pack_network_h2(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_h2(self.h, 1, _fptr(p), PACKED_FLOATS))
+                self.h2_range = (self.h2_range[0], h2_report(self._sd_fine_np))
 
     def close(self):
         if getattr(self, "h", None):
@@ -212,6 +216,7 @@ class NsrModel:
         rays_o = self._f32(rays_o, (-1, 3))
         rays_d = self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
+        self.rays_launched += n
         o, ro, dbg = self._outs(n, debug)
         ex, keep = self._extras(extras, n)
         _lib.check(self.lib.nsr_render_rays_ex(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
@@ -247,6 +252,7 @@ class NsrModel:
         c2w = c2w[:, :3, :4].contiguous()
         v = c2w.shape[0]
         n = v * int(H) * int(W)
+        self.rays_launched += n
         K9 = (C.c_double * 9)(*[float(K[i][j]) for i in range(3) for j in range(3)])
         o, ro, dbg = self._outs(n, debug)
         _lib.check(self.lib.nsr_render_views(self.h, _dev(c2w), v, int(H), int(W), K9, float(near), float(far),
@@ -289,6 +295,7 @@ class NsrModel:
         rays_o = self._f32(rays_o, (-1, 3))
         rays_d = self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
+        self.rays_launched += n
         g = self._f32(grad_rgb, (n, 3))
         zf = self._f32(z_fine, (n, 192)) if z_fine is not None else None
         go, gd = self._new(n, 3), self._new(n, 3)

@@ -516,6 +516,45 @@ def h2_scales(sd, act_scale_log2=None):
     return sw, ca
 
 
+def h2_report(sd, coord_max=4.0, act_scale_log2=None):
+    """Pack-time range report of the f16x2 layout for one network: per layer (pts_linears.0-7, feature_linear,
+    views_linears.0) the weight scale sw (weights are stored x 2^sw, largest entry in [2^14, 2^15)), the activation scale ca,
+    and two bounds on the largest hidden activation ENTERING the layer, log2, against the fp16 ceiling 2^16 (a scaled
+    activation >= 65504 sends the point to the fp32 kernel: include/nsr.h, range safety net):
+      worst_log2  -- guaranteed: interval arithmetic with the infinity-norm of every layer (sum_k |W_jk| x_max + |b_j|),
+                     inputs |sin|, |cos| <= 1 and |coordinate| <= coord_max.  Loose by construction (it assumes every
+                     term of every dot product aligned), but a network whose worst case fits can NEVER overflow;
+      typical_log2 -- the same recursion with the 2-norm of the rows and an RMS input: what a random-sign sum gives.
+    headroom_* = 16 + ... - that bound - ca, in bits; negative worst-case head-room is normal for real networks (the kernels
+    check every point at run time), negative TYPICAL head-room means most points will take the fp32 route: use mlp="fp32"."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float64)
+    sw, ca = h2_scales(sd, act_scale_log2)
+    names = ["pts_linears.%d" % l for l in range(8)] + ["feature_linear", "views_linears.0"]
+    x_inf = np.concatenate([np.full(3, coord_max), np.ones(60)])            # the 63 encoding channels (RH:39-48)
+    x_rms = np.concatenate([np.full(3, coord_max / np.sqrt(3.0)), np.full(60, np.sqrt(0.5))])
+    d_inf, d_rms = np.ones(27), np.concatenate([np.full(3, 1 / np.sqrt(3.0)), np.full(24, np.sqrt(0.5))])
+    rows = []
+    h_inf = h_rms = None
+    for l, name in enumerate(names):
+        W, b = g(name + ".weight"), g(name + ".bias")
+        if l == 0:
+            in_inf, in_rms = x_inf, x_rms
+        elif l == 5:
+            in_inf, in_rms = np.concatenate([x_inf, h_inf]), np.concatenate([x_rms, h_rms])
+        elif l == 9:
+            in_inf, in_rms = np.concatenate([h_inf, d_inf]), np.concatenate([h_rms, d_rms])
+        else:
+            in_inf, in_rms = h_inf, h_rms
+        ent_inf, ent_rms = float(in_inf[-256:].max() if l else 1.0), float(np.abs(in_rms[-256:]).max() if l else 1.0)
+        rows.append(dict(layer=name, sw=int(sw[l]), ca=int(ca[l]), max_abs_weight=float(np.abs(W).max()),
+                         worst_log2=float(np.log2(max(ent_inf, 1e-300))), typical_log2=float(np.log2(max(ent_rms, 1e-300))),
+                         headroom_worst_bits=float(16 - ca[l] - np.log2(max(ent_inf, 1e-300))),
+                         headroom_typical_bits=float(16 - ca[l] - np.log2(max(ent_rms, 1e-300)))))
+        h_inf = np.abs(W) @ in_inf + np.abs(b)
+        h_rms = np.sqrt((W * W) @ (in_rms * in_rms) + b * b)                # relu / identity: magnitude carried forward
+    return rows
+
+
 def pack_network_h2(sd, act_scale_log2=None):
     """The forward stream of pack_network with every (scaled) weight as two fp16 pieces, in the chunk order of k_render_h2,
     followed by the aux block with scaled biases / head weights and the activation multipliers.  Returns float32

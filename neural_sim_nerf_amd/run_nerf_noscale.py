@@ -57,8 +57,10 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
         raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
     white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
-    key = (n_importance, NeRF.weights_version_of(network_fn, network_fine),
-           os.environ.get("NSR_MLP"))           # forward-kernel arithmetic (engine.NsrModel: "fp32" / "bf16x3")
+    wv = NeRF.weights_version_of(network_fn, network_fine)
+    forced = network_fn.__dict__.get("_nsr_force_mlp")     # set by _note_range: THESE weights keep leaving f16x2's range
+    forced = forced[0] if forced and forced[1] == wv else None
+    key = (n_importance, wv, forced or os.environ.get("NSR_MLP"))     # forward-kernel arithmetic (engine.NsrModel(mlp=...))
     # a native handle owns ONE argument block / work queue / scratch set (include/nsr.h: one handle per (model,
     # stream)), so the cache is also keyed on the device and on the torch stream the launch will be issued on
     p0 = next(network_fn.parameters())
@@ -77,27 +79,38 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
         with torch.cuda.device(dev):
             cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
                                       else None, device=dev, n_importance=n_importance, white_bkgd=white,
-                                      lindisp=lindisp)
+                                      lindisp=lindisp, mlp=forced)
+            cache["model"].weights_version = wv
         cache["key"] = key
     return cache["model"]
 
 
 _RANGE_WARNED = set()
+_RANGE_SWITCH_FRAC = 0.10         # more than this share of a handle's rays re-rendered by the fp32 kernel: use it outright
 
 
-def _note_range(model):
+def _note_range(model, network_fn=None):
     """f16x2 range safety net (include/nsr.h: NSR_FLAG_MLP_F16X2): called where the API has synchronised anyway.  Rays whose
     network evaluation left the fp16 range were rendered again by the fp32 kernel inside the same launch call -- the
-    results are the fp32 kernel's -- so this only says so, once per handle."""
-    if getattr(model, "mlp", None) != "f16x2" or id(model) in _RANGE_WARNED:
+    results are the fp32 kernel's -- so this only says so, once per handle.  A network that sends more than a tenth of its
+    rays down that route pays for both kernels: its later handles are built with the fp32 kernels (`_model_for` reads the
+    mark), which is the same arithmetic without the detour."""
+    if getattr(model, "mlp", None) != "f16x2":
         return
     st = model.range_status()
-    if st["points"]:
+    if not st["points"]:
+        return
+    switch = network_fn is not None and st["rays"] > _RANGE_SWITCH_FRAC * max(1, model.rays_launched)
+    if switch:
+        network_fn.__dict__["_nsr_force_mlp"] = ("fp32", getattr(model, "weights_version", None))
+    if id(model) not in _RANGE_WARNED:
         import warnings
         _RANGE_WARNED.add(id(model))
-        warnings.warn("neural_sim_nerf_amd: %d network evaluations left the fp16 range of the f16x2 kernels; %d rays were "
-                      "rendered again by the fp32 kernel (%d items could not be and hold NaN).  NSR_MLP=fp32 selects the fp32 "
-                      "kernels for this network outright." % (st["points"], st["rays"], st["dropped_items"]), RuntimeWarning)
+        warnings.warn("neural_sim_nerf_amd: %d network evaluations left the fp16 range of the f16x2 kernels; %d of %d rays were "
+                      "rendered again by the fp32 kernel (%d items could not be and hold NaN).%s"
+                      % (st["points"], st["rays"], model.rays_launched, st["dropped_items"],
+                         "  This network now gets the fp32 kernels outright." if switch else
+                         "  NSR_MLP=fp32 selects the fp32 kernels outright."), RuntimeWarning)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -444,7 +457,7 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
             return rgbs, disps
         rgb, disp = render_fn(poses)
         rgbs, disps = rgb.cpu().numpy(), disp.cpu().numpy()
-        _note_range(model)
+        _note_range(model, render_kwargs.get("network_fn"))
     print("rendered %d views in %.3f s" % (rgbs.shape[0], time.time() - t))
     if savedir is not None:
         png.imwrite_many([os.path.join(savedir, str(object_id), "{:03d}.png".format(i)) for i in range(rgbs.shape[0])],
@@ -518,7 +531,7 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
         grads = D.gather_patch_grads(grads, n_poses).cpu()
         if savedir is not None:
             torch.distributed.barrier()
-    _note_range(model)
+    _note_range(model, render_kwargs.get("network_fn"))
     dLdpsis = [grads[i, p] for i in range(grads.shape[0]) for p in range(n_patches)]         # RN:190 order
     return rgbs.numpy(), dLdpsis
 

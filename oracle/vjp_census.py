@@ -166,5 +166,5 @@ def per_point(nets, rays_o, rays_d, z_fine, got, viewdirs=None):
     k = got["grad_pts"].astype(f64)
     scale = np.abs(ref).reshape(N, -1).max(1)[:, None, None] + 1e-300
     err = (np.abs(k - ref) / scale).reshape(N, -1).max(1)                           # per ray: worst sample, relative to the ray
-    return dict(p50=float(np.percentile(err, 50)), p99=float(np.percentile(err, 99)), max=float(err.max()),
-                argmax_ray=int(err.argmax()))
+    return dict(p50=float(np.percentile(err, 50)), p90=float(np.percentile(err, 90)), p99=float(np.percentile(err, 99)),
+                max=float(err.max()), argmax_ray=int(err.argmax()))

@@ -600,9 +600,10 @@ def mlp_bwd_pass_h2(packed_h2_fwd, stream_bwd_h2, masks, pts, dirs, g_raw):
     # per-point normalisation by a power of two (h2_norm_scale)
     m = np.abs(G).max(1)
     ef = (m.view(np.uint32) >> 23) & 0xff
-    ok = (ef >= 1) & (ef <= 253)
-    s = np.where(ok, ((254 - ef.astype(np.int64)) << 23).astype(np.uint32).view(np.float32), np.float32(1))
-    inv = np.where(ok, (ef.astype(np.uint32) << 23).view(np.float32), np.float32(1))
+    K = 7                                            # kH2GradLog2: the largest input lands in [2^7, 2^8)
+    ok = (ef >= 1 + K) & (ef <= 253)
+    s = np.where(ok, ((254 - ef.astype(np.int64) + K) << 23).astype(np.uint32).view(np.float32), np.float32(1))
+    inv = np.where(ok, ((ef.astype(np.int64) - K) << 23).astype(np.uint32).view(np.float32), np.float32(1))
     G = (G * s[:, None]).astype(np.float32)
     gv = np.zeros((4, 64, 16), np.float32)
     for mo in range(4):

@@ -48,14 +48,14 @@ def _census_chunked(V, nets, ro, rd, near, far, cot, zf, got, thr, chunk=256):
                  grad_raw=got["grad_raw"][s], grad_pts=got["grad_pts"][s])
         c = V.census(nets, ro[s], rd[s], near, far, cot[s], zf[s], g, thr)
         p = V.per_point(nets, ro[s], rd[s], zf[s], g)
-        c["per_point_max"], c["per_point_p99"] = p["max"], p["p99"]
+        c["per_point_max"], c["per_point_p99"], c["per_point_p50"] = p["max"], p["p99"], p["p50"]
         if tot is None:
             tot = c
         else:
             for k in ("rays", "rays_above_thr", "attributed", "unattributed", "rays_with_flips", "flipped_units_total",
                       "flagged_without_flips", "sigma_flips_total"):
                 tot[k] += c[k]
-            for k in ("worst_flip_margin", "err_max", "replay_max", "max_err_unflagged", "per_point_max", "per_point_p99"):
+            for k in ("worst_flip_margin", "err_max", "replay_max", "max_err_unflagged", "per_point_max", "per_point_p99", "per_point_p50"):
                 tot[k] = max(tot[k], c[k])
             tot["worst"] = sorted(tot["worst"] + [dict(w, ray=w["ray"] + i) for w in c["worst"]], key=lambda w: -w["err"])[:8]
     return tot
@@ -98,7 +98,7 @@ def test_vjp_relu_flip_census(kind, oracle, synth_nets, fp32_errors):
                                                                            fp32_errors["max"], c))
     assert c["unattributed"] == 0, c
     assert c["worst_flip_margin"] <= V.MARGIN, c
-    assert c["replay_max"] <= thr and c["per_point_max"] <= 2e-5, c
+    assert c["replay_max"] <= thr and c["per_point_max"] <= 1e-5, c      # r04 measured: fp32 x32 2.7e-6, bf16x3 4.9e-6
     m.close()
 
 
@@ -117,7 +117,7 @@ def test_f16x2_vjp_census_wide_cotangents_and_full_view(oracle, synth_nets, fp32
     got = _vjp_with_taps(m, ro, rd, near, far, cot, fp32_errors["zf"])
     c = _census_chunked(V, synth_nets, ro, rd, near, far, cot, fp32_errors["zf"], got, thr)
     print("vjp census f16x2, cotangents 1e-6..1e+6:", c)
-    assert c["unattributed"] == 0 and c["per_point_max"] <= 2e-5, c
+    assert c["unattributed"] == 0 and c["per_point_max"] <= 1e-5, c
     # 2000 rays of a BASELINE configs[1] view, at the kernel's own depths
     K = oracle.YCBV_K
     c2w = np.asarray(oracle.sweep_poses(1, seed=21))[0]
@@ -129,7 +129,7 @@ def test_f16x2_vjp_census_wide_cotangents_and_full_view(oracle, synth_nets, fp32
     got = _vjp_with_taps(m, fo, fd, near, far, cotv, zf)
     c = _census_chunked(V, synth_nets, fo, fd, near, far, cotv, zf, got, thr)
     print("vjp census f16x2, 2000 rays of a 400x400 view:", c)
-    assert c["unattributed"] == 0 and c["per_point_max"] <= 2e-5, c
+    assert c["unattributed"] == 0 and c["per_point_max"] <= 1e-5, c
     m.close()
 
 
@@ -259,6 +259,10 @@ def test_dropin_api_warns_once_about_the_range(oracle, synth_nets, tmp_path):
     with pytest.warns(RuntimeWarning, match="left the fp16 range"):
         rgbs, _ = R.render_path(None, poses, [8, 8, K[0][0]], K, 512, kw, savedir=str(tmp_path))
     assert np.isfinite(rgbs).all()
+    # every ray took the fp32 route: these weights get the fp32 kernels outright from now on (no second kernel per launch)
+    assert R._model_for(nets[0], nets[1], 128, kw).mlp == "fp32"
+    again, _ = R.render_path(None, poses, [8, 8, K[0][0]], K, 512, kw)
+    assert np.abs(again - rgbs).max() < 1e-4                            # (fallback: the x32 fp32 kernel; outright: the x16 one)
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -1,8 +1,6 @@
-# round 4, session a: the new tests (VJP census, range safety net, full-size default kernels) + A/B of the experiment builds
+# round 4, session c: new tests after the gradient entry scale 2^7; full parity suite; VJP A/B timing
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_r4.py -q -s -x > $O/r4_tests.log 2>&1; tail -5 $O/r4_tests.log
-grep -E "vjp census|range status|per-ray" $O/r4_tests.log | cut -c1-900
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -s -k "f16x2_vjp_over or out_of_range or test_render_rays_vjp or odd_ray_count" > $O/parity_sel.log 2>&1; tail -3 $O/parity_sel.log
-grep -E "f16x2 VJP, cot|per-ray relative" $O/parity_sel.log | cut -c1-900
-L=neural_sim_nerf_amd/csrc
-timeout 600 python tools/ab_h2.py --n 8 $L/libnsr.so $L/ab/libnsr_norange.so $L/ab/libnsr_samenet.so $L/ab/libnsr_halfbar.so $L/ab/libnsr_nofrag.so $L/libnsr.so $L/ab/libnsr_norange.so 2>&1 | tee $O/ab.txt
+timeout 1500 python -m pytest tests/test_gpu_r4.py -q -s > $O/r4_tests.log 2>&1; tail -6 $O/r4_tests.log
+grep -E "vjp census" $O/r4_tests.log | grep -o "^vjp census[^{]*\|'rays_above_thr': [0-9]*\|'unattributed': [0-9]*\|'flipped_units_total': [0-9]*\|'per_point_[a-z0-9]*': [0-9.e-]*\|'replay_max': [0-9.e-]*\|'err_max': [0-9.e-]*" | tr '\n' ' '; echo
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_handoff.py tests/test_data_readers.py -q -m gpu -x > $O/parity.log 2>&1; tail -6 $O/parity.log
+NSR_MLP=f16x2 python tools/bench_vjp.py 400 4 2>&1 | tail -2
