@@ -106,13 +106,15 @@ typedef struct NsrConfig {
                                    on fp16 MFMAs, the gradients of every point normalised by a power of two on entry) once
                                    nsr_upload_weights_bwd_h2 has been called; before that, the fp32 kernels of `variant`.
                                    RANGE SAFETY NET (ABI 3): a NaN never reaches the caller because of the fp16 range.  The
-                                   f16x2 kernels append every item (2 consecutive rays) with a NaN network output or
-                                   gradient to a device-side list, and the same launch call enqueues the fp32 kernel of the
-                                   same template (k_render / k_render_vjp, RH:99-118 has no range limit) over exactly that
-                                   list -- list and length stay on the device, no host round trip; with an empty list every
-                                   workgroup of the second launch returns at once (~10 us).  The reported items then hold
-                                   the fp32 kernel's results (a NaN the fp32 arithmetic itself produces -- NaN inputs, the
-                                   encoder's domain -- stays a NaN).  nsr_range_status counts what happened.  The input-
+                                   f16x2 kernels append every work item (2 consecutive rays) in which a ray had a NaN
+                                   network output or gradient to a device-side list, with the mask of those rays, and the
+                                   same launch call enqueues the fp32 kernel of the same template (k_render / k_render_vjp,
+                                   RH:99-118 has no range limit) over exactly that list -- list and length stay on the
+                                   device, no host round trip; with an empty list every workgroup of the second launch
+                                   returns at once (~10 us).  The second launch writes ONLY the reported rays: they then
+                                   hold the fp32 kernel's results (a NaN the fp32 arithmetic itself produces -- NaN inputs,
+                                   the encoder's domain -- stays a NaN), every other ray keeps the f16x2 kernel's bits,
+                                   so a ray's result never depends on its neighbours.  nsr_range_status counts what happened.  The input-
                                    gradient launch needs nsr_upload_weights_bwd (fp32 transposed stream) for its fallback;
                                    without it the affected rays keep their NaN gradients and are counted as dropped.       */
 

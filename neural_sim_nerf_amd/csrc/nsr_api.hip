@@ -133,7 +133,8 @@ static int allocate_handle(nsr_handle h) {
   // one allocation: coarse | fine | fine^T (backward stream), NSR_PACKED_FLOATS apart
   NSR_HIP(hipMalloc(&h->d_nets, sizeof(float) * 3 * NSR_PACKED_FLOATS));
   for (int i = 0; i < 3; ++i) h->d_packed[i] = h->d_nets + (size_t)i * NSR_PACKED_FLOATS;
-  NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));
+  // d_nets16 (the x16 images) is allocated by the first nsr_upload_weights16 / _bwd16: handles whose kernels never read
+  // it (f16x2 / bf16x3 handles run k_render_h2 / _b3, their fallback and the stage kernels read the x32 image) do not pay for it
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVjp16Lds));
   NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRender16Lds));
   if (cfg->flags & NSR_FLAG_MLP_BF16X3) {
@@ -268,6 +269,7 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
   if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights16: net_id must be 0 (coarse) or 1 (fine)");
   if (n_floats != (size_t)NSR_PACKED_FLOATS) return fail("nsr_upload_weights16: wrong packed size");
   NSR_DEVICE(h);
+  if (!h->d_nets16) NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));      // setup call
   NSR_HIP(hipMemcpy(h->d_nets16 + (size_t)net_id * NSR_PACKED_FLOATS, packed, sizeof(float) * n_floats,
                     hipMemcpyHostToDevice));
   h->have_net16[net_id] = true;
@@ -339,6 +341,7 @@ int nsr_upload_weights_bwd16(nsr_handle h, const float* stream, size_t n_floats)
   if (!h || !stream) return fail("nsr_upload_weights_bwd16: null argument");
   if (n_floats != (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd16: wrong stream size");
   NSR_DEVICE(h);
+  if (!h->d_nets16) NSR_HIP(hipMalloc(&h->d_nets16, sizeof(float) * 3 * NSR_PACKED_FLOATS));      // setup call
   NSR_HIP(hipMemcpy(h->d_nets16 + (size_t)2 * NSR_PACKED_FLOATS, stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   if (int e = alloc_mask_scratch(h)) return e;
   h->have_net16[2] = true;

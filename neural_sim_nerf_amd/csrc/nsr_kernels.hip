@@ -599,7 +599,7 @@ __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[12
                                                 const float* w /*[R][stride]*/, int wstride, BinsFn bins,
                                                 int64_t* inds_out /*[R][128] or null*/, int64_t inds_stride, int tid,
                                                 int valid_rays, const float* u_rays = nullptr /* global [rays][128]: RH:211 */,
-                                                long long row0 = 0) {
+                                                long long row0 = 0, int write_mask = 3 /* rays whose inds are written */) {
   // (1) x = w + 1e-5 and the 8 vector-lane partial sums of ATen's cascade, 8 lanes per ray
   if (tid < 64 * R && (tid & 63) < 62) {
     const int r = tid >> 6, i = tid & 63;
@@ -665,7 +665,7 @@ __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[12
     if (denom < 1e-5f) denom = 1.0f;                            // RH:238-239
     const float t = (u - c0) / denom;
     st.zs[r][k] = b0 + t * (b1 - b0);                           // RH:241
-    if (inds_out && r < valid_rays) inds_out[r * inds_stride + k] = (int64_t)ind;
+    if (inds_out && r < valid_rays && ((write_mask >> r) & 1)) inds_out[r * inds_stride + k] = (int64_t)ind;
   }
   __syncthreads();
 }
@@ -859,8 +859,11 @@ __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) {
   if (a.epoch_counter) dst->epoch = *a.epoch_counter = *a.epoch_counter % 4094u + 1u;
 }
 
-// Work queue of the x32-structured kernels: the next item (2 rays) of this launch, or -1 when there is none left.  A
-// fallback launch (item_list) hands out the items the f16x2 kernel reported.  Thread 0 only.
+// Work queue of the x32-structured kernels: the next item (2 rays) of this launch as  item | write mask << 62  (bit r of
+// the mask: ray r of the item is this launch's to write), or -1 when there is none left.  A fallback launch (item_list)
+// hands out the entries the f16x2 kernel reported: it renders the whole item and writes ONLY the reported rays, so a ray
+// that stayed inside the fp16 range keeps the f16x2 kernel's bits whatever its neighbour did.  Thread 0 only.
+constexpr long long kItemMask = (1ll << 62) - 1;
 __device__ __forceinline__ long long queue_next_item(const RenderArgs& q) {
   const unsigned long long v = atomicAdd(q.work_counter, 1ull);
   if (q.item_list) {
@@ -868,13 +871,13 @@ __device__ __forceinline__ long long queue_next_item(const RenderArgs& q) {
     n = n < q.item_cap ? n : q.item_cap;
     return v < (unsigned long long)n ? (long long)q.item_list[v] : -1ll;
   }
-  return v < (unsigned long long)((q.n_rays + 1) >> 1) ? (long long)v : -1ll;
+  return v < (unsigned long long)((q.n_rays + 1) >> 1) ? (long long)(v | (3ull << 62)) : -1ll;
 }
 __device__ __forceinline__ long long queue_items(const RenderArgs& q) {
   if (q.item_list) { const unsigned n = *q.item_count; return (long long)(n < q.item_cap ? n : q.item_cap); }
   return (q.n_rays + 1) >> 1;
 }
-// f16x2: a NaN network output marks the item (LDS counter of the item's affected points)
+// f16x2: a NaN network output marks the ray (LDS counters ovf[0], ovf[1] of the item's two rays: affected points)
 __device__ __forceinline__ void range_mark(int* ovf, float chk, int lane) {
 #ifndef NSR_EXP_NO_RANGE     // (timing experiment: the kernels without the safety net)
   if (chk != chk && lane < 32) atomicAdd(ovf, 1);
@@ -885,12 +888,17 @@ __device__ __forceinline__ void range_report(const RenderArgs& a, int* ovf, long
 #ifdef NSR_EXP_NO_RANGE
   return;
 #endif
-  const int pts = *ovf;
-  if (pts != 0 && a.ovf_stat) {
+  const int p0 = ovf[0], p1 = valid == 2 ? ovf[1] : 0;      // (an item's missing second ray repeats the first)
+  if ((p0 | p1) != 0 && a.ovf_stat) {
+    const unsigned long long mask = (p0 ? 1ull : 0ull) | (p1 ? 2ull : 0ull);
     const unsigned n = atomicAdd(a.ovf_stat, 1u);
-    atomicAdd(a.ovf_stat + 1, (unsigned)pts);
-    if (n < a.ovf_cap) { a.ovf_items[n] = (unsigned long long)item; atomicAdd(a.ovf_stat + 2, (unsigned)valid); }
-    else atomicAdd(a.ovf_stat + 3, 1u);
+    atomicAdd(a.ovf_stat + 1, (unsigned)(p0 + p1));
+    if (n < a.ovf_cap) {
+      a.ovf_items[n] = (unsigned long long)item | (mask << 62);
+      atomicAdd(a.ovf_stat + 2, (unsigned)((p0 != 0) + (p1 != 0)));
+    } else {
+      atomicAdd(a.ovf_stat + 3, 1u);
+    }
   }
 }
 
@@ -921,7 +929,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   const long long n_rays = a_setup.n_rays;
   if ((long long)blockIdx.x >= queue_items(a_setup)) return;
   const int fine = a_setup.fine;
-  int* ovf = (int*)&st.ray[1][14];                       // f16x2: points of the current item with NaN network outputs
+  int* ovf = (int*)&st.ray[1][14];                       // f16x2: [2] points with NaN network outputs, per ray of the current item
 
   Ring rg;
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 4 : 1, wave, lane);
@@ -945,12 +953,15 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
     __syncthreads();
     return v;
   };
-  long long item = next_item();
+  long long packed = next_item();
   int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current item
 #pragma unroll 1
-  while (item >= 0) {
+  while (packed != -1ll) {
+    const long long item = packed & kItemMask;
     const long long ray0 = item * 2;
     const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
+    const int wmask = (int)((unsigned long long)packed >> 62) & (valid == 2 ? 3 : 1);     // rays this launch writes
+    auto wr = [&](int r) { return ((wmask >> r) & 1) != 0; };
     if (pass == 0) {
       // ---- stage the two rays --------------------------------------------------------------------
       const RenderArgs& a = *opaque_s(ap);                // see opaque_v / opaque_s
@@ -980,7 +991,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
-      if (MODE == kMlpH2 && tid == 64) *ovf = 0;
+      if (MODE == kMlpH2 && (tid == 64 || tid == 65)) ovf[tid - 64] = 0;
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
@@ -1013,7 +1024,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       mlp_pass<false, MODE>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, nullptr, 0, NSR_TPASS);
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
-      if constexpr (MODE == kMlpH2) range_mark(ovf, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
+      if constexpr (MODE == kMlpH2) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
     }
     NSR_T(1);
 
@@ -1022,11 +1033,11 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
     if (pass == 0) {
       __syncthreads();
       if (a.dbg_raw0) {
-        for (int idx = tid; idx < valid * 256; idx += 256) a.dbg_raw0[ray0 * 256 + idx] = (&st.rawc[0][0][0])[idx];
+        for (int idx = tid; idx < 2 * 256; idx += 256) if (wr(idx >> 8)) a.dbg_raw0[ray0 * 256 + idx] = (&st.rawc[0][0][0])[idx];
         __syncthreads();
       }
       composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
-      if (tid < valid * 8) {
+      if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
         const float v = st.res[r][c];
@@ -1038,10 +1049,10 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         else if (c == 4) { if (acc_dst) acc_dst[rr] = v; }
       }
       if (a.dbg_w0)
-        for (int idx = tid; idx < valid * 64; idx += 256) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
+        for (int idx = tid; idx < 2 * 64; idx += 256) if (wr(idx >> 6)) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
       if (!fine) {
         if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
-        __syncthreads(); item = next_item(); continue;
+        __syncthreads(); packed = next_item(); continue;
       }
       NSR_T(2);
 
@@ -1053,18 +1064,18 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 #endif
       sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
                       [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
-                      inds ? inds + ray0 * 128 : nullptr, 128, tid, valid, a.u_rays, ray0);
+                      inds ? inds + ray0 * 128 : nullptr, 128, tid, valid, a.u_rays, ray0, wmask);
       NSR_T(3);
       if (wave < 2) {
         const float sd = zstd_wave(st, wave, lane);
-        if (lane == 0 && wave < valid && a.z_std) a.z_std[ray0 + wave] = sd;
+        if (lane == 0 && wr(wave) && a.z_std) a.z_std[ray0 + wave] = sd;
       }
       if (a.dbg_zs)
-        for (int idx = tid; idx < valid * 128; idx += 256) a.dbg_zs[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
+        for (int idx = tid; idx < 2 * 128; idx += 256) if (wr(idx >> 7)) a.dbg_zs[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
       NSR_T(4);
       merge_sort_item(st, tid);
       if (a.dbg_zf)
-        for (int idx = tid; idx < valid * 192; idx += 256) a.dbg_zf[ray0 * 192 + idx] = (&st.zf[0][0])[idx];
+        for (int idx = tid; idx < 2 * 192; idx += 256) if (wr(idx / 192)) a.dbg_zf[ray0 * 192 + idx] = (&st.zf[0][0])[idx];
       NSR_T(5);
       pass = 1;
     } else if (pass < 3) {
@@ -1072,11 +1083,11 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
     } else {
       __syncthreads();
       if (a.dbg_raw) {
-        for (int idx = tid; idx < valid * 768; idx += 256) a.dbg_raw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
+        for (int idx = tid; idx < 2 * 768; idx += 256) if (wr(idx / 768)) a.dbg_raw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
         __syncthreads();
       }
       composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
-      if (tid < valid * 8) {
+      if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
         const float v = st.res[r][c];
@@ -1088,7 +1099,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       __syncthreads();
       NSR_T(6);
       pass = 0;
-      item = next_item();
+      packed = next_item();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive the workgroup
@@ -1402,7 +1413,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
 
   const long long n_rays = a_setup.n_rays;
   if ((long long)blockIdx.x >= queue_items(a_setup)) return;
-  int* ovf = (int*)&st.ray[1][14];                       // f16x2: points of the current item with NaN outputs / gradients
+  int* ovf = (int*)&st.ray[1][14];                       // f16x2: [2] points with NaN outputs / gradients, per ray of the item
 
   Ring rg;
   ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);
@@ -1430,12 +1441,15 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
     __syncthreads();
     return v;
   };
-  long long item = next_item();
+  long long packed = next_item();
   int pass = 0;
 #pragma unroll 1
-  while (item >= 0) {
+  while (packed != -1ll) {
+    const long long item = packed & kItemMask;
     const long long ray0 = item * 2;
     const int valid = (ray0 + 1 < n_rays) ? 2 : 1;
+    const int wmask = (int)((unsigned long long)packed >> 62) & (valid == 2 ? 3 : 1);     // rays this launch writes
+    auto wr = [&](int r) { return ((wmask >> r) & 1) != 0; };
     if (pass == 0) {
       const RenderArgs& a = opaque_s(vp)->r;              // see opaque_v / opaque_s
       const int tid = opaque_v(tid0);
@@ -1457,7 +1471,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         st.ray[tid][11] = nrm;
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
-      if (MODE == kMlpH2 && tid == 64) *ovf = 0;
+      if (MODE == kMlpH2 && (tid == 64 || tid == 65)) ovf[tid - 64] = 0;
       if (tid < 128) {
         const int r = tid >> 6, i = tid & 63;
         const float t = st.tcoarse[i];
@@ -1487,7 +1501,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       mlp_pass<true, MODE>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                          ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
       if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
-      if constexpr (MODE == kMlpH2) range_mark(ovf, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
+      if constexpr (MODE == kMlpH2) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
     } else {
       // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
       const int q0 = 128 * (pass - 4) + 32 * wave;
@@ -1498,9 +1512,9 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       float dp[3], dv[3];
       mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
                        ry, &st.zf[r][i - j], dp, dv);
-      if constexpr (MODE == kMlpH2) range_mark(ovf, dp[0] + dv[0], lane);
+      if constexpr (MODE == kMlpH2) range_mark(ovf + r, dp[0] + dv[0], lane);
       if (float* gp = opaque_s(vp)->dbg_gpts) {            // debug tap: the per-sample results of the network backward
-        if (lane < 32 && r < valid) {
+        if (lane < 32 && wr(r)) {
           float* q = gp + ((ray0 + r) * 192 + i) * 6;
           q[0] = dp[0]; q[1] = dp[1]; q[2] = dp[2]; q[3] = dv[0]; q[4] = dv[1]; q[5] = dv[2];
         }
@@ -1540,7 +1554,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
     } else if (pass == 3) {
       __syncthreads();
       composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
-      if (tid < valid * 8) {
+      if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
         const float v = st.res[r][c];
@@ -1556,13 +1570,13 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       __syncthreads();
       composite_bwd(st, grgb, tid);
       if (va.dbg_graw)                                     // debug tap: dL/d raw as the network backward receives it
-        for (int idx = tid; idx < valid * 768; idx += 256) va.dbg_graw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
+        for (int idx = tid; idx < 2 * 768; idx += 256) if (wr(idx / 768)) va.dbg_graw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
       pass = 4;
     } else if (pass < 6) {
       ++pass;
     } else {
       __syncthreads();
-      if (tid < valid) {
+      if (tid < 2 && wr(tid)) {
         const int r = tid;
         float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
         for (int s = 0; s < 6; ++s)
@@ -1592,12 +1606,13 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
           }
         }
       }
-      if (va.dbg_masks)                                    // debug tap: the relu patterns of this item's three fine passes
-        for (int k = 0; k < 27; ++k) va.dbg_masks[((size_t)item * 27 + k) * 256 + tid] = my_masks[k * 256 + tid];
+      if (va.dbg_masks && wmask == (valid == 2 ? 3 : 1))   // debug tap: the relu patterns of this item's three fine passes (the
+        for (int k = 0; k < 27; ++k)                       // fallback launch rewrites them only when it owns the whole item)
+          va.dbg_masks[((size_t)item * 27 + k) * 256 + tid] = my_masks[k * 256 + tid];
       if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
       __syncthreads();
       pass = 0;
-      item = next_item();
+      packed = next_item();
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

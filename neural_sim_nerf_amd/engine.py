@@ -126,7 +126,10 @@ class NsrModel:
         sd_c = to_np(sd_coarse)
         p = pack_network(sd_c)
         _lib.check(self.lib.nsr_upload_weights(self.h, 0, _fptr(p), PACKED_FLOATS))
-        if self.variant != 32:                       # 0 = library default = x16
+        # only the images this handle's kernels read: the x32 fp32 image always (stage kernels; an fp32 handle's per-ray
+        # extras; the fallback of an f16x2 handle's range safety net), the x16 image for fp32 handles of variant 0 / 16 only
+        x16 = self.variant != 32 and self.mlp == "fp32"
+        if x16:
             p = pack_network16(sd_c)
             _lib.check(self.lib.nsr_upload_weights16(self.h, 0, _fptr(p), PACKED_FLOATS))
         if self.mlp == "bf16x3":
@@ -142,7 +145,7 @@ class NsrModel:
             self._sd_fine_np = to_np(sd_fine)
             p = pack_network(self._sd_fine_np)
             _lib.check(self.lib.nsr_upload_weights(self.h, 1, _fptr(p), PACKED_FLOATS))
-            if self.variant != 32:
+            if x16:
                 p = pack_network16(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights16(self.h, 1, _fptr(p), PACKED_FLOATS))
             if self.mlp == "bf16x3":

@@ -55,10 +55,10 @@ def alpha_last(sigma_last, rays_d):
         return (f32(1) - np.exp((-np.maximum(sigma_last.astype(f32), f32(0)) * d).astype(f32))).astype(f32)
 
 
-def _pdf_terms(z_coarse, w0_inner):
+def _pdf_terms(z_coarse, w0_inner, n_importance=O.N_IMPORTANCE, u=None):
     """cdf and, per importance sample, (index, denominator as computed, switched flag) -- RH:199-240 via the oracle."""
     z_mid = (f32(0.5) * (z_coarse[:, 1:] + z_coarse[:, :-1])).astype(f32)
-    zs, inds, cdf = O.sample_pdf(z_mid, w0_inner)
+    zs, inds, cdf = O.sample_pdf(z_mid, w0_inner, n_importance, u)
     below = np.maximum(inds - 1, 0)
     above = np.minimum(inds, cdf.shape[-1] - 1)
     den = (np.take_along_axis(cdf, above, -1) - np.take_along_axis(cdf, below, -1)).astype(f32)
@@ -78,14 +78,20 @@ def psnr_delta(rgb, rgb_oracle, mask=None):
 
 
 def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STAGE, white_bkgd=False, lindisp=False,
-           coarse_only=False, max_listed=8):
+           coarse_only=False, max_listed=8, rnd=None, viewdirs=None, n_importance=O.N_IMPORTANCE):
     """nets = (sd_coarse, sd_fine); rays [N,3]; got: the render's outputs as numpy arrays [N, ...] -- rgb_map, acc_map,
     disp_map, raw0 [N,64,4] and, unless coarse_only, weights0, inds, z_samples, z_fine, raw [N,192,4], rgb0, acc0;
     ref: the oracle's render of the same rays with extras (O.render_rays(..., extras=True): rgb_map, acc_map, disp_map,
     raw0 (or sigma0_last [N]), weights0 (or pdf_weights [N,62] = weights0[:, 1:-1]), inds, z_samples, z_fine, rgb0,
     acc0) -- or the same quantities captured from the reference itself (tests/golden/g13_census.npz).
+    The render options: rnd = the draws both renders were given (t_rand [N,64], u [N,n], noise0 [N,64], noise1 [N,64+n]:
+    RN:447-459, RH:211, RN:365-374) -- they move the coarse depths, replace the linspace of sample_pdf and shift every
+    sigma before its relu, so every replay below takes them; viewdirs [N,3]: given view directions (RN:91-103);
+    n_importance: the number of importance samples of BOTH renders (taps then have 64 + n fine samples).
     Returns a JSON-able dict of counts; `unattributed` must be 0 for the render to pass."""
     sd_c, sd_f = nets
+    rnd = rnd or {}
+    noise0, noise1, u_draw = rnd.get("noise0"), rnd.get("noise1"), rnd.get("u")
     rays_o = np.ascontiguousarray(rays_o, f32).reshape(-1, 3)
     rays_d = np.ascontiguousarray(rays_d, f32).reshape(-1, 3)
     n = rays_o.shape[0]
@@ -93,8 +99,10 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
          if v is not None and k in _TRAIL}
     r = {k: np.asarray(v).reshape((n,) + np.asarray(v).shape[np.asarray(v).ndim - _trail(k):]) for k, v in ref.items()
          if v is not None and k in _TRAIL}
-    vd = O.normalize_dirs(rays_d)
-    zc = O.coarse_z(np.full(n, near, f32), np.full(n, far, f32), lindisp=lindisp)
+    vd = O.normalize_dirs(rays_d) if viewdirs is None else np.ascontiguousarray(viewdirs, f32).reshape(-1, 3)
+    zc = O.coarse_z(np.broadcast_to(np.asarray(near, f32), (n,)), np.broadcast_to(np.asarray(far, f32), (n,)), lindisp=lindisp)
+    if rnd.get("t_rand") is not None:
+        zc = O.perturb_z(zc, np.asarray(rnd["t_rand"], f32))                                # RN:447-459
     for d in (g, r):
         if "inds" in d:
             d["inds"] = d["inds"].astype(np.int64)
@@ -119,8 +127,10 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
 
     # the coarse image has its own cliff (it is an output too: rgb0 / acc0, or the image itself when coarse_only)
     ck = ("rgb_map", "acc_map") if coarse_only else ("rgb0", "acc0")
-    a0_g = alpha_last(_sigma0_last(g), rays_d)
-    a0_r = alpha_last(_sigma0_last(r), rays_d)
+    n0_last = 0.0 if noise0 is None else np.asarray(noise0, f32)[:, -1]                 # RN:374: the relu sees raw + noise
+    n1_last = 0.0 if noise1 is None else np.asarray(noise1, f32)[:, -1]
+    a0_g = alpha_last(_sigma0_last(g) + n0_last, rays_d)
+    a0_r = alpha_last(_sigma0_last(r) + n0_last, rays_d)
     coarse_cliff = np.abs(a0_g - a0_r) > 1e-3
     d0 = np.maximum(np.abs(g[ck[0]] - r[ck[0]]).max(-1), np.abs(g[ck[1]] - r[ck[1]]))
     flagged0 = d0 > tol
@@ -132,7 +142,8 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
         # counterfactual: the render's own coarse raw with the oracle's sigma_last must give the oracle's coarse pixel
         raw_cf = g["raw0"][idx0].copy()
         raw_cf[:, -1, 3] = _sigma0_last(r)[idx0]
-        rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zc[idx0], rays_d[idx0], white_bkgd)
+        rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zc[idx0], rays_d[idx0], white_bkgd,
+                                                None if noise0 is None else np.asarray(noise0, f32)[idx0])
         ok = coarse_cliff[idx0] & (np.abs(rgb_cf - r[ck[0]][idx0]).max(-1) <= tol_stage) & \
             (np.abs(acc_cf - r[ck[1]][idx0]) <= tol_stage)
         un0[idx0[~ok]] = True
@@ -156,18 +167,21 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
         # P1: the oracle's fine pass at the render's own depths
         pts = O._add(ro[:, None, :], (rd[:, None, :] * zf_g[:, :, None]).astype(f32))
         raw_rep = O.run_network(sd_f if sd_f is not None else sd_c, pts, v)
-        rgb_rep, _, acc_rep, _, _ = O.raw2outputs(raw_rep, zf_g, rd, white_bkgd)
-        fine_cliff = np.abs(alpha_last(g["raw"][idx, -1, 3], rd) - alpha_last(raw_rep[:, -1, 3], rd)) > 1e-3
+        nz1 = None if noise1 is None else np.asarray(noise1, f32)[idx]
+        nl = 0.0 if nz1 is None else nz1[:, -1]
+        rgb_rep, _, acc_rep, _, _ = O.raw2outputs(raw_rep, zf_g, rd, white_bkgd, nz1)
+        fine_cliff = np.abs(alpha_last(g["raw"][idx, -1, 3] + nl, rd) - alpha_last(raw_rep[:, -1, 3] + nl, rd)) > 1e-3
         raw_cf = g["raw"][idx].copy()
         raw_cf[fine_cliff, -1, 3] = raw_rep[fine_cliff, -1, 3]
-        rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zf_g, rd, white_bkgd)
-        own = O.raw2outputs(g["raw"][idx], zf_g, rd, white_bkgd)             # the render's compositing of its own raw
+        rgb_cf, _, acc_cf, _, _ = O.raw2outputs(raw_cf, zf_g, rd, white_bkgd, nz1)
+        own = O.raw2outputs(g["raw"][idx], zf_g, rd, white_bkgd, nz1)        # the render's compositing of its own raw
         p1 = (np.abs(rgb_cf - rgb_rep).max(-1) <= tol_stage) & (np.abs(acc_cf - acc_rep) <= tol_stage) & \
             (np.abs(own[0] - g["rgb_map"][idx]).max(-1) <= tol_stage) & (np.abs(own[2] - g["acc_map"][idx]) <= tol_stage)
         # P2: why the depths moved
         moved = (zf_g != zf_r).any(-1)
-        zs_g, inds_g, cdf_g, den_g, binw = _pdf_terms(zc[idx], _w0_inner(g)[idx])
-        zs_r, inds_r, cdf_r, den_r, _ = _pdf_terms(zc[idx], _w0_inner(r)[idx])
+        u_idx = None if u_draw is None else np.broadcast_to(np.asarray(u_draw, f32), (n, np.shape(u_draw)[-1]))[idx]
+        zs_g, inds_g, cdf_g, den_g, binw = _pdf_terms(zc[idx], _w0_inner(g)[idx], n_importance, u_idx)
+        zs_r, inds_r, cdf_r, den_r, _ = _pdf_terms(zc[idx], _w0_inner(r)[idx], n_importance, u_idx)
         consistent = (inds_g == g["inds"][idx]).all(-1) & (zs_g == g["z_samples"][idx]).all(-1) & \
             (inds_r == r["inds"][idx]).all(-1) & (zs_r == r["z_samples"][idx]).all(-1)   # the bit-exact stage, again
         flip = (inds_g != inds_r).any(-1)
@@ -202,8 +216,8 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
                unattributed=int(un.sum()), unattributed_rays=[int(i) for i in np.nonzero(un)[0][:max_listed]],
                worst=worst)
     # over ALL rays: how far the inputs of sample_pdf are from the reference's (the attribution rule above needs them close)
-    _, _, cdf_all_g, _, _ = _pdf_terms(zc, _w0_inner(g))
-    _, _, cdf_all_r, _, _ = _pdf_terms(zc, _w0_inner(r))
+    _, _, cdf_all_g, _, _ = _pdf_terms(zc, _w0_inner(g), n_importance, u_draw)
+    _, _, cdf_all_r, _, _ = _pdf_terms(zc, _w0_inner(r), n_importance, u_draw)
     out["max_abs_dweights0"] = float(np.abs(_w0_inner(g) - _w0_inner(r)).max())
     out["max_abs_dcdf"] = float(np.abs(cdf_all_g - cdf_all_r).max())
     out["max_rel_disp_times_acc_unflagged"] = float(d_disp[~flagged].max()) if (~flagged).any() else 0.0

@@ -242,7 +242,7 @@ def net_shape(sd):
     return D, W, input_ch, input_ch_views, skips, use_viewdirs
 
 
-def mlp(sd, x_embedded, keep=None):
+def mlp(sd, x_embedded, keep=None, all_rows=False):
     """RH:99-122 for the network the state dict describes (net_shape): x_embedded [P, 63 + 27] = the FULL encodings
     (10 / 4 frequencies) -> [P, 4] = (rgb logits, sigma).  A network built for fewer frequencies reads the leading
     3 + 6 L columns of each (the encoder emits its bands in increasing order, RH:35-48); a state dict with `output_linear`
@@ -257,8 +257,9 @@ def mlp(sd, x_embedded, keep=None):
             keep["h%d" % i] = h
         if i in skips:
             h = np.concatenate([pts, h], -1)
-    if not use_viewdirs:
-        return lin("output_linear", h)[:, :4]
+    if not use_viewdirs:                                  # RH:119-120: every row of output_linear (5 when N_importance > 0,
+        out = lin("output_linear", h)                     # RN:267); render_rays reads the first four (RN:363-374)
+        return out if all_rows else out[:, :4]
     alpha = lin("alpha_linear", h)
     feature = lin("feature_linear", h)
     hv = np.maximum(lin("views_linears.0", np.concatenate([feature, views], -1)), f32(0))

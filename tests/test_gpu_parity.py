@@ -201,6 +201,35 @@ def _census(nets, r, ro, rd, near, far, ref, **kw):
     return c
 
 
+def _census_vs_oracle(oracle, nets, r, ro, rd, near, far, n_importance=128, reference_rgb=None, **kw):
+    """The same acceptance rule for the renders beyond the YCB-V configuration (other networks, fewer importance samples):
+    the census against the ORACLE's end-to-end render of the same rays -- the oracle is held to the reference's outputs for
+    exactly these cases by tests/test_oracle_golden.py (g15, g16, g17) -- plus, when the reference's own pixels are at
+    hand, an overall bound against them: PSNR-delta <= 0.1 dB (north_star) over all rays, cliffs included."""
+    import census as C
+    ref = oracle.render_rays(nets[0], nets[1], ro, rd, oracle.normalize_dirs(rd), near, far, n_importance=n_importance, extras=True)
+    taps = {k: cpu(r[k]) for k in _TAPS if k in r and r[k] is not None}
+    if taps["z_fine"].shape[1] != 64 + n_importance:          # duplicated importance samples (engine._host_tables): distinct ones
+        rep = 128 // n_importance
+        taps["inds"], taps["z_samples"] = taps["inds"][:, ::rep], taps["z_samples"][:, ::rep]
+        zf, raw = taps["z_fine"], taps["raw"]
+        keep = np.ones(zf.shape, bool)
+        for i in range(zf.shape[0]):                          # a sample depth appears `rep` times in a row: keep the first
+            smp = np.isin(zf[i], taps["z_samples"][i])
+            dup = smp & np.concatenate([[False], zf[i, 1:] == zf[i, :-1]])
+            keep[i] = ~dup
+        assert (keep.sum(1) == 64 + n_importance).all()
+        taps["z_fine"] = zf[keep].reshape(zf.shape[0], -1)
+        taps["raw"] = raw[keep].reshape(zf.shape[0], -1, 4)
+    c = C.census(nets, ro, rd, near, far, taps, ref, n_importance=n_importance, **kw)
+    assert C.passes(c), c
+    yard = 43.0 / 1600.0          # the reference's torch GEMMs vs the oracle's numpy GEMMs on g13's view: rays beyond 1e-4
+    assert c["rays_above_tol"] <= max(3, 3.0 * yard * c["rays"]) and c["psnr_delta_db"] <= 0.1, c
+    if reference_rgb is not None:
+        assert C.psnr_delta(cpu(r["rgb_map"]), reference_rgb) <= 0.1
+    return c
+
+
 # ---- the options of render() beyond the deterministic test-time path (include/nsr.h: NsrRayExtras) ---------------------
 EXTRA_KERNELS = {"f16x2": dict(mlp="f16x2"), "bf16x3": dict(mlp="bf16x3"), "x32": dict(variant=32),
                  "fp32-default-variant": dict(mlp="fp32")}
@@ -233,8 +262,9 @@ def test_stochastic_options_with_the_references_draws(kernel, oracle, synth_nets
         assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
         assert_close(cpu(r["acc0"]), g["acc0"], atol=1e-5, what="acc0 vs reference")
         assert (cpu(r["inds"]) == g["inds"]).mean() > 0.995
-        d = np.abs(cpu(r["rgb_map"]) - g["rgb"]).max(-1)
-        assert (d > 1e-4).mean() <= 0.08 and d.mean() < 2e-4, ((d > 1e-4).mean(), d.mean())
+        # end to end against what the REFERENCE produced with these draws: the census (r04; r03 held this to a mean bound)
+        c = _census(synth_nets, r, ro, rd, near, far, census_ref(g), rnd=rnd)
+        assert c["rays_above_tol"] <= 3 * (43.0 / 1600.0) * c["rays"] and c["psnr_delta_db"] <= 0.1, c
         # each option alone changes the render, and the plain call is still the deterministic one
         plain = m.render_rays(ro, rd, near, far)
         for k in rnd:
@@ -401,8 +431,7 @@ def test_noviewdirs_network(mlp, oracle):
         r = m.render_rays(ro, rd, near, far, debug=True)
         _stagewise(m, oracle, (sd_c, sd_f), r, ro, rd, near, far)
         assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
-        d = np.abs(cpu(r["rgb_map"]) - g["rgb"]).max(-1)
-        assert (d > 1e-4).mean() <= 0.08 and d.mean() < 2e-4
+        _census_vs_oracle(oracle, (sd_c, sd_f), r, ro, rd, near, far, reference_rgb=g["rgb"])
         z = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
         zf = np.sort(np.concatenate([z, g["z_samples"]], -1), -1)
         go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf)
@@ -433,8 +462,12 @@ def test_noviewdirs_network(mlp, oracle):
     pts = torch.tensor(ro[:8, None, :] + rd[:8, None, :] * 1.0, device=R.device)
     out = R.run_network(pts, None, nets[0])
     e = oracle.embed(cpu(pts).reshape(-1, 3), 10)
-    assert_close(cpu(out).reshape(-1, 4), oracle.mlp(sd_c, np.concatenate([e, np.zeros((8, 27), np.float32)], -1)), atol=5e-5,
-                 rtol=5e-5, what="run_network(viewdirs=None)")
+    # RH:119-120 + RN:267: a use_viewdirs=False module built for N_importance > 0 returns all FIVE rows of output_linear
+    assert tuple(out.shape) == (8, 1, 5)
+    assert_close(cpu(out).reshape(-1, 5), oracle.mlp(sd_c, np.concatenate([e, np.zeros((8, 27), np.float32)], -1), all_rows=True),
+                 atol=5e-5, rtol=5e-5, what="run_network(viewdirs=None)")
+    with pytest.raises(NotImplementedError, match="retraw"):
+        R.render(400, 400, oracle.YCBV_K, rays=rays, retraw=True, **kw)
     with pytest.raises(NotImplementedError, match="use_viewdirs"):
         R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, use_viewdirs=True))
     for n in nets:
@@ -467,8 +500,8 @@ def test_networks_of_other_shapes(tag, oracle):
         # (network b is a 64-wide net with densities up to ~2e3: fp32 rounding of its sums scales with that)
         _stagewise(m, oracle, (sd_c, sd_f), r, ro, rd, near, far, raw_atol=max(5e-5, 1e-6 * np.abs(cpu(r["raw0"])).max()))
         assert_close(cpu(r["rgb0"]), g[tag + "_rgb0"], atol=1e-5, what="rgb0 vs reference")
-        d = np.abs(cpu(r["rgb_map"]) - g[tag + "_rgb"]).max(-1)
-        assert (d > 1e-4).mean() <= 0.1 and d.mean() < 2e-4, ((d > 1e-4).mean(), d.mean())
+        _census_vs_oracle(oracle, (sd_c, sd_f), r, ro, rd, near, far, reference_rgb=g[tag + "_rgb"],
+                          tol_stage=max(3e-5, 1e-6 * float(np.abs(cpu(r["raw0"])).max())))
         z = oracle.coarse_z(np.full(len(ro), near, np.float32), np.full(len(ro), far, np.float32))
         zf = np.sort(np.concatenate([z, g[tag + "_z_samples"]], -1), -1)
         go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf)
@@ -525,8 +558,7 @@ def test_fewer_importance_samples(oracle, synth_nets):
             assert_close(cpu(r["z_std"]), np.std(s.astype(np.float64), -1), atol=1e-6, what="z_std")
             if ni == 64:
                 assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
-                d = np.abs(cpu(r["rgb_map"]) - g["rgb"]).max(-1)
-                assert (d > 1e-4).mean() <= 0.08 and d.mean() < 2e-4
+                _census_vs_oracle(oracle, synth_nets, r, ro, rd, near, far, n_importance=64, reference_rgb=g["rgb"])
                 assert_close(cpu(r["z_std"]), g["z_std"], atol=2e-3, what="z_std vs reference")
                 # gradient at the reference's depths: its 128 sorted depths with the 64 samples doubled
                 zf_ref = np.sort(np.concatenate([z, g["z_samples"], g["z_samples"]], -1), -1)
