@@ -66,7 +66,11 @@ typedef struct NsrConfig {
   int32_t abi_version;     /* must be NSR_ABI_VERSION                                              */
   int32_t device;          /* HIP device ordinal                                                   */
   int32_t n_samples;       /* must be 64                                                           */
-  int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1)               */
+  int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1); NSR_FLAG_MLP_F16X2 handles also take
+                              64 and 32 (RN:474 with N_importance = 64 / 32): kernels specialised to 64 + n fine samples per
+                              ray -- two fine network passes per item instead of three.  For such a handle every
+                              [.,128] / [.,192] array below is [.,n] / [.,64 + n] (d_u keeps its row stride of 128, the
+                              first n entries of a row are read; u_fine of nsr_upload_tables: its first n entries)  */
   int32_t max_workgroups;  /* 0 = fill the chip (one workgroup per CU for x32, two for x16)        */
   int32_t variant;         /* render AND input-gradient kernels: 0 = library default (= 16); 16 = 16 points/wave, two
                               workgroups per CU (needs nsr_upload_weights16 / _bwd16); 32 = 32 points/wave, one
@@ -118,7 +122,8 @@ typedef struct NsrConfig {
                                    gradient launch needs nsr_upload_weights_bwd (fp32 transposed stream) for its fallback;
                                    without it the affected rays keep their NaN gradients and are counted as dropped.       */
 
-/* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL). */
+/* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL).  128 / 192 = N_importance /
+ * 64 + N_importance of the handle. */
 typedef struct NsrDebugOut {
   float*   d_weights0;   /* [N,64]   coarse weights             (RN:467)   */
   float*   d_z_samples;  /* [N,128]  importance samples         (RH:241)   */
@@ -240,7 +245,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
 
 /* Debug taps of the input-gradient launch (x32-structured kernels: f16x2, bf16x3 and fp32 `variant` 32 handles; an fp32
  * handle of another variant runs k_render_vjp for a call with taps, like for the extras).  All pointers nullable.
- *   d_relu_masks [ceil(N/2)][3][9][256][4] uint32: the relu patterns the backward pass applied, as captured by the
+ *   d_relu_masks [ceil(N/2)][3][9][256][4] uint32 (3 = fine passes per item; 2 on an N_importance 64 / 32 handle, whose
+ *       point mapping is q = 128 p + 32 w + j -> sample q % (64 + n) of ray 2t + q / (64 + n)): the relu patterns the backward pass applied, as captured by the
  *       forward passes of the same launch -- item t = rays 2t, 2t+1; fine pass p of the item covers the 128 points
  *       q = 128 p + 32 w + j (wave w = thread / 64, j = thread % 32) = sample q % 192 of ray 2t + q / 192; layer 0..7 =
  *       pts_linears, 8 = views_linears.0; thread (w, lane) holds, for its point, the units

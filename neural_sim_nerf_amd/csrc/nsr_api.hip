@@ -151,6 +151,12 @@ static int allocate_handle(nsr_handle h) {
     NSR_HIP(hipMemset(h->d_ovf_stat, 0, 4 * sizeof(unsigned)));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+    if (cfg->n_importance == 64 || cfg->n_importance == 32) {
+      for (const void* k : {(const void*)nsr::k_render_h2_n64, (const void*)nsr::k_render_h2_n32, (const void*)nsr::k_render_n64,
+                            (const void*)nsr::k_render_n32, (const void*)nsr::k_render_vjp_h2_n64, (const void*)nsr::k_render_vjp_h2_n32,
+                            (const void*)nsr::k_render_vjp_n64, (const void*)nsr::k_render_vjp_n32})
+        NSR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+    }
   }
   NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
@@ -202,8 +208,11 @@ int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (cfg->chunk < 0 || cfg->chunk > 256) return fail("nsr_create: chunk must be 0 (default) or 1..256");
   if (cfg->variant != 0 && cfg->variant != 16 && cfg->variant != 32)
     return fail("nsr_create: variant must be 0 (default), 16 or 32");
-  if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0)
-    return fail("nsr_create: unsupported N_importance (128, or 0 for coarse-only)");
+  if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0 && cfg->n_importance != 64 && cfg->n_importance != 32)
+    return fail("nsr_create: unsupported N_importance (128; 0 for coarse-only; 64 or 32 on NSR_FLAG_MLP_F16X2 handles)");
+  if ((cfg->n_importance == 64 || cfg->n_importance == 32) && !(cfg->flags & NSR_FLAG_MLP_F16X2))
+    return fail("nsr_create: N_importance 64 / 32 is served by the f16x2 kernels (NSR_FLAG_MLP_F16X2); other handles render it "
+                "with N_importance = 128 and a uniforms table of repeated values (engine._host_tables)");
   int ndev = 0;
   NSR_HIP(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail("nsr_create: no such HIP device");
@@ -378,6 +387,7 @@ static bool use_x16(nsr_handle h) { return h->cfg.variant != 32; }
 static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* out, const NsrDebugOut* dbg,
                          void* stream) {
   const bool fine = h->cfg.n_importance > 0;
+  const int ni = h->cfg.n_importance;                      // 64 / 32: the kernels specialised to that many importance samples
   const bool b3 = (h->cfg.flags & NSR_FLAG_MLP_BF16X3) != 0;
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) != 0;
   // the per-ray extras (NsrRayExtras) are read by the x32-structured kernels: an fp32 handle serves them with k_render
@@ -459,6 +469,10 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   else if (b3)
     hipLaunchKernelGGL(nsr::k_render_b3, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
+  else if (h2 && ni == 64)
+    hipLaunchKernelGGL(nsr::k_render_h2_n64, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
+  else if (h2 && ni == 32)
+    hipLaunchKernelGGL(nsr::k_render_h2_n32, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   else if (h2)
     hipLaunchKernelGGL(nsr::k_render_h2, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   else
@@ -477,7 +491,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     f.item_list = h->d_ovf_items; f.item_count = h->d_ovf_stat; f.item_cap = kOvfCap;
     f.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, f, h->d_args_fb);
-    hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args_fb);
+    hipLaunchKernelGGL(ni == 64 ? nsr::k_render_n64 : (ni == 32 ? nsr::k_render_n32 : nsr::k_render), dim3((int)g), dim3(256),
+                       kRenderLds, s, (const nsr::RenderArgs*)h->d_args_fb);
   }
 #endif
   NSR_HIP(hipGetLastError());
@@ -549,12 +564,15 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
                             const NsrVjpDebugOut* dbg, void* stream) {
   if (h && n_rays == 0) return 0;      // an empty batch is a valid no-op (buffers may be null)
   if (!h) return fail("nsr_render_rays_vjp: null handle");
-  if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance=128)");
+  if (h->cfg.n_importance == 0) return fail("nsr_render_rays_vjp: needs the coarse+fine configuration (N_importance > 0)");
+  const int ni = h->cfg.n_importance;
   if (int e = check_ready(h, true)) return e;
   const bool b3 = (h->cfg.flags & NSR_FLAG_MLP_BF16X3) != 0;
   // an f16x2 handle runs its input gradients on fp16 MFMAs too once the transposed stream is there (nsr_upload_weights_bwd_h2);
   // without it the fp32 kernels of `variant` serve (they need their own uploads)
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) && h->have_net_h2[0] && h->have_net_h2[1] && h->have_net_h2[2];
+  if (ni != NSR_N_IMPORTANCE && !h2)
+    return fail("nsr_render_rays_vjp: an N_importance 64 / 32 handle needs nsr_upload_weights_bwd_h2 (only the f16x2 kernels are specialised to it)");
   const bool extras = ex && (ex->d_viewdirs || ex->d_t_rand || ex->d_u || ex->d_noise0 || ex->d_noise1 || ex->d_near);
   if (ex && ((ex->d_near == nullptr) != (ex->d_far == nullptr))) return fail("nsr_render_rays_vjp_ex: d_near and d_far come together");
   if (d_grad_viewdirs && !(ex && ex->d_viewdirs))
@@ -628,6 +646,10 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
     hipLaunchKernelGGL(nsr::k_render_vjp16, dim3((int)grid), dim3(256), kVjp16Lds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else if (b3)
     hipLaunchKernelGGL(nsr::k_render_vjp_b3, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  else if (h2 && ni == 64)
+    hipLaunchKernelGGL(nsr::k_render_vjp_h2_n64, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  else if (h2 && ni == 32)
+    hipLaunchKernelGGL(nsr::k_render_vjp_h2_n32, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else if (h2)
     hipLaunchKernelGGL(nsr::k_render_vjp_h2, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else
@@ -643,7 +665,8 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
     fa.item_list = h->d_ovf_items; fa.item_count = h->d_ovf_stat; fa.item_cap = kOvfCap;
     fa.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, f, h->d_vjp_args_fb);
-    hipLaunchKernelGGL(nsr::k_render_vjp, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
+    hipLaunchKernelGGL(ni == 64 ? nsr::k_render_vjp_n64 : (ni == 32 ? nsr::k_render_vjp_n32 : nsr::k_render_vjp), dim3((int)grid),
+                       dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
   }
   NSR_HIP(hipGetLastError());
   if (!capturing) {

@@ -519,17 +519,18 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 // inherently serial part: torch-CPU cumprod is a sequential fp64 product with every prefix rounded to fp32
 // (RN:376), one lane per ray, 8 factors per LDS round trip; (3) weights and the five weighted sums, one wave per
 // ray (lane l owns samples l, l+64, l+128), xor-shuffle tree.
-template <int S, int R = 2, typename ST>
+// STRIDE: samples per ray of the z / raw / wout / tout arrays (>= S; the item state is laid out for the largest S).
+template <int S, int R = 2, int STRIDE = S, typename ST>
 __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, float* wout, float* tout, int tid,
                                           const float* noise = nullptr /* global [rays][S]: RN:365-374 */,
                                           long long row0 = 0, int valid = R) {
   static_assert(S % 8 == 0, "scan is unrolled by 8");
   for (int idx = tid; idx < R * S; idx += 256) {
     const int r = idx / S, i = idx - r * S;
-    const float* zr = z + r * S;
+    const float* zr = z + r * STRIDE;
     float dist = (i < S - 1) ? (zr[i + 1] - zr[i]) : 1e10f;   // RN:358-359
     dist = dist * st.ray[r][11];                               // RN:361
-    float* q = raw + (r * S + i) * 4;
+    float* q = raw + (r * STRIDE + i) * 4;
     if (noise) q[3] = q[3] + noise[(row0 + (r < valid ? r : 0)) * S + i];   // RN:374 (kept: the backward's relu' sees it too)
     const float sigma = fmaxf(q[3], 0.0f);
     const float a = 1.0f - expf(-sigma * dist);                // RN:356
@@ -550,7 +551,7 @@ __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, fl
       for (int k = 0; k < 8; ++k) f[k] = (double)st.om[r][i0 + k];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        tout[r * S + i0 + k] = (float)T;                       // exclusive product, rounded per prefix
+        tout[r * STRIDE + i0 + k] = (float)T;                  // exclusive product, rounded per prefix
         T = T * f[k];
       }
     }
@@ -558,13 +559,13 @@ __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, fl
   __syncthreads();
   if (tid < 64 * R) {
     const int r = tid >> 6, l = tid & 63;
-    const float* zr = z + r * S;
-    const float* q = raw + r * S * 4;
+    const float* zr = z + r * STRIDE;
+    const float* q = raw + r * STRIDE * 4;
     float cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, acc = 0.f;
 #pragma unroll
     for (int i = l; i < S; i += 64) {
-      const float w = st.alpha[r][i] * tout[r * S + i];        // RN:376
-      wout[r * S + i] = w;
+      const float w = st.alpha[r][i] * tout[r * STRIDE + i];   // RN:376
+      wout[r * STRIDE + i] = w;
       cr = cr + w * q[i * 4 + 0];                              // RN:378
       cg = cg + w * q[i * 4 + 1];
       cb = cb + w * q[i * 4 + 2];
@@ -594,8 +595,10 @@ __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, fl
 
 // sample_pdf RH:199-243 (det=True) for both rays: weights w[r][0..61] (= coarse weights[1:-1]), bins = mid-points.
 // Writes st.cdf, st.zs; optional inds.  `bins` is a callable: bins(r, k), k in 0..62.
-template <int R = 2, typename ST, typename BinsFn>
-__device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[128], LDS or global*/,
+// NI: importance samples per ray (128, or 64 / 32 for the kernels specialised to N_importance = 64 / 32); the thread
+// mapping and the row stride of u_rays stay those of 128.
+template <int R = 2, int NI = 128, typename ST, typename BinsFn>
+__device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[NI of 128], LDS or global*/,
                                                 const float* w /*[R][stride]*/, int wstride, BinsFn bins,
                                                 int64_t* inds_out /*[R][128] or null*/, int64_t inds_stride, int tid,
                                                 int valid_rays, const float* u_rays = nullptr /* global [rays][128]: RH:211 */,
@@ -646,7 +649,7 @@ __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[12
     for (int i = 56; i < 62; ++i) { run = run + (double)st.om[r][i]; st.cdf[r][i + 1] = (float)run; }
   }
   __syncthreads();
-  if (tid < 128 * R) {
+  if (tid < 128 * R && (tid & 127) < NI) {
     const int r = tid >> 7, k = tid & 127;
     const float u = u_rays ? u_rays[(row0 + (r < valid_rays ? r : 0)) * 128 + k] : ufine[k];
     const float* cdf = st.cdf[r];
@@ -671,17 +674,18 @@ __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[12
 }
 
 // std(z_samples, unbiased=False) RN:495, fp64 two-pass; result valid in lane 0 of waves 0 / 1 (ray = wave).
-template <typename ST>
+template <int NI = 128, typename ST>
 __device__ __forceinline__ float zstd_wave(const ST& st, int r, int lane) {
-  double s = (double)st.zs[r][lane] + (double)st.zs[r][lane + 64];
+  const bool in0 = lane < NI, in1 = lane + 64 < NI;             // NI = 128: both, always
+  double s = (in0 ? (double)st.zs[r][lane] : 0.0) + (in1 ? (double)st.zs[r][lane + 64] : 0.0);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) s += shfl_xor_f64(s, m);
-  const double mean = s * (1.0 / 128.0);
-  const double d0 = (double)st.zs[r][lane] - mean, d1 = (double)st.zs[r][lane + 64] - mean;
+  const double mean = s * (1.0 / NI);
+  const double d0 = in0 ? (double)st.zs[r][lane] - mean : 0.0, d1 = in1 ? (double)st.zs[r][lane + 64] - mean : 0.0;
   double v = d0 * d0 + d1 * d1;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
-  return (float)sqrt(v * (1.0 / 128.0));
+  return (float)sqrt(v * (1.0 / NI));
 }
 
 // z_vals = sort(cat([z_coarse, z_samples])) RN:477, exact and stable: the rank of an element is the number of
@@ -691,13 +695,14 @@ __device__ __forceinline__ float zstd_wave(const ST& st, int r, int lane) {
 // half: ~25 VALU instructions instead of ~400, which matters because this code runs next to another workgroup's
 // MFMA stream ("Two waves per SIMD").  A workgroup-wide check picks the path; any inversion or NaN
 // falls back to the full rank count, so the result never depends on the sortedness assumption.
-template <int R = 2, typename ST>
+template <int R = 2, int NI = 128, typename ST>
 __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
+  constexpr int NF = 64 + NI;                        // merged depths per ray (the arrays keep their 192 / 128 strides)
   int bad = 0;
-  for (int e = tid; e < 192 * R; e += 256) {
-    const int r = e / 192, k = e - r * 192;
+  for (int e = tid; e < NF * R; e += 256) {
+    const int r = e / NF, k = e - r * NF;
     if (k < 63) bad |= !(st.zc[r][k] <= st.zc[r][k + 1]);
-    else if (k >= 64 && k < 191) bad |= !(st.zs[r][k - 64] <= st.zs[r][k - 63]);
+    else if (k >= 64 && k < NF - 1) bad |= !(st.zs[r][k - 64] <= st.zs[r][k - 63]);
   }
   // workgroup-wide OR through four LDS words (st.res is free here).  Not __syncthreads_or: its library implementation
   // rebuilds the flat thread id from threadIdx.y/z, which keeps two more VGPRs alive through the whole kernel.
@@ -708,15 +713,15 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
   const int any_bad = (orw[0] | orw[1]) | (orw[2] | orw[3]);
   __syncthreads();
   if (!any_bad) {
-    for (int e = tid; e < 192 * R; e += 256) {
-      const int r = e / 192, k = e - r * 192;
+    for (int e = tid; e < NF * R; e += 256) {
+      const int r = e / NF, k = e - r * NF;
       int rank;
       float x;
       if (k < 64) {                                  // own index + #(z_samples < x)
         x = st.zc[r][k];
         int lb = 0;
 #pragma unroll
-        for (int sft = 64; sft > 0; sft >>= 1) lb += (st.zs[r][lb + sft - 1] < x) ? sft : 0;
+        for (int sft = NI / 2; sft > 0; sft >>= 1) lb += (st.zs[r][lb + sft - 1] < x) ? sft : 0;
         lb += (st.zs[r][lb] < x) ? 1 : 0;
         rank = k + lb;
       } else {                                       // own index + #(z_coarse <= x)
@@ -727,22 +732,22 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
         ub += (st.zc[r][ub] <= x) ? 1 : 0;
         rank = (k - 64) + ub;
       }
-      st.zf[r][NSR_IDX(rank, 192)] = x;
+      st.zf[r][NSR_IDX(rank, NF)] = x;
     }
   } else {
-    for (int e = tid; e < 192 * R; e += 256) {
-      const int r = e / 192, k = e - r * 192;
+    for (int e = tid; e < NF * R; e += 256) {
+      const int r = e / NF, k = e - r * NF;
       const float x = (k < 64) ? st.zc[r][k] : st.zs[r][k - 64];
       int rank = 0;
       for (int j = 0; j < 64; ++j) {
         const float y = st.zc[r][j];
         rank += (y < x) || (y == x && j < k);
       }
-      for (int j = 0; j < 128; ++j) {
+      for (int j = 0; j < NI; ++j) {
         const float y = st.zs[r][j];
         rank += (y < x) || (y == x && (j + 64) < k);
       }
-      st.zf[r][NSR_IDX(rank, 192)] = x;
+      st.zf[r][NSR_IDX(rank, NF)] = x;
     }
   }
   __syncthreads();
@@ -908,9 +913,16 @@ __device__ __forceinline__ void range_report(const RenderArgs& a, int* ovf, long
 #define NSR_T(i) do { } while (0)
 #endif
 
-template <int MODE>
+// NI: importance samples per ray.  128 = the YCB-V configuration; 64 / 32 = kernels specialised to N_importance = 64 / 32
+// (RN:474: 64 + NI fine samples per ray, ceil(2 (64 + NI) / 128) = 2 fine passes per item instead of 3; a wave's 32 points
+// belong to one ray because 64 + NI is a multiple of 32; with NI = 32 the last two waves of the second pass have no points:
+// they run the pass on a repeated point -- the weight ring is consumed in lock-step -- and store nothing).
+template <int MODE, int NI = 128>
 __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap, char* smem) {
   constexpr bool B3 = MODE == kMlpB3;
+  constexpr int NF = 64 + NI;                              // fine samples per ray
+  constexpr int NP = (2 * NF + 127) / 128;                 // fine passes per item
+  static_assert(NF % 32 == 0 && NF <= 192, "a wave's points belong to one ray; the item state holds 192 samples per ray");
   const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -932,7 +944,8 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   int* ovf = (int*)&st.ray[1][14];                       // f16x2: [2] points with NaN network outputs, per ray of the current item
 
   Ring rg;
-  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 4 : 1, wave, lane);
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 1 + NP : 1, wave, lane);
+  rg.pn1 = 1 + NP;
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
@@ -940,7 +953,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
-  if (tid0 < 128) st.ufine[tid0] = a_setup.ufine[tid0];
+  if (tid0 < NI) st.ufine[tid0] = a_setup.ufine[tid0];
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
 
@@ -954,7 +967,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
     return v;
   };
   long long packed = next_item();
-  int pass = 0;              // 0 = coarse pass, 1..3 = fine passes of the current item
+  int pass = 0;              // 0 = coarse pass, 1..NP = fine passes of the current item
 #pragma unroll 1
   while (packed != -1ll) {
     const long long item = packed & kItemMask;
@@ -1005,17 +1018,19 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 
     // ---- one network pass: 128 points -------------------------------------------------------------
     //   coarse: wave w -> ray w>>1, samples 32*(w&1) + j              (RN:463-466)
-    //   fine p: point q = 128(p-1) + 32w + j -> ray q/192, sample q%192 (RN:478-483)
+    //   fine p: point q = 128(p-1) + 32w + j -> ray q/NF, sample q%NF (RN:478-483)
     {
       int r, i;
       const float* zsrc;
       float* dst;
+      bool real = true;                                    // (NI = 32: the second pass has points for two waves only)
       if (pass == 0) {
         r = wave >> 1; i = 32 * (wave & 1) + j;
         zsrc = &st.zc[r][i]; dst = st.rawc[r][i];
       } else {
-        const int q0 = 128 * (pass - 1) + 32 * wave;
-        r = q0 / 192; i = q0 - r * 192 + j;
+        int q0 = 128 * (pass - 1) + 32 * wave;
+        if (2 * NF % 128 != 0 && q0 >= 2 * NF) { q0 = 2 * NF - 32; real = false; }
+        r = q0 / NF; i = q0 - r * NF + j;
         zsrc = &st.zf[r][i]; dst = st.rawf[r][i];
       }
       const float z = *zsrc;
@@ -1023,8 +1038,8 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       float raw[4];
       mlp_pass<false, MODE>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, nullptr, 0, NSR_TPASS);
-      if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
-      if constexpr (MODE == kMlpH2) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
+      if (lane < 32 && real) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
+      if constexpr (MODE == kMlpH2) { if (real) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane); }
     }
     NSR_T(1);
 
@@ -1062,31 +1077,34 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 #else
       int64_t* inds = (int64_t*)a.dbg_inds;
 #endif
-      sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
-                      [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
-                      inds ? inds + ray0 * 128 : nullptr, 128, tid, valid, a.u_rays, ray0, wmask);
+      sample_pdf_item<2, NI>(st, st.ufine, &st.w0[0][1], 64,
+                             [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
+                             inds ? inds + ray0 * NI : nullptr, NI, tid, valid, a.u_rays, ray0, wmask);
       NSR_T(3);
       if (wave < 2) {
-        const float sd = zstd_wave(st, wave, lane);
+        const float sd = zstd_wave<NI>(st, wave, lane);
         if (lane == 0 && wr(wave) && a.z_std) a.z_std[ray0 + wave] = sd;
       }
       if (a.dbg_zs)
-        for (int idx = tid; idx < 2 * 128; idx += 256) if (wr(idx >> 7)) a.dbg_zs[ray0 * 128 + idx] = (&st.zs[0][0])[idx];
+        for (int idx = tid; idx < 2 * 128; idx += 256)      // st.zs rows are 128 apart, the tap's NI
+          if (wr(idx >> 7) && (idx & 127) < NI) a.dbg_zs[(ray0 + (idx >> 7)) * NI + (idx & 127)] = (&st.zs[0][0])[idx];
       NSR_T(4);
-      merge_sort_item(st, tid);
+      merge_sort_item<2, NI>(st, tid);
       if (a.dbg_zf)
-        for (int idx = tid; idx < 2 * 192; idx += 256) if (wr(idx / 192)) a.dbg_zf[ray0 * 192 + idx] = (&st.zf[0][0])[idx];
+        for (int idx = tid; idx < 2 * 192; idx += 256)      // st.zf rows are 192 apart, the tap's NF
+          if (wr(idx / 192) && idx % 192 < NF) a.dbg_zf[(ray0 + idx / 192) * NF + idx % 192] = (&st.zf[0][0])[idx];
       NSR_T(5);
       pass = 1;
-    } else if (pass < 3) {
+    } else if (pass < NP) {
       ++pass;
     } else {
       __syncthreads();
       if (a.dbg_raw) {
-        for (int idx = tid; idx < 2 * 768; idx += 256) if (wr(idx / 768)) a.dbg_raw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
+        for (int idx = tid; idx < 2 * 768; idx += 256)      // st.rawf rows are 192 x 4 apart, the tap's NF x 4
+          if (wr(idx / 768) && idx % 768 < NF * 4) a.dbg_raw[(ray0 + idx / 768) * (NF * 4) + idx % 768] = (&st.rawf[0][0][0])[idx];
         __syncthreads();
       }
-      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
+      composite<NF, 2, 192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
       if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1125,6 +1143,24 @@ __global__ void __launch_bounds__(256, 1) k_render_b3(const RenderArgs* __restri
 __global__ void __launch_bounds__(256, 1) k_render_h2(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render32_body<kMlpH2>(ap, smem);
+}
+// N_importance = 64 / 32 (RN:474), evaluated at their own 64 + 64 / 64 + 32 fine samples per ray: two fine passes per item
+// instead of three.  f16x2 handles, and the fp32 kernels their range safety net falls back to.
+__global__ void __launch_bounds__(256, 1) k_render_h2_n64(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<kMlpH2, 64>(ap, smem);
+}
+__global__ void __launch_bounds__(256, 1) k_render_h2_n32(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<kMlpH2, 32>(ap, smem);
+}
+__global__ void __launch_bounds__(256, 1) k_render_n64(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<kMlpF32, 64>(ap, smem);
+}
+__global__ void __launch_bounds__(256, 1) k_render_n32(const RenderArgs* __restrict__ ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render32_body<kMlpF32, 32>(ap, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1316,8 +1352,8 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
 // st.rawf holds sigmoid(rgb) and the raw sigma, st.alpha / st.wf / st.tf the forward alpha, weights, T.
 //   dL/dw_i = g . c_i ;  dL/dalpha_i = A_i T_i - (sum_{k>i} A_k w_k) / (1 - alpha_i + 1e-10)
 // Only the suffix sum is serial (one lane per ray, fp32, 8 terms per LDS round trip).
+template <int S = 192>
 __device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /* [2][3] in LDS */, int tid) {
-  constexpr int S = 192;
   float* aw = &st.bwd_scratch[0][0][0];   // [2][S] A_i * w_i, then the exclusive suffix sums
   float* at = aw + 2 * S;                 // [2][S] A_i * T_i
   for (int idx = tid; idx < 2 * S; idx += 256) {
@@ -1400,9 +1436,12 @@ __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) {
 //   pass 4-6    fine backward through the transposed network -> dL/d pts, dL/d viewdir per sample
 //   --          per-ray reduction: dL/d rays_o, dL/d rays_d
 // ------------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int NI = 128>
 __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp, char* smem) {
   constexpr bool B3 = MODE == kMlpB3;
+  constexpr int NF = 64 + NI;                              // fine samples per ray (see render32_body)
+  constexpr int NP = (2 * NF + 127) / 128;                 // fine passes per item, forward and again backward
+  static_assert(NF % 32 == 0 && NF <= 192, "a wave's points belong to one ray; the item state holds 192 samples per ray");
   const VjpArgs& va_setup = *vp;
   const RenderArgs& a_setup = va_setup.r;
   const int tid0 = threadIdx.x;
@@ -1416,7 +1455,8 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
   int* ovf = (int*)&st.ray[1][14];                       // f16x2: [2] points with NaN outputs / gradients, per ray of the item
 
   Ring rg;
-  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 7, wave, lane);
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1 + 2 * NP, wave, lane);
+  rg.pn1 = 1 + NP;
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
@@ -1424,7 +1464,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
   else ring_start(rg, A0, lane);
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
-  if (tid0 < 128) st.ufine[tid0] = a_setup.ufine[tid0];
+  if (tid0 < NI) st.ufine[tid0] = a_setup.ufine[tid0];
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
   const float* aux_f = aux_c + kAuxFloats;
@@ -1482,17 +1522,19 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);
     }
 
-    if (pass <= 3) {
-      // ---- forward passes (coarse, then 3 fine with relu capture) ----
+    if (pass <= NP) {
+      // ---- forward passes (coarse, then NP fine with relu capture) ----
       int r, i;
       const float* zsrc;
       float* dst;
+      bool real = true;
       if (pass == 0) {
         r = wave >> 1; i = 32 * (wave & 1) + j;
         zsrc = &st.zc[r][i]; dst = st.rawc[r][i];
       } else {
-        const int q0 = 128 * (pass - 1) + 32 * wave;
-        r = q0 / 192; i = q0 - r * 192 + j;
+        int q0 = 128 * (pass - 1) + 32 * wave;
+        if (2 * NF % 128 != 0 && q0 >= 2 * NF) { q0 = 2 * NF - 32; real = false; }
+        r = q0 / NF; i = q0 - r * NF + j;
         zsrc = &st.zf[r][i]; dst = st.rawf[r][i];
       }
       const float z = *zsrc;
@@ -1500,22 +1542,24 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       float raw[4];
       mlp_pass<true, MODE>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                          ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
-      if (lane < 32) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
-      if constexpr (MODE == kMlpH2) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane);
+      if (lane < 32 && real) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
+      if constexpr (MODE == kMlpH2) { if (real) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane); }
     } else {
-      // ---- backward passes: same point mapping as the fine forward pass p = pass-4 ----
-      const int q0 = 128 * (pass - 4) + 32 * wave;
-      const int r = q0 / 192, slot = (q0 - r * 192) >> 5, i = q0 - r * 192 + j;
+      // ---- backward passes: same point mapping as the fine forward pass p = pass - (NP + 1) ----
+      int q0 = 128 * (pass - (NP + 1)) + 32 * wave;
+      bool real = true;
+      if (2 * NF % 128 != 0 && q0 >= 2 * NF) { q0 = 2 * NF - 32; real = false; }
+      const int r = q0 / NF, slot = (q0 - r * NF) >> 5, i = q0 - r * NF + j;
       const float z = st.zf[r][i];
       const float* ry = st.ray[r];
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
-      mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - 4) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
+      mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - (NP + 1)) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
                        ry, &st.zf[r][i - j], dp, dv);
-      if constexpr (MODE == kMlpH2) range_mark(ovf + r, dp[0] + dv[0], lane);
+      if constexpr (MODE == kMlpH2) { if (real) range_mark(ovf + r, dp[0] + dv[0], lane); }
       if (float* gp = opaque_s(vp)->dbg_gpts) {            // debug tap: the per-sample results of the network backward
-        if (lane < 32 && wr(r)) {
-          float* q = gp + ((ray0 + r) * 192 + i) * 6;
+        if (lane < 32 && wr(r) && real) {
+          float* q = gp + ((ray0 + r) * NF + i) * 6;
           q[0] = dp[0]; q[1] = dp[1]; q[2] = dp[2]; q[3] = dv[0]; q[4] = dv[1]; q[5] = dv[2];
         }
       }
@@ -1525,7 +1569,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       for (int m = 16; m >= 1; m >>= 1)
 #pragma unroll
         for (int c = 0; c < 9; ++c) red[c] += __shfl_xor(red[c], m);
-      if (lane == 0)
+      if (lane == 0 && real)
 #pragma unroll
         for (int c = 0; c < 9; ++c) st.psum[r][slot][c] = red[c];
     }
@@ -1537,23 +1581,23 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       __syncthreads();
       composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
       int64_t* none = nullptr;
-      sample_pdf_item(st, st.ufine, &st.w0[0][1], 64,
-                      [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, 128, tid, valid,
-                      a.u_rays, ray0);
-      merge_sort_item(st, tid);
+      sample_pdf_item<2, NI>(st, st.ufine, &st.w0[0][1], 64,
+                             [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, NI, tid, valid,
+                             a.u_rays, ray0);
+      merge_sort_item<2, NI>(st, tid);
       if (va.z_fine) {                                       // caller-supplied depths replace the resampled ones
-        for (int idx = tid; idx < 2 * 192; idx += 256) {
-          const int r = idx / 192, k = idx - r * 192;
-          st.zf[r][k] = va.z_fine[(ray0 + (r < valid ? r : 0)) * 192 + k];
+        for (int idx = tid; idx < 2 * NF; idx += 256) {
+          const int r = idx / NF, k = idx - r * NF;
+          st.zf[r][k] = va.z_fine[(ray0 + (r < valid ? r : 0)) * NF + k];
         }
         __syncthreads();
       }
       pass = 1;
-    } else if (pass < 3) {
+    } else if (pass < NP) {
       ++pass;
-    } else if (pass == 3) {
+    } else if (pass == NP) {
       __syncthreads();
-      composite<192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
+      composite<NF, 2, 192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
       if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1568,18 +1612,19 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         grgb[tid] = va.grad_rgb[(ray0 + (r < valid ? r : 0)) * 3 + (tid - r * 3)];
       }
       __syncthreads();
-      composite_bwd(st, grgb, tid);
+      composite_bwd<NF>(st, grgb, tid);
       if (va.dbg_graw)                                     // debug tap: dL/d raw as the network backward receives it
-        for (int idx = tid; idx < 2 * 768; idx += 256) if (wr(idx / 768)) va.dbg_graw[ray0 * 768 + idx] = (&st.rawf[0][0][0])[idx];
-      pass = 4;
-    } else if (pass < 6) {
+        for (int idx = tid; idx < 2 * 768; idx += 256)
+          if (wr(idx / 768) && idx % 768 < NF * 4) va.dbg_graw[(ray0 + idx / 768) * (NF * 4) + idx % 768] = (&st.rawf[0][0][0])[idx];
+      pass = NP + 1;
+    } else if (pass < 2 * NP) {
       ++pass;
     } else {
       __syncthreads();
       if (tid < 2 && wr(tid)) {
         const int r = tid;
         float so[3] = {0, 0, 0}, sd[3] = {0, 0, 0}, sv[3] = {0, 0, 0};
-        for (int s = 0; s < 6; ++s)
+        for (int s = 0; s < NF / 32; ++s)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
             so[c] += st.psum[r][s][c];
@@ -1607,8 +1652,8 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         }
       }
       if (va.dbg_masks && wmask == (valid == 2 ? 3 : 1))   // debug tap: the relu patterns of this item's three fine passes (the
-        for (int k = 0; k < 27; ++k)                       // fallback launch rewrites them only when it owns the whole item)
-          va.dbg_masks[((size_t)item * 27 + k) * 256 + tid] = my_masks[k * 256 + tid];
+        for (int k = 0; k < 9 * NP; ++k)                   // fallback launch rewrites them only when it owns the whole item)
+          va.dbg_masks[((size_t)item * (9 * NP) + k) * 256 + tid] = my_masks[k * 256 + tid];
       if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
       __syncthreads();
       pass = 0;
@@ -1631,6 +1676,23 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp_b3(const VjpArgs* __restr
 __global__ void __launch_bounds__(256, 1) k_render_vjp_h2(const VjpArgs* __restrict__ vp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render_vjp32_body<kMlpH2>(vp, smem);
+}
+// N_importance = 64 / 32 (see k_render_h2_n64): two fine forward + two backward passes per item instead of three + three
+__global__ void __launch_bounds__(256, 1) k_render_vjp_h2_n64(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<kMlpH2, 64>(vp, smem);
+}
+__global__ void __launch_bounds__(256, 1) k_render_vjp_h2_n32(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<kMlpH2, 32>(vp, smem);
+}
+__global__ void __launch_bounds__(256, 1) k_render_vjp_n64(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<kMlpF32, 64>(vp, smem);
+}
+__global__ void __launch_bounds__(256, 1) k_render_vjp_n32(const VjpArgs* __restrict__ vp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  render_vjp32_body<kMlpF32, 32>(vp, smem);
 }
 
 // dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):

@@ -28,7 +28,7 @@ DEFAULT_MLP = "f16x2"
 MLP_MODES = ("fp32", "bf16x3", "f16x2")
 
 
-def _host_tables(n_importance=N_IMPORTANCE):
+def _host_tables(n_importance=N_IMPORTANCE, native=False):
     """The reference builds both linspace tables on the HOST and moves them (RN:439, RH:208); torch's CPU
     linspace is not bit-equal to numpy's, so the same call is made here.
     n_importance < 128 (a divisor of 128): the kernels always draw 128 importance samples, from the 128 uniforms of this
@@ -37,13 +37,20 @@ def _host_tables(n_importance=N_IMPORTANCE):
     transmittance moves by the 1e-10 of RN:376 only), and every value being repeated equally often leaves
     std(z_samples) (RN:495) what it was.  The render is the reference's N_importance = n render to 2.4e-7
     (tests/test_oracle_golden.py::test_fewer_importance_samples_by_duplicated_uniforms), at the price of all 192 fine
-    evaluations."""
+    evaluations.
+    native: the handle's kernels are specialised to n_importance (f16x2 handles, 64 and 32: NATIVE_IMPORTANCE) -- 64 + n fine
+    evaluations per ray, two network passes per item instead of three; the table is the reference's linspace itself."""
     n = n_importance if n_importance else N_IMPORTANCE
-    u = torch.linspace(0., 1., steps=n).repeat_interleave(N_IMPORTANCE // n)
+    u = torch.linspace(0., 1., steps=n)
+    if native:                 # a kernel specialised to n importance samples reads the first n entries
+        u = torch.cat([u, torch.zeros(N_IMPORTANCE - n)])
+    else:
+        u = u.repeat_interleave(N_IMPORTANCE // n)
     return torch.linspace(0., 1., steps=N_SAMPLES).numpy().astype(np.float32), u.numpy().astype(np.float32)
 
 
 IMPORTANCE_COUNTS = (0, 1, 2, 4, 8, 16, 32, 64, 128)       # 0 = coarse only; the divisors of the kernels' 128
+NATIVE_IMPORTANCE = (64, 32)       # f16x2 handles: kernels specialised to these counts (k_render_h2_n64 / _n32 and their VJPs)
 
 
 def _fptr(a):
@@ -102,11 +109,16 @@ class NsrModel:
         if n_importance > 0 and sd_fine is None:
             sd_fine = sd_coarse          # RN:482: run_fn = network_fn if network_fine is None
         self.n_importance = n_importance
+        # importance samples per ray of the KERNELS this handle runs: n_importance itself where they are specialised to it
+        # (f16x2, 64 / 32: 0.75x the time of 128), else 128 with duplicated uniforms (_host_tables); 0 = coarse only
+        native = mlp == "f16x2" and n_importance in NATIVE_IMPORTANCE
+        self.ni_kernel = n_importance if (native or n_importance == 0) else N_IMPORTANCE
+        self.nf_kernel = N_SAMPLES + self.ni_kernel
         if variant not in (0, 16, 32):
             raise NotImplementedError("variant must be 0 (library default), 16 or 32")
         self.variant = variant
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
-        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, N_IMPORTANCE if n_importance else 0, max_workgroups, variant,
+        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, self.ni_kernel, max_workgroups, variant,
                              (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0)
                              | (8 if mlp == "bf16x3" else 0) | (16 if mlp == "f16x2" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
@@ -117,7 +129,7 @@ class NsrModel:
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.upload(sd_coarse, sd_fine)
-        t, u = _host_tables(n_importance)
+        t, u = _host_tables(n_importance, native)
         _lib.check(self.lib.nsr_upload_tables(self.h, _fptr(t), 64, _fptr(u), 128))
 
     def upload(self, sd_coarse, sd_fine=None):
@@ -188,8 +200,9 @@ class NsrModel:
         if debug:
             d = dict(weights0=self._new(n, 64), raw0=self._new(n, 64, 4))
             if fine:
-                d.update(z_samples=self._new(n, 128), inds=self._new(n, 128, dtype=torch.int64),
-                         z_fine=self._new(n, 192), raw=self._new(n, 192, 4))
+                ni, nf = self.ni_kernel, self.nf_kernel
+                d.update(z_samples=self._new(n, ni), inds=self._new(n, ni, dtype=torch.int64),
+                         z_fine=self._new(n, nf), raw=self._new(n, nf, 4))
             o.update(d)
             dbg = _lib.NsrDebugOut(_dev(d["weights0"]), _dev(d.get("z_samples")), _dev(d.get("inds")),
                                    _dev(d.get("z_fine")), _dev(d["raw0"]), _dev(d.get("raw")))
@@ -206,7 +219,8 @@ class NsrModel:
         unknown = set(extras) - set(self.EXTRA_WIDTHS)
         if unknown:
             raise ValueError("unknown ray extras: %s" % sorted(unknown))
-        keep = {k: self._f32(v, (n, self.EXTRA_WIDTHS[k])) for k, v in extras.items() if v is not None}
+        widths = dict(self.EXTRA_WIDTHS, noise1=self.nf_kernel)      # (u keeps its row stride of 128: the first ni_kernel are read)
+        keep = {k: self._f32(v, (n, widths[k])) for k, v in extras.items() if v is not None}
         if ("near" in keep) != ("far" in keep):
             raise ValueError("per-ray bounds: near and far come together")
         ex = _lib.NsrRayExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "t_rand", "u", "noise0", "noise1", "near", "far")])
@@ -272,7 +286,7 @@ class NsrModel:
         debug: append a dict with the taps of include/nsr.h: NsrVjpDebugOut (relu_masks uint32 [ceil(N/2),3,9,256,4],
         grad_raw [N,192,4], grad_pts [N,192,6]) -- served by the x32-structured kernels."""
         if self.n_importance == 0:
-            raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance=128)")
+            raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance > 0)")
         has_extras = bool(extras) and any(v is not None for v in extras.values())
         need32 = ((has_extras or debug) and self.mlp == "fp32" and self.variant != 32) or self.mlp == "f16x2"
         if need32 and not self._bwd32_ready:
@@ -300,7 +314,7 @@ class NsrModel:
         n = rays_o.shape[0]
         self.rays_launched += n
         g = self._f32(grad_rgb, (n, 3))
-        zf = self._f32(z_fine, (n, 192)) if z_fine is not None else None
+        zf = self._f32(z_fine, (n, self.nf_kernel)) if z_fine is not None else None
         go, gd = self._new(n, 3), self._new(n, 3)
         ro, fwd = None, None
         if with_forward:
@@ -311,8 +325,9 @@ class NsrModel:
         gv = self._new(n, 3) if (keep and "viewdirs" in keep) else None
         taps, dbg = None, None
         if debug:
-            taps = dict(relu_masks=torch.zeros(((n + 1) // 2, 3, 9, 256, 4), dtype=torch.int32, device=self.device),
-                        grad_raw=self._new(n, 192, 4), grad_pts=self._new(n, 192, 6))
+            nf = self.nf_kernel
+            taps = dict(relu_masks=torch.zeros(((n + 1) // 2, (2 * nf + 127) // 128, 9, 256, 4), dtype=torch.int32, device=self.device),
+                        grad_raw=self._new(n, nf, 4), grad_pts=self._new(n, nf, 6))
             dbg = _lib.NsrVjpDebugOut(_dev(taps["relu_masks"]), _dev(taps["grad_raw"]), _dev(taps["grad_pts"]))
         _lib.check(self.lib.nsr_render_rays_vjp_dbg(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
                                                     C.byref(ex) if ex else None, _dev(g), _dev(go), _dev(gd), _dev(gv),

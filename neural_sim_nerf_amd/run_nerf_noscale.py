@@ -216,14 +216,23 @@ class _NdcRays(torch.autograd.Function):
         return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None, None
 
 
-def _draws(kw, n, n_importance, dev, chunk=None):
+def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128):
     """The random draws of the stochastic options, in the reference's order within one chunk of rays: t_rand (RN:451),
     the coarse density noise (RN:368), the resampling uniforms (RH:211), the fine density noise.  From torch's generator
     of the render device: the reference's stream is reproduced when it, too, renders all N rays as ONE chunk on that
     device; for pinned comparisons hand the reference's own draws to NsrModel.render_rays(extras=...).
     pytest=True (the reference's test hook, RN:454-457, RH:214-222): every draw site reseeds numpy's GLOBAL generator
     with 0 and takes its numbers from it -- once per `chunk` of rays, so ray i gets row i mod chunk -- and the
-    deterministic resampling uses NUMPY's linspace (a few ulp from torch's); reproduced exactly, side effect included."""
+    deterministic resampling uses NUMPY's linspace (a few ulp from torch's); reproduced exactly, side effect included.
+    ni_kernel: importance samples per ray of the handle's kernels (NsrModel.ni_kernel): n_importance itself where they are
+    specialised to it -- a row of u then holds the n draws followed by padding, the fine noise has 64 + n columns -- else 128
+    with every draw repeated 128 / n times."""
+    native = n_importance > 0 and ni_kernel == n_importance and n_importance != 128
+
+    def widen(u):               # [.., n_importance] -> the [.., 128] row the kernels read
+        if native:
+            return torch.nn.functional.pad(u, (0, 128 - n_importance))
+        return u.repeat_interleave(128 // n_importance, dim=-1)
     perturb = kw.get("perturb", 0.)
     perturbed = perturb not in (0, 0., False) and perturb > 0.
     std = float(kw.get("raw_noise_std", 0.) or 0.)
@@ -234,8 +243,6 @@ def _draws(kw, n, n_importance, dev, chunk=None):
                                       "calls .cuda() on a numpy array)")
         c = n if not chunk else max(1, min(int(chunk), n))
         rows = torch.arange(n) % c
-        rep = 128 // n_importance if n_importance else 1
-
         def seeded(width):
             np.random.seed(0)
             return torch.Tensor(np.random.rand(c, width))[rows]
@@ -243,10 +250,10 @@ def _draws(kw, n, n_importance, dev, chunk=None):
             d["t_rand"] = seeded(64).to(dev)
         if n_importance > 0:
             if perturbed:
-                d["u"] = seeded(n_importance).repeat_interleave(rep, dim=1).to(dev)
+                d["u"] = widen(seeded(n_importance)).to(dev)
             else:
                 np.random.seed(0)                           # RH:216 reseeds on the deterministic branch too
-                u = torch.Tensor(np.linspace(0., 1., n_importance)).repeat_interleave(rep)
+                u = widen(torch.Tensor(np.linspace(0., 1., n_importance)))
                 d["u"] = u[None].expand(n, 128).contiguous().to(dev)
         return d
     if perturbed:
@@ -255,9 +262,9 @@ def _draws(kw, n, n_importance, dev, chunk=None):
         d["noise0"] = torch.randn(n, 64, device=dev) * std
     if n_importance > 0:
         if "t_rand" in d:                                   # det = (perturb == 0.), RN:474; fewer than 128: duplicated, as
-            d["u"] = torch.rand(n, n_importance, device=dev).repeat_interleave(128 // n_importance, dim=1)   # engine._host_tables
+            d["u"] = widen(torch.rand(n, n_importance, device=dev))                      # engine._host_tables
         if std > 0.:
-            d["noise1"] = torch.randn(n, 192, device=dev) * std
+            d["noise1"] = torch.randn(n, 64 + ni_kernel, device=dev) * std
     return d
 
 
@@ -308,9 +315,12 @@ def _check_kwargs(kw):
     from .engine import IMPORTANCE_COUNTS
     if kw.get("N_importance", 0) not in IMPORTANCE_COUNTS:
         bad.append("N_importance=%r (128, 0, or a divisor of 128)" % kw.get("N_importance"))
-    if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128):
-        bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4])"
-                   % kw.get("N_importance"))
+    from .engine import NATIVE_IMPORTANCE, DEFAULT_MLP
+    native = (os.environ.get("NSR_MLP", DEFAULT_MLP) == "f16x2" and kw.get("N_importance", 0) in NATIVE_IMPORTANCE
+              and not (kw.get("network_fn") is not None and kw["network_fn"].__dict__.get("_nsr_force_mlp")))
+    if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128) and not native:
+        bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4]; the f16x2 "
+                   "kernels are specialised to N_importance 64 and 32 and return the reference's raw there)" % kw.get("N_importance"))
     net = kw.get("network_fine") if kw.get("N_importance", 0) > 0 and kw.get("network_fine") is not None else kw.get("network_fn")
     if kw.get("retraw", False) and not getattr(net, "use_viewdirs", True) and getattr(net, "output_ch", 4) != 4:
         bad.append("retraw with a use_viewdirs=False network of output_ch=%r (the reference's raw is [N,S,%r]: RN:267, RH:119-120; "
@@ -367,7 +377,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
         ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]), 1.0)
     if special:
-        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk)
+        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk, model.ni_kernel)
         if per_ray_bounds:                                  # one bound per ray (the reference multiplies them into [N,1])
             for k, v in (("near", near), ("far", far)):
                 t = torch.as_tensor(v, dtype=torch.float32).to(model.device).reshape(-1)

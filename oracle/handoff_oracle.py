@@ -23,7 +23,10 @@ to8b and the PNG round trip are pinned (numpy semantics; PNG files against image
 writes and reads them with -- via tests/golden/io_*.png, oracle/gen_io_golden.py).  connected_components_with_stats is
 pinned to a second implementation of the same documented contract: scikit-image 0.18.3 measure.label(connectivity=2) +
 regionprops on 24 masks (tests/golden/g12_io.npz, tests/test_data_readers.py).  What stays a restated formula is the
-8-bit RGB2GRAY fixed-point conversion: nothing in this image implements OpenCV's.
+8-bit RGB2GRAY fixed-point conversion: nothing in this image implements OpenCV's.  It is unpinned AND shown not to matter:
+the reference only thresholds the grey image at > 1 (NM:795), and over all 2^24 colours the restated formula, OpenCV 3.x's
+14-bit variant and the float formula under either rounding rule give the same mask bit
+(tests/test_handoff.py::test_mask_is_insensitive_to_the_unpinned_gray_arithmetic), hence the same components and boxes.
 """
 import numpy as np
 from scipy import ndimage

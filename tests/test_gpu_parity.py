@@ -539,16 +539,22 @@ def test_fewer_importance_samples(oracle, synth_nets):
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     ro, rd = g["rays_o"], g["rays_d"]
     vd = oracle.normalize_dirs(rd)
-    for ni, mlp in ((64, "f16x2"), (32, "fp32")):
+    # f16x2 handles run kernels SPECIALISED to 64 / 32 importance samples (64 + n fine evaluations per ray: r04); fp32 handles
+    # the 128-sample kernels on a uniforms table with every value repeated
+    for ni, mlp in ((64, "f16x2"), (32, "f16x2"), (64, "fp32"), (32, "fp32")):
         m = NsrModel(synth_nets[0], synth_nets[1], n_importance=ni, mlp=mlp)
         try:
             r = m.render_rays(ro, rd, near, far, debug=True)
             zs = cpu(r["z_samples"])
-            assert np.array_equal(zs[:, ::128 // ni], zs[:, 128 // ni - 1::128 // ni])           # exact duplicates
+            assert zs.shape[1] == (ni if mlp == "f16x2" else 128) == m.ni_kernel and cpu(r["z_fine"]).shape[1] == 64 + m.ni_kernel
+            rep = zs.shape[1] // ni
+            assert np.array_equal(zs[:, ::rep], zs[:, rep - 1::rep])                               # exact duplicates (rep > 1)
             z = oracle.coarse_z(np.full(len(ro), near, np.float32), np.full(len(ro), far, np.float32))
             z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
             s, inds, _ = oracle.sample_pdf(z_mid, cpu(r["weights0"])[:, 1:-1], ni)
-            assert np.array_equal(zs[:, ::128 // ni], s) and np.array_equal(cpu(r["inds"])[:, ::128 // ni], inds)
+            assert np.array_equal(zs[:, ::rep], s) and np.array_equal(cpu(r["inds"])[:, ::rep], inds)
+            if rep == 1:                                                                           # the reference's own arrays
+                assert np.array_equal(cpu(r["z_fine"]), np.sort(np.concatenate([z, s], -1), -1))
             # the oracle's ni-sample fine pass at the kernel's distinct depths
             zf = np.sort(np.concatenate([z, s], -1), -1)
             pts = (ro[:, None, :] + rd[:, None, :] * zf[:, :, None]).astype(np.float32)
@@ -559,14 +565,15 @@ def test_fewer_importance_samples(oracle, synth_nets):
             if ni == 64:
                 assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
                 _census_vs_oracle(oracle, synth_nets, r, ro, rd, near, far, n_importance=64, reference_rgb=g["rgb"])
-                assert_close(cpu(r["z_std"]), g["z_std"], atol=2e-3, what="z_std vs reference")
-                # gradient at the reference's depths: its 128 sorted depths with the 64 samples doubled
-                zf_ref = np.sort(np.concatenate([z, g["z_samples"], g["z_samples"]], -1), -1)
+                assert_close(cpu(r["z_std"]), g["z_std"], atol=2e-3, what="z_std vs reference")      # (a few rays resample differently)
+                # gradient at the reference's depths: its 128 sorted depths (with the 64 samples doubled for the 192-sample kernels)
+                zf_ref = np.sort(np.concatenate([z] + [g["z_samples"]] * rep, -1), -1)
                 go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf_ref)
                 for a, b in ((cpu(go), g["grad_rays"][0]), (cpu(gd), g["grad_rays"][1])):
                     e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
                     assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (np.percentile(e, 90), e.max())
-                want = cpu(r["rgb_map"])
+                if mlp == "f16x2":
+                    want, want_raw = cpu(r["rgb_map"]), cpu(r["raw"])
         finally:
             m.close()
     import neural_sim_nerf_amd.run_nerf_noscale as R
@@ -580,8 +587,11 @@ def test_fewer_importance_samples(oracle, synth_nets):
               near=near, far=far)
     rgb = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), **kw)[0]
     assert np.array_equal(cpu(rgb), want, equal_nan=True)
+    # retraw: the specialised kernels return the reference's [N, 64 + 64, 4] raw; 16 (duplicated samples) still refuses
+    raw = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **kw)[3]["raw"]
+    assert tuple(raw.shape) == (len(ro), 128, 4) and np.array_equal(cpu(raw), want_raw)
     with pytest.raises(NotImplementedError, match="retraw"):
-        R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **kw)
+        R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **dict(kw, N_importance=16))
     with pytest.raises(NotImplementedError, match="N_importance"):
         R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), **dict(kw, N_importance=100))
     for n in nets:

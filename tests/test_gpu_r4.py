@@ -378,3 +378,36 @@ def test_render_path_grad_full_size(synth_nets, oracle, tmp_path):
         # 512-ray patch sums cancel: bound by the largest component (VJP itself: 2e-4 relative Frobenius)
         assert np.abs(got[p] - want).max() < 2e-3 * np.abs(want).max(), (p, got[p], want)
     m.close()
+
+
+def test_native_importance_counts_cost_three_quarters(synth_nets, oracle):
+    """N_importance = 64 / 32 on the default (f16x2) handle evaluates 64 + n fine samples per ray -- 1 coarse + 2
+    fine network passes per item instead of 1 + 3 -- so a full view costs 3/4 of the 128-sample view (r03: the full price),
+    forward and input gradient; and it is the reference's render (the census of test_fewer_importance_samples)."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.YCBV_K
+    pose = np.asarray(oracle.sweep_poses(1, seed=21))[0]
+    ms, ms_vjp = {}, {}
+    cot = np.random.RandomState(1).standard_normal((160000, 3)).astype(np.float32)
+    for ni in (128, 64, 32):
+        m = NsrModel(synth_nets[0], synth_nets[1], n_importance=ni)
+        assert m.mlp == "f16x2" and m.ni_kernel == ni
+        t = []
+        for _ in range(4):
+            out = m.render_views(pose, 400, 400, K, near, far)
+            t.append(m.last_kernel_ms())
+        ms[ni] = float(np.median(t[1:]))
+        assert np.isfinite(cpu(out["rgb_map"])).all() and m.range_status()["points"] == 0
+        ro, rd = m.get_rays(400, 400, K, pose)
+        t = []
+        for _ in range(3):
+            go, gd = m.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, cot)
+            t.append(m.last_kernel_ms())
+        ms_vjp[ni] = float(np.median(t[1:]))
+        assert np.isfinite(cpu(gd)).all()
+        m.close()
+    print("kernel ms per 400x400 view by N_importance: forward %s, forward + input gradient %s" % (ms, ms_vjp))
+    for ni in (64, 32):
+        assert 0.70 <= ms[ni] / ms[128] <= 0.79, ms                     # 3 of 4 passes (+ the per-ray phases, which shrink too)
+        assert 0.64 <= ms_vjp[ni] / ms_vjp[128] <= 0.76, ms_vjp          # 5 of 7 passes

@@ -60,6 +60,31 @@ def test_oracle_gray_formula():
     assert list(HO.mask_as_reference(px)[0]) == [255, 0, 0, 255, 255, 255, 255]      # gray > 1
 
 
+def test_mask_is_insensitive_to_the_unpinned_gray_arithmetic():
+    """f-3's one unpinned piece is cv2's 8-bit RGB2GRAY arithmetic (opencv-python is an un-pinned requirement and is not
+    installable here).  The reference only ever looks at `gray > 1` (cv2.threshold(gray, 1, 255, THRESH_BINARY), NM:795), so
+    what matters is on which side of 1.5 a colour's luma falls.  EXHAUSTIVELY over all 2^24 colours: the restated OpenCV 4.x
+    fixed-point formula (15-bit coefficients, +2^14, >> 15), OpenCV 3.x's (14-bit, +2^13, >> 14), and the textbook float
+    formula 0.299 c0 + 0.587 c1 + 0.114 c2 in float64 and float32 with round-half-even and with round-half-up give grey
+    values that differ on tens of thousands of colours -- and the SAME mask bit on every one of them.  So no image exists
+    on which any of these cv2 candidates would produce another mask, component set or box than the oracle's."""
+    v = np.arange(256, dtype=np.int64)
+    c0, c1, c2 = np.meshgrid(v, v, v, indexing="ij")            # c0 = first channel of the array handed to cvtColor (blue: NM:793)
+    rgb8 = np.stack([c2, c1, c0], -1).astype(np.uint8)          # ... of a PNG holding (r, g, b) = (c2, c1, c0)
+    gray = HO.gray_as_reference(rgb8.reshape(-1, 1, 3)).reshape(256, 256, 256).astype(np.int64)
+    assert np.array_equal(gray, (c0 * 9798 + c1 * 19235 + c2 * 3735 + (1 << 14)) >> 15)
+    x64 = 0.299 * c0 + 0.587 * c1 + 0.114 * c2
+    x32 = (np.float32(0.299) * c0.astype(np.float32) + np.float32(0.587) * c1.astype(np.float32)) + np.float32(0.114) * c2.astype(np.float32)
+    variants = {"opencv 3.x fixed point (>> 14)": (c0 * 4899 + c1 * 9617 + c2 * 1868 + (1 << 13)) >> 14,
+                "float64, round half even": np.rint(x64).astype(np.int64),
+                "float64, round half up": np.floor(x64 + 0.5).astype(np.int64),
+                "float32, round half even": np.rint(x32).astype(np.int64),
+                "float32, round half up": np.floor(x32 + np.float32(0.5)).astype(np.int64)}
+    for name, g in variants.items():
+        assert (g != gray).sum() > 1000, name                   # the grey values themselves do differ ...
+        assert not ((g > 1) != (gray > 1)).any(), name          # ... the thresholded mask never does
+
+
 def test_oracle_to8b_truncates():
     x = np.array([-0.5, 0.0, 0.5, 1.0, 1.5, 254.999 / 255, 0.999999, 1 / 255, np.nextafter(np.float32(1 / 255), 0)], np.float32)
     assert list(HO.to8b(x)) == [0, 0, 127, 255, 255, 254, 254, 1, 0]

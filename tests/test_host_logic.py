@@ -61,10 +61,14 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
     res, targets = kernel_resources(lib)
     assert targets == ["hipv4-amdgcn-amd-amdhsa--gfx950"], targets
     fused = ["k_render_h2", "k_render_vjp_h2", "k_render_b3", "k_render_vjp_b3", "k_render16p", "k_render16", "k_render",
-             "k_render_vjp16p", "k_render_vjp16", "k_run_network"]
+             "k_render_vjp16p", "k_render_vjp16", "k_run_network",
+             "k_render_h2_n64", "k_render_h2_n32", "k_render_vjp_h2_n64", "k_render_vjp_h2_n32",       # N_importance 64 / 32 (r04)
+             "k_render_n64", "k_render_n32"]
     for k in fused:
         assert res[k]["vgpr_spill_count"] == 0 and res[k]["private_segment_fixed_size"] == 0, (k, res[k])
     assert res["k_render_vjp"]["vgpr_spill_count"] <= 4 and res["k_render_vjp"]["private_segment_fixed_size"] <= 20, res["k_render_vjp"]
+    for k in ("k_render_vjp_n64", "k_render_vjp_n32"):       # its N_importance 64 / 32 twins: fallback of the range safety net only
+        assert res[k]["vgpr_spill_count"] <= 8 and res[k]["private_segment_fixed_size"] <= 32, (k, res[k])
     # the x32-structured kernels own a whole SIMD's register file (one workgroup per CU); the x16 ones share it two ways
     assert res["k_render_h2"]["vgpr_count"] > 256 and res["k_render16p"]["vgpr_count"] <= 256
 
@@ -409,7 +413,7 @@ def test_api_rejects_unsupported_configurations():
     base["network_fn"] = net
     for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=32), "N_samples"),
                      (dict(N_importance=100), "N_importance"),
-                     (dict(N_importance=64, retraw=True), "retraw")):
+                     (dict(N_importance=16, retraw=True), "retraw")):
         kw = dict(base)
         kw.update(bad)
         with pytest.raises(NotImplementedError, match=pat):
