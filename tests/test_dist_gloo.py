@@ -54,6 +54,9 @@ def _worker(rank, world, port, n_views, tmp, q):
     local = [torch.full((8,), float(i)) for i in D.shard_indices(n_views, world, rank)]   # "patch gradients"
     g = D.mean_psi_grad(local)
     ok = ok and torch.allclose(g, torch.full((8,), (n_views - 1) / 2.0))
+    # a rank WITHOUT gradients (fewer poses than ranks) and a psi of another length (r03 hard-coded 8 for that rank)
+    g5 = D.mean_psi_grad([torch.full((5,), 4.0), torch.full((5,), 6.0)] if rank == 0 else [])
+    ok = ok and tuple(g5.shape) == (5,) and torch.allclose(g5, torch.full((5,), 5.0))
     q.put((rank, bool(ok), D.shard_indices(n_views, world, rank)))
     dist.barrier()
     dist.destroy_process_group()

@@ -69,6 +69,9 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
     assert res["k_render_vjp"]["vgpr_spill_count"] <= 4 and res["k_render_vjp"]["private_segment_fixed_size"] <= 20, res["k_render_vjp"]
     for k in ("k_render_vjp_n64", "k_render_vjp_n32"):       # its N_importance 64 / 32 twins: fallback of the range safety net only
         assert res[k]["vgpr_spill_count"] <= 8 and res[k]["private_segment_fixed_size"] <= 32, (k, res[k])
+    # the register allocation of the default forward kernel is part of its performance contract (r04: a control-flow change
+    # that moved it from 412 to 449 registers cost 16 % on MI355X); a change here wants an A/B on hardware
+    assert res["k_render_h2"]["vgpr_count"] + 0 <= 420, res["k_render_h2"]
     # the x32-structured kernels own a whole SIMD's register file (one workgroup per CU); the x16 ones share it two ways
     assert res["k_render_h2"]["vgpr_count"] > 256 and res["k_render16p"]["vgpr_count"] <= 256
 
