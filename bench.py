@@ -469,6 +469,8 @@ def vjp_roofline(model, c2w, pmc_file=None):
         return {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4), "issued": round(issued, 1),
                 "issued_frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                "attainable_frac": round(1.0 / (6 if model.mlp == "bf16x3" else 3), 4),
+                "frac_of_attainable": round(ach / PEAK_BF16_MFMA_TFLOPS * (6 if model.mlp == "bf16x3" else 3), 4),
                 "achieved_over_fp32_mfma_peak": round(ach / PEAK_F32_MFMA_TFLOPS, 3), "traffic": traffic,
                 "kernel": "nsr::k_render_vjp_b3" if model.mlp == "bf16x3" else "nsr::k_render_vjp_h2",
                 "kernel_ms": round(k_ms, 3), "flop_per_launch": H * W * FLOP_PER_RAY_VJP, "flop_note": flop_note}

@@ -5,6 +5,8 @@ backed by the native gfx950 library.  The positional encoder and the 8x256 MLP a
 Differences from RH, all deliberate: no global torch.autograd.set_detect_anomaly(True) (RH:2: debug aid that
 slows every autograd call); no .cuda() hard-coding; unsupported configurations raise instead of running a
 different code path."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -39,6 +41,15 @@ def get_embedder(multires, i=0):
     eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
                   log_sampling=True, periodic_fns=[torch.sin, torch.cos])
     return eo.embed, eo.out_dim
+
+
+# NSR_TRUST_VERSIONS=1 (read once, at import): the packed-weight cache is keyed on storage identity + autograd version of
+# every parameter only -- no content fingerprint, i.e. no kernel launch and no 8-byte read-back (a host-device sync) per
+# render() call: 0.43 instead of 0.48 ms for the bilevel loop's 512-ray patch call.  Safe when nothing writes the weights
+# through `.data` between renders (load_state_dict, optimizer steps and `p.copy_()` under no_grad all bump the version); the
+# reference's loop renders with frozen networks (NM:128, NM:184).  Default off: a missed in-place write would render stale
+# weights silently.
+TRUST_VERSIONS = os.environ.get("NSR_TRUST_VERSIONS", "0") == "1"
 
 
 class NeRF(nn.Module):
@@ -90,6 +101,8 @@ class NeRF(nn.Module):
         device (render()'s cache key covers network_fn and network_fine: two launches + two syncs per call otherwise)."""
         nets = [n for n in nets if n is not None]
         ps = [p for n in nets for p in n.parameters()]
+        if TRUST_VERSIONS:
+            return tuple((p.data_ptr(), p._version) for p in ps), ()
         if len(nets) < 2 or not ps or not all(p.is_cuda and p.device == ps[0].device and p.dtype == torch.float32
                                               and p.is_contiguous() for p in ps):
             return tuple(n.weights_version() for n in nets)
@@ -115,6 +128,8 @@ class NeRF(nn.Module):
         `extra_workloads.api_overhead` of bench.py.  CPU-resident modules hash on the host."""
         ps = list(self.parameters())
         ident = tuple((p.data_ptr(), p._version) for p in ps)
+        if TRUST_VERSIONS:
+            return ident, ()
         if ps and ps[0].is_cuda and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
             from .run_nerf_noscale import _util_model
             dev = ps[0].device

@@ -52,4 +52,26 @@ if [ -f $T ]; then
   done
 fi
 NSR_MLP=f16x2 timeout 200 python $R/tools/bench_path_grad.py > $O/path_grad_f16x2.json 2> /dev/null
+# r04: the kernels specialised to N_importance 64 / 32 (forward and input gradient), one 400x400 view each
+timeout 200 python - > $O/importance_counts.txt 2>&1 <<PY
+import sys, numpy as np
+sys.path.insert(0, "$R")
+from neural_sim_nerf_amd import synthetic as S
+from neural_sim_nerf_amd.engine import NsrModel
+c = S.synth_weights(0); f = S.synth_weights(1000, fine_of=c)
+pose = S.sweep_poses(1, 0)[0]
+cot = np.random.RandomState(1).standard_normal((160000, 3)).astype(np.float32)
+for ni in (128, 64, 32):
+    m = NsrModel(c, f, n_importance=ni)
+    t = []
+    for _ in range(5):
+        m.render_views(pose, 400, 400, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR); t.append(m.last_kernel_ms())
+    ro, rd = m.get_rays(400, 400, S.YCBV_K, pose)
+    v = []
+    for _ in range(4):
+        m.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot); v.append(m.last_kernel_ms())
+    print("N_importance %3d (kernels for %3d): forward %.2f ms, forward + input gradient %.2f ms per 400x400 view (medians after warm-up)"
+          % (ni, m.ni_kernel, float(np.median(t[1:])), float(np.median(v[1:]))))
+    m.close()
+PY
 ls $O
