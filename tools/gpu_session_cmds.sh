@@ -1,5 +1,5 @@
-# round 4, session j: everything profiles/r04 holds (tools/collect_profiles.sh)
+# round 4, session l: phase timers on the timing build
 cd $GRAFT_REPO_ROOT
-bash tools/collect_profiles.sh 2>&1 | tail -5
-cat gpurun_out/prof/importance_counts.txt
-tail -c 600 gpurun_out/prof/bench.json
+T=neural_sim_nerf_amd/csrc/ab/libnsr_timing.so
+for mlp in f16x2 bf16x3 fp32; do echo "== $mlp"; NSR_MLP=$mlp NSR_LIB_PATH=$T V=32 timeout 120 python tools/phase_timers.py 2>&1 | grep -v amdgpu.ids; done > $O/phase_timers.txt
+cat $O/phase_timers.txt | cut -c1-300
