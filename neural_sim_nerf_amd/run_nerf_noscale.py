@@ -85,7 +85,6 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     return cache["model"]
 
 
-_RANGE_WARNED = set()
 _RANGE_SWITCH_FRAC = 0.10         # more than this share of a handle's rays re-rendered by the fp32 kernel: use it outright
 
 
@@ -103,9 +102,9 @@ def _note_range(model, network_fn=None):
     switch = network_fn is not None and st["rays"] > _RANGE_SWITCH_FRAC * max(1, model.rays_launched)
     if switch:
         network_fn.__dict__["_nsr_force_mlp"] = ("fp32", getattr(model, "weights_version", None))
-    if id(model) not in _RANGE_WARNED:
+    if not getattr(model, "_range_warned", False):
         import warnings
-        _RANGE_WARNED.add(id(model))
+        model._range_warned = True
         warnings.warn("neural_sim_nerf_amd: %d network evaluations left the fp16 range of the f16x2 kernels; %d of %d rays were "
                       "rendered again by the fp32 kernel (%d items could not be and hold NaN).%s"
                       % (st["points"], st["rays"], model.rays_launched, st["dropped_items"],
