@@ -104,7 +104,7 @@ typedef struct NsrConfig {
                                    power-of-two scales chosen by the packer so that no piece leaves the fp16 range -- fp32-
                                    grade results (error against fp64 within that of an fp32 GEMM chain) at half the MFMA
                                    work of bf16x3.  Domain: a hidden activation whose scaled magnitude reaches 65504 makes
-                                   that point's outputs NaN (loud, never a wrong number).  One workgroup per CU, 32 points
+                                   that point's outputs NaN inside the kernel (never a wrong number) -- see RANGE SAFETY NET below for what the caller gets.  One workgroup per CU, 32 points
                                    per wave; needs nsr_upload_weights_h2.  Mutually exclusive with NSR_FLAG_MLP_BF16X3.
                                    nsr_render_rays_vjp runs the same scheme (k_render_vjp_h2: forward and transposed GEMMs
                                    on fp16 MFMAs, the gradients of every point normalised by a power of two on entry) once

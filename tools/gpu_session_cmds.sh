@@ -1,5 +1,4 @@
-# round 4, session l: phase timers on the timing build
+# round 4: the full -m gpu suite + smoke on the final tree
 cd $GRAFT_REPO_ROOT
-T=neural_sim_nerf_amd/csrc/ab/libnsr_timing.so
-for mlp in f16x2 bf16x3 fp32; do echo "== $mlp"; NSR_MLP=$mlp NSR_LIB_PATH=$T V=32 timeout 120 python tools/phase_timers.py 2>&1 | grep -v amdgpu.ids; done > $O/phase_timers.txt
-cat $O/phase_timers.txt | cut -c1-300
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/gpu_suite.log 2>&1; tail -6 $O/gpu_suite.log
+timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
