@@ -168,3 +168,84 @@ def per_point(nets, rays_o, rays_d, z_fine, got, viewdirs=None):
     err = (np.abs(k - ref) / scale).reshape(N, -1).max(1)                           # per ray: worst sample, relative to the ray
     return dict(p50=float(np.percentile(err, 50)), p90=float(np.percentile(err, 90)), p99=float(np.percentile(err, 99)),
                 max=float(err.max()), argmax_ray=int(err.argmax()))
+
+
+def attribute_without_taps(nets, rays_o, rays_d, near, far, cot, z_fine, grad_o, grad_d, rays, thr, margin=MARGIN,
+                           max_candidates=48, white_bkgd=False):
+    """The same attribution for a kernel that has NO debug taps (the x16 fp32 kernels): for each ray of `rays`, the hidden
+    units of its 192 samples whose float64 pre-activation sits within `margin` of zero (relative to sum |w||h| + |b|) are
+    the only ones whose relu' another evaluation can see differently.  A flip of one unit changes the gradient of ONE sample;
+    its effect on (dL/d rays_o, dL/d rays_d) is computed by re-running the float64 backprop of that sample with the unit
+    flipped.  The ray is attributed if the oracle's gradient plus the effect of ONE such flip -- or of a pair -- reproduces
+    the kernel's gradient to `thr`.  Returns {ray: dict(flips=[(sample, layer, unit, margin), ...] or None, err, err_after)}."""
+    sd_c, sd_f = nets
+    sd = sd_f if sd_f is not None else sd_c
+    out = {}
+    for r in rays:
+        r = int(r)
+        ro, rd, ct, zf = rays_o[r:r + 1], rays_d[r:r + 1], cot[r:r + 1], z_fine[r:r + 1]
+        parts = {}
+        go, gd, _ = O.render_rays_vjp(sd_c, sd_f, ro, rd, near, far, ct, z_fine=zf, white_bkgd=white_bkgd, parts=parts)
+        g0 = np.concatenate([go, gd], 1)[0].astype(f64)
+        gk = np.concatenate([grad_o[r], grad_d[r]]).astype(f64)
+        err = np.linalg.norm(gk - g0) / (np.linalg.norm(g0) + 1e-300)
+        fwd, pts, dirs, g_raw = parts["fwd"], parts["pts"], parts["dirs"], parts["g_raw"].reshape(-1, 4)
+        e_p = O.embed(pts, O.MULTIRES).astype(f64)
+        e_d = O.embed(dirs, O.MULTIRES_VIEWS).astype(f64)
+        # candidates: units within `margin` of the discontinuity, closest first
+        cand = []
+        W = lambda k: sd[k + ".weight"].astype(f64)
+        B = lambda k: sd[k + ".bias"].astype(f64)
+        for L in range(9):
+            if L < 8:
+                x = e_p if L == 0 else np.maximum(fwd["pre"][L - 1], 0)
+                if L - 1 == O.SKIP_AT:
+                    x = np.concatenate([e_p, x], 1)
+                w, b, pre = W("pts_linears.%d" % L), B("pts_linears.%d" % L), fwd["pre"][L]
+            else:
+                feat = np.maximum(fwd["pre"][7], 0) @ W("feature_linear").T + B("feature_linear")
+                x = np.concatenate([feat, e_d], 1)
+                w, b, pre = W("views_linears.0"), B("views_linears.0"), fwd["av"]
+            mag = np.abs(x) @ np.abs(w).T + np.abs(b)
+            rel = np.abs(pre) / (mag + 1e-300)
+            for s, u in zip(*np.nonzero(rel <= margin)):
+                cand.append((float(rel[s, u]), int(s), L, int(u)))
+        cand.sort()
+        cand = cand[:max_candidates]
+        v = O.normalize_dirs(rd.astype(np.float32)).astype(f64)[0]
+        nrm = float(O.dir_norm(rd)[0])
+        base = {}
+
+        def point_grad(s, flip=None):
+            on = dict(pre=[(fwd["pre"][L][s:s + 1] > 0).copy() for L in range(8)], av=(fwd["av"][s:s + 1] > 0).copy())
+            if flip is not None:
+                L, u = flip
+                (on["pre"][L] if L < 8 else on["av"])[0, u] ^= True
+            one = dict(pre=[p[s:s + 1] for p in fwd["pre"]], av=fwd["av"][s:s + 1], sigma=None, rgb_raw=None)
+            gp, gv = O.network_vjp(sd, pts[s:s + 1], dirs[s:s + 1], g_raw[s:s + 1], one, relu_on=on)
+            return gp[0], gv[0]
+
+        effects = []
+        for rel, s, L, u in cand:
+            if s not in base:
+                base[s] = point_grad(s)
+            gp, gv = point_grad(s, (L, u))
+            dgp, dgv = gp - base[s][0], gv - base[s][1]
+            z = float(zf[0, s])
+            effects.append(np.concatenate([dgp, z * dgp + (dgv - v * float(dgv @ v)) / nrm]))
+        best, best_err = None, err
+        rel_err = lambda g: np.linalg.norm(gk - g) / (np.linalg.norm(g) + 1e-300)
+        for i, e1 in enumerate(effects):
+            e_ = rel_err(g0 + e1)
+            if e_ < best_err:
+                best, best_err = [i], e_
+        if best_err > thr:
+            for i in range(len(effects)):
+                for j in range(i + 1, len(effects)):
+                    e_ = rel_err(g0 + effects[i] + effects[j])
+                    if e_ < best_err:
+                        best, best_err = [i, j], e_
+        ok = best is not None and best_err <= thr
+        out[r] = dict(err=float(err), err_after=float(best_err), candidates=len(cand),
+                      flips=[(cand[i][1], cand[i][2], cand[i][3], cand[i][0]) for i in best] if ok else None)
+    return out

@@ -138,3 +138,24 @@ def test_wrong_network_backward_shows_per_point(oracle, synth_nets, case):
     got["grad_pts"][3, smp] *= 1.001
     pp = V.per_point(synth_nets, case["ro"], case["rd"], case["zf"], got)
     assert pp["argmax_ray"] == 3 and pp["max"] > 5e-4, pp
+
+
+def test_attribution_without_taps_finds_the_flipped_unit(oracle, synth_nets, case):
+    """oracle/vjp_census.attribute_without_taps (for the x16 fp32 kernels, which have no debug taps): from the gradient
+    alone it names the unit that was flipped -- and refuses a fabricated gradient."""
+    import vjp_census as V
+    on_pre, on_av = _own_patterns(case)
+    flipped, pre = _flip(case, on_pre, want_small=True)
+    got = _kernel_like(oracle, synth_nets, case, flipped, on_av)
+    where = np.argwhere(flipped != on_pre)[0]                      # (ray 2, sample, layer 6, unit)
+    a = V.attribute_without_taps(synth_nets, case["ro"], case["rd"], oracle.YCBV_NEAR, oracle.YCBV_FAR, case["cot"], case["zf"],
+                                 got["grad_o"], got["grad_d"], rays=[2], thr=1e-6, margin=1.0, max_candidates=4000)
+    # (margin 1.0 admits every unit; the candidate list is cut to the 4000 closest to zero -- the fabricated flip is the closest
+    # unit of its sample's layer 6, far inside that)
+    assert a[2]["flips"] is not None and a[2]["err_after"] <= 1e-6 < a[2]["err"], a[2]
+    assert (int(where[1]), 6, int(where[3])) in [f[:3] for f in a[2]["flips"]], (a[2], where)
+    bad_d = got["grad_d"].copy()
+    bad_d[2] *= 1.01
+    b = V.attribute_without_taps(synth_nets, case["ro"], case["rd"], oracle.YCBV_NEAR, oracle.YCBV_FAR, case["cot"], case["zf"],
+                                 got["grad_o"], bad_d, rays=[2], thr=1e-6, margin=2e-5)
+    assert b[2]["flips"] is None, b[2]

@@ -1,4 +1,3 @@
-# round 4: the full -m gpu suite + smoke on the final tree
+# round 4, session n: tapless attribution of the fp32 x16 input-gradient kernels' outlier rays
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -q -m gpu > $O/gpu_suite.log 2>&1; tail -6 $O/gpu_suite.log
-timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_r4.py -q -s -k "fp32_x16_vjp" > $O/t.log 2>&1; tail -5 $O/t.log | cut -c1-400; grep "k_render_vjp16" $O/t.log | cut -c1-900
