@@ -499,6 +499,18 @@ def main():
     del sig_last[:]
     save("g18_pytest_hook", **g18)
 
+    # ---- G19 c2w_staticcam WITHOUT view directions: RN:91-96 sits inside `if use_viewdirs:`, so the reference ignores the
+    # static camera there and renders c2w's own rays ----------------------------------------------------------
+    K16 = O.scaled_K(25.0)
+    with torch.no_grad():
+        rgb, disp, acc, ex = RN.render(16, 16, K16, chunk=512, c2w=torch.from_numpy(poses[0])[:3, :4],
+                                       c2w_staticcam=torch.from_numpy(poses[2])[:3, :4], **kw15)
+        plain = RN.render(16, 16, K16, chunk=512, c2w=torch.from_numpy(poses[0])[:3, :4], **kw15)[0]
+    assert torch.equal(rgb, plain)
+    del sig_last[:]
+    save("g19_noviews_staticcam", seed=np.int64(SEED), K=np.array(K16), c2w=poses[0], c2w_static=poses[2], rgb=rgb.numpy(),
+         disp=disp.numpy(), acc=acc.numpy(), rgb0=ex["rgb0"].numpy(), z_std=ex["z_std"].numpy())
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

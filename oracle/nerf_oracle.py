@@ -501,9 +501,10 @@ def render_rays(sd_coarse, sd_fine, rays_o, rays_d, viewdirs, near, far,
 
 def render(sd_coarse, sd_fine, H, W, K, c2w=None, rays=None, near=0.0, far=1.0,
            n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, chunk=4096, extras=False, white_bkgd=False, lindisp=False,
-           ndc=False, c2w_staticcam=None, randoms=None):
+           ndc=False, c2w_staticcam=None, randoms=None, use_viewdirs=True):
     """RN:58-123 with use_viewdirs=True.  ndc: RN:101-103 (the caller passes near=0, far=1 as the reference's callers
-    do); c2w_staticcam: RN:91-96 (view directions from c2w, rays from the static camera); randoms: dict with any of
+    do); c2w_staticcam: RN:91-96 (view directions from c2w, rays from the static camera; ignored with use_viewdirs=False,
+    as upstream); randoms: dict with any of
     t_rand, u, noise0, noise1 for ALL rays (see render_rays), sliced per chunk here.
     Returns dict of [H,W,...] (c2w form) or [N,...]."""
     if c2w is not None:
@@ -511,7 +512,7 @@ def render(sd_coarse, sd_fine, H, W, K, c2w=None, rays=None, near=0.0, far=1.0,
     else:
         rays_o, rays_d = rays
     viewdirs = normalize_dirs(rays_d.reshape(-1, 3).astype(f32))              # RN:89-98: from the rays BEFORE the next two
-    if c2w_staticcam is not None:
+    if c2w_staticcam is not None and use_viewdirs:                            # RN:91-96 sits inside `if use_viewdirs:`
         rays_o, rays_d = get_rays(H, W, K, c2w_staticcam)
     sh = rays_d.shape[:-1]
     if ndc:

@@ -468,6 +468,21 @@ def test_noviewdirs_network(mlp, oracle):
                  atol=5e-5, rtol=5e-5, what="run_network(viewdirs=None)")
     with pytest.raises(NotImplementedError, match="retraw"):
         R.render(400, 400, oracle.YCBV_K, rays=rays, retraw=True, **kw)
+    # the fifth row against the REFERENCE's own raw (g15 keeps all five channels of its first 16 rays)
+    z15 = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
+    zf15 = np.sort(np.concatenate([z15, g["z_samples"]], -1), -1)[:16]
+    p15 = torch.tensor((ro[:16, None, :] + (rd[:16, None, :] * zf15[:, :, None]).astype(np.float32)).astype(np.float32), device=R.device)
+    raw5 = cpu(R.run_network(p15, None, nets[1]))
+    assert_close(raw5, g["raw16"], atol=5e-5, rtol=5e-5, what="run_network: all five rows vs the reference")
+    # c2w_staticcam without view directions: ignored, as upstream (RN:91-96 sits inside `if use_viewdirs:`; g19)
+    g19 = load_golden("g19_noviews_staticcam")
+    K19 = g19["K"].tolist()
+    a19 = R.render(16, 16, K19, c2w=torch.tensor(g19["c2w"][:3, :4]), c2w_staticcam=torch.tensor(g19["c2w_static"][:3, :4]), **kw)
+    b19 = R.render(16, 16, K19, c2w=torch.tensor(g19["c2w"][:3, :4]), **kw)
+    assert np.array_equal(cpu(a19[0]), cpu(b19[0]))
+    assert_close(cpu(a19[3]["rgb0"]), g19["rgb0"], atol=1e-5, what="g19 rgb0 vs reference")
+    d19 = np.abs(cpu(a19[0]) - g19["rgb"]).max(-1)
+    assert (d19 > 1e-4).mean() <= 0.08 and d19.mean() < 2e-4
     with pytest.raises(NotImplementedError, match="use_viewdirs"):
         R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, use_viewdirs=True))
     for n in nets:

@@ -265,6 +265,18 @@ def test_noviewdirs_network_against_the_reference(golden, oracle):
     zf = np.sort(np.concatenate([z, g["z_samples"]], -1), -1)
     pts = (g["rays_o"][:16, None, :] + (g["rays_d"][:16, None, :] * zf[:16, :, None]).astype(np.float32)).astype(np.float32)
     assert_close(oracle.run_network(sd_f, pts, vd[:16]), g["raw16"][..., :4], atol=2e-5, rtol=1e-5, what="raw")
+    # ... and the oracle's all-rows form of the module (RH:119-120) against all five, the unused fifth included
+    e15 = np.concatenate([oracle.embed(pts.reshape(-1, 3), 10), np.zeros((16 * 192, 27), np.float32)], -1)
+    assert_close(oracle.mlp(sd_f, e15, all_rows=True), g["raw16"].reshape(-1, 5), atol=2e-5, rtol=1e-5, what="all five rows")
+    # c2w_staticcam without view directions is ignored by the reference (RN:91-96 sits inside `if use_viewdirs:`): g19
+    g19 = golden("g19_noviews_staticcam")
+    r19 = oracle.render(sd_c, sd_f, 16, 16, g19["K"].tolist(), c2w=g19["c2w"][:3, :4], c2w_staticcam=g19["c2w_static"][:3, :4],
+                        near=near, far=far, use_viewdirs=False)
+    assert_close(r19["rgb0"], g19["rgb0"], atol=1e-5, what="g19 rgb0")
+    d19 = np.abs(r19["rgb_map"] - g19["rgb"]).max(-1)
+    assert (d19 > 1e-4).mean() <= 0.08 and d19.mean() < 2e-4
+    other = oracle.render(sd_c, sd_f, 16, 16, g19["K"].tolist(), c2w=g19["c2w_static"][:3, :4], near=near, far=far)
+    assert np.abs(other["rgb0"] - g19["rgb0"]).max() > 1e-3            # (the static camera's own view is another image)
     go, gd, _ = oracle.render_rays_vjp(sd_c, sd_f, g["rays_o"], g["rays_d"], near, far, g["cot"], z_fine=zf)
     for a, b in ((go, g["grad_rays"][0]), (gd, g["grad_rays"][1])):
         e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
