@@ -531,7 +531,7 @@ def live_traffic(mlp):
             d = os.path.join(tmp, ctr)
             r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                 os.path.join(ROOT, "tools", "one_view.py"), "0"], cwd=tmp, capture_output=True, text=True,
-                               timeout=240, env=dict(os.environ, NSR_MLP=mlp, TMPDIR=tmp))
+                               timeout=120, env=dict(os.environ, NSR_MLP=mlp, TMPDIR=tmp))
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, (r.stderr or r.stdout)[-200:])
