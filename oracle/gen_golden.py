@@ -511,6 +511,18 @@ def main():
     save("g19_noviews_staticcam", seed=np.int64(SEED), K=np.array(K16), c2w=poses[0], c2w_static=poses[2], rgb=rgb.numpy(),
          disp=disp.numpy(), acc=acc.numpy(), rgb0=ex["rgb0"].numpy(), z_std=ex["z_std"].numpy())
 
+    # ---- G20 N_importance = 32 on g17's rays and cotangent (the kernels specialised to 32 samples run their second fine pass
+    # with two idle waves; this pins them to the reference) ------------------------------------------------------------
+    rays = torch.stack([ro17, rd17], 0).clone().requires_grad_(True)
+    with Capture(RN, RH) as cap:
+        rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=48, rays=rays, **dict(kwargs, N_importance=32))
+    (g20g,) = torch.autograd.grad(rgb, rays, grad_outputs=cot17)
+    del sig_last[:]
+    save("g20_importance32", seed=np.int64(SEED), rays_o=ro17.numpy(), rays_d=rd17.numpy(), rgb=rgb.detach().numpy(),
+         disp=disp.detach().numpy(), acc=acc.detach().numpy(), rgb0=ex["rgb0"].detach().numpy(),
+         z_std=ex["z_std"].detach().numpy(), z_samples=cap.log[0]["samples"], inds=cap.log[0]["inds"].astype(np.int8),
+         pdf_weights=cap.log[0]["weights"], cot=cot17.numpy(), grad_rays=g20g.numpy())
+
     # ---- linspace tables the host glue must reproduce (RN:439, RH:208) ------------------------
     save("g0_tables", t64=torch.linspace(0., 1., 64).numpy(), t128=torch.linspace(0., 1., 128).numpy())
 

@@ -589,6 +589,15 @@ def test_fewer_importance_samples(oracle, synth_nets):
                     assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (np.percentile(e, 90), e.max())
                 if mlp == "f16x2":
                     want, want_raw = cpu(r["rgb_map"]), cpu(r["raw"])
+            if ni == 32:                                       # against the reference's N_importance = 32 render (g20)
+                g20 = load_golden("g20_importance32")
+                assert_close(cpu(r["rgb0"]), g20["rgb0"], atol=1e-5, what="rgb0 vs reference, 32 samples")
+                _census_vs_oracle(oracle, synth_nets, r, ro, rd, near, far, n_importance=32, reference_rgb=g20["rgb"])
+                zf_ref = np.sort(np.concatenate([z] + [g20["z_samples"]] * rep, -1), -1)
+                go, gd = m.render_rays_vjp(ro, rd, near, far, g20["cot"], z_fine=zf_ref)
+                for a, b in ((cpu(go), g20["grad_rays"][0]), (cpu(gd), g20["grad_rays"][1])):
+                    e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+                    assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (np.percentile(e, 90), e.max())
         finally:
             m.close()
     import neural_sim_nerf_amd.run_nerf_noscale as R

@@ -389,6 +389,24 @@ def test_fewer_importance_samples_by_duplicated_uniforms(golden, oracle, synth_n
         for k in ("rgb_map", "acc_map", "disp_map", "z_std"):
             assert_close(emu[k], want[k], atol=5e-7, rtol=5e-7, what="%s with %d importance samples" % (k, ni))
     assert np.array_equal(_host_tables(128)[1], oracle.torch_linspace01(128)) and np.array_equal(_host_tables(0)[0], oracle.torch_linspace01(64))
+    # the table of the kernels SPECIALISED to n samples (f16x2 handles, 64 and 32): the reference's linspace itself, padded
+    for ni in (64, 32):
+        t, u = _host_tables(ni, native=True)
+        assert u.shape == (128,) and np.array_equal(u[:ni], oracle.torch_linspace01(ni))
+    # N_importance = 32 against the reference (g20, same rays and cotangent as g17)
+    g20 = golden("g20_importance32")
+    assert np.array_equal(g20["rays_o"], g["rays_o"])
+    s32, inds32, _ = oracle.sample_pdf(z_mid, g20["pdf_weights"], 32)
+    assert s32.shape == (n, 32) and np.array_equal(inds32, g20["inds"].astype(np.int64)) and np.array_equal(s32, g20["z_samples"])
+    ref32 = oracle.render_rays(sd_c, sd_f, g["rays_o"], g["rays_d"], vd, near, far, n_importance=32, extras=True)
+    assert_close(ref32["rgb0"], g20["rgb0"], atol=1e-5, what="rgb0, 32 samples")
+    d32 = np.abs(ref32["rgb_map"] - g20["rgb"]).max(-1)
+    assert (d32 > 1e-4).mean() <= 0.08 and d32.mean() < 2e-4
+    zf32 = np.sort(np.concatenate([z, g20["z_samples"]], -1), -1)
+    go, gd, _ = oracle.render_rays_vjp(sd_c, sd_f, g["rays_o"], g["rays_d"], near, far, g20["cot"], n_importance=32, z_fine=zf32)
+    for a, b in ((go, g20["grad_rays"][0]), (gd, g20["grad_rays"][1])):
+        e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+        assert np.percentile(e, 90) < 1e-4, e.max()
 
 
 def test_render_image(golden, oracle, synth_nets):

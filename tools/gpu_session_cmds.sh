@@ -1,5 +1,3 @@
-# round 4, session p: compiler-flag lottery on the shipped kernels (A/B, one box)
+# round 4, session q: N_importance 32 against the reference (g20)
 cd $GRAFT_REPO_ROOT
-L=neural_sim_nerf_amd/csrc
-timeout 600 python tools/ab_h2.py --n 8 $L/libnsr.so $L/ab/libnsr_nomisched.so $L/ab/libnsr_rcprio.so $L/ab/libnsr_o2.so $L/ab/libnsr_maxilp.so $L/libnsr.so $L/ab/libnsr_nomisched.so 2>&1 | tee $O/ab_flags.txt
-for lib in $L/libnsr.so $L/ab/libnsr_nomisched.so; do echo "vjp $lib"; NSR_LIB_PATH=$lib NSR_MLP=f16x2 python tools/bench_vjp.py 400 4 2>/dev/null | tail -1 | cut -c1-120; done | tee -a $O/ab_flags.txt
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -k "fewer_importance" > $O/t.log 2>&1; tail -8 $O/t.log | cut -c1-600
