@@ -1,3 +1,5 @@
-# round 4, session q: N_importance 32 against the reference (g20)
+# what the last GPU session of round 4 ran (scratch file: tools/gpu_session.sh <label> executes it on the gpurun box)
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -k "fewer_importance" > $O/t.log 2>&1; tail -8 $O/t.log | cut -c1-600
+timeout 2400 python -m pytest tests/ -q -m gpu > $O/gpu_suite.log 2>&1; tail -6 $O/gpu_suite.log
+timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_nocpu.json 2> $O/bench_nocpu.err; tail -c 400 $O/bench_nocpu.json
