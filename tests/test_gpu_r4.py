@@ -268,6 +268,70 @@ def test_f16x2_out_of_range_items_are_the_fp32_kernels(oracle, synth_nets):
         m.close()
 
 
+def test_partial_overflow_is_ray_granular_and_graph_replayable(oracle, synth_nets):
+    """A network on the EDGE of the fp16 range: a hidden bias just below the ceiling puts some points of a view beyond it and
+    leaves the others inside.  Rays that the safety net re-rendered carry the fp32 x32 kernel's bits; every other ray carries the f16x2
+    kernel's -- the very bits it gets when it is rendered alone, whatever its item partner did; the input gradient
+    likewise; and a hipGraph capture of the launch pair replays with a DIFFERENT list each time (another camera)."""
+    import torch
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    edge = [{k: np.array(v, copy=True) for k, v in sd.items()} for sd in synth_nets]
+    # layer-0 unit 7 of the COARSE network: its pre-activation without bias spans about -2.2 .. 2.2 over these views, the largest
+    # per ray is 1.2 .. 1.4 in the median; the kernels' ceiling is 65504 (1 - 2^-12) = 65488
+    edge[0]["pts_linears.0.bias"][7] = np.float32(65488.0 - 1.35)
+    mh, m32 = _mk(edge, "f16x2"), _mk(edge, "x32")
+    K = oracle.scaled_K(10.0)                                        # 40 x 40
+    poses = np.asarray(oracle.sweep_poses(3, seed=5))
+    a = mh.render_views(poses[0], 40, 40, K, near, far)
+    st = mh.range_status()
+    b = m32.render_views(poses[0], 40, 40, K, near, far)
+    n = 1600
+    assert 0 < st["rays"] < n and st["dropped_items"] == 0, st       # SOME rays took the fp32 route
+    ra, rb = cpu(a["rgb_map"]), cpu(b["rgb_map"])
+    same32 = (ra == rb).all(1)
+    assert same32.sum() >= st["rays"] and np.isfinite(ra).all()
+    # the rays that kept the f16x2 bits: each rendered ALONE (pairs broken up: a batch of the odd-numbered clean rays only)
+    ro, rd = mh.get_rays(40, 40, K, poses[0])
+    ro, rd = cpu(ro).reshape(-1, 3), cpu(rd).reshape(-1, 3)
+    before = mh.range_status()["rays"]
+    clean = np.nonzero(~same32)[0]
+    assert len(clean) > 50
+    sub = mh.render_rays(ro[clean], rd[clean], near, far)
+    assert mh.range_status()["rays"] == before                       # none of them overflows on its own either
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+        assert np.array_equal(cpu(sub[k]), cpu(a[k])[clean], equal_nan=True), k
+    # ... and the re-rendered ones alone on the fp32 handle
+    hot = np.nonzero(same32)[0]
+    sub32 = m32.render_rays(ro[hot], rd[hot], near, far)
+    assert np.array_equal(cpu(sub32["rgb_map"]), ra[hot])
+    # input gradients: same partition
+    cot = np.random.RandomState(3).standard_normal((n, 3)).astype(np.float32)
+    go, gd = mh.render_rays_vjp(ro, rd, near, far, cot)
+    go32, gd32 = m32.render_rays_vjp(ro, rd, near, far, cot)
+    eq = (cpu(gd) == cpu(gd32)).all(1)
+    assert eq.sum() >= (mh.range_status()["rays"] - before) > 0 and np.isfinite(cpu(gd)).all()
+    gs, gds = mh.render_rays_vjp(ro[~eq], rd[~eq], near, far, cot[~eq])
+    assert np.array_equal(cpu(gds), cpu(gd)[~eq]) and np.array_equal(cpu(gs), cpu(go)[~eq])
+    # hipGraph: capture once, replay on three cameras (three different lists)
+    cam = torch.as_tensor(poses[0:1, :3, :4], dtype=torch.float32, device=mh.device).clone()
+    eager = [cpu(mh.render_views(poses[i], 40, 40, K, near, far)["rgb_map"]) for i in range(3)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        mh.render_views(cam, 40, 40, K, near, far)
+        side.synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            out = mh.render_views(cam, 40, 40, K, near, far)
+    for i in (1, 2, 0):
+        cam.copy_(torch.as_tensor(poses[i:i + 1, :3, :4], dtype=torch.float32))
+        out["rgb_map"].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(cpu(out["rgb_map"]), eager[i]), i
+    mh.close(); m32.close()
+
+
 def test_dropin_api_warns_once_about_the_range(oracle, synth_nets, tmp_path):
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
