@@ -524,6 +524,8 @@ def live_traffic(mlp):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found on this box"
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ):
+        return None, "bench.py is itself running under a profiler: the live PMC passes are skipped (no nested rocprofv3)"
     tot = {}
     tmp = tempfile.mkdtemp(prefix="nsr_pmc_")
     try:
