@@ -373,9 +373,16 @@ int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays);
 /* f16x2 range safety net (NSR_FLAG_MLP_F16X2): what the handle's launches reported so far.  *last_items = items (2 rays)
  * the LAST launch handed to its fp32 fallback; cumulative over the handle's life: *points = network evaluations whose
  * outputs / gradients were NaN, *rays = rays rendered again by the fp32 kernel, *dropped_items = items that could not be
- * (beyond the list's capacity of 2^17 items per launch, or an input-gradient launch without nsr_upload_weights_bwd): those
- * kept their NaN.  Any pointer may be NULL.  All zero for other handles.  Synchronises the device. */
+ * (beyond the list's capacity -- 2^17 items per launch unless nsr_reserve_range grew it -- or an input-gradient launch without
+ * nsr_upload_weights_bwd): those kept the f16x2 kernel's output for out-of-range activations (see nsr_reserve_range).  Any pointer may be NULL.  All zero for other handles.  Synchronises the device. */
 int nsr_range_status(nsr_handle h, unsigned* last_items, unsigned* points, unsigned* rays, unsigned* dropped_items);
+
+/* SETUP call: make the safety net's list large enough for launches of up to n_rays rays (default: 2^18 rays), so that no
+ * item can be dropped -- a dropped item keeps what the f16x2 kernel produced from out-of-range activations, which is a NaN
+ * where the overflow reaches the output and can be a finite value computed from a degenerate coarse pass where it does not
+ * (sigma = NaN composites as zero density).  8 bytes per 2 rays.  The Python engine calls it before any launch that needs
+ * it; no-op for handles without NSR_FLAG_MLP_F16X2. */
+int nsr_reserve_range(nsr_handle h, int64_t n_rays);
 
 /* Debug build (`make -C neural_sim_nerf_amd/csrc debug` -> libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent
  * LDS / scratch index of the kernels (searchsorted results, merge ranks, hand-off slots) is range-checked; a violation

@@ -62,6 +62,7 @@ SIGNATURES = {
                                           C.POINTER(NsrRenderOut), C.POINTER(NsrVjpDebugOut), C.c_void_p]),
     "nsr_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint),
                                    C.POINTER(C.c_uint)]),
+    "nsr_reserve_range": (C.c_int, [C.c_void_p, C.c_int64]),
     "nsr_ndc_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsr_ndc_rays_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,

@@ -51,7 +51,8 @@ struct DeviceGuard {
 };
 #define NSR_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSR_HIP(guard_.err)
 
-constexpr unsigned kOvfCap = 1u << 17;      // items (2 rays each) one launch can hand to its fp32 fallback: 1 MiB per handle
+constexpr unsigned kOvfCap = 1u << 17;      // items (2 rays each) one launch can hand to its fp32 fallback by default: 1 MiB per handle
+                                            // (nsr_reserve_range grows it to the largest launch the caller plans)
 static int kSuperLg = 12;              // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
@@ -90,7 +91,8 @@ struct nsr_handle_s {
   unsigned long long* d_work_counter = nullptr;  // work-queue heads: [0] the launch, [1] its fp32 fallback launch (f16x2)
   nsr::RenderArgs* d_args_fb = nullptr;          // f16x2 range safety net: argument blocks of the fallback launches,
   nsr::VjpArgs* d_vjp_args_fb = nullptr;
-  unsigned long long* d_ovf_items = nullptr;     // ... the items (2 rays) the f16x2 kernel reported, [kOvfCap]
+  unsigned long long* d_ovf_items = nullptr;     // ... the items (2 rays) the f16x2 kernel reported, [ovf_cap]
+  unsigned ovf_cap = 0;
   unsigned* d_ovf_stat = nullptr;                // ... [0] items of the last launch, [1] points, [2] rays, [3] items beyond the cap
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
   int zf_grid = 0;
@@ -147,6 +149,7 @@ static int allocate_handle(nsr_handle h) {
     NSR_HIP(hipMalloc(&h->d_args_fb, sizeof(nsr::RenderArgs)));
     NSR_HIP(hipMalloc(&h->d_vjp_args_fb, sizeof(nsr::VjpArgs)));
     NSR_HIP(hipMalloc(&h->d_ovf_items, sizeof(unsigned long long) * kOvfCap));
+    h->ovf_cap = kOvfCap;
     NSR_HIP(hipMalloc(&h->d_ovf_stat, 4 * sizeof(unsigned)));
     NSR_HIP(hipMemset(h->d_ovf_stat, 0, 4 * sizeof(unsigned)));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
@@ -457,7 +460,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     g = grid_for(h, (a.n_rays + 1) / 2);
   }
   a.work_counter = h->d_work_counter;
-  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = kOvfCap; }
+  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = h->ovf_cap; }
 #ifdef NSR_EXP_SAMENET       // timing experiment: every pass streams the SAME weight image (L2-resident); results are wrong
   a.net_stride = 0;
 #endif
@@ -488,7 +491,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     f.aux[0] = h->d_nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
     f.aux[1] = h->d_nets + (fine ? (size_t)NSR_PACKED_FLOATS : 0) + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
     f.ovf_items = nullptr; f.ovf_stat = nullptr; f.ovf_cap = 0;
-    f.item_list = h->d_ovf_items; f.item_count = h->d_ovf_stat; f.item_cap = kOvfCap;
+    f.item_list = h->d_ovf_items; f.item_count = h->d_ovf_stat; f.item_cap = h->ovf_cap;
     f.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, f, h->d_args_fb);
     hipLaunchKernelGGL(ni == 64 ? nsr::k_render_n64 : (ni == 32 ? nsr::k_render_n32 : nsr::k_render), dim3((int)g), dim3(256),
@@ -626,7 +629,7 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   if (dbg) { v.dbg_masks = (uint4*)dbg->d_relu_masks; v.dbg_graw = dbg->d_grad_raw; v.dbg_gpts = dbg->d_grad_pts; }
   // f16x2 range safety net (see launch_render): needs the fp32 transposed stream (nsr_upload_weights_bwd) for its fallback
   const bool fallback = h2 && h->have_net[2];
-  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = fallback ? kOvfCap : 0u; }
+  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = fallback ? h->ovf_cap : 0u; }
   // global-phases schedule (k_render_vjp16p) unless the caller supplies the depths itself (then nothing is handed over)
   const bool phases = x16 && (h->cfg.flags & NSR_FLAG_SCHED_PHASES) && !d_z_fine;
   if (phases) {
@@ -662,7 +665,7 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
     fa.aux[0] = h->d_nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
     fa.aux[1] = h->d_nets + (size_t)NSR_PACKED_FLOATS + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
     fa.ovf_items = nullptr; fa.ovf_stat = nullptr; fa.ovf_cap = 0;
-    fa.item_list = h->d_ovf_items; fa.item_count = h->d_ovf_stat; fa.item_cap = kOvfCap;
+    fa.item_list = h->d_ovf_items; fa.item_count = h->d_ovf_stat; fa.item_cap = h->ovf_cap;
     fa.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, f, h->d_vjp_args_fb);
     hipLaunchKernelGGL(ni == 64 ? nsr::k_render_vjp_n64 : (ni == 32 ? nsr::k_render_vjp_n32 : nsr::k_render_vjp), dim3((int)grid),
@@ -947,6 +950,22 @@ int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays) {
   NSR_DEVICE(h);
   NSR_HIP(hipDeviceSynchronize());
   NSR_HIP(hipMemcpy(recomputed_rays, h->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nsr_reserve_range(nsr_handle h, int64_t n_rays) {
+  if (!h) return fail("nsr_reserve_range: null handle");
+  if (n_rays < 0 || n_rays > ((int64_t)1 << 33)) return fail("nsr_reserve_range: 0 .. 2^33 rays");
+  if (!h->d_ovf_items) return 0;                           // not an f16x2 handle: nothing to reserve
+  const unsigned long long items = (unsigned long long)(n_rays + 1) / 2;
+  if (items <= h->ovf_cap) return 0;
+  NSR_DEVICE(h);
+  NSR_HIP(hipDeviceSynchronize());                         // setup call: a launch may still be reading the old list
+  unsigned long long* grown = nullptr;
+  NSR_HIP(hipMalloc(&grown, sizeof(unsigned long long) * items));
+  NSR_HIP(hipFree(h->d_ovf_items));
+  h->d_ovf_items = grown;
+  h->ovf_cap = (unsigned)items;
   return 0;
 }
 

@@ -124,6 +124,7 @@ class NsrModel:
         self._bbox_reserved = (0, 0)
         self._bwd_ready = self._bwd32_ready = False
         self.rays_launched = 0                       # rays handed to the render / input-gradient launches so far (host count)
+        self._range_rays = 1 << 18                   # f16x2: rays per launch the safety net's list holds (nsr_reserve_range)
         self.h2_range = None                         # f16x2: pack.h2_report of (coarse, fine) -- pack-time range report
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
@@ -226,6 +227,13 @@ class NsrModel:
         ex = _lib.NsrRayExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "t_rand", "u", "noise0", "noise1", "near", "far")])
         return ex, keep
 
+    def _count(self, n):
+        """host bookkeeping of a launch of n rays; grows the f16x2 safety net's list so that no item of it can be dropped"""
+        self.rays_launched += n
+        if self.mlp == "f16x2" and n > self._range_rays:
+            _lib.check(self.lib.nsr_reserve_range(self.h, int(n)))       # setup call (allocates, synchronises): once per size
+            self._range_rays = int(n)
+
     def render_rays(self, rays_o, rays_d, near, far, debug=False, extras=None):
         """render(rays=...) (RN:58-123): rays_o, rays_d [N,3] -> dict of [N,...] tensors on the device.
         extras: the per-ray inputs of the stochastic options / given view directions (see _extras); the draws are the
@@ -233,7 +241,7 @@ class NsrModel:
         rays_o = self._f32(rays_o, (-1, 3))
         rays_d = self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
-        self.rays_launched += n
+        self._count(n)
         o, ro, dbg = self._outs(n, debug)
         ex, keep = self._extras(extras, n)
         _lib.check(self.lib.nsr_render_rays_ex(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
@@ -269,7 +277,7 @@ class NsrModel:
         c2w = c2w[:, :3, :4].contiguous()
         v = c2w.shape[0]
         n = v * int(H) * int(W)
-        self.rays_launched += n
+        self._count(n)
         K9 = (C.c_double * 9)(*[float(K[i][j]) for i in range(3) for j in range(3)])
         o, ro, dbg = self._outs(n, debug)
         _lib.check(self.lib.nsr_render_views(self.h, _dev(c2w), v, int(H), int(W), K9, float(near), float(far),
@@ -312,7 +320,7 @@ class NsrModel:
         rays_o = self._f32(rays_o, (-1, 3))
         rays_d = self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
-        self.rays_launched += n
+        self._count(n)
         g = self._f32(grad_rgb, (n, 3))
         zf = self._f32(z_fine, (n, self.nf_kernel)) if z_fine is not None else None
         go, gd = self._new(n, 3), self._new(n, 3)

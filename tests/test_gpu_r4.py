@@ -332,6 +332,37 @@ def test_partial_overflow_is_ray_granular_and_graph_replayable(oracle, synth_net
     mh.close(); m32.close()
 
 
+def test_range_list_never_drops_through_the_engine_and_counts_through_the_c_abi(oracle, synth_nets):
+    """One launch hands at most `capacity` items to its fp32 fallback (2^17 by default = 262 144 rays).  The Python engine
+    grows the list to the launch (nsr_reserve_range, a setup call) so nothing can be dropped: 300 000 overflowing rays come
+    back as the fp32 kernel's.  Straight through the C ABI without the reservation the excess is COUNTED (dropped_items)."""
+    import ctypes as C
+    from neural_sim_nerf_amd import _lib
+    from neural_sim_nerf_amd.engine import _dev, _stream_ptr
+    g = load_golden("g6_render_rays")
+    near, far = float(g["near"]), float(g["far"])
+    big = [{k: np.array(v, copy=True) for k, v in sd.items()} for sd in synth_nets]
+    big[0]["pts_linears.0.bias"][7] = 7.0e4                             # every coarse point leaves the range
+    n = 300000
+    idx = np.arange(n) % len(g["rays_o"])
+    ro, rd = g["rays_o"][idx], g["rays_d"][idx]
+    m, m32 = _mk(big, "f16x2"), _mk(big, "x32")
+    out = m.render_rays(ro, rd, near, far)
+    st = m.range_status()
+    assert st["last_items"] == n // 2 and st["rays"] == n and st["dropped_items"] == 0, st
+    want = m32.render_rays(ro[:1024], rd[:1024], near, far)
+    assert np.array_equal(cpu(out["rgb_map"])[:1024], cpu(want["rgb_map"])) and np.isfinite(cpu(out["rgb_map"])).all()
+    # the C ABI without nsr_reserve_range: a fresh handle keeps the default capacity
+    m2 = _mk(big, "f16x2")
+    o2, ro2, _ = m2._outs(n, False)
+    ro_t, rd_t = m2._f32(ro, (-1, 3)), m2._f32(rd, (-1, 3))
+    _lib.check(m2.lib.nsr_render_rays_ex(m2.h, _dev(ro_t), _dev(rd_t), n, near, far, None, C.byref(ro2), None, _stream_ptr(m2.device)))
+    st2 = m2.range_status()
+    assert st2["last_items"] == n // 2 and st2["rays"] == 2 * (1 << 17) and st2["dropped_items"] == n // 2 - (1 << 17), st2
+    for x in (m, m32, m2):
+        x.close()
+
+
 def test_dropin_api_warns_once_about_the_range(oracle, synth_nets, tmp_path):
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R

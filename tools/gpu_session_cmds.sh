@@ -2,4 +2,3 @@
 cd $GRAFT_REPO_ROOT
 timeout 2400 python -m pytest tests/ -q -m gpu > $O/gpu_suite.log 2>&1; tail -6 $O/gpu_suite.log
 timeout 60 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_nocpu.json 2> $O/bench_nocpu.err; tail -c 400 $O/bench_nocpu.json
