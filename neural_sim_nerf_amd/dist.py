@@ -191,32 +191,42 @@ def gather_patch_grads(local, n_poses, group=None):
 
 def mean_psi_grad(local_dLdpsis, group=None, n_cat=None):
     """torch.mean(torch.stack(dLdpsis), 0) (NM:191) when the per-patch gradients are spread over ranks:
-    all-reduce(sum) of [sum of local [n_cat] vectors | local count].  n_cat (the length of psi; 8 in the reference,
-    NM:1164) is taken from the local gradients; a rank that holds none (fewer poses than ranks) learns it from the others
-    through one all-reduce(max) -- or from the argument."""
+    all-reduce(sum) of [sum of local [n_cat] vectors | local count | error flag].  n_cat (the length of psi; 8 in the
+    reference, NM:1164) is taken from the local gradients; a rank that holds none (fewer poses than ranks) learns it from
+    the others through one all-reduce(max) of (length, -length) -- skipped when the caller supplies n_cat.  A length
+    disagreement is an error on EVERY rank (the collectives are finished first: a rank that raised alone would leave the
+    others hanging in the next one)."""
     world, _ = world_info(group)
+    comm = world > 1 or _FORCE
     if len(local_dLdpsis):
         s = torch.stack([torch.as_tensor(g, dtype=torch.float64) for g in local_dLdpsis]).sum(0)
     else:
         s = None
-    mine = s.numel() if s is not None else (int(n_cat) if n_cat else 0)
-    if n_cat is not None and mine != int(n_cat):
-        raise ValueError("mean_psi_grad: local gradients have %d entries, n_cat=%d" % (mine, int(n_cat)))
-    if world > 1 or _FORCE:
-        t = torch.tensor([mine], dtype=torch.int64, device=_comm_device(group))
+    mine = s.numel() if s is not None else 0
+    length = int(n_cat) if n_cat else mine
+    if comm and not n_cat:
+        none = 1 << 40
+        t = torch.tensor([mine, -(mine if mine else none)], dtype=torch.int64, device=_comm_device(group))
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        agreed = int(t.item())
-        if mine and mine != agreed:
-            raise ValueError("mean_psi_grad: this rank's gradients have %d entries, another rank's %d" % (mine, agreed))
-        mine = agreed
-    if mine == 0:
+        longest, shortest = int(t[0].item()), -int(t[1].item())
+        if longest and shortest != longest:
+            raise ValueError("mean_psi_grad: the ranks' gradients have between %d and %d entries" % (shortest, longest))
+        length = longest
+    if length == 0:
         raise ValueError("mean_psi_grad: no rank holds a gradient")
-    buf = torch.zeros(mine + 1, dtype=torch.float64)
-    if s is not None:
-        buf[:mine] = s
-        buf[mine] = len(local_dLdpsis)
-    if world > 1 or _FORCE:
+    bad = bool(mine) and mine != length                 # (only possible against a caller-supplied n_cat)
+    if bad and not comm:
+        raise ValueError("mean_psi_grad: local gradients have %d entries, n_cat=%d" % (mine, length))
+    buf = torch.zeros(length + 2, dtype=torch.float64)
+    if s is not None and not bad:
+        buf[:length] = s
+        buf[length] = len(local_dLdpsis)
+    buf[length + 1] = 1.0 if bad else 0.0
+    if comm:
         buf = buf.to(_comm_device(group))
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
         buf = buf.cpu()
-    return (buf[:mine] / buf[mine]).to(torch.float32)
+    if buf[length + 1] > 0:
+        raise ValueError("mean_psi_grad: %d rank(s) hold gradients whose length is not n_cat=%d (this rank: %d entries)"
+                         % (int(buf[length + 1]), length, mine))
+    return (buf[:length] / buf[length]).to(torch.float32)

@@ -1,6 +1,8 @@
-"""world_size-2 `gloo` tests of the multi-GPU path (view sharding, image all-gather, psi-gradient all-reduce) on
-CPU.  The renderer is replaced by a deterministic function of the pose: what is under test is the sharding,
-ordering, padding and reduction logic of neural_sim_nerf_amd/dist.py, not the kernel."""
+"""`gloo` tests of the multi-GPU path (view sharding, image all-gather, psi-gradient all-reduce) on CPU, at world sizes
+2, 3, 5 and 8 -- the 8-rank layout of BASELINE configs[2] / [4] included: 100 views -> 13 / 12 per rank, 21 models ->
+3,3,3,3,3,2,2,2, and K = 5 views on 8 ranks (three ranks with nothing to render).  The renderer is replaced by a
+deterministic function of the pose: what is under test is the sharding, ordering, padding and reduction logic of
+neural_sim_nerf_amd/dist.py, not the kernel."""
 import os
 import socket
 
@@ -57,27 +59,43 @@ def _worker(rank, world, port, n_views, tmp, q):
     # a rank WITHOUT gradients (fewer poses than ranks) and a psi of another length (r03 hard-coded 8 for that rank)
     g5 = D.mean_psi_grad([torch.full((5,), 4.0), torch.full((5,), 6.0)] if rank == 0 else [])
     ok = ok and tuple(g5.shape) == (5,) and torch.allclose(g5, torch.full((5,), 5.0))
+    # ... the same with n_cat supplied by the caller (no length agreement round), and ranks whose gradients disagree in
+    # length: EVERY rank raises (a rank that raised alone would leave the others hanging in the next collective)
+    g5 = D.mean_psi_grad([torch.full((5,), 4.0), torch.full((5,), 6.0)] if rank == world - 1 else [], n_cat=5)
+    ok = ok and tuple(g5.shape) == (5,) and torch.allclose(g5, torch.full((5,), 5.0))
+    try:
+        D.mean_psi_grad([torch.ones(8 if rank == 0 else 7)])
+        ok = False
+    except ValueError as e:
+        ok = ok and "entries" in str(e)
+    # the sharding rule itself: every rank within one view of the others, models like views (configs[4])
+    ok = ok and len(mine) in (n_views // world, -(-n_views // world))
+    ok = ok and D.shard_models(21, world, rank) == list(range(rank, 21, world))
     q.put((rank, bool(ok), D.shard_indices(n_views, world, rank)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views", [5, 4, 1])
-def test_view_sharding_gather_and_grad_allreduce(tmp_path, n_views):
-    world = 2
+@pytest.mark.parametrize("world,n_views", [(2, 5), (2, 4), (2, 1), (8, 100), (8, 5), (5, 21), (3, 100)])
+def test_view_sharding_gather_and_grad_allreduce(tmp_path, world, n_views):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_views, str(tmp_path), q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     seen = sorted(i for _, _, idx in res for i in idx)
     assert seen == list(range(n_views))                       # every view rendered exactly once
+    sizes = sorted((len(idx) for _, _, idx in res), reverse=True)
+    if (world, n_views) == (8, 100):
+        assert sizes == [13, 13, 13, 13, 12, 12, 12, 12]      # BASELINE configs[2] on one node: ideal speed-up 100 / 13 = 7.7
+    if (world, n_views) == (8, 5):
+        assert sizes == [1, 1, 1, 1, 1, 0, 0, 0]              # K < N: three ranks render nothing and still take part
     files = sorted(os.listdir(tmp_path / "7"))
     assert files == ["%03d.png" % i for i in range(n_views)]  # each rank wrote its own views, named by pose index
 
@@ -172,15 +190,17 @@ def _dropin_worker(rank, world, port, n_views, tmp, q, desync):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_views", [3, 2])
-def test_dropin_render_path_and_grad_shard_themselves(tmp_path, n_views):
+@pytest.mark.parametrize("world,n_views", [(2, 3), (2, 2), (8, 5), (8, 21), (3, 7)])
+def test_dropin_render_path_and_grad_shard_themselves(tmp_path, world, n_views):
+    """(8, 5): fewer poses than ranks -- three ranks render nothing, pad the gathers with zero views and contribute a zero
+    patch count to the psi-gradient mean; (8, 21) and (3, 7): uneven shares (k_max != local count on most ranks)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dropin_worker, args=(r, 2, port, n_views, str(tmp_path), q, False)) for r in range(2)]
+    procs = [ctx.Process(target=_dropin_worker, args=(r, world, port, n_views, str(tmp_path), q, False)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=300) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
