@@ -11,10 +11,12 @@
  *   - plain C types only; every `const float*` / `float*` / `int64_t*` named d_* is a DEVICE pointer
  *     owned by the caller (e.g. a PyTorch-ROCm tensor's data_ptr); the library never frees them;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is stream-ordered.
- *     SETUP calls (nsr_create, nsr_destroy, nsr_upload_*, nsr_reserve_bbox, nsr_selftest, nsr_last_kernel_ms)
- *     may allocate and synchronise.  LAUNCH calls (everything else) only enqueue kernels on `stream`: no
- *     allocation, no synchronisation, no environment reads, the calling thread's current HIP device is left as
- *     it was found -- they can be captured into a hipGraph and replayed (tests/test_gpu_parity.py);
+ *     SETUP calls (nsr_create, nsr_destroy, nsr_upload_*, nsr_reserve_bbox, nsr_reserve_range, nsr_selftest,
+ *     nsr_last_kernel_ms) may allocate and synchronise.  LAUNCH calls (everything else) only enqueue kernels on `stream`:
+ *     no synchronisation, no environment reads, the calling thread's current HIP device is left as it was found, and no
+ *     allocation -- with ONE exception outside stream capture: an f16x2 handle's render / input-gradient launch that is
+ *     larger than every launch before it first grows the range safety net's list (nsr_reserve_range).  They can be
+ *     captured into a hipGraph and replayed (tests/test_gpu_parity.py);
  *   - return value: 0 = OK, non-zero = error, message via nsr_last_error() (thread-local);
  *   - one handle per (model, stream): a handle owns one argument block, one work-queue head and its scratch
  *     buffers, so launches are ordered by the stream they are issued on; a launch on a DIFFERENT stream while the
@@ -120,7 +122,7 @@ typedef struct NsrConfig {
                                    the encoder's domain -- stays a NaN), every other ray keeps the f16x2 kernel's bits,
                                    so a ray's result never depends on its neighbours.  nsr_range_status counts what happened.  The input-
                                    gradient launch needs nsr_upload_weights_bwd (fp32 transposed stream) for its fallback;
-                                   without it the affected rays keep their NaN gradients and are counted as dropped.       */
+                                   without it every output of the affected rays is NaN and they are counted as dropped.    */
 
 /* Optional per-ray debug taps of the fused kernel (all device pointers, any may be NULL).  128 / 192 = N_importance /
  * 64 + N_importance of the handle. */
@@ -372,16 +374,20 @@ int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays);
 
 /* f16x2 range safety net (NSR_FLAG_MLP_F16X2): what the handle's launches reported so far.  *last_items = items (2 rays)
  * the LAST launch handed to its fp32 fallback; cumulative over the handle's life: *points = network evaluations whose
- * outputs / gradients were NaN, *rays = rays rendered again by the fp32 kernel, *dropped_items = items that could not be
- * (beyond the list's capacity -- 2^17 items per launch unless nsr_reserve_range grew it -- or an input-gradient launch without
- * nsr_upload_weights_bwd): those kept the f16x2 kernel's output for out-of-range activations (see nsr_reserve_range).  Any pointer may be NULL.  All zero for other handles.  Synchronises the device. */
+ * outputs / gradients were NaN, *rays = rays rendered again by the fp32 kernel, *dropped_items = items that could not be:
+ * EVERY OUTPUT OF THEIR REPORTED RAYS IS NaN (never a finite number computed from out-of-range activations).  An item is
+ * dropped only (a) by a launch CAPTURED into a hipGraph that is larger than the list was when the capture began (a capture
+ * cannot allocate: call nsr_reserve_range first), (b) by an input-gradient launch without nsr_upload_weights_bwd (no fp32
+ * transposed stream to fall back to), or (c) when the device is out of memory for the list.  Any pointer may be NULL.  All
+ * zero for other handles.  Synchronises the device. */
 int nsr_range_status(nsr_handle h, unsigned* last_items, unsigned* points, unsigned* rays, unsigned* dropped_items);
 
-/* SETUP call: make the safety net's list large enough for launches of up to n_rays rays (default: 2^18 rays), so that no
- * item can be dropped -- a dropped item keeps what the f16x2 kernel produced from out-of-range activations, which is a NaN
- * where the overflow reaches the output and can be a finite value computed from a degenerate coarse pass where it does not
- * (sigma = NaN composites as zero density).  8 bytes per 2 rays.  The Python engine calls it before any launch that needs
- * it; no-op for handles without NSR_FLAG_MLP_F16X2. */
+/* SETUP call: make the safety net's list large enough for launches of up to n_rays rays (8 bytes per 2 rays).  EAGER launch
+ * calls do this themselves -- nsr_render_rays* / nsr_render_views / nsr_render_rays_vjp* grow the list to their own size
+ * before they enqueue anything (one hipMalloc per new largest size, no synchronisation; the outgrown list stays allocated
+ * until nsr_destroy because a launch in flight or a graph captured earlier still addresses it) -- so this call is needed
+ * only before CAPTURING a launch larger than anything the handle has launched so far (at most 2^33 - 2 rays).  Fails while
+ * the handle's stream is being captured.  No-op for handles without NSR_FLAG_MLP_F16X2. */
 int nsr_reserve_range(nsr_handle h, int64_t n_rays);
 
 /* Debug build (`make -C neural_sim_nerf_amd/csrc debug` -> libnsr_debug.so, -DNSR_DEBUG_BOUNDS): every data-dependent

@@ -51,8 +51,9 @@ struct DeviceGuard {
 };
 #define NSR_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSR_HIP(guard_.err)
 
-constexpr unsigned kOvfCap = 1u << 17;      // items (2 rays each) one launch can hand to its fp32 fallback by default: 1 MiB per handle
-                                            // (nsr_reserve_range grows it to the largest launch the caller plans)
+constexpr unsigned kOvfCap = 1u << 17;      // items (2 rays each) the safety net's list holds at first: 1 MiB per handle; every launch
+                                            // call grows it to its own size first (ensure_range), so no item is ever dropped
+constexpr long long kMaxRaysH2 = 2 * 0xFFFFFFFFll;   // f16x2 handles: the launch's item count is a 32-bit device word
 static int kSuperLg = 12;              // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
@@ -93,6 +94,9 @@ struct nsr_handle_s {
   nsr::VjpArgs* d_vjp_args_fb = nullptr;
   unsigned long long* d_ovf_items = nullptr;     // ... the items (2 rays) the f16x2 kernel reported, [ovf_cap]
   unsigned ovf_cap = 0;
+  std::vector<void*> retired;                    // ... lists the handle has outgrown: a launch still in flight, or a hipGraph
+                                                 // captured earlier, holds their address in its argument block (by value),
+                                                 // so they live as long as the handle does
   unsigned* d_ovf_stat = nullptr;                // ... [0] items of the last launch, [1] points, [2] rays, [3] items beyond the cap
   float* d_zf_scratch = nullptr;      // k_render16: sorted fine z values between the two phases of a chunk, [2 n_cu][chunk][192]
   int zf_grid = 0;
@@ -154,10 +158,13 @@ static int allocate_handle(nsr_handle h) {
     NSR_HIP(hipMemset(h->d_ovf_stat, 0, 4 * sizeof(unsigned)));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_h2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+    // the safety net's fallback kernels: bf16x3 once nsr_upload_weights_b3 has been called on this handle
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+    NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     if (cfg->n_importance == 64 || cfg->n_importance == 32) {
-      for (const void* k : {(const void*)nsr::k_render_h2_n64, (const void*)nsr::k_render_h2_n32, (const void*)nsr::k_render_n64,
-                            (const void*)nsr::k_render_n32, (const void*)nsr::k_render_vjp_h2_n64, (const void*)nsr::k_render_vjp_h2_n32,
-                            (const void*)nsr::k_render_vjp_n64, (const void*)nsr::k_render_vjp_n32})
+      for (const void* k : {(const void*)nsr::k_render_h2_n64, (const void*)nsr::k_render_h2_n32, (const void*)nsr::k_render_b3_n64,
+                            (const void*)nsr::k_render_b3_n32, (const void*)nsr::k_render_vjp_h2_n64, (const void*)nsr::k_render_vjp_h2_n32,
+                            (const void*)nsr::k_render_vjp_b3_n64, (const void*)nsr::k_render_vjp_b3_n32})
         NSR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     }
   }
@@ -256,6 +263,7 @@ int nsr_destroy(nsr_handle h) {
   hipFree(h->d_args_fb);
   hipFree(h->d_vjp_args_fb);
   hipFree(h->d_ovf_items);
+  for (void* p : h->retired) hipFree(p);
   hipFree(h->d_ovf_stat);
   hipFree(h->d_sched_flags);
   hipFree(h->d_status);
@@ -290,10 +298,12 @@ int nsr_upload_weights16(nsr_handle h, int net_id, const float* packed, size_t n
 
 int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t n_floats) {
   if (!h || !packed) return fail("nsr_upload_weights_b3: null argument");
-  if (!(h->cfg.flags & NSR_FLAG_MLP_BF16X3)) return fail("nsr_upload_weights_b3: the handle was not created with NSR_FLAG_MLP_BF16X3");
+  if (!(h->cfg.flags & (NSR_FLAG_MLP_BF16X3 | NSR_FLAG_MLP_F16X2)))
+    return fail("nsr_upload_weights_b3: the handle was created with neither NSR_FLAG_MLP_BF16X3 nor NSR_FLAG_MLP_F16X2");
   if (net_id < 0 || net_id > 1) return fail("nsr_upload_weights_b3: net_id must be 0 (coarse) or 1 (fine)");
   if (n_floats != (size_t)NSR_PACKED_B3_FLOATS) return fail("nsr_upload_weights_b3: wrong packed size");
   NSR_DEVICE(h);
+  if (!h->d_nets_b3) NSR_HIP(hipMalloc(&h->d_nets_b3, sizeof(float) * 3 * kB3Stride));      // f16x2 handle: the fallback's images (setup call)
   NSR_HIP(hipMemcpy(h->d_nets_b3 + (size_t)net_id * kB3Stride, packed, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   h->have_net_b3[net_id] = true;
   return 0;
@@ -340,9 +350,11 @@ int nsr_upload_weights_bwd_h2(nsr_handle h, const float* stream, size_t n_floats
 
 int nsr_upload_weights_bwd_b3(nsr_handle h, const float* stream, size_t n_floats) {
   if (!h || !stream) return fail("nsr_upload_weights_bwd_b3: null argument");
-  if (!(h->cfg.flags & NSR_FLAG_MLP_BF16X3)) return fail("nsr_upload_weights_bwd_b3: the handle was not created with NSR_FLAG_MLP_BF16X3");
+  if (!(h->cfg.flags & (NSR_FLAG_MLP_BF16X3 | NSR_FLAG_MLP_F16X2)))
+    return fail("nsr_upload_weights_bwd_b3: the handle was created with neither NSR_FLAG_MLP_BF16X3 nor NSR_FLAG_MLP_F16X2");
   if (n_floats != (size_t)NSR_STREAM_SLABS_B3_BWD * NSR_SLAB_FLOATS) return fail("nsr_upload_weights_bwd_b3: wrong stream size");
   NSR_DEVICE(h);
+  if (!h->d_nets_b3) NSR_HIP(hipMalloc(&h->d_nets_b3, sizeof(float) * 3 * kB3Stride));      // (setup call)
   NSR_HIP(hipMemcpy(h->d_nets_b3 + 2 * kB3Stride, stream, sizeof(float) * n_floats, hipMemcpyHostToDevice));
   if (int e = alloc_mask_scratch(h)) return e;
   h->have_net_b3[2] = true;
@@ -386,6 +398,32 @@ static int grid_for(nsr_handle h, long long n_items) {
 
 // library default (variant 0) = x16: measured 145.0 vs 141.5 TFLOP/s for x32 on one 400x400 view (tools/compare_variants.py)
 static bool use_x16(nsr_handle h) { return h->cfg.variant != 32; }
+
+// f16x2 range safety net: the list must hold every item of the launch (each may overflow), so that none is dropped.
+// Grows geometrically; the outgrown list is RETIRED, never freed while the handle lives (see nsr_handle_s::retired), and
+// nothing synchronises.  Not while the stream is capturing (no allocation inside a capture): a captured launch larger
+// than the list keeps the present capacity, and the kernel stores NaN into the rays of the items it cannot list
+// (range_poison) -- call nsr_reserve_range before capturing to avoid that.  An allocation failure is not an error either:
+// same NaN semantics, counted by nsr_range_status.
+static int ensure_range(nsr_handle h, long long n_rays, bool capturing) {
+  if (!h->d_ovf_items) return 0;
+  if (n_rays > kMaxRaysH2) return fail("f16x2 handles take at most 2^33 - 2 rays per launch");
+  const unsigned long long items = (unsigned long long)(n_rays + 1) / 2;
+  if (items <= h->ovf_cap || capturing) return 0;
+  unsigned long long want = 2ull * h->ovf_cap;
+  if (want < items) want = items;
+  if (want > 0xFFFFFFFFull) want = 0xFFFFFFFFull;
+  unsigned long long* grown = nullptr;
+  if (hipMalloc(&grown, sizeof(unsigned long long) * want) != hipSuccess) {
+    (void)hipGetLastError();
+    if (want == items || hipMalloc(&grown, sizeof(unsigned long long) * items) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    want = items;
+  }
+  h->retired.push_back(h->d_ovf_items);
+  h->d_ovf_items = grown;
+  h->ovf_cap = (unsigned)want;
+  return 0;
+}
 
 static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* out, const NsrDebugOut* dbg,
                          void* stream) {
@@ -431,6 +469,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   bool capturing = false;
   if (int e = stream_capturing(s, &capturing)) return e;
   if (int e = claim_stream(h, s, capturing)) return e;
+  if (h2) { if (int e = ensure_range(h, a.n_rays, capturing)) return e; }
   long long g = 0;
   const bool phases = x16 && fine && (h->cfg.flags & NSR_FLAG_SCHED_PHASES);
   if (phases) {                                            // global-phases schedule: k_render16p
@@ -460,7 +499,10 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     g = grid_for(h, (a.n_rays + 1) / 2);
   }
   a.work_counter = h->d_work_counter;
-  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = h->ovf_cap; }
+  // (the N_importance 64 / 32 kernels have a bf16x3 fallback only: without nsr_upload_weights_b3 every reported item is
+  // dropped -- NaN outputs, counted)
+  const bool have_fb = h2 && ((h->have_net_b3[0] && (!fine || h->have_net_b3[1])) || ni == NSR_N_IMPORTANCE || ni == 0);
+  if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = have_fb ? h->ovf_cap : 0u; }
 #ifdef NSR_EXP_SAMENET       // timing experiment: every pass streams the SAME weight image (L2-resident); results are wrong
   a.net_stride = 0;
 #endif
@@ -481,21 +523,28 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   else
     hipLaunchKernelGGL(nsr::k_render, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
 #ifndef NSR_EXP_NO_RANGE
-  if (h2) {
+  if (have_fb) {
     // f16x2 range safety net: the items k_render_h2 reported (a NaN network output: a scaled activation beyond the fp16
     // range) are rendered again by the fp32 kernel of the same template, which overwrites their outputs.  The list and
     // its length stay on the device; with an empty list every workgroup of this launch returns at once.
     nsr::RenderArgs f = a;
-    f.nets = h->d_nets;
-    f.net_stride = (long long)sizeof(float) * (long long)NSR_PACKED_FLOATS;
-    f.aux[0] = h->d_nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
-    f.aux[1] = h->d_nets + (fine ? (size_t)NSR_PACKED_FLOATS : 0) + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+    // ... on bf16 MFMAs (three-way split: fp32's exponent range, no failure domain, 1.7x the fp32-MFMA kernel) once the
+    // handle holds the bf16x3 images (nsr_upload_weights_b3; the Python engine uploads them), else on fp32 MFMAs
+    const bool fb3 = h->have_net_b3[0] && (!fine || h->have_net_b3[1]);
+    float* fnets = fb3 ? h->d_nets_b3 : h->d_nets;
+    const size_t fnet_floats = fb3 ? kB3Stride : (size_t)NSR_PACKED_FLOATS;
+    const size_t fstream_floats = (size_t)(fb3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
+    f.nets = fnets;
+    f.net_stride = (long long)sizeof(float) * (long long)fnet_floats;
+    f.aux[0] = fnets + fstream_floats;
+    f.aux[1] = fnets + (fine ? fnet_floats : 0) + fstream_floats;
     f.ovf_items = nullptr; f.ovf_stat = nullptr; f.ovf_cap = 0;
     f.item_list = h->d_ovf_items; f.item_count = h->d_ovf_stat; f.item_cap = h->ovf_cap;
     f.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, f, h->d_args_fb);
-    hipLaunchKernelGGL(ni == 64 ? nsr::k_render_n64 : (ni == 32 ? nsr::k_render_n32 : nsr::k_render), dim3((int)g), dim3(256),
-                       kRenderLds, s, (const nsr::RenderArgs*)h->d_args_fb);
+    void (*fk)(const nsr::RenderArgs*) = fb3 ? (ni == 64 ? nsr::k_render_b3_n64 : (ni == 32 ? nsr::k_render_b3_n32 : nsr::k_render_b3))
+                                             : nsr::k_render;
+    hipLaunchKernelGGL(fk, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args_fb);
   }
 #endif
   NSR_HIP(hipGetLastError());
@@ -595,6 +644,7 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   bool capturing = false;
   if (int e = stream_capturing(s, &capturing)) return e;
   if (int e = claim_stream(h, s, capturing)) return e;
+  if (h2) { if (int e = ensure_range(h, n_rays, capturing)) return e; }
   long long grid;
   if (x16) {                                               // one ray per item, two workgroups per CU
     grid = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : 2LL * h->n_cu;
@@ -627,8 +677,11 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   v.grad_rgb = d_grad_rgb; v.grad_o = d_grad_o; v.grad_d = d_grad_d; v.mask_scratch = h->d_mask_scratch;
   v.z_fine = d_z_fine;
   if (dbg) { v.dbg_masks = (uint4*)dbg->d_relu_masks; v.dbg_graw = dbg->d_grad_raw; v.dbg_gpts = dbg->d_grad_pts; }
-  // f16x2 range safety net (see launch_render): needs the fp32 transposed stream (nsr_upload_weights_bwd) for its fallback
-  const bool fallback = h2 && h->have_net[2];
+  // f16x2 range safety net (see launch_render): the fallback runs on bf16 MFMAs when the handle holds the bf16x3 images
+  // and their transposed stream (nsr_upload_weights_b3 / _bwd_b3), else on fp32 MFMAs (nsr_upload_weights_bwd; N_importance
+  // 128 only); with neither, the reported items are dropped (NaN, counted)
+  const bool fb3 = h2 && h->have_net_b3[0] && h->have_net_b3[1] && h->have_net_b3[2];
+  const bool fallback = fb3 || (h2 && h->have_net[2] && ni == NSR_N_IMPORTANCE);
   if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = fallback ? h->ovf_cap : 0u; }
   // global-phases schedule (k_render_vjp16p) unless the caller supplies the depths itself (then nothing is handed over)
   const bool phases = x16 && (h->cfg.flags & NSR_FLAG_SCHED_PHASES) && !d_z_fine;
@@ -660,16 +713,20 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   if (fallback) {          // the reported items again, forward and backward, on the fp32 kernel of the same template
     nsr::VjpArgs f = v;
     nsr::RenderArgs& fa = f.r;
-    fa.nets = h->d_nets;
-    fa.net_stride = (long long)sizeof(float) * (long long)NSR_PACKED_FLOATS;
-    fa.aux[0] = h->d_nets + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
-    fa.aux[1] = h->d_nets + (size_t)NSR_PACKED_FLOATS + (size_t)NSR_STREAM_SLABS * NSR_SLAB_FLOATS;
+    float* fnets = fb3 ? h->d_nets_b3 : h->d_nets;
+    const size_t fnet_floats = fb3 ? kB3Stride : (size_t)NSR_PACKED_FLOATS;
+    const size_t fstream_floats = (size_t)(fb3 ? NSR_STREAM_SLABS_B3 : NSR_STREAM_SLABS) * NSR_SLAB_FLOATS;
+    fa.nets = fnets;
+    fa.net_stride = (long long)sizeof(float) * (long long)fnet_floats;
+    fa.aux[0] = fnets + fstream_floats;
+    fa.aux[1] = fnets + fnet_floats + fstream_floats;
     fa.ovf_items = nullptr; fa.ovf_stat = nullptr; fa.ovf_cap = 0;
     fa.item_list = h->d_ovf_items; fa.item_count = h->d_ovf_stat; fa.item_cap = h->ovf_cap;
     fa.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, f, h->d_vjp_args_fb);
-    hipLaunchKernelGGL(ni == 64 ? nsr::k_render_vjp_n64 : (ni == 32 ? nsr::k_render_vjp_n32 : nsr::k_render_vjp), dim3((int)grid),
-                       dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
+    void (*fk)(const nsr::VjpArgs*) = fb3 ? (ni == 64 ? nsr::k_render_vjp_b3_n64 : (ni == 32 ? nsr::k_render_vjp_b3_n32 : nsr::k_render_vjp_b3))
+                                          : nsr::k_render_vjp;
+    hipLaunchKernelGGL(fk, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
   }
   NSR_HIP(hipGetLastError());
   if (!capturing) {
@@ -955,17 +1012,15 @@ int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays) {
 
 int nsr_reserve_range(nsr_handle h, int64_t n_rays) {
   if (!h) return fail("nsr_reserve_range: null handle");
-  if (n_rays < 0 || n_rays > ((int64_t)1 << 33)) return fail("nsr_reserve_range: 0 .. 2^33 rays");
+  if (n_rays < 0 || n_rays > kMaxRaysH2) return fail("nsr_reserve_range: 0 .. 2^33 - 2 rays");
   if (!h->d_ovf_items) return 0;                           // not an f16x2 handle: nothing to reserve
-  const unsigned long long items = (unsigned long long)(n_rays + 1) / 2;
-  if (items <= h->ovf_cap) return 0;
   NSR_DEVICE(h);
-  NSR_HIP(hipDeviceSynchronize());                         // setup call: a launch may still be reading the old list
-  unsigned long long* grown = nullptr;
-  NSR_HIP(hipMalloc(&grown, sizeof(unsigned long long) * items));
-  NSR_HIP(hipFree(h->d_ovf_items));
-  h->d_ovf_items = grown;
-  h->ovf_cap = (unsigned)items;
+  bool capturing = false;                                  // a setup call: it allocates, so not while the handle's stream captures
+  if (h->launched && h->last_stream) { if (int e = stream_capturing(h->last_stream, &capturing)) return e; }
+  if (capturing) return fail("nsr_reserve_range: the handle's stream is being captured (reserve before the capture begins)");
+  const unsigned long long items = (unsigned long long)(n_rays + 1) / 2;
+  if (int e = ensure_range(h, n_rays, false)) return e;
+  if (items > h->ovf_cap) return fail("nsr_reserve_range: out of device memory for the list");
   return 0;
 }
 

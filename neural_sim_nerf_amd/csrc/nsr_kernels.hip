@@ -888,10 +888,13 @@ __device__ __forceinline__ void range_mark(int* ovf, float chk, int lane) {
   if (chk != chk && lane < 32) atomicAdd(ovf, 1);
 #endif
 }
-// ... and the item is reported once it is complete (thread 0)
-__device__ __forceinline__ void range_report(const RenderArgs& a, int* ovf, long long item, int valid) {
+// ... and the item is reported once it is complete (thread 0).  Returns the mask of the rays that could NOT be listed (the
+// list is full: only a launch captured into a graph before the list was grown to its size can get there, see
+// ensure_range in nsr_api.hip); the caller poisons them -- a ray the fp32 kernel will not render again must not keep what
+// the f16x2 kernel made of out-of-range activations (sigma = NaN composites as zero density: a finite, wrong pixel).
+__device__ __forceinline__ unsigned range_report(const RenderArgs& a, int* ovf, long long item, int valid) {
 #ifdef NSR_EXP_NO_RANGE
-  return;
+  return 0u;
 #endif
   const int p0 = ovf[0], p1 = valid == 2 ? ovf[1] : 0;      // (an item's missing second ray repeats the first)
   if ((p0 | p1) != 0 && a.ovf_stat) {
@@ -903,7 +906,21 @@ __device__ __forceinline__ void range_report(const RenderArgs& a, int* ovf, long
       atomicAdd(a.ovf_stat + 2, (unsigned)((p0 != 0) + (p1 != 0)));
     } else {
       atomicAdd(a.ovf_stat + 3, 1u);
+      return (unsigned)mask;
     }
+  }
+  return 0u;
+}
+// NaN into every output of the rays of `mask` (thread 0, after the item's own output stores of the same wave)
+__device__ __forceinline__ void range_poison(const RenderArgs& a, long long ray0, unsigned mask) {
+  const float qn = __builtin_nanf("");
+  for (int r = 0; r < 2; ++r) {
+    if (!((mask >> r) & 1u)) continue;
+    const long long rr = ray0 + r;
+    float* const v3[2] = {a.rgb, a.rgb0};
+    float* const v1[5] = {a.disp, a.acc, a.disp0, a.acc0, a.z_std};
+    for (int k = 0; k < 2; ++k) if (v3[k]) { v3[k][rr * 3] = qn; v3[k][rr * 3 + 1] = qn; v3[k][rr * 3 + 2] = qn; }
+    for (int k = 0; k < 5; ++k) if (v1[k]) v1[k][rr] = qn;
   }
 }
 
@@ -1066,7 +1083,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       if (a.dbg_w0)
         for (int idx = tid; idx < 2 * 64; idx += 256) if (wr(idx >> 6)) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
       if (!fine) {
-        if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
+        if (MODE == kMlpH2 && tid == 0) { if (const unsigned m = range_report(a, ovf, item, valid)) range_poison(a, ray0, m); }
         __syncthreads(); packed = next_item(); continue;
       }
       NSR_T(2);
@@ -1113,7 +1130,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         else if (c == 3) { if (a.disp) a.disp[rr] = v; }
         else if (c == 4) { if (a.acc) a.acc[rr] = v; }
       }
-      if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
+      if (MODE == kMlpH2 && tid == 0) { if (const unsigned m = range_report(a, ovf, item, valid)) range_poison(a, ray0, m); }
       __syncthreads();
       NSR_T(6);
       pass = 0;
@@ -1145,7 +1162,8 @@ __global__ void __launch_bounds__(256, 1) k_render_h2(const RenderArgs* __restri
   render32_body<kMlpH2>(ap, smem);
 }
 // N_importance = 64 / 32 (RN:474), evaluated at their own 64 + 64 / 64 + 32 fine samples per ray: two fine passes per item
-// instead of three.  f16x2 handles, and the fp32 kernels their range safety net falls back to.
+// instead of three.  f16x2 handles, and the bf16x3 kernels their range safety net falls back to (bf16x3 has fp32's exponent
+// range -- no failure domain -- and fp32-grade error, at 1.7x the fp32-MFMA kernels' speed).
 __global__ void __launch_bounds__(256, 1) k_render_h2_n64(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render32_body<kMlpH2, 64>(ap, smem);
@@ -1154,13 +1172,13 @@ __global__ void __launch_bounds__(256, 1) k_render_h2_n32(const RenderArgs* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render32_body<kMlpH2, 32>(ap, smem);
 }
-__global__ void __launch_bounds__(256, 1) k_render_n64(const RenderArgs* __restrict__ ap) {
+__global__ void __launch_bounds__(256, 1) k_render_b3_n64(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpF32, 64>(ap, smem);
+  render32_body<kMlpB3, 64>(ap, smem);
 }
-__global__ void __launch_bounds__(256, 1) k_render_n32(const RenderArgs* __restrict__ ap) {
+__global__ void __launch_bounds__(256, 1) k_render_b3_n32(const RenderArgs* __restrict__ ap) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpF32, 32>(ap, smem);
+  render32_body<kMlpB3, 32>(ap, smem);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1654,7 +1672,18 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       if (va.dbg_masks && wmask == (valid == 2 ? 3 : 1))   // debug tap: the relu patterns of this item's three fine passes (the
         for (int k = 0; k < 9 * NP; ++k)                   // fallback launch rewrites them only when it owns the whole item)
           va.dbg_masks[((size_t)item * (9 * NP) + k) * 256 + tid] = my_masks[k * 256 + tid];
-      if (MODE == kMlpH2 && tid == 0) range_report(a, ovf, item, valid);
+      if (MODE == kMlpH2 && tid == 0) {
+        if (const unsigned m = range_report(a, ovf, item, valid)) {      // not listed: no fp32 re-render -> NaN, never a wrong number
+          range_poison(a, ray0, m);
+          const float qn = __builtin_nanf("");
+          for (int r = 0; r < 2; ++r)
+            if ((m >> r) & 1u)
+              for (int c = 0; c < 3; ++c) {
+                va.grad_o[(ray0 + r) * 3 + c] = qn; va.grad_d[(ray0 + r) * 3 + c] = qn;
+                if (va.grad_viewdirs) va.grad_viewdirs[(ray0 + r) * 3 + c] = qn;
+              }
+        }
+      }
       __syncthreads();
       pass = 0;
       packed = next_item();
@@ -1686,13 +1715,13 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp_h2_n32(const VjpArgs* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render_vjp32_body<kMlpH2, 32>(vp, smem);
 }
-__global__ void __launch_bounds__(256, 1) k_render_vjp_n64(const VjpArgs* __restrict__ vp) {
+__global__ void __launch_bounds__(256, 1) k_render_vjp_b3_n64(const VjpArgs* __restrict__ vp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpF32, 64>(vp, smem);
+  render_vjp32_body<kMlpB3, 64>(vp, smem);
 }
-__global__ void __launch_bounds__(256, 1) k_render_vjp_n32(const VjpArgs* __restrict__ vp) {
+__global__ void __launch_bounds__(256, 1) k_render_vjp_b3_n32(const VjpArgs* __restrict__ vp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpF32, 32>(vp, smem);
+  render_vjp32_body<kMlpB3, 32>(vp, smem);
 }
 
 // dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):

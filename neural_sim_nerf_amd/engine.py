@@ -124,7 +124,6 @@ class NsrModel:
         self._bbox_reserved = (0, 0)
         self._bwd_ready = self._bwd32_ready = False
         self.rays_launched = 0                       # rays handed to the render / input-gradient launches so far (host count)
-        self._range_rays = 1 << 18                   # f16x2: rays per launch the safety net's list holds (nsr_reserve_range)
         self.h2_range = None                         # f16x2: pack.h2_report of (coarse, fine) -- pack-time range report
         h = C.c_void_p()
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
@@ -140,12 +139,13 @@ class NsrModel:
         p = pack_network(sd_c)
         _lib.check(self.lib.nsr_upload_weights(self.h, 0, _fptr(p), PACKED_FLOATS))
         # only the images this handle's kernels read: the x32 fp32 image always (stage kernels; an fp32 handle's per-ray
-        # extras; the fallback of an f16x2 handle's range safety net), the x16 image for fp32 handles of variant 0 / 16 only
+        # extras), the x16 image for fp32 handles of variant 0 / 16 only, the bf16x3 image for bf16x3 handles and -- as the
+        # fallback of the range safety net -- for f16x2 handles
         x16 = self.variant != 32 and self.mlp == "fp32"
         if x16:
             p = pack_network16(sd_c)
             _lib.check(self.lib.nsr_upload_weights16(self.h, 0, _fptr(p), PACKED_FLOATS))
-        if self.mlp == "bf16x3":
+        if self.mlp in ("bf16x3", "f16x2"):          # (f16x2: the images of the range safety net's bf16x3 fallback)
             p = pack_network_b3(sd_c)
             _lib.check(self.lib.nsr_upload_weights_b3(self.h, 0, _fptr(p), PACKED_B3_FLOATS))
         if self.mlp == "f16x2":
@@ -161,7 +161,7 @@ class NsrModel:
             if x16:
                 p = pack_network16(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights16(self.h, 1, _fptr(p), PACKED_FLOATS))
-            if self.mlp == "bf16x3":
+            if self.mlp in ("bf16x3", "f16x2"):
                 p = pack_network_b3(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_b3(self.h, 1, _fptr(p), PACKED_B3_FLOATS))
             if self.mlp == "f16x2":
@@ -228,11 +228,13 @@ class NsrModel:
         return ex, keep
 
     def _count(self, n):
-        """host bookkeeping of a launch of n rays; grows the f16x2 safety net's list so that no item of it can be dropped"""
+        """host bookkeeping of a launch of n rays (the launch calls grow the f16x2 safety net's list themselves)"""
         self.rays_launched += n
-        if self.mlp == "f16x2" and n > self._range_rays:
-            _lib.check(self.lib.nsr_reserve_range(self.h, int(n)))       # setup call (allocates, synchronises): once per size
-            self._range_rays = int(n)
+
+    def reserve_range(self, n_rays):
+        """nsr_reserve_range: room in the f16x2 safety net's list for launches of up to n_rays rays.  Eager launches make it
+        themselves; needed only before CAPTURING (torch.cuda.graph) a launch larger than any this handle has made."""
+        _lib.check(self.lib.nsr_reserve_range(self.h, int(n_rays)))
 
     def render_rays(self, rays_o, rays_d, near, far, debug=False, extras=None):
         """render(rays=...) (RN:58-123): rays_o, rays_d [N,3] -> dict of [N,...] tensors on the device.
@@ -296,10 +298,10 @@ class NsrModel:
         if self.n_importance == 0:
             raise NotImplementedError("the VJP kernel needs the coarse+fine configuration (N_importance > 0)")
         has_extras = bool(extras) and any(v is not None for v in extras.values())
-        need32 = ((has_extras or debug) and self.mlp == "fp32" and self.variant != 32) or self.mlp == "f16x2"
+        need32 = (has_extras or debug) and self.mlp == "fp32" and self.variant != 32
         if need32 and not self._bwd32_ready:
             # the fp32 x32 transposed stream: the extras and the debug taps are served by the x32-structured kernels (an fp32
-            # handle of another variant runs k_render_vjp for them), and it is the fallback of an f16x2 handle's range safety net
+            # handle of another variant runs k_render_vjp for them)
             b = pack_network_backward(self._sd_fine_np)
             _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
             self._bwd32_ready = True
@@ -310,6 +312,8 @@ class NsrModel:
             elif self.mlp == "f16x2":
                 b = pack_network_backward_h2(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd_h2(self.h, _fptr(b), b.size))
+                b = pack_network_backward_b3(self._sd_fine_np)          # ... and the range safety net's bf16x3 fallback
+                _lib.check(self.lib.nsr_upload_weights_bwd_b3(self.h, _fptr(b), b.size))
             elif self.variant == 32:
                 b = pack_network_backward(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
@@ -452,7 +456,14 @@ class NsrModel:
                                             _dev(disp), _dev(acc), _dev(w), _dev(depth), _stream_ptr(self.device)))
         return rgb, disp, acc, w, depth
 
+    def _stage_tables_ok(self, what):
+        if self.ni_kernel not in (0, N_IMPORTANCE):      # a native N_importance 64 / 32 handle's u table is linspace(0,1,n) + padding
+            raise NotImplementedError("%s is specialised to 128 importance samples and reads the handle's uniforms table; this "
+                                      "handle's kernels (and table) are specialised to N_importance = %d -- use a 128 handle"
+                                      % (what, self.ni_kernel))
+
     def sample_pdf(self, bins, weights):
+        self._stage_tables_ok("sample_pdf")
         bins = self._f32(bins)
         n = bins.shape[0]
         if bins.shape[1] != 63 or tuple(weights.shape) != (n, 62):
@@ -488,7 +499,8 @@ class NsrModel:
     def range_status(self):
         """f16x2 range safety net (include/nsr.h: nsr_range_status): dict(last_items, points, rays, dropped_items) --
         items (2 rays) the last launch handed to its fp32 fallback; cumulative network evaluations with NaN outputs /
-        gradients, rays re-rendered by the fp32 kernel, items that could not be.  Synchronises the device."""
+        gradients, rays re-rendered by the fp32 kernel, items that could not be (their rays hold NaN; only a launch captured
+        into a graph before reserve_range, or an out-of-memory list, gets there).  Synchronises the device."""
         v = [C.c_uint() for _ in range(4)]
         _lib.check(self.lib.nsr_range_status(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("last_items", "points", "rays", "dropped_items"), (int(x.value) for x in v)))

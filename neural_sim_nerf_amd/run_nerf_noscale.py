@@ -85,15 +85,17 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
     return cache["model"]
 
 
-_RANGE_SWITCH_FRAC = 0.10         # more than this share of a handle's rays re-rendered by the fp32 kernel: use it outright
+_RANGE_SWITCH_FRAC = 0.10         # more than this share of a handle's rays re-rendered by the fallback kernel: use bf16x3 outright
+_RANGE_SWITCH_MLP = "bf16x3"      # ... the arithmetic with fp32's exponent range (no failure domain) at 1.7x the fp32-MFMA speed
 
 
 def _note_range(model, network_fn=None):
     """f16x2 range safety net (include/nsr.h: NSR_FLAG_MLP_F16X2): called where the API has synchronised anyway.  Rays whose
-    network evaluation left the fp16 range were rendered again by the fp32 kernel inside the same launch call -- the
-    results are the fp32 kernel's -- so this only says so, once per handle.  A network that sends more than a tenth of its
-    rays down that route pays for both kernels: its later handles are built with the fp32 kernels (`_model_for` reads the
-    mark), which is the same arithmetic without the detour."""
+    network evaluation left the fp16 range were rendered again by the bf16x3 kernel inside the same launch call -- the
+    results are that kernel's (fp32-grade, fp32's exponent range) -- so this only says so, once per handle.  A network that
+    sends more than a tenth of its rays down that route pays for both kernels: its later handles are built with the bf16x3
+    kernels (`_model_for` reads the mark), which is the same arithmetic without the detour -- 157 against 94 Mray-samples/s
+    for the fp32-MFMA kernels r04 switched to."""
     if getattr(model, "mlp", None) != "f16x2":
         return
     st = model.range_status()
@@ -101,15 +103,18 @@ def _note_range(model, network_fn=None):
         return
     switch = network_fn is not None and st["rays"] > _RANGE_SWITCH_FRAC * max(1, model.rays_launched)
     if switch:
-        network_fn.__dict__["_nsr_force_mlp"] = ("fp32", getattr(model, "weights_version", None))
+        network_fn.__dict__["_nsr_force_mlp"] = (_RANGE_SWITCH_MLP, getattr(model, "weights_version", None))
     if not getattr(model, "_range_warned", False):
         import warnings
         model._range_warned = True
+        dropped = ("" if not st["dropped_items"] else
+                   "; %d items (2 rays each) could NOT be -- a launch captured into a graph before NsrModel.reserve_range, or "
+                   "no memory for the list -- and every output of their out-of-range rays is NaN" % st["dropped_items"])
         warnings.warn("neural_sim_nerf_amd: %d network evaluations left the fp16 range of the f16x2 kernels; %d of %d rays were "
-                      "rendered again by the fp32 kernel (%d items could not be and hold NaN).%s"
-                      % (st["points"], st["rays"], model.rays_launched, st["dropped_items"],
-                         "  This network now gets the fp32 kernels outright." if switch else
-                         "  NSR_MLP=fp32 selects the fp32 kernels outright."), RuntimeWarning)
+                      "rendered again by the bf16x3 kernel%s.%s"
+                      % (st["points"], st["rays"], model.rays_launched, dropped,
+                         "  This network now gets the bf16x3 kernels outright." if switch else
+                         "  NSR_MLP=bf16x3 selects the bf16x3 kernels outright."), RuntimeWarning)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -314,10 +319,8 @@ def _check_kwargs(kw):
     from .engine import IMPORTANCE_COUNTS
     if kw.get("N_importance", 0) not in IMPORTANCE_COUNTS:
         bad.append("N_importance=%r (128, 0, or a divisor of 128)" % kw.get("N_importance"))
-    from .engine import NATIVE_IMPORTANCE, DEFAULT_MLP
-    native = (os.environ.get("NSR_MLP", DEFAULT_MLP) == "f16x2" and kw.get("N_importance", 0) in NATIVE_IMPORTANCE
-              and not (kw.get("network_fn") is not None and kw["network_fn"].__dict__.get("_nsr_force_mlp")))
-    if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128) and not native:
+    from .engine import NATIVE_IMPORTANCE
+    if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128) + tuple(NATIVE_IMPORTANCE):
         bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4]; the f16x2 "
                    "kernels are specialised to N_importance 64 and 32 and return the reference's raw there)" % kw.get("N_importance"))
     net = kw.get("network_fine") if kw.get("N_importance", 0) > 0 and kw.get("network_fine") is not None else kw.get("network_fn")
@@ -327,6 +330,16 @@ def _check_kwargs(kw):
                    % (net.output_ch, net.output_ch))
     if bad:
         raise NotImplementedError("render: unsupported option(s): " + ", ".join(bad))
+
+
+def _check_retraw(kw, model):
+    """retraw wants the reference's [N, 64 + N_importance, 4]: served where the handle's kernels evaluate exactly that many
+    fine samples (128; 64 / 32 on f16x2 handles) -- decided on the handle that will run, not on a guess about it."""
+    n_imp = kw.get("N_importance", 0)
+    if kw.get("retraw", False) and n_imp not in (0, 128) and getattr(model, "ni_kernel", n_imp) != n_imp:
+        raise NotImplementedError("render: retraw with N_importance=%r on a %s handle (its fine pass carries duplicated samples: "
+                                  "raw would be [N,192,4]; the f16x2 kernels are specialised to N_importance 64 and 32 and return "
+                                  "the reference's raw there)" % (n_imp, getattr(model, "mlp", "?")))
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
@@ -342,6 +355,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
     model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs)
+    _check_retraw(kwargs, model)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
     special = bool(ndc) or (c2w_staticcam is not None and use_viewdirs) or _stochastic(kwargs) or per_ray_bounds

@@ -1,7 +1,7 @@
 """GPU tests added in round 4 (run with -m gpu on an MI355X), through the C ABI like tests/test_gpu_parity.py:
   * the relu-flip census of the input-gradient kernels (oracle/vjp_census.py) on the kernels' own debug taps;
-  * the f16x2 range safety net: a point that leaves the fp16 range is rendered again by the fp32 kernel inside the same
-    launch call -- no NaN reaches the caller that the fp32 kernel would not produce;
+  * the f16x2 range safety net: a point that leaves the fp16 range is rendered again by the bf16x3 kernel (r05; fp32 in r04)
+    inside the same launch call -- no NaN reaches the caller that the fp32 kernel would not produce;
   * the DEFAULT (f16x2) kernels at full size: size-independent properties forward and VJP, and render_path_grad on a
     400x400 pose with 313 patches (BASELINE configs[3]'s render leg at its real size)."""
 import os
@@ -195,13 +195,15 @@ def test_f16x2_never_returns_a_nan_the_fp32_kernel_would_not(case, oracle, synth
     g = load_golden("g8_backward")
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     ro, rd, cot = g["rays"][0][:96], g["rays"][1][:96], g["cot"][:96]
-    mh, m32 = _mk(nets, "f16x2"), _mk(nets, "x32")
+    mh, m32, mb3 = _mk(nets, "f16x2"), _mk(nets, "x32"), _mk(nets, "bf16x3")
     a = mh.render_rays(ro, rd, near, far, debug=True)
     st = mh.range_status()
     b = m32.render_rays(ro, rd, near, far, debug=True)
+    b3 = mb3.render_rays(ro, rd, near, far, debug=True)
     keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std")
     for k in keys:
         assert np.array_equal(np.isnan(cpu(a[k])), np.isnan(cpu(b[k]))), (case, k)
+        assert np.array_equal(np.isnan(cpu(b3[k])), np.isnan(cpu(b[k]))), (case, k)      # bf16x3 has no failure domain of its own
     print("%s: range status after the forward launch %s" % (case, st))
     assert st["dropped_items"] == 0
     raw, raw32 = cpu(a["raw"]), cpu(b["raw"])
@@ -210,8 +212,8 @@ def test_f16x2_never_returns_a_nan_the_fp32_kernel_would_not(case, oracle, synth
         zf = cpu(a["z_fine"])
         want = oracle.run_network(nets[1], (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), oracle.normalize_dirs(rd))
         assert np.abs(raw - want).max() <= 5e-5 * max(1.0, float(np.abs(want).max())), (case, np.abs(raw - want).max())
-    else:                                           # re-rendered items hold the fp32 kernel's bits
-        diff = np.array([not np.array_equal(cpu(a["rgb_map"])[i], cpu(b["rgb_map"])[i], equal_nan=True) for i in range(96)])
+    else:                                           # re-rendered items hold the bf16x3 kernel's bits
+        diff = np.array([not np.array_equal(cpu(a["rgb_map"])[i], cpu(b3["rgb_map"])[i], equal_nan=True) for i in range(96)])
         assert st["rays"] >= 2 * st["last_items"] - 1 and st["points"] > 0
         assert (~diff).sum() >= st["rays"], (case, (~diff).sum(), st)      # at least the re-rendered rays are bit-equal
     # input gradients: finite wherever the fp32 kernel's are
@@ -227,24 +229,29 @@ def test_f16x2_never_returns_a_nan_the_fp32_kernel_would_not(case, oracle, synth
     if fin.any():
         e = _rel_rows(cpu(gd)[fin], cpu(gd32)[fin].astype(np.float64))
         assert np.median(e) < 1e-4, (case, np.median(e))
-    mh.close(); m32.close()
+    mh.close(); m32.close(); mb3.close()
 
 
-def test_f16x2_out_of_range_items_are_the_fp32_kernels(oracle, synth_nets):
+def test_f16x2_out_of_range_items_are_the_bf16x3_kernels(oracle, synth_nets):
     """A hidden bias of 7e4 puts every point outside the fp16 range (r03: every output NaN).  Now every item goes through
-    the fallback: outputs, debug taps and input gradients are the fp32 x32 kernel's, bit for bit; the status counts them."""
+    the fallback: outputs, debug taps and input gradients are the bf16x3 kernel's (r04: the fp32 x32 kernel's), bit for bit;
+    the status counts them."""
     g = load_golden("g6_render_rays")
     near, far = float(g["near"]), float(g["far"])
     ro, rd = g["rays_o"][:65], g["rays_d"][:65]                       # an odd count: the last item holds one ray
     big = [{k: np.array(v, copy=True) for k, v in sd.items()} for sd in synth_nets]
     big[0]["pts_linears.0.bias"][7] = 7.0e4
     big[1]["pts_linears.0.bias"][7] = 7.0e4
-    mh, m32 = _mk(big, "f16x2"), _mk(big, "x32")
+    mh, m32 = _mk(big, "f16x2"), _mk(big, "bf16x3")
     a = mh.render_rays(ro, rd, near, far, debug=True)
     b = m32.render_rays(ro, rd, near, far, debug=True)
     for k in a:
         assert np.array_equal(cpu(a[k]), cpu(b[k]), equal_nan=True), k
     assert np.isfinite(cpu(a["rgb_map"])).all()
+    mx = _mk(big, "x32")                                                # ... which is the fp32 kernel's render to fp32-MLP rounding
+    c = mx.render_rays(ro, rd, near, far)
+    assert np.abs(cpu(c["rgb0"]) - cpu(a["rgb0"])).max() < 1e-5
+    mx.close()
     st = mh.range_status()
     assert st["last_items"] == 33 and st["rays"] == 65 and st["dropped_items"] == 0 and st["points"] >= 65 * 64, st
     cot = np.random.RandomState(0).standard_normal((65, 3)).astype(np.float32)
@@ -253,7 +260,7 @@ def test_f16x2_out_of_range_items_are_the_fp32_kernels(oracle, synth_nets):
     assert np.array_equal(cpu(ga[0]), cpu(gb[0])) and np.array_equal(cpu(ga[1]), cpu(gb[1]))
     assert mh.range_status()["rays"] == 130
     # coarse-only handles and the view form take the same route
-    mc, mc32 = _mk([big[0], None], "f16x2", n_importance=0), _mk([big[0], None], "x32", n_importance=0)
+    mc, mc32 = _mk([big[0], None], "f16x2", n_importance=0), _mk([big[0], None], "bf16x3", n_importance=0)
     K = oracle.scaled_K(50.0)
     c2w = np.asarray(oracle.sweep_poses(1, seed=3))[0]
     va, vb = mc.render_views(c2w, 8, 8, K, near, far), mc32.render_views(c2w, 8, 8, K, near, far)
@@ -270,7 +277,7 @@ def test_f16x2_out_of_range_items_are_the_fp32_kernels(oracle, synth_nets):
 
 def test_partial_overflow_is_ray_granular_and_graph_replayable(oracle, synth_nets):
     """A network on the EDGE of the fp16 range: a hidden bias just below the ceiling puts some points of a view beyond it and
-    leaves the others inside.  Rays that the safety net re-rendered carry the fp32 x32 kernel's bits; every other ray carries the f16x2
+    leaves the others inside.  Rays that the safety net re-rendered carry the bf16x3 kernel's bits; every other ray carries the f16x2
     kernel's -- the very bits it gets when it is rendered alone, whatever its item partner did; the input gradient
     likewise; and a hipGraph capture of the launch pair replays with a DIFFERENT list each time (another camera)."""
     import torch
@@ -279,7 +286,7 @@ def test_partial_overflow_is_ray_granular_and_graph_replayable(oracle, synth_net
     # layer-0 unit 7 of the COARSE network: its pre-activation without bias spans about -2.2 .. 2.2 over these views, the largest
     # per ray is 1.2 .. 1.4 in the median; the kernels' ceiling is 65504 (1 - 2^-12) = 65488
     edge[0]["pts_linears.0.bias"][7] = np.float32(65488.0 - 1.35)
-    mh, m32 = _mk(edge, "f16x2"), _mk(edge, "x32")
+    mh, m32 = _mk(edge, "f16x2"), _mk(edge, "bf16x3")                # (m32: the handle whose bits the fallback reproduces)
     K = oracle.scaled_K(10.0)                                        # 40 x 40
     poses = np.asarray(oracle.sweep_poses(3, seed=5))
     a = mh.render_views(poses[0], 40, 40, K, near, far)
@@ -300,7 +307,7 @@ def test_partial_overflow_is_ray_granular_and_graph_replayable(oracle, synth_net
     assert mh.range_status()["rays"] == before                       # none of them overflows on its own either
     for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
         assert np.array_equal(cpu(sub[k]), cpu(a[k])[clean], equal_nan=True), k
-    # ... and the re-rendered ones alone on the fp32 handle
+    # ... and the re-rendered ones alone on the bf16x3 handle
     hot = np.nonzero(same32)[0]
     sub32 = m32.render_rays(ro[hot], rd[hot], near, far)
     assert np.array_equal(cpu(sub32["rgb_map"]), ra[hot])
@@ -332,11 +339,16 @@ def test_partial_overflow_is_ray_granular_and_graph_replayable(oracle, synth_net
     mh.close(); m32.close()
 
 
-def test_range_list_never_drops_through_the_engine_and_counts_through_the_c_abi(oracle, synth_nets):
-    """One launch hands at most `capacity` items to its fp32 fallback (2^17 by default = 262 144 rays).  The Python engine
-    grows the list to the launch (nsr_reserve_range, a setup call) so nothing can be dropped: 300 000 overflowing rays come
-    back as the fp32 kernel's.  Straight through the C ABI without the reservation the excess is COUNTED (dropped_items)."""
+def test_range_list_grows_with_the_launch_and_a_captured_launch_poisons_what_it_cannot_list(oracle, synth_nets):
+    """no silent wrong pixel from the safety net.  The list starts at 2^17 items (262 144 rays); every EAGER
+    launch call -- through the engine or through the raw C ABI, no reservation -- grows it to its own size first, so 300 000
+    overflowing rays come back as the fallback kernel's and nothing is dropped.  A launch CAPTURED into a hipGraph cannot
+    allocate: larger than the list was when the capture began, it lists what fits and stores NaN into every output of the
+    rays it could not list (r04: finite pixels computed from a degenerate coarse pass), counted as dropped_items;
+    nsr_reserve_range before the capture avoids that.  The list an earlier capture addressed stays alive after the handle
+    has outgrown it (replaying that graph read freed memory)."""
     import ctypes as C
+    import torch
     from neural_sim_nerf_amd import _lib
     from neural_sim_nerf_amd.engine import _dev, _stream_ptr
     g = load_golden("g6_render_rays")
@@ -346,20 +358,73 @@ def test_range_list_never_drops_through_the_engine_and_counts_through_the_c_abi(
     n = 300000
     idx = np.arange(n) % len(g["rays_o"])
     ro, rd = g["rays_o"][idx], g["rays_d"][idx]
-    m, m32 = _mk(big, "f16x2"), _mk(big, "x32")
+    m, mb3 = _mk(big, "f16x2"), _mk(big, "bf16x3")
     out = m.render_rays(ro, rd, near, far)
     st = m.range_status()
     assert st["last_items"] == n // 2 and st["rays"] == n and st["dropped_items"] == 0, st
-    want = m32.render_rays(ro[:1024], rd[:1024], near, far)
+    want = mb3.render_rays(ro[:1024], rd[:1024], near, far)
     assert np.array_equal(cpu(out["rgb_map"])[:1024], cpu(want["rgb_map"])) and np.isfinite(cpu(out["rgb_map"])).all()
-    # the C ABI without nsr_reserve_range: a fresh handle keeps the default capacity
+    # the raw C ABI on a fresh handle, no nsr_reserve_range: the launch call grows the list itself
     m2 = _mk(big, "f16x2")
     o2, ro2, _ = m2._outs(n, False)
     ro_t, rd_t = m2._f32(ro, (-1, 3)), m2._f32(rd, (-1, 3))
     _lib.check(m2.lib.nsr_render_rays_ex(m2.h, _dev(ro_t), _dev(rd_t), n, near, far, None, C.byref(ro2), None, _stream_ptr(m2.device)))
     st2 = m2.range_status()
-    assert st2["last_items"] == n // 2 and st2["rays"] == 2 * (1 << 17) and st2["dropped_items"] == n // 2 - (1 << 17), st2
-    for x in (m, m32, m2):
+    assert st2["last_items"] == n // 2 and st2["rays"] == n and st2["dropped_items"] == 0, st2
+    assert np.array_equal(cpu(o2["rgb_map"]), cpu(out["rgb_map"]))
+    # a captured launch larger than the list: a fresh handle (2^17 items), a SMALL eager warm-up, then the capture
+    m3 = _mk(big, "f16x2")
+    ro3, rd3 = m3._f32(ro, (-1, 3)), m3._f32(rd, (-1, 3))
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        m3.render_rays(ro3[:512], rd3[:512], near, far)
+        side.synchronize()
+        before = m3.range_status()
+        with torch.cuda.graph(graph, stream=side):
+            cap = m3.render_rays(ro3, rd3, near, far)
+    for _ in range(2):
+        for v in cap.values():
+            v.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        rgb = cpu(cap["rgb_map"])
+        bad = np.isnan(rgb).all(1)
+        keep = ~bad
+        assert bad.sum() == n - 2 * (1 << 17), (bad.sum(), n - 2 * (1 << 17))      # every unlisted ray is NaN in every output
+        for k in ("disp_map", "acc_map", "rgb0", "disp0", "acc0", "z_std"):
+            assert np.isnan(cpu(cap[k])[bad]).all(), k
+        assert np.array_equal(rgb[keep], cpu(out["rgb_map"])[keep])                 # every listed ray is the fallback kernel's
+    st3 = m3.range_status()
+    assert st3["dropped_items"] - before["dropped_items"] == 2 * (n // 2 - (1 << 17)), (st3, before)
+    # an eager launch of the same size grows the list (the old one is retired, not freed) ...
+    eager = m3.render_rays(ro3, rd3, near, far)
+    assert np.array_equal(cpu(eager["rgb_map"]), cpu(out["rgb_map"]))
+    # ... and the graph captured BEFORE still replays on the list it was captured with
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.isnan(cpu(cap["rgb_map"])).all(1).sum() == bad.sum()      # (which items fit the list is a race; how many is not)
+    # reserve first, capture after: nothing is dropped
+    m4 = _mk(big, "f16x2")
+    m4.reserve_range(n)
+    ro4, rd4 = m4._f32(ro, (-1, 3)), m4._f32(rd, (-1, 3))
+    g4 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        m4.render_rays(ro4[:512], rd4[:512], near, far)
+        side.synchronize()
+        with torch.cuda.graph(g4, stream=side):
+            cap4 = m4.render_rays(ro4, rd4, near, far)
+    g4.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(cpu(cap4["rgb_map"]), cpu(out["rgb_map"])) and m4.range_status()["dropped_items"] == 0
+    # the input-gradient launch: same contract (eager: grows; results are the bf16x3 kernel's)
+    cot = np.random.RandomState(0).standard_normal((n, 3)).astype(np.float32)
+    m5 = _mk(big, "f16x2")
+    go, gd = m5.render_rays_vjp(ro, rd, near, far, cot)
+    g3o, g3d = mb3.render_rays_vjp(ro[:1024], rd[:1024], near, far, cot[:1024])
+    assert np.array_equal(cpu(gd)[:1024], cpu(g3d)) and np.array_equal(cpu(go)[:1024], cpu(g3o))
+    assert m5.range_status()["dropped_items"] == 0 and np.isfinite(cpu(gd)).all()
+    for x in (m, mb3, m2, m3, m4, m5):
         x.close()
 
 
@@ -381,10 +446,16 @@ def test_dropin_api_warns_once_about_the_range(oracle, synth_nets, tmp_path):
     with pytest.warns(RuntimeWarning, match="left the fp16 range"):
         rgbs, _ = R.render_path(None, poses, [8, 8, K[0][0]], K, 512, kw, savedir=str(tmp_path))
     assert np.isfinite(rgbs).all()
-    # every ray took the fp32 route: these weights get the fp32 kernels outright from now on (no second kernel per launch)
-    assert R._model_for(nets[0], nets[1], 128, kw).mlp == "fp32"
+    # every ray took the fallback route: these weights get the bf16x3 kernels outright from now on (no second kernel per
+    # launch; r04 switched to the fp32-MFMA kernels, 94 against 157 Mray-samples/s)
+    assert R._model_for(nets[0], nets[1], 128, kw).mlp == "bf16x3"
     again, _ = R.render_path(None, poses, [8, 8, K[0][0]], K, 512, kw)
-    assert np.abs(again - rgbs).max() < 1e-4                            # (fallback: the x32 fp32 kernel; outright: the x16 one)
+    assert np.array_equal(again, rgbs)                                  # (fallback and outright: the same kernel body, the same bits)
+    # new weights: the mark dies with the weights it was made for
+    with torch.no_grad():
+        nets[0].pts_linears[0].bias[7] = 0.1
+        nets[1].pts_linears[0].bias[7] = 0.1
+    assert R._model_for(nets[0], nets[1], 128, kw).mlp == "f16x2"
 
 
 # ------------------------------------------------------------------------------------------------------------------

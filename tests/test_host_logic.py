@@ -63,12 +63,11 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
     fused = ["k_render_h2", "k_render_vjp_h2", "k_render_b3", "k_render_vjp_b3", "k_render16p", "k_render16", "k_render",
              "k_render_vjp16p", "k_render_vjp16", "k_run_network",
              "k_render_h2_n64", "k_render_h2_n32", "k_render_vjp_h2_n64", "k_render_vjp_h2_n32",       # N_importance 64 / 32 (r04)
-             "k_render_n64", "k_render_n32"]
+             "k_render_b3_n64", "k_render_b3_n32",     # ... and the bf16x3 kernels their range safety net falls back to (r05)
+             "k_render_vjp_b3_n64", "k_render_vjp_b3_n32"]
     for k in fused:
         assert res[k]["vgpr_spill_count"] == 0 and res[k]["private_segment_fixed_size"] == 0, (k, res[k])
     assert res["k_render_vjp"]["vgpr_spill_count"] <= 4 and res["k_render_vjp"]["private_segment_fixed_size"] <= 20, res["k_render_vjp"]
-    for k in ("k_render_vjp_n64", "k_render_vjp_n32"):       # its N_importance 64 / 32 twins: fallback of the range safety net only
-        assert res[k]["vgpr_spill_count"] <= 8 and res[k]["private_segment_fixed_size"] <= 32, (k, res[k])
     # the register allocation of the default forward kernel is part of its performance contract (r04: a control-flow change
     # that moved it from 412 to 449 registers cost 16 % on MI355X); a change here wants an A/B on hardware
     assert res["k_render_h2"]["vgpr_count"] + 0 <= 420, res["k_render_h2"]
