@@ -323,6 +323,49 @@ def render_options_workload(sd_c, sd_f, c2w, device):
             "extra_hbm_bytes_per_ray": 448 * 4}
 
 
+def range_stress_workload(sd_c, sd_f, c2w, device, target=0.10):
+    """f16x2 range safety net under load: a network ON the edge of the fp16 range -- a hidden bias of the
+    coarse network's layer 0 just below the kernels' ceiling, calibrated (bisection on a 100x100 view) so that about `target`
+    of the rays of this 400x400 view overflow -- rendered by the default handle (reported items re-rendered by the bf16x3
+    kernel within the same launch call, r05) and by a handle whose fallback is the fp32-MFMA kernel (r04's route), next to
+    the same view with the plain weights.  last_kernel_ms covers both launches of a call."""
+    edge_c = {k: np.array(v, copy=True) for k, v in sd_c.items()}
+    pose = torch.as_tensor(c2w[:3, :4])
+    K100 = S.scaled_K(4.0)
+
+    def frac(off, fallback, side, K):
+        edge_c["pts_linears.0.bias"][7] = np.float32(65488.0 - off)
+        m = NsrModel(edge_c, sd_f, device=device, range_fallback=fallback)
+        m.render_views(pose, side, side, K, S.YCBV_NEAR, S.YCBV_FAR)
+        t = []
+        for _ in range(3):
+            m.render_views(pose, side, side, K, S.YCBV_NEAR, S.YCBV_FAR)
+            t.append(m.last_kernel_ms())
+        st = m.range_status()
+        m.close()
+        return st["rays"] / (4.0 * side * side), float(np.mean(t)), st
+    lo, hi = 0.0, 4.0                      # offset below the ceiling: larger = fewer rays overflow
+    for _ in range(9):
+        mid = 0.5 * (lo + hi)
+        f, _, _ = frac(mid, "bf16x3", 100, K100)
+        lo, hi = (mid, hi) if f > target else (lo, mid)
+    off = 0.5 * (lo + hi)
+    fb3, ms_b3, st_b3 = frac(off, "bf16x3", H, S.YCBV_K)
+    f32, ms_32, st_32 = frac(off, "fp32", H, S.YCBV_K)
+    plain = NsrModel(sd_c, sd_f, device=device)
+    plain.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+    t = []
+    for _ in range(3):
+        plain.render_views(pose, H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+        t.append(plain.last_kernel_ms())
+    plain.close()
+    return {"workload": "400x400 view of a network whose coarse layer-0 bias[7] = 65488 - %.3f: %.1f %% of the rays leave the fp16 "
+                        "range and are re-rendered inside the same launch call (kernel ms, HIP events over both launches)" % (off, 100 * fb3),
+            "rays_rerendered_frac": round(fb3, 4), "ms_per_view_bf16x3_fallback": round(ms_b3, 3),
+            "ms_per_view_fp32_fallback_r04": round(ms_32, 3), "ms_per_view_in_range_network": round(float(np.mean(t)), 3),
+            "dropped_items": st_b3["dropped_items"] + st_32["dropped_items"]}
+
+
 def config1_workload(sd_c, c2w, device, cpu_setting):
     """BASELINE configs[0]: 64x64 view, 64 coarse samples only.  GPU: 50 launches, HIP-event mean.
     CPU: the oracle on the same view at the reference's chunk (512, CF:25) and at 4096."""
@@ -514,45 +557,130 @@ _KNAME = {"f16x2": "k_render_h2", "bf16x3": "k_render_b3", "fp32": "k_render16p"
 
 def live_traffic(mlp):
     """HBM-side bytes of ONE launch of the forward kernel, measured NOW: two extra launches of the same view in child
-    processes under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters + kernel trace only, as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per that guide's gfx950 correction), when
-    rocprofv3 is on the box.  Returns (bytes or None, note)."""
+    processes under `rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE` and `--pmc WRITE_SIZE` (separate passes, counters + kernel
+    trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled per that guide's gfx950 correction;
+    GRBM has its own counter slots), when rocprofv3 is on the box.  The first pass also gives the shader clock the kernel
+    sustained: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the kernel's duration in that pass.
+    Returns (bytes or None, note, dict(clock_GHz, kernel_ms_under_pmc) or None)."""
     import csv
     import glob
     import shutil
     import subprocess
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
-        return None, "rocprofv3 not found on this box"
+        return None, "rocprofv3 not found on this box", None
     if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ):
-        return None, "bench.py is itself running under a profiler: the live PMC passes are skipped (no nested rocprofv3)"
-    tot = {}
+        return None, "bench.py is itself running under a profiler: the live PMC passes are skipped (no nested rocprofv3)", None
+    tot, clock = {}, None
     tmp = tempfile.mkdtemp(prefix="nsr_pmc_")
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, ctr)
-            r = subprocess.run([exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+        for ctrs in (("FETCH_SIZE", "GRBM_GUI_ACTIVE"), ("WRITE_SIZE",)):
+            d = os.path.join(tmp, ctrs[0])
+            r = subprocess.run([exe, "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                                 os.path.join(ROOT, "tools", "one_view.py"), "0"], cwd=tmp, capture_output=True, text=True,
                                timeout=120, env=dict(os.environ, NSR_MLP=mlp, TMPDIR=tmp))
             files = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctr, r.returncode, (r.stderr or r.stdout)[-200:])
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (ctrs[0], r.returncode, (r.stderr or r.stdout)[-200:]), None
             first = None
             for row in csv.DictReader(open(files[0])):
-                if _KNAME[mlp] in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                if _KNAME[mlp] in row["Kernel_Name"] and row["Counter_Name"] in ctrs:
                     first = first or row["Dispatch_Id"]
                     if row["Dispatch_Id"] == first:
-                        tot[ctr] = tot.get(ctr, 0.0) + float(row["Counter_Value"])
-            if ctr not in tot:
-                return None, "rocprofv3 --pmc %s: no %s dispatch in the counter file" % (ctr, _KNAME[mlp])
+                        tot[row["Counter_Name"]] = tot.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            if ctrs[0] not in tot:
+                return None, "rocprofv3 --pmc %s: no %s dispatch in the counter file" % (ctrs[0], _KNAME[mlp]), None
+            if "GRBM_GUI_ACTIVE" in ctrs and "GRBM_GUI_ACTIVE" in tot:
+                for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if _KNAME[mlp] in row["Kernel_Name"] and clock is None:
+                            ns = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                            clock = {"clock_GHz": round(tot["GRBM_GUI_ACTIVE"] / 8.0 / ns, 4), "kernel_ms_under_pmc": round(ns / 1e6, 3)}
     except (OSError, subprocess.SubprocessError, KeyError, ValueError) as e:
-        return None, "live PMC pass failed: %r" % (e,)
+        return None, "live PMC pass failed: %r" % (e,), None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0, (
         "measured in THIS run: one extra launch of the same view per counter under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE in "
         "separate passes, summed over the XCDs); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; L2 misses served by Infinity Cache "
-        "(weight re-streaming), not HBM reads -- algorithmic HBM bytes are 7.0e6 per launch (DESIGN.md 4)")
+        "(weight re-streaming), not HBM reads -- algorithmic HBM bytes are 7.0e6 per launch (DESIGN.md 4)"), clock
+
+
+class PowerSampler:
+    """Socket power and shader clock of one GPU while the timed steps run, from the amdgpu hwmon files of its PCI device
+    (power1_average / power1_input in microwatt, freq1_input in Hz), sampled by a thread every 20 ms; falls back to ONE
+    `amd-smi metric --json` / `rocm-smi --json` reading taken by a child process during the steps.  Reported as evidence
+    for "these kernels run at the power limit" (DESIGN.md 4): a number the driver's own bench line carries."""
+
+    def __init__(self, device_index):
+        import glob
+        import threading
+        self.samples, self.note, self.stop_flag, self.thread, self.proc = [], None, False, None, None
+        self.files = None
+        try:
+            bus = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x" % (getattr(bus, "pci_domain_id", 0), getattr(bus, "pci_bus_id", -1), getattr(bus, "pci_device_id", 0))
+        except Exception:                              # noqa: BLE001 -- evidence only, never fatal
+            want = None
+        cands = []
+        for hw in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            pw = next((os.path.join(hw, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))), None)
+            fq = os.path.join(hw, "freq1_input") if os.path.exists(os.path.join(hw, "freq1_input")) else None
+            if pw or fq:
+                real = os.path.realpath(os.path.join(hw, "..", ".."))
+                cands.append((want is not None and want in real, pw, fq, real))
+        cands.sort(key=lambda c: not c[0])
+        if cands and (cands[0][0] or len(cands) == 1 or want is None):
+            self.files = cands[0][1:3]
+            self.note = "amdgpu hwmon of %s (%s, %s), 20 ms samples over the timed steps" % (
+                os.path.basename(cands[0][3]), os.path.basename(self.files[0] or "-"), os.path.basename(self.files[1] or "-"))
+            self.thread = threading.Thread(target=self._run, daemon=True)
+        self.device_index = device_index
+
+    def _read(self, f):
+        try:
+            return float(open(f).read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self.stop_flag:
+            self.samples.append((self._read(self.files[0]) if self.files[0] else None, self._read(self.files[1]) if self.files[1] else None))
+            time.sleep(0.02)
+
+    def start(self):
+        import shutil
+        if self.thread is not None:
+            self.thread.start()
+            return
+        exe = shutil.which("amd-smi")
+        if exe:          # one reading, taken while the steps run (the child starts now and samples ~0.5-1 s later)
+            self.proc = subprocess.Popen([exe, "metric", "-g", str(self.device_index), "-p", "-c", "--json"], stdout=subprocess.PIPE,
+                                         stderr=subprocess.DEVNULL, text=True)
+            self.note = "one `amd-smi metric -p -c --json` reading taken while the timed steps ran"
+
+    def stop(self):
+        self.stop_flag = True
+        if self.thread is not None:
+            self.thread.join(timeout=1.0)
+            pw = [a for a, _ in self.samples if a]
+            fq = [b for _, b in self.samples if b]
+            if not pw and not fq:
+                return {"note": "hwmon files unreadable"}
+            out = {"samples": len(self.samples), "source": self.note}
+            if pw:
+                out.update(socket_power_W_mean=round(float(np.mean(pw)) / 1e6, 1), socket_power_W_max=round(max(pw) / 1e6, 1))
+            if fq:
+                out.update(sclk_MHz_mean=round(float(np.mean(fq)) / 1e6, 1), sclk_MHz_min=round(min(fq) / 1e6, 1))
+            return out
+        if self.proc is not None:
+            try:
+                txt = self.proc.communicate(timeout=20)[0]
+                data = json.loads(txt)
+                return {"source": self.note, "amd_smi": data[0] if isinstance(data, list) and data else data}
+            except Exception as e:                     # noqa: BLE001
+                return {"note": "amd-smi reading failed: %r" % (e,)}
+        return {"note": "no hwmon power / clock files and no amd-smi on this box"}
 
 
 def strict_fp32_line(sd_c, sd_f, device, c2w, launches=3):
@@ -683,7 +811,10 @@ def main():
             dummy = torch.zeros((args.steps, H * W, 3), device=cdev)
             dist.all_gather([torch.empty_like(dummy) for _ in range(world)], dummy)
             del dummy
+        sampler = PowerSampler(local) if rank == 0 else None      # (a reader thread / child process: nothing on the GPU)
         barrier()
+        if sampler is not None:
+            sampler.start()
         kernel_ms, images = [], []
         t0 = time.perf_counter()
         for i in range(args.warmup, n_total):
@@ -696,11 +827,13 @@ def main():
             dist.all_gather(gathered, mine)
         barrier()
         dt = allmax(time.perf_counter() - t0)
+        power = sampler.stop() if sampler is not None else None
         k_ms = float(np.mean(kernel_ms))
         ranks_seen, per_rank = rank_stats(k_ms)
         if rank == 0:
             rays = args.steps * H * W * world
             roof = forward_roofline(model, k_ms)
+            roof["power_and_clock_over_the_timed_steps"] = power
             if model.mlp == "bf16x3":
                 traffic, traffic_note = pmc_traffic(args.pmc_file, "bf16x3")
                 kernel_desc = "fused persistent kernel k_render_b3 (one workgroup per CU, 32 points per wave, layer GEMMs on bf16 MFMAs with three-way split fp32 operands)"
@@ -715,11 +848,16 @@ def main():
             traffic_source = ("offline rocprofv3 --pmc passes of this kernel, used only if their recorded kernel-source hash "
                               "equals this tree's (else null)")
             if world == 1 and not args.no_extras:            # measured in this run when rocprofv3 is on the box
-                live, live_note = live_traffic(model.mlp)
+                live, live_note, clock = live_traffic(model.mlp)
                 if live is not None:
                     traffic, traffic_note, traffic_source = live, live_note, "live"
                 else:
                     traffic_note = "%s | live pass: %s" % (traffic_note, live_note)
+                if clock is not None:          # GRBM_GUI_ACTIVE / 8 XCDs / kernel duration, both from the live FETCH_SIZE pass
+                    roof["clock_GHz"] = clock["clock_GHz"]
+                    roof["clock_note"] = ("shader clock the kernel sustained in the live PMC pass of this run (kernel %.3f ms under "
+                                          "the profiler; profiled passes clock ~3 %% below un-profiled ones, MI355X_MICROARCH.md "
+                                          "DVFS note); peak 2.4 GHz" % clock["kernel_ms_under_pmc"])
             roof.update({"traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note})
             if world == 1 and model.mlp != "fp32":
                 roof["strict_fp32"] = strict_fp32_line(sd_c, sd_f, local, poses[args.warmup])
@@ -753,7 +891,8 @@ def main():
                 line["extra_workloads"] = {"config1": config1_workload(sd_c, poses[args.warmup], local, cpu_setting),
                                            "handoff": handoff_workload(model, not args.no_cpu_baseline),
                                            "api_overhead": api_overhead_workload(sd_c, sd_f, local),
-                                           "render_options": render_options_workload(sd_c, sd_f, poses[0], local)}
+                                           "render_options": render_options_workload(sd_c, sd_f, poses[0], local),
+                                           "range_stress": range_stress_workload(sd_c, sd_f, poses[args.warmup], local)}
                 ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
                 for mlp in MLP_MODES:
                     if mlp != model.mlp:

@@ -67,7 +67,7 @@ def _stream_ptr(device):
 
 class NsrModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0,
-                 white_bkgd=False, lindisp=False, chunk=None, schedule=None, mlp=None):
+                 white_bkgd=False, lindisp=False, chunk=None, schedule=None, mlp=None, range_fallback="bf16x3"):
         """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu).
         white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration).
         chunk: rays per work-queue chunk of the x16 kernel (None: $NSR_CHUNK, read HERE once, else the library default).
@@ -78,7 +78,13 @@ class NsrModel:
         rate) or "f16x2" (fp16 MFMAs on fp32 operands split into two fp16 pieces with power-of-two range management,
         NSR_FLAG_MLP_F16X2: fp32-grade results at half of bf16x3's MFMA work; the input-gradient kernel of such a handle
         runs the same scheme with per-point normalised gradients); None: "fp32" when `variant` (16 / 32) or `schedule` is given -- they name
-        fp32 forward kernels --, else $NSR_MLP, else DEFAULT_MLP."""
+        fp32 forward kernels --, else $NSR_MLP, else DEFAULT_MLP.
+        range_fallback (f16x2 handles): the arithmetic that re-renders the rays whose activations left the fp16 range --
+        "bf16x3" (default: fp32's exponent range, fp32-grade error, 1.7x the fp32-MFMA kernels) or "fp32" (r04's route; kept
+        for the A/B in bench.py's range_stress workload; N_importance 128 / 0 only)."""
+        if range_fallback not in ("bf16x3", "fp32"):
+            raise ValueError("range_fallback must be 'bf16x3' or 'fp32'")
+        self.range_fallback = range_fallback
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = _lib.load()
@@ -145,7 +151,8 @@ class NsrModel:
         if x16:
             p = pack_network16(sd_c)
             _lib.check(self.lib.nsr_upload_weights16(self.h, 0, _fptr(p), PACKED_FLOATS))
-        if self.mlp in ("bf16x3", "f16x2"):          # (f16x2: the images of the range safety net's bf16x3 fallback)
+        fb3 = self.mlp == "bf16x3" or (self.mlp == "f16x2" and self.range_fallback == "bf16x3")
+        if fb3:                                      # (f16x2: the images of the range safety net's bf16x3 fallback)
             p = pack_network_b3(sd_c)
             _lib.check(self.lib.nsr_upload_weights_b3(self.h, 0, _fptr(p), PACKED_B3_FLOATS))
         if self.mlp == "f16x2":
@@ -161,7 +168,7 @@ class NsrModel:
             if x16:
                 p = pack_network16(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights16(self.h, 1, _fptr(p), PACKED_FLOATS))
-            if self.mlp in ("bf16x3", "f16x2"):
+            if fb3:
                 p = pack_network_b3(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_b3(self.h, 1, _fptr(p), PACKED_B3_FLOATS))
             if self.mlp == "f16x2":
@@ -312,8 +319,12 @@ class NsrModel:
             elif self.mlp == "f16x2":
                 b = pack_network_backward_h2(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd_h2(self.h, _fptr(b), b.size))
-                b = pack_network_backward_b3(self._sd_fine_np)          # ... and the range safety net's bf16x3 fallback
-                _lib.check(self.lib.nsr_upload_weights_bwd_b3(self.h, _fptr(b), b.size))
+                if self.range_fallback == "bf16x3":                     # ... and the range safety net's fallback stream
+                    b = pack_network_backward_b3(self._sd_fine_np)
+                    _lib.check(self.lib.nsr_upload_weights_bwd_b3(self.h, _fptr(b), b.size))
+                else:
+                    b = pack_network_backward(self._sd_fine_np)
+                    _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))
             elif self.variant == 32:
                 b = pack_network_backward(self._sd_fine_np)
                 _lib.check(self.lib.nsr_upload_weights_bwd(self.h, _fptr(b), b.size))

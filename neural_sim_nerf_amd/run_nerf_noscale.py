@@ -221,10 +221,12 @@ class _NdcRays(torch.autograd.Function):
 
 
 def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128):
-    """The random draws of the stochastic options, in the reference's order within one chunk of rays: t_rand (RN:451),
-    the coarse density noise (RN:368), the resampling uniforms (RH:211), the fine density noise.  From torch's generator
-    of the render device: the reference's stream is reproduced when it, too, renders all N rays as ONE chunk on that
-    device; for pinned comparisons hand the reference's own draws to NsrModel.render_rays(extras=...).
+    """The random draws of the stochastic options, in the reference's order: per `chunk` of rays (the reference draws inside
+    render_rays, which batchify_rays calls once per chunk) t_rand (RN:451), the coarse density noise (RN:368), the
+    resampling uniforms (RH:211), the fine density noise.  From torch's generator of the render device, by the same calls
+    with the same shapes: a process that seeds -- or, like tests/golden/g21, replaces -- torch.rand / torch.randn gets the
+    same numbers into the same rays as the reference; pinned comparisons can also hand the reference's own draws to
+    NsrModel.render_rays(extras=...).
     pytest=True (the reference's test hook, RN:454-457, RH:214-222): every draw site reseeds numpy's GLOBAL generator
     with 0 and takes its numbers from it -- once per `chunk` of rays, so ray i gets row i mod chunk -- and the
     deterministic resampling uses NUMPY's linspace (a few ulp from torch's); reproduced exactly, side effect included.
@@ -260,15 +262,27 @@ def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128):
                 u = widen(torch.Tensor(np.linspace(0., 1., n_importance)))
                 d["u"] = u[None].expand(n, 128).contiguous().to(dev)
         return d
-    if perturbed:
-        d["t_rand"] = torch.rand(n, 64, device=dev)
-    if std > 0.:
-        d["noise0"] = torch.randn(n, 64, device=dev) * std
-    if n_importance > 0:
-        if "t_rand" in d:                                   # det = (perturb == 0.), RN:474; fewer than 128: duplicated, as
-            d["u"] = widen(torch.rand(n, n_importance, device=dev))                      # engine._host_tables
+    # the reference draws inside render_rays, i.e. once per `chunk` of rays (batchify_rays RN:43-55), in the order t_rand,
+    # coarse noise, u, fine noise: the same calls in the same order here, chunk by chunk, so that a caller who seeds (or
+    # replaces) torch's generator the way it does for the reference gets the reference's stream for ANY number of rays
+    c = n if not chunk else max(1, min(int(chunk), n))
+    parts = {}
+    for i0 in range(0, n, c):
+        m = min(c, n - i0)
+        if perturbed:
+            parts.setdefault("t_rand", []).append(torch.rand(m, 64, device=dev))
         if std > 0.:
-            d["noise1"] = torch.randn(n, 64 + ni_kernel, device=dev) * std
+            parts.setdefault("noise0", []).append(torch.randn(m, 64, device=dev) * std)
+        if n_importance > 0:
+            if perturbed:                                   # det = (perturb == 0.), RN:474; fewer than 128: duplicated, as
+                parts.setdefault("u", []).append(widen(torch.rand(m, n_importance, device=dev)))      # engine._host_tables
+            if std > 0.:
+                # (RN:371 draws [m, 64 + n_importance]; a 128-sample kernel rendering fewer importance samples through
+                # duplicated uniforms takes 192 columns: the duplicates are zero-length intervals whose density is moot)
+                parts.setdefault("noise1", []).append(torch.randn(m, 64 + ni_kernel, device=dev) * std)
+    for k in ("t_rand", "noise0", "u", "noise1"):           # (the order the tests and the docs name)
+        if k in parts:
+            d[k] = parts[k][0] if len(parts[k]) == 1 else torch.cat(parts[k], 0)
     return d
 
 
@@ -426,25 +440,21 @@ def _scaled_hw(hwf, render_factor):
     return int(H), int(W), focal
 
 
-def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False, general_ok=False):
+def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False):
+    """-> (H, W, near, far, handle, general).  general: ndc=True / perturb > 0 / raw_noise_std > 0 are in the kwargs -- the
+    reference forwards **render_kwargs to render() unchanged (RN:233, RN:168), so render_kwargs_train works there; here
+    such a call goes through render() too (per pose), the deterministic one through the batched launches."""
     H, W, _ = _scaled_hw(hwf, render_factor)
     kw = dict(render_kwargs)
     near, far = kw.pop("near", 0.), kw.pop("far", 1.)
-    if kw.pop("ndc", True) or _stochastic(kw):
-        if not general_ok:
-            raise NotImplementedError("%s: ndc=True / perturb>0 / raw_noise_std>0 are served by render() only" % name)
-        general = True
-    else:
-        general = False
+    general = bool(kw.pop("ndc", True)) or _stochastic(kw)
     _check_viewdirs(name, kw.pop("use_viewdirs", False), kw)
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
     if need_fine and n_imp == 0:
         raise NotImplementedError("%s needs the coarse+fine configuration (N_importance > 0)" % name)
     model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
-    if general_ok:
-        return H, W, near, far, model, general
-    return H, W, near, far, model
+    return H, W, near, far, model, general
 
 
 def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt_imgs=None, savedir=None,
@@ -458,7 +468,7 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
     poses, the images are all-gathered (RCCL) and EVERY rank returns all K views in pose order -- the call site
     NM:128 needs no change.  NSR_AUTO_SHARD=0 disables it."""
     from . import dist as D
-    H, W, near, far, model, general = _path_setup("render_path", hwf, render_factor, render_kwargs, general_ok=True)
+    H, W, near, far, model, general = _path_setup("render_path", hwf, render_factor, render_kwargs)
     if savedir is not None:
         os.makedirs(os.path.join(savedir, str(object_id)), exist_ok=True)
     poses = torch.as_tensor(render_poses, dtype=torch.float32).detach()
@@ -488,10 +498,22 @@ def render_path(categorical_prob, render_poses, hwf, K, chunk, render_kwargs, gt
     return rgbs, disps
 
 
-def _pose_patch_grads(model, c2w, cot, H, W, K, near, far, N_rand):
-    """One pose of render_path_grad on the device: (rgb [H,W,3], dL/d c2w[3,4] per patch [n_patches,3,4])."""
+def _pose_patch_grads(model, c2w, cot, H, W, K, near, far, N_rand, render_kwargs=None):
+    """One pose of render_path_grad on the device: (rgb [H,W,3], dL/d c2w[3,4] per patch [n_patches,3,4]).
+    render_kwargs (given for ndc=True / perturb > 0 / raw_noise_std > 0, which RN:168 forwards to render() like everything
+    else): the whole image goes through render() -- its autograd Functions carry the ndc projection, the given view
+    directions and the draws -- as ONE forward and ONE input-gradient launch; with chunk = N_rand the draws are made patch
+    by patch in the reference's order (one render() call = one chunk per patch there, RN:168 / _draws)."""
     with torch.no_grad():
         ro, rd = model.get_rays(H, W, K, c2w[:3, :4].detach().to(model.device))
+    if render_kwargs is not None:
+        rays = torch.stack([ro.reshape(-1, 3), rd.reshape(-1, 3)], 0).requires_grad_(True)
+        rgb = render(H, W, K, chunk=N_rand, rays=rays, **render_kwargs)[0]
+        (g,) = torch.autograd.grad(rgb, rays, grad_outputs=cot.to(rgb.device))
+        with torch.no_grad():
+            g_pose = model.pose_grad(g[0].contiguous(), g[1].contiguous(), H, W, K, N_rand)
+        return rgb.detach().reshape(H, W, 3), g_pose
+    with torch.no_grad():
         go, gd, out = model.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), near, far, cot, with_forward=True)
         g_pose = model.pose_grad(go, gd, H, W, K, N_rand)
     return out["rgb_map"].reshape(H, W, 3), g_pose
@@ -511,7 +533,7 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
     are all-gathered, so every rank returns the reference's full (rgbs, dLdpsis) in pose-major order and NM:184-191
     run unchanged (the mean over the stacked list equals dist.mean_psi_grad's all-reduce)."""
     from . import dist as D
-    H, W, near, far, model = _path_setup("render_path_grad", hwf, render_factor, render_kwargs, need_fine=True)
+    H, W, near, far, model, general = _path_setup("render_path_grad", hwf, render_factor, render_kwargs, need_fine=True)
     n_rays = H * W
     N_rand = int(chunk)
     n_patches = (n_rays + N_rand - 1) // N_rand
@@ -532,7 +554,8 @@ def render_path_grad(categorical_prob, render_poses, hwf, K, chunk, grad_E, rend
         g = torch.as_tensor(g.detach().cpu().numpy().transpose(1, 2, 0) if isinstance(g, torch.Tensor)
                             else np.asarray(g).transpose(1, 2, 0), dtype=torch.float32)      # RN:154 CHW -> HWC
         cot = g.reshape(-1, 3).to(model.device).contiguous()
-        rgb, g_pose = _pose_patch_grads(model, pose, cot, H, W, K, near, far, N_rand)        # [n_patches,3,4]
+        rgb, g_pose = _pose_patch_grads(model, pose, cot, H, W, K, near, far, N_rand,        # [n_patches,3,4]
+                                        render_kwargs if general else None)
         if jac_all is not None:
             J = jac_all[i_pose]                    # the device sampler's own Jacobian (pose.sample_pose_device): no autograd
         else:

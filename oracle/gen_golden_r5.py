@@ -1,0 +1,129 @@
+"""Round-5 golden vectors, produced by IMPORTING AND RUNNING the reference (same rules and shims as oracle/gen_golden.py,
+whose helpers it uses; runs only in the authoring container, needs /root/reference read-only; nothing of the reference
+travels -- inputs and outputs only).
+
+    python oracle/gen_golden_r5.py            # writes tests/golden/g21_path_options.npz [, g22.. with --counts]
+
+g21_path_options: the reference's render_path (RN:213-255) and render_path_grad (RN:126-210) called with
+render_kwargs_TRAIN -- perturb = 1, raw_noise_std > 0 (RN:318-330): both functions forward **render_kwargs to render()
+unchanged (RN:233, RN:168), so the stochastic options apply there too.  The reference draws from torch's global generator
+inside render_rays, once per chunk of rays and in the order t_rand, coarse noise, u, fine noise; torch.rand / torch.randn are
+wrapped to RECORD every draw in call order, so that a build fed the same numbers must reproduce the reference's images and
+per-patch psi-gradients.
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import nerf_oracle as O  # noqa: E402  (synthetic-weight recipe and camera constants only)
+import gen_golden as G  # noqa: E402  (import_reference, build_nets, Capture, save)
+
+
+def main():
+    RN, RH, LL = G.import_reference()
+    sys.modules["imageio"].imwrite = lambda *a, **k: None        # render_path / render_path_grad write PNGs (RN:206, RN:250)
+    torch.manual_seed(0)
+    rng = np.random.RandomState(4321)
+    SEED = 7
+    nets, kwargs, embed_fn, embeddirs_fn = G.build_nets(RN, RH, SEED)
+    g10 = np.load(os.path.join(G.OUT, "g10_path_grad.npz"))
+
+    sig_last = []
+    orig_r2o = RN.raw2outputs
+
+    def r2o(raw, *a, **k):
+        sig_last.append(raw[..., -1, 3].detach().numpy().copy())
+        return orig_r2o(raw, *a, **k)
+    RN.raw2outputs = r2o
+
+    drawn = []
+    orig_rand, orig_randn = torch.rand, torch.randn
+
+    def rec(fn):
+        def w(*a, **k):
+            out = fn(*a, **k)
+            drawn.append(out.detach().numpy().copy())
+            return out
+        return w
+
+    NOISE_STD = 0.5
+    kw_train = dict(kwargs, perturb=1.0, raw_noise_std=NOISE_STD)          # = render_kwargs_train of RN:318-330
+    log = {"gumbel_noises": g10["gumbel"].tolist(), "uniform_noises": g10["uniform"].tolist(), "thetas": g10["thetas"].tolist()}
+    psi = torch.tensor(g10["psi"])
+    prob = torch.softmax(psi / 0.25, 0).requires_grad_()                   # NM:141-142
+    poses = LL.sample_pose(prob, 2, 0.1, log)                              # the graph to psi (LL:202-247)
+    assert np.array_equal(poses.detach().numpy(), g10["poses_grad"])
+    Hs = 8
+    Ks = O.scaled_K(50.0)
+    hwf = [Hs, Hs, Ks[0][0]]
+    chunk = 16
+
+    # ---- render_path(render_kwargs_train): 2 poses x 4 chunks of 16 rays, 4 draws per chunk -------------------------
+    tmp = tempfile.mkdtemp()
+    torch.rand, torch.randn = rec(orig_rand), rec(orig_randn)
+    try:
+        with G.Capture(RN, RH) as cap:
+            rgbs, disps = RN.render_path(None, poses.detach(), hwf, Ks, chunk, kw_train, savedir=tmp, object_id=2)
+    finally:
+        torch.rand, torch.randn = orig_rand, orig_randn
+    n_chunks = 2 * (Hs * Hs // chunk)
+    assert [d.shape for d in drawn] == [(16, 64), (16, 64), (16, 128), (16, 192)] * n_chunks, [d.shape for d in drawn]
+    path_draws = list(drawn)
+    del drawn[:]
+    s0 = np.concatenate(sig_last[0::2])
+    s1 = np.concatenate(sig_last[1::2])
+    del sig_last[:]
+    catc = lambda k: np.concatenate([c[k] for c in cap.log], 0)
+    g = dict(seed=np.int64(SEED), noise_std=np.float64(NOISE_STD), K=np.array(Ks), chunk=np.int64(chunk),
+             poses=poses.detach().numpy(),
+             path_t_rand=np.stack(path_draws[0::4]), path_randn0=np.stack(path_draws[1::4]), path_u=np.stack(path_draws[2::4]),
+             path_randn1=np.stack(path_draws[3::4]), path_rgbs=rgbs, path_disps=disps,
+             path_pdf_weights=catc("weights"), path_inds=catc("inds").astype(np.int8), path_z_samples=catc("samples"),
+             path_sigma0_last=s0, path_sigma_last=s1)
+    # the coarse image, accumulation etc. are not returned by render_path: one more call of render() per pose with the SAME
+    # draws replayed gives them (rgb0 / acc0 / acc for the census' coarse leg)
+    replay = []
+
+    def feed(*a, **k):
+        return torch.from_numpy(replay.pop(0).copy())
+    extra = {k: [] for k in ("acc", "rgb0", "acc0", "disp0", "z_std")}
+    torch.rand, torch.randn = feed, feed
+    try:
+        for i in range(2):
+            replay.extend(path_draws[16 * i:16 * (i + 1)])
+            with torch.no_grad():
+                rgb, disp, acc, ex = RN.render(Hs, Hs, Ks, chunk=chunk, c2w=poses[i, :3, :4].detach(), **kw_train)
+            assert np.array_equal(rgb.numpy(), rgbs[i]) and np.array_equal(disp.numpy(), disps[i])      # the draws replay exactly
+            extra["acc"].append(acc.numpy())
+            for k in ("rgb0", "acc0", "disp0", "z_std"):
+                extra[k].append(ex[k].numpy())
+    finally:
+        torch.rand, torch.randn = orig_rand, orig_randn
+    del sig_last[:]
+    g.update({"path_" + k: np.stack(v) for k, v in extra.items()})
+
+    # ---- render_path_grad(render_kwargs_train): per pose, per 16-ray patch one render() call = one chunk = 4 draws ----
+    gE = [{"grad_E": [torch.from_numpy(rng.standard_normal((3, Hs, Hs)).astype(np.float32))]} for _ in range(2)]
+    torch.rand, torch.randn = rec(orig_rand), rec(orig_randn)
+    try:
+        rgbs_g, dl = RN.render_path_grad(prob, poses, hwf, Ks, chunk, gE, kw_train, savedir=None)
+    finally:
+        torch.rand, torch.randn = orig_rand, orig_randn
+    assert [d.shape for d in drawn] == [(16, 64), (16, 64), (16, 128), (16, 192)] * n_chunks
+    g.update(grad_E=np.stack([x["grad_E"][0].numpy() for x in gE]),
+             grad_t_rand=np.stack(drawn[0::4]), grad_randn0=np.stack(drawn[1::4]), grad_u=np.stack(drawn[2::4]),
+             grad_randn1=np.stack(drawn[3::4]), grad_rgbs=rgbs_g, dLdpsis=np.stack([d.numpy() for d in dl]))
+    G.save("g21_path_options", **g)
+    RN.raw2outputs = orig_r2o
+
+
+if __name__ == "__main__":
+    main()

@@ -604,3 +604,4 @@ def test_native_importance_counts_cost_three_quarters(synth_nets, oracle):
     for ni in (64, 32):
         assert 0.70 <= ms[ni] / ms[128] <= 0.79, ms                     # 3 of 4 passes (+ the per-ray phases, which shrink too)
         assert 0.64 <= ms_vjp[ni] / ms_vjp[128] <= 0.76, ms_vjp          # 5 of 7 passes
+

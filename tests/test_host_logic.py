@@ -451,6 +451,16 @@ def test_random_draws_follow_the_references_order():
     torch.manual_seed(4)
     t = torch.rand(7, 64); n0 = torch.randn(7, 64) * 2.0; u = torch.rand(7, 128); n1 = torch.randn(7, 192) * 2.0
     assert all(torch.equal(x, y) for x, y in zip(a.values(), (t, n0, u, n1)))
+    # more rays than `chunk`: the reference draws inside render_rays, once per chunk (batchify_rays RN:43-55) -- the same
+    # calls, chunk by chunk (7 rays, chunk 3 -> 3 + 3 + 1), so a seeded generator gives every ray the reference's numbers
+    torch.manual_seed(9)
+    a = R._draws(dict(perturb=1.0, raw_noise_std=2.0), 7, 128, cpu, chunk=3)
+    torch.manual_seed(9)
+    want = {k: [] for k in ("t_rand", "noise0", "u", "noise1")}
+    for m in (3, 3, 1):
+        want["t_rand"].append(torch.rand(m, 64)); want["noise0"].append(torch.randn(m, 64) * 2.0)
+        want["u"].append(torch.rand(m, 128)); want["noise1"].append(torch.randn(m, 192) * 2.0)
+    assert list(a) == list(want) and all(torch.equal(a[k], torch.cat(want[k])) for k in want)
 
 
 def test_pytest_hook_draws_are_the_references(oracle, synth_nets):

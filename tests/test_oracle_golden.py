@@ -186,6 +186,74 @@ def test_stochastic_options_against_the_reference(golden, oracle, synth_nets):
         assert np.percentile(e[ok], 95) < 1e-4 and np.linalg.norm(a[ok] - b[ok]) / np.linalg.norm(b[ok]) < 1e-2, e.max()
 
 
+def _g21_pose_draws(g, which, i):
+    """the draws the reference made for pose i of g21's render_path ('path') / render_path_grad ('grad') run: 4 chunks of 16
+    rays, concatenated in ray order"""
+    std = np.float32(float(g["noise_std"]))
+    sl = slice(4 * i, 4 * (i + 1))
+    cat = lambda k: np.concatenate(list(g[which + "_" + k][sl]), 0)
+    return dict(t_rand=cat("t_rand"), u=cat("u"), noise0=(cat("randn0") * std).astype(np.float32),
+                noise1=(cat("randn1") * std).astype(np.float32))
+
+
+def test_path_functions_with_train_kwargs_against_the_reference(golden, oracle, synth_nets):
+    """render_path / render_path_grad called with render_kwargs_TRAIN (perturb = 1, raw_noise_std > 0): the reference
+    forwards **render_kwargs to render() (RN:233, RN:168), draws per chunk of 16 rays inside render_rays, and g21 holds those
+    draws with what it rendered.  The oracle with the same numbers in the same rays: stratified depths and the inverse CDF
+    on the reference's own coarse weights bit for bit, the coarse image 1e-5, the fine image within the usual conditioning,
+    and the per-patch psi-gradients through the oracle's float64 backprop, d rays / d c2w and the pose Jacobian."""
+    import torch
+    g = golden("g21_path_options")
+    sd_c, sd_f = synth_nets
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = g["K"].tolist()
+    H = W = 8
+    n = H * W
+    for i in range(2):
+        rnd = _g21_pose_draws(g, "path", i)
+        ro, rd = oracle.get_rays(H, W, K, g["poses"][i][:3, :4])
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        vd = oracle.normalize_dirs(rd)
+        r = oracle.render_rays(sd_c, sd_f, ro, rd, vd, near, far, extras=True, **rnd)
+        assert_close(r["rgb0"], g["path_rgb0"][i].reshape(-1, 3), atol=1e-5, what="rgb0")
+        assert_close(r["acc0"], g["path_acc0"][i].ravel(), atol=1e-5, what="acc0")
+        z_mid = (np.float32(0.5) * (r["z_coarse"][:, 1:] + r["z_coarse"][:, :-1])).astype(np.float32)
+        sl = slice(n * i, n * (i + 1))
+        s, inds, _ = oracle.sample_pdf(z_mid, g["path_pdf_weights"][sl], 128, rnd["u"])
+        assert np.array_equal(inds, g["path_inds"][sl].astype(np.int64)) and np.array_equal(s, g["path_z_samples"][sl])
+        d = np.abs(r["rgb_map"] - g["path_rgbs"][i].reshape(-1, 3)).max(-1)
+        assert (d > 1e-4).mean() <= 0.1 and oracle.psnr(r["rgb_map"], g["path_rgbs"][i].reshape(-1, 3)) > 50.0, (i, d.max())
+    # the psi-gradient: per pose, float64 backprop (own resampling) -> per-patch contraction with d rays / d c2w -> Jacobian
+    from neural_sim_nerf_amd import pose as P
+    log = None
+    g10 = golden("g10_path_grad")
+    log = {"gumbel_noises": g10["gumbel"].tolist(), "uniform_noises": g10["uniform"].tolist(), "thetas": g10["thetas"].tolist()}
+    prob = torch.softmax(torch.tensor(g10["psi"]) / 0.25, 0).requires_grad_()
+    poses = P.sample_pose(prob, 2, 0.1, log)
+    assert np.array_equal(poses.detach().numpy(), g["poses"])
+    basis = torch.eye(12).reshape(12, 3, 4)
+    got = []
+    for i in range(2):
+        rnd = _g21_pose_draws(g, "grad", i)
+        ro, rd = oracle.get_rays(H, W, K, g["poses"][i][:3, :4])
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        cot = g["grad_E"][i].transpose(1, 2, 0).reshape(-1, 3)
+        go, gd, rgb = oracle.render_rays_vjp(sd_c, sd_f, ro, rd, near, far, cot, randoms=rnd)
+        assert oracle.psnr(rgb, g["grad_rgbs"][i].reshape(-1, 3)) > 50.0
+        (J,) = torch.autograd.grad(poses[i, :3, :4], prob, grad_outputs=basis, retain_graph=True, is_grads_batched=True)
+        col, row = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))       # RH:157-160
+        dirs = np.stack([(col - K[0][2]) / K[0][0], -(row - K[1][2]) / K[1][1], -np.ones_like(col)], -1).reshape(-1, 3)
+        for p0 in range(0, n, 16):
+            gp = np.zeros((3, 4))
+            gp[:, :3] = gd[p0:p0 + 16].astype(np.float64).T @ dirs[p0:p0 + 16].astype(np.float64)
+            gp[:, 3] = go[p0:p0 + 16].astype(np.float64).sum(0)
+            got.append(gp.reshape(12) @ J.numpy().astype(np.float64))
+    got = np.stack(got)
+    scale = np.abs(g["dLdpsis"]).max()
+    assert np.abs(got - g["dLdpsis"]).max() < 3e-2 * scale, np.abs(got - g["dLdpsis"]).max() / scale
+    assert np.abs(got.mean(0) - g["dLdpsis"].mean(0)).max() < 1e-2 * scale
+
+
 def test_c2w_staticcam_against_the_reference(golden, oracle, synth_nets):
     """RN:91-96: rays of the static camera, view directions of the other one."""
     g = golden("g14_stochastic")

@@ -10,7 +10,7 @@ sys.path.insert(0, %(root)r)
 from neural_sim_nerf_amd import synthetic as S
 from neural_sim_nerf_amd.engine import NsrModel
 sd_c = S.synth_weights(0); sd_f = S.synth_weights(1000, fine_of=sd_c)
-m = NsrModel(sd_c, sd_f, mlp=%(mlp)r)
+m = NsrModel(sd_c, sd_f, mlp=%(mlp)r, range_fallback=%(fb)r)
 ms = []
 for _ in range(%(n)d):
     out = m.render_views(S.sweep_poses(1, 0)[0], 400, 400, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
@@ -30,7 +30,8 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for lib in args:
         env = dict(os.environ, NSR_LIB_PATH=os.path.abspath(lib))
-        code = CHILD % dict(root=root, mlp=mlp, n=n, tag=os.path.basename(lib))
+        # (libraries older than r05 have no bf16x3 fallback images on f16x2 handles)
+        code = CHILD % dict(root=root, mlp=mlp, n=n, tag=os.path.basename(lib), fb="fp32" if "r04" in os.path.basename(lib) else "bf16x3")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         print((r.stdout.strip() or "(no output)") + ("" if r.returncode == 0 else "\n  FAILED: " + r.stderr.strip()[-400:]))
 
