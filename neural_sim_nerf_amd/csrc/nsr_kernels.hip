@@ -124,11 +124,17 @@ __device__ __forceinline__ void ring_assert_uniform(Ring& rg) {
 
 // Fill the ring (NS slabs in flight), certify slab 0 and load the first step's fragments.
 // A step = 4 chunks of 1 KiB = 4 float4 fragments per lane = 16 MFMAs; a slab = 4 steps.
-template <int NS = kRingSlots, int SLABS = kStreamSlabs, int SLABS_BWD = SLABS>
+#ifndef NSR_H2_SCHED
+#define NSR_H2_SCHED 3     // step schedule of the f16x2 layer GEMMs (nsr_h2.inc: step_h2): 3 = one LDS-DMA piece per step (r05);
+#endif                     // 0 = r03 / r04 (four pieces behind the slab change), kept for A/B builds (-DNSR_H2_SCHED=0)
+constexpr int kH2RingLag = NSR_H2_SCHED == 3 ? 1 : 0;
+// LAG = 1: the ring starts one slab short -- the consumer's steps then issue the pieces of slab n + NS - 1 DURING slab n,
+// one piece per step (nsr_h2.inc, NSR_H2_SCHED 3), instead of the four pieces of slab n + NS at the end of slab n.
+template <int NS = kRingSlots, int SLABS = kStreamSlabs, int SLABS_BWD = SLABS, int LAG = 0>
 __device__ __forceinline__ void ring_start(Ring& rg, f32x4 (&A0)[4], int lane) {
 #pragma unroll 1
-  for (int s = 0; s < NS; ++s) ring_issue<NS, SLABS, SLABS_BWD>(rg);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 1)) : "memory");
+  for (int s = 0; s < NS - LAG; ++s) ring_issue<NS, SLABS, SLABS_BWD>(rg);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - LAG - 1)) : "memory");
   __builtin_amdgcn_s_barrier();
   const char* p = rg.smem + rg.cslot * kSlabBytes + lane * 16;
 #pragma unroll
@@ -966,6 +972,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
+  else if constexpr (MODE == kMlpH2) ring_start<kRingSlots, kStreamSlabs, kStreamSlabs, kH2RingLag>(rg, A0, lane);
   else ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
 
   load_aux(smem, a_setup, tid0);
@@ -1478,7 +1485,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
-  else if constexpr (MODE == kMlpH2) ring_start<kRingSlots, kStreamSlabs, kStreamSlabsH2Bwd>(rg, A0, lane);
+  else if constexpr (MODE == kMlpH2) ring_start<kRingSlots, kStreamSlabs, kStreamSlabsH2Bwd, kH2RingLag>(rg, A0, lane);
   else ring_start(rg, A0, lane);
   load_aux(smem, a_setup, tid0);
   if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
