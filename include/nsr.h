@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define NSR_ABI_VERSION 3
+#define NSR_ABI_VERSION 4
 
 /* Fixed architecture of the path (configs/nerf_param_ycbv_general.txt:12-13; NM:1232-1272). */
 #define NSR_N_SAMPLES     64   /* N_samples    (coarse, RN:439)          */
@@ -67,12 +67,15 @@ typedef struct nsr_handle_s* nsr_handle;
 typedef struct NsrConfig {
   int32_t abi_version;     /* must be NSR_ABI_VERSION                                              */
   int32_t device;          /* HIP device ordinal                                                   */
-  int32_t n_samples;       /* must be 64                                                           */
-  int32_t n_importance;    /* 128, or 0 for a coarse-only render (BASELINE config 1); NSR_FLAG_MLP_F16X2 handles also take
-                              64 and 32 (RN:474 with N_importance = 64 / 32): kernels specialised to 64 + n fine samples per
-                              ray -- two fine network passes per item instead of three.  For such a handle every
-                              [.,128] / [.,192] array below is [.,n] / [.,64 + n] (d_u keeps its row stride of 128, the
-                              first n entries of a row are read; u_fine of nsr_upload_tables: its first n entries)  */
+  int32_t n_samples;       /* N_samples (RN:439): 64; NSR_FLAG_MLP_F16X2 handles also take 32 (with n_importance 64 or 0) and 128
+                              (with n_importance 128 or 0) -- r05: kernels specialised to those counts (one coarse network pass
+                              with two idle waves / two coarse passes per item)                                              */
+  int32_t n_importance;    /* N_importance (RN:474): 128, or 0 for a coarse-only render (BASELINE config 1); NSR_FLAG_MLP_F16X2
+                              handles with n_samples = 64 also take 96, 64 and 32: kernels specialised to 64 + n fine samples
+                              per ray -- two fine network passes per item instead of three for 64 and 32.  For a handle of
+                              (n_samples, n_importance) = (S, n) every [.,64] / [.,128] / [.,192] array below is [.,S] / [.,n] /
+                              [.,S + n] (d_u keeps its row stride of 128, the first n entries of a row are read; u_fine of
+                              nsr_upload_tables: its first n entries)                                                         */
   int32_t max_workgroups;  /* 0 = fill the chip (one workgroup per CU for x32, two for x16)        */
   int32_t variant;         /* render AND input-gradient kernels: 0 = library default (= 16); 16 = 16 points/wave, two
                               workgroups per CU (needs nsr_upload_weights16 / _bwd16); 32 = 32 points/wave, one
@@ -185,7 +188,7 @@ int nsr_upload_weights_bwd(nsr_handle h, const float* stream, size_t n_floats);
 int nsr_upload_weights_bwd16(nsr_handle h, const float* stream, size_t n_floats);
 
 /* The two linspace tables the reference builds on the host and moves to the device
- * (RN:439 t_vals[64], RH:208 u[128]); host buffers. */
+ * (RN:439 t_vals[N_samples], RH:208 u[128]); host buffers; n_coarse = the handle's n_samples, n_fine = 128. */
 int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine);
 
 /* render(rays=...) -> batchify_rays -> render_rays (RN:58-123, RN:43-55, RN:390-501), use_viewdirs=True, on the

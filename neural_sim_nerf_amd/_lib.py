@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "csrc", "libnsr.so"))   # override: A/B builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 PACKED_FLOATS = 145 * 4096 + 3328
 
 

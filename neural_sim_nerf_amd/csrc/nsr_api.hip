@@ -57,6 +57,8 @@ constexpr long long kMaxRaysH2 = 2 * 0xFFFFFFFFll;   // f16x2 handles: the launc
 static int kSuperLg = 12;              // k_render16p: 4096 rays per super-chunk (8 rounds of the 512-workgroup grid)
 
 constexpr size_t kRenderLds = nsr::kLdsState + sizeof(nsr::ItemState);
+constexpr size_t kRenderLdsBig = nsr::kLdsState + sizeof(nsr::ItemStateBig);      // N_samples = 128 (r05)
+static_assert(kRenderLdsBig <= 163840, "the N_samples = 128 item state fits the 160 KiB LDS next to the ring and the aux blocks");
 constexpr size_t kRender16Lds = nsr::kLds16State + sizeof(nsr::ItemState16);
 constexpr size_t kVjp16Lds = nsr::kLds16State + sizeof(nsr::ItemStateV16);
 constexpr size_t kNetLds = nsr::kLdsAux + nsr::kAuxFloats * 4;
@@ -66,6 +68,24 @@ static_assert(kB3Stride >= (size_t)NSR_PACKED_B3_FLOATS, "stride covers the forw
 // f16x2 images in d_nets_h2: coarse | fine | fine transposed, kH2Stride floats apart (the transposed stream is one slab longer)
 constexpr size_t kH2Stride = (size_t)NSR_STREAM_SLABS_H2_BWD * NSR_SLAB_FLOATS + NSR_AUX_FLOATS;
 static_assert(kH2Stride >= (size_t)NSR_PACKED_FLOATS, "stride covers the forward images");
+
+
+// The sample counts the x32-structured kernels are instantiated for (RN:439 N_samples, RN:474 N_importance).  N_samples = 64:
+// N_importance 128 on every handle; 0 (coarse only); 96 / 64 / 32 on f16x2 handles.  r05: N_samples = 32 with N_importance 64 (or
+// 0) and N_samples = 128 with N_importance 128 (or 0), f16x2 handles only.
+struct Counts { int ns, ni; };
+typedef void (*RenderKernel)(const nsr::RenderArgs*);
+typedef void (*VjpKernel)(const nsr::VjpArgs*);
+struct KernelSet { RenderKernel h2, b3; VjpKernel vjp_h2, vjp_b3; };
+inline bool special_counts(int ns, int ni) { return ns != NSR_N_SAMPLES || (ni != NSR_N_IMPORTANCE && ni != 0); }
+// kernels of an f16x2 handle with `special_counts`: the coarse-only form of N_samples 32 / 128 runs the kernel of its fine partner
+inline KernelSet special_kernels(int ns, int ni) {
+  if (ns == 32) return {nsr::k_render_h2_c32_n64, nsr::k_render_b3_c32_n64, nsr::k_render_vjp_h2_c32_n64, nsr::k_render_vjp_b3_c32_n64};
+  if (ns == 128) return {nsr::k_render_h2_c128_n128, nsr::k_render_b3_c128_n128, nsr::k_render_vjp_h2_c128_n128, nsr::k_render_vjp_b3_c128_n128};
+  if (ni == 96) return {nsr::k_render_h2_n96, nsr::k_render_b3_n96, nsr::k_render_vjp_h2_n96, nsr::k_render_vjp_b3_n96};
+  if (ni == 64) return {nsr::k_render_h2_n64, nsr::k_render_b3_n64, nsr::k_render_vjp_h2_n64, nsr::k_render_vjp_b3_n64};
+  return {nsr::k_render_h2_n32, nsr::k_render_b3_n32, nsr::k_render_vjp_h2_n32, nsr::k_render_vjp_b3_n32};
+}
 
 }  // namespace
 
@@ -161,14 +181,14 @@ static int allocate_handle(nsr_handle h) {
     // the safety net's fallback kernels: bf16x3 once nsr_upload_weights_b3 has been called on this handle
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
     NSR_HIP(hipFuncSetAttribute((const void*)nsr::k_render_vjp_b3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
-    if (cfg->n_importance == 64 || cfg->n_importance == 32) {
-      for (const void* k : {(const void*)nsr::k_render_h2_n64, (const void*)nsr::k_render_h2_n32, (const void*)nsr::k_render_b3_n64,
-                            (const void*)nsr::k_render_b3_n32, (const void*)nsr::k_render_vjp_h2_n64, (const void*)nsr::k_render_vjp_h2_n32,
-                            (const void*)nsr::k_render_vjp_b3_n64, (const void*)nsr::k_render_vjp_b3_n32})
-        NSR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRenderLds));
+    if (special_counts(cfg->n_samples, cfg->n_importance)) {
+      const KernelSet ks = special_kernels(cfg->n_samples, cfg->n_importance);
+      const int lds = (int)(cfg->n_samples == 128 ? kRenderLdsBig : kRenderLds);
+      for (const void* k : {(const void*)ks.h2, (const void*)ks.b3, (const void*)ks.vjp_h2, (const void*)ks.vjp_b3})
+        NSR_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
   }
-  NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 192));
+  NSR_HIP(hipMalloc(&h->d_tables, sizeof(float) * 256));      // [N_samples <= 128] + [128]
   NSR_HIP(hipMalloc(&h->d_scratch, sizeof(float) * 4096));
   NSR_HIP(hipMalloc(&h->d_args, sizeof(nsr::RenderArgs)));
   NSR_HIP(hipMalloc(&h->d_work_counter, 2 * sizeof(unsigned long long)));
@@ -207,22 +227,26 @@ int nsr_abi_version(void) { return NSR_ABI_VERSION; }
 int nsr_create(const NsrConfig* cfg, nsr_handle* out) {
   if (!cfg || !out) return fail("nsr_create: null argument");
   if (cfg->abi_version != NSR_ABI_VERSION) return fail("nsr_create: ABI version mismatch");
-  if (cfg->n_samples != NSR_N_SAMPLES)
-    return fail("nsr_create: unsupported N_samples (kernel is specialised to 64, configs/nerf_param_ycbv_general.txt:12)");
   if ((cfg->flags & NSR_FLAG_MLP_BF16X3) && (cfg->flags & NSR_FLAG_MLP_F16X2))
     return fail("nsr_create: NSR_FLAG_MLP_BF16X3 and NSR_FLAG_MLP_F16X2 are mutually exclusive");
   if (cfg->flags & ~(NSR_FLAG_WHITE_BKGD | NSR_FLAG_LINDISP | NSR_FLAG_SCHED_PHASES | NSR_FLAG_MLP_BF16X3 | NSR_FLAG_MLP_F16X2))
     return fail("nsr_create: unknown bits in flags");
+  {
+    const int ns = cfg->n_samples, ni = cfg->n_importance;
+    const bool h2cfg = (cfg->flags & NSR_FLAG_MLP_F16X2) != 0;
+    const bool ok = (ns == NSR_N_SAMPLES && (ni == NSR_N_IMPORTANCE || ni == 0)) ||
+                    (h2cfg && ns == NSR_N_SAMPLES && (ni == 96 || ni == 64 || ni == 32)) ||
+                    (h2cfg && ns == 32 && (ni == 64 || ni == 0)) || (h2cfg && ns == 128 && (ni == 128 || ni == 0));
+    if (!ok)
+      return fail("nsr_create: unsupported (N_samples, N_importance): (64, 128) and (64, 0) on every handle; on NSR_FLAG_MLP_F16X2 "
+                  "handles also (64, 96 / 64 / 32), (32, 64 / 0) and (128, 128 / 0) -- other handles render fewer importance samples "
+                  "with N_importance = 128 and a uniforms table of repeated values (engine._host_tables)");
+  }
   if ((cfg->flags & NSR_FLAG_SCHED_PHASES) && (cfg->variant == 32 || cfg->n_importance == 0))
     return fail("nsr_create: NSR_FLAG_SCHED_PHASES applies to the x16 coarse+fine forward kernel only");
   if (cfg->chunk < 0 || cfg->chunk > 256) return fail("nsr_create: chunk must be 0 (default) or 1..256");
   if (cfg->variant != 0 && cfg->variant != 16 && cfg->variant != 32)
     return fail("nsr_create: variant must be 0 (default), 16 or 32");
-  if (cfg->n_importance != NSR_N_IMPORTANCE && cfg->n_importance != 0 && cfg->n_importance != 64 && cfg->n_importance != 32)
-    return fail("nsr_create: unsupported N_importance (128; 0 for coarse-only; 64 or 32 on NSR_FLAG_MLP_F16X2 handles)");
-  if ((cfg->n_importance == 64 || cfg->n_importance == 32) && !(cfg->flags & NSR_FLAG_MLP_F16X2))
-    return fail("nsr_create: N_importance 64 / 32 is served by the f16x2 kernels (NSR_FLAG_MLP_F16X2); other handles render it "
-                "with N_importance = 128 and a uniforms table of repeated values (engine._host_tables)");
   int ndev = 0;
   NSR_HIP(hipGetDeviceCount(&ndev));
   if (cfg->device < 0 || cfg->device >= ndev) return fail("nsr_create: no such HIP device");
@@ -312,7 +336,8 @@ int nsr_upload_weights_b3(nsr_handle h, int net_id, const float* packed, size_t 
 static int alloc_mask_scratch(nsr_handle h) {
   if (h->d_mask_scratch) return 0;   // setup call: the VJP kernels' relu-pattern scratch, one block per workgroup
   h->mask_grid = h->cfg.max_workgroups > 0 ? h->cfg.max_workgroups : h->n_cu;     // in x32 workgroups (16 B entries)
-  NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)h->mask_grid * 3 * 9 * 256));
+  const int passes = h->cfg.n_samples == 128 ? 4 : 3;      // fine forward passes per item (render_vjp32_body: kMaskPasses)
+  NSR_HIP(hipMalloc(&h->d_mask_scratch, sizeof(uint4) * (size_t)h->mask_grid * passes * 9 * 256));
   return 0;
 }
 
@@ -374,10 +399,11 @@ int nsr_upload_weights_bwd16(nsr_handle h, const float* stream, size_t n_floats)
 
 int nsr_upload_tables(nsr_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine) {
   if (!h || !t_coarse || !u_fine) return fail("nsr_upload_tables: null argument");
-  if (n_coarse != 64 || n_fine != 128) return fail("nsr_upload_tables: tables must have 64 and 128 entries");
+  if (n_coarse != h->cfg.n_samples || n_fine != 128)
+    return fail("nsr_upload_tables: tables must have N_samples (the handle's) and 128 entries");
   NSR_DEVICE(h);
-  NSR_HIP(hipMemcpy(h->d_tables, t_coarse, sizeof(float) * 64, hipMemcpyHostToDevice));
-  NSR_HIP(hipMemcpy(h->d_tables + 64, u_fine, sizeof(float) * 128, hipMemcpyHostToDevice));
+  NSR_HIP(hipMemcpy(h->d_tables, t_coarse, sizeof(float) * n_coarse, hipMemcpyHostToDevice));
+  NSR_HIP(hipMemcpy(h->d_tables + 128, u_fine, sizeof(float) * 128, hipMemcpyHostToDevice));
   h->have_tables = true;
   return 0;
 }
@@ -453,7 +479,7 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
   a.aux[0] = nets + stream_floats;
   a.aux[1] = nets + (fine ? net_floats : 0) + stream_floats;
   a.tcoarse = h->d_tables;
-  a.ufine = h->d_tables + 64;
+  a.ufine = h->d_tables + 128;
   a.fine = fine ? 1 : 0;
   a.white_bkgd = (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0;
   a.lindisp = (h->cfg.flags & NSR_FLAG_LINDISP) ? 1 : 0;
@@ -499,9 +525,12 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     g = grid_for(h, (a.n_rays + 1) / 2);
   }
   a.work_counter = h->d_work_counter;
-  // (the N_importance 64 / 32 kernels have a bf16x3 fallback only: without nsr_upload_weights_b3 every reported item is
+  // (the kernels specialised to other sample counts have a bf16x3 fallback only: without nsr_upload_weights_b3 every reported item is
   // dropped -- NaN outputs, counted)
-  const bool have_fb = h2 && ((h->have_net_b3[0] && (!fine || h->have_net_b3[1])) || ni == NSR_N_IMPORTANCE || ni == 0);
+  const int ns = h->cfg.n_samples;
+  const bool special = special_counts(ns, ni);            // f16x2 handles only (nsr_create): kernels specialised to the counts
+  const size_t lds32 = ns == 128 ? kRenderLdsBig : kRenderLds;
+  const bool have_fb = h2 && ((h->have_net_b3[0] && (!fine || h->have_net_b3[1])) || !special);
   if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = have_fb ? h->ovf_cap : 0u; }
 #ifdef NSR_EXP_SAMENET       // timing experiment: every pass streams the SAME weight image (L2-resident); results are wrong
   a.net_stride = 0;
@@ -514,10 +543,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     hipLaunchKernelGGL(nsr::k_render16, dim3((int)g), dim3(256), kRender16Lds, s, (const nsr::RenderArgs*)h->d_args);
   else if (b3)
     hipLaunchKernelGGL(nsr::k_render_b3, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
-  else if (h2 && ni == 64)
-    hipLaunchKernelGGL(nsr::k_render_h2_n64, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
-  else if (h2 && ni == 32)
-    hipLaunchKernelGGL(nsr::k_render_h2_n32, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
+  else if (h2 && special)
+    hipLaunchKernelGGL(special_kernels(ns, ni).h2, dim3((int)g), dim3(256), lds32, s, (const nsr::RenderArgs*)h->d_args);
   else if (h2)
     hipLaunchKernelGGL(nsr::k_render_h2, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args);
   else
@@ -542,9 +569,8 @@ static int launch_render(nsr_handle h, nsr::RenderArgs& a, const NsrRenderOut* o
     f.item_list = h->d_ovf_items; f.item_count = h->d_ovf_stat; f.item_cap = h->ovf_cap;
     f.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_args, dim3(1), dim3(1), 0, s, f, h->d_args_fb);
-    void (*fk)(const nsr::RenderArgs*) = fb3 ? (ni == 64 ? nsr::k_render_b3_n64 : (ni == 32 ? nsr::k_render_b3_n32 : nsr::k_render_b3))
-                                             : nsr::k_render;
-    hipLaunchKernelGGL(fk, dim3((int)g), dim3(256), kRenderLds, s, (const nsr::RenderArgs*)h->d_args_fb);
+    RenderKernel fk = fb3 ? (special ? special_kernels(ns, ni).b3 : nsr::k_render_b3) : nsr::k_render;
+    hipLaunchKernelGGL(fk, dim3((int)g), dim3(256), lds32, s, (const nsr::RenderArgs*)h->d_args_fb);
   }
 #endif
   NSR_HIP(hipGetLastError());
@@ -623,8 +649,11 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   // an f16x2 handle runs its input gradients on fp16 MFMAs too once the transposed stream is there (nsr_upload_weights_bwd_h2);
   // without it the fp32 kernels of `variant` serve (they need their own uploads)
   const bool h2 = (h->cfg.flags & NSR_FLAG_MLP_F16X2) && h->have_net_h2[0] && h->have_net_h2[1] && h->have_net_h2[2];
-  if (ni != NSR_N_IMPORTANCE && !h2)
-    return fail("nsr_render_rays_vjp: an N_importance 64 / 32 handle needs nsr_upload_weights_bwd_h2 (only the f16x2 kernels are specialised to it)");
+  const int ns = h->cfg.n_samples;
+  const bool special = special_counts(ns, ni);
+  const size_t lds32 = ns == 128 ? kRenderLdsBig : kRenderLds;
+  if (special && !h2)
+    return fail("nsr_render_rays_vjp: a handle of these sample counts needs nsr_upload_weights_bwd_h2 (only the f16x2 kernels are specialised to them)");
   const bool extras = ex && (ex->d_viewdirs || ex->d_t_rand || ex->d_u || ex->d_noise0 || ex->d_noise1 || ex->d_near);
   if (ex && ((ex->d_near == nullptr) != (ex->d_far == nullptr))) return fail("nsr_render_rays_vjp_ex: d_near and d_far come together");
   if (d_grad_viewdirs && !(ex && ex->d_viewdirs))
@@ -668,7 +697,7 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   a.aux[0] = nets + stream_floats;
   a.aux[1] = nets + net_floats + stream_floats;
   a.tcoarse = h->d_tables;
-  a.ufine = h->d_tables + 64;
+  a.ufine = h->d_tables + 128;
   a.fine = 1;
   a.work_counter = h->d_work_counter;
   a.white_bkgd = (h->cfg.flags & NSR_FLAG_WHITE_BKGD) ? 1 : 0;
@@ -681,7 +710,7 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
   // and their transposed stream (nsr_upload_weights_b3 / _bwd_b3), else on fp32 MFMAs (nsr_upload_weights_bwd; N_importance
   // 128 only); with neither, the reported items are dropped (NaN, counted)
   const bool fb3 = h2 && h->have_net_b3[0] && h->have_net_b3[1] && h->have_net_b3[2];
-  const bool fallback = fb3 || (h2 && h->have_net[2] && ni == NSR_N_IMPORTANCE);
+  const bool fallback = fb3 || (h2 && h->have_net[2] && !special);
   if (h2) { a.ovf_items = h->d_ovf_items; a.ovf_stat = h->d_ovf_stat; a.ovf_cap = fallback ? h->ovf_cap : 0u; }
   // global-phases schedule (k_render_vjp16p) unless the caller supplies the depths itself (then nothing is handed over)
   const bool phases = x16 && (h->cfg.flags & NSR_FLAG_SCHED_PHASES) && !d_z_fine;
@@ -702,10 +731,8 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
     hipLaunchKernelGGL(nsr::k_render_vjp16, dim3((int)grid), dim3(256), kVjp16Lds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else if (b3)
     hipLaunchKernelGGL(nsr::k_render_vjp_b3, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
-  else if (h2 && ni == 64)
-    hipLaunchKernelGGL(nsr::k_render_vjp_h2_n64, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
-  else if (h2 && ni == 32)
-    hipLaunchKernelGGL(nsr::k_render_vjp_h2_n32, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
+  else if (h2 && special)
+    hipLaunchKernelGGL(special_kernels(ns, ni).vjp_h2, dim3((int)grid), dim3(256), lds32, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else if (h2)
     hipLaunchKernelGGL(nsr::k_render_vjp_h2, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args);
   else
@@ -724,9 +751,8 @@ int nsr_render_rays_vjp_dbg(nsr_handle h, const float* d_rays_o, const float* d_
     fa.item_list = h->d_ovf_items; fa.item_count = h->d_ovf_stat; fa.item_cap = h->ovf_cap;
     fa.work_counter = h->d_work_counter + 1;
     hipLaunchKernelGGL(nsr::k_set_vjp_args, dim3(1), dim3(1), 0, s, f, h->d_vjp_args_fb);
-    void (*fk)(const nsr::VjpArgs*) = fb3 ? (ni == 64 ? nsr::k_render_vjp_b3_n64 : (ni == 32 ? nsr::k_render_vjp_b3_n32 : nsr::k_render_vjp_b3))
-                                          : nsr::k_render_vjp;
-    hipLaunchKernelGGL(fk, dim3((int)grid), dim3(256), kRenderLds, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
+    VjpKernel fk = fb3 ? (special ? special_kernels(ns, ni).vjp_b3 : nsr::k_render_vjp_b3) : nsr::k_render_vjp;
+    hipLaunchKernelGGL(fk, dim3((int)grid), dim3(256), lds32, s, (const nsr::VjpArgs*)h->d_vjp_args_fb);
   }
   NSR_HIP(hipGetLastError());
   if (!capturing) {
@@ -953,7 +979,8 @@ int nsr_sample_pdf(nsr_handle h, const float* d_bins, const float* d_weights, in
   if (!h->have_tables) return fail("nsr_sample_pdf: tables not uploaded");
   if (n_rays <= 0) return n_rays == 0 ? 0 : fail("nsr_sample_pdf: negative ray count");
   NSR_DEVICE(h);
-  nsr::PdfArgs a{d_bins, d_weights, h->d_tables + 64, n_rays, d_samples, (long long*)d_inds};
+  if (h->cfg.n_samples != NSR_N_SAMPLES) return fail("nsr_sample_pdf: the stage kernel is specialised to N_samples = 64");
+  nsr::PdfArgs a{d_bins, d_weights, h->d_tables + 128, n_rays, d_samples, (long long*)d_inds};
   const long long items = (n_rays + 1) / 2;
   const int grid = (int)(items < 4096 ? items : 4096);
   hipLaunchKernelGGL(nsr::k_sample_pdf, dim3(grid), dim3(256), sizeof(nsr::ItemState), (hipStream_t)stream, a);

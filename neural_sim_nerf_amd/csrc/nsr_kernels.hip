@@ -496,26 +496,36 @@ __device__ __forceinline__ void mlp_pass(Ring& rg, const float* aux, f32x4 (&A0)
 // ------------------------------------------------------------------------------------------------------
 // per-item state in LDS (2 rays)
 // ------------------------------------------------------------------------------------------------------
-struct ItemState {
-  float tcoarse[64];        // torch.linspace(0,1,64)   RN:439
+// NSS / NFS: row strides of the coarse / fine arrays = the largest N_samples / N_samples + N_importance the kernels using this
+// layout are instantiated for.  ItemState (64, 192) is the YCB-V configuration's and every kernel's whose N_samples is <= 64;
+// ItemStateBig (128, 256) serves N_samples = 128 (r05).
+template <int NSS, int NFS>
+struct ItemStateT {
+  static constexpr int kNS = NSS, kNF = NFS;
+  float tcoarse[NSS];       // torch.linspace(0,1,N_samples)   RN:439
   float ufine[128];         // torch.linspace(0,1,128)  RH:208
   float ray[2][16];         // o[0..2] d[3..5] viewdir[6..8] near far |d|
-  float zc[2][64];          // coarse z               RN:441
-  float rawc[2][64][4];     // coarse raw             RN:466
-  float w0[2][64];          // coarse weights         RN:467
-  float cdf[2][64];         // 63 used                RH:203-204
+  float zc[2][NSS];         // coarse z               RN:441
+  float rawc[2][NSS][4];    // coarse raw             RN:466
+  float w0[2][NSS];         // coarse weights         RN:467
+  float cdf[2][NSS];        // N_samples - 1 used     RH:203-204
   float zs[2][128];         // importance samples     RH:241
-  float zf[2][192];         // sorted merged z        RN:477
-  float rawf[2][192][4];    // fine raw               RN:483
-  float alpha[2][192];      // compositing scratch
-  float wf[2][192];         // fine weights           RN:485
-  float tf[2][192];         // transmittance T_i (RN:376)
-  float om[2][192];         // 1 - alpha + 1e-10 (RN:376) / pdf (RH:202): fp32 values, widened to fp64 inside the scans
-  float bwd_scratch[2][192][2];   // backward compositing: A_i*w_i suffix sums and A_i*T_i
-  float psum[2][6][12];     // backward: per (pass, wave) partial sums of d/dpts, z*d/dpts, d/dviewdir
+  float zf[2][NFS];         // sorted merged z        RN:477
+  float rawf[2][NFS][4];    // fine raw               RN:483
+  float alpha[2][NFS];      // compositing scratch
+  float wf[2][NFS];         // fine weights           RN:485
+  float tf[2][NFS];         // transmittance T_i (RN:376)
+  float om[2][NFS];         // 1 - alpha + 1e-10 (RN:376) / pdf (RH:202): fp32 values, widened to fp64 inside the scans
+  float bwd_scratch[2][NFS][2];   // backward compositing: A_i*w_i suffix sums and A_i*T_i
+  float psum[2][NFS / 32][12];    // backward: per (pass, wave) partial sums of d/dpts, z*d/dpts, d/dviewdir
   float gnorm[2];           // backward: dL/d|rays_d| from dists*|d| (RN:361)
   float res[2][8];          // rgb(3) disp acc depth
 };
+typedef ItemStateT<64, 192> ItemState;
+typedef ItemStateT<128, 256> ItemStateBig;
+static_assert(sizeof(ItemState) == 23048, "the YCB-V layout is part of the shipped kernels' LDS budget");
+template <int NS> struct ItemStateFor { typedef ItemState type; };
+template <> struct ItemStateFor<128> { typedef ItemStateBig type; };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -603,12 +613,90 @@ __device__ __forceinline__ void composite(ST& st, const float* z, float* raw, fl
 // Writes st.cdf, st.zs; optional inds.  `bins` is a callable: bins(r, k), k in 0..62.
 // NI: importance samples per ray (128, or 64 / 32 for the kernels specialised to N_importance = 64 / 32); the thread
 // mapping and the row stride of u_rays stay those of 128.
-template <int R = 2, int NI = 128, typename ST, typename BinsFn>
+// sample_pdf_item for N_samples != 64 (NS - 2 weights, NS - 1 bins and cdf entries).  Same arithmetic: torch.sum in ATen's
+// association order for n = NS - 2 contiguous floats (oracle/nerf_oracle.py: _torch_sum_lastdim -- 8 vector lanes, 4-way ILP:
+// size_ilp = (n / 8) / 4 rounds into four partial vectors, the remaining whole vectors into the first, the partials folded
+// 0 += 1, 2, 3, then the scalar tail and the eight lanes sequentially), the cdf as a sequential fp64 scan rounded per prefix.
+template <int R, int NI, int NS, typename ST, typename BinsFn>
+__device__ __forceinline__ void sample_pdf_item_ns(ST& st, const float* ufine, const float* w, int wstride, BinsFn bins,
+                                                   int64_t* inds_out, int64_t inds_stride, int tid, int valid_rays,
+                                                   const float* u_rays, long long row0, int write_mask) {
+  constexpr int NW = NS - 2, NC = NS - 1;            // weights; bins = cdf entries
+  constexpr int NVEC = NW / 8, SILP = NVEC / 4;
+  for (int e = tid; e < R * NW; e += 256) {
+    const int r = e / NW, i = e - r * NW;
+    st.alpha[r][i] = (w + r * wstride)[i] + 1e-5f;               // RH:201
+  }
+  __syncthreads();
+  if ((tid & 63) == 0 && tid < 64 * R) {
+    const int r = tid >> 6;
+    const float* x = st.alpha[r];
+    float lanes[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float ps[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < SILP; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ps[k] = ps[k] + x[(i * 4 + k) * 8 + j];
+#pragma unroll
+      for (int v = SILP * 4; v < NVEC; ++v) ps[0] = ps[0] + x[v * 8 + j];
+      lanes[j] = ((ps[0] + ps[1]) + ps[2]) + ps[3];
+    }
+    float total = 0.0f;
+#pragma unroll
+    for (int i = NVEC * 8; i < NW; ++i) total = total + x[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) total = total + lanes[j];
+    st.res[r][7] = total;
+  }
+  __syncthreads();
+  for (int e = tid; e < R * NW; e += 256) {
+    const int r = e / NW, i = e - r * NW;
+    st.om[r][i] = st.alpha[r][i] / st.res[r][7];                // pdf (RH:202)
+  }
+  __syncthreads();
+  if ((tid & 63) == 0 && tid < 64 * R) {
+    const int r = tid >> 6;
+    double run = 0.0;
+    st.cdf[r][0] = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < NW; ++i) { run = run + (double)st.om[r][i]; st.cdf[r][i + 1] = (float)run; }      // RH:203-204
+  }
+  __syncthreads();
+  if (tid < 128 * R && (tid & 127) < NI) {
+    const int r = tid >> 7, k = tid & 127;
+    const float u = u_rays ? u_rays[(row0 + (r < valid_rays ? r : 0)) * 128 + k] : ufine[k];
+    const float* cdf = st.cdf[r];
+    int lo = 0, hi = NC;                                         // searchsorted(cdf, u, right=True) among NC entries (RH:227)
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[NSR_IDX(mid, NC)] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int ind = lo;
+    const int below = max(ind - 1, 0);
+    const int above = min(ind, NC - 1);
+    const float c0 = cdf[NSR_IDX(below, NC)], c1 = cdf[NSR_IDX(above, NC)];
+    const float b0 = bins(r, NSR_IDX(below, NC)), b1 = bins(r, NSR_IDX(above, NC));
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;                            // RH:238-239
+    const float t = (u - c0) / denom;
+    st.zs[r][k] = b0 + t * (b1 - b0);                           // RH:241
+    if (inds_out && r < valid_rays && ((write_mask >> r) & 1)) inds_out[r * inds_stride + k] = (int64_t)ind;
+  }
+  __syncthreads();
+}
+
+template <int R = 2, int NI = 128, int NS = 64, typename ST, typename BinsFn>
 __device__ __forceinline__ void sample_pdf_item(ST& st, const float* ufine /*[NI of 128], LDS or global*/,
                                                 const float* w /*[R][stride]*/, int wstride, BinsFn bins,
                                                 int64_t* inds_out /*[R][128] or null*/, int64_t inds_stride, int tid,
                                                 int valid_rays, const float* u_rays = nullptr /* global [rays][128]: RH:211 */,
                                                 long long row0 = 0, int write_mask = 3 /* rays whose inds are written */) {
+  if constexpr (NS != 64) {      // N_samples 32 / 128 (r05): the same arithmetic over NS - 2 weights / NS - 1 bins, see below
+    sample_pdf_item_ns<R, NI, NS>(st, ufine, w, wstride, bins, inds_out, inds_stride, tid, valid_rays, u_rays, row0, write_mask);
+    return;
+  }
   // (1) x = w + 1e-5 and the 8 vector-lane partial sums of ATen's cascade, 8 lanes per ray
   if (tid < 64 * R && (tid & 63) < 62) {
     const int r = tid >> 6, i = tid & 63;
@@ -701,14 +789,15 @@ __device__ __forceinline__ float zstd_wave(const ST& st, int r, int lane) {
 // half: ~25 VALU instructions instead of ~400, which matters because this code runs next to another workgroup's
 // MFMA stream ("Two waves per SIMD").  A workgroup-wide check picks the path; any inversion or NaN
 // falls back to the full rank count, so the result never depends on the sortedness assumption.
-template <int R = 2, int NI = 128, typename ST>
+template <int R = 2, int NI = 128, int NS = 64, typename ST>
 __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
-  constexpr int NF = 64 + NI;                        // merged depths per ray (the arrays keep their 192 / 128 strides)
+  constexpr int NF = NS + NI;                        // merged depths per ray (the arrays keep their row strides)
+  constexpr bool kPow2 = (NI & (NI - 1)) == 0 && (NS & (NS - 1)) == 0;      // (NI = 96: plain binary searches, r05)
   int bad = 0;
   for (int e = tid; e < NF * R; e += 256) {
     const int r = e / NF, k = e - r * NF;
-    if (k < 63) bad |= !(st.zc[r][k] <= st.zc[r][k + 1]);
-    else if (k >= 64 && k < NF - 1) bad |= !(st.zs[r][k - 64] <= st.zs[r][k - 63]);
+    if (k < NS - 1) bad |= !(st.zc[r][k] <= st.zc[r][k + 1]);
+    else if (k >= NS && k < NF - 1) bad |= !(st.zs[r][k - NS] <= st.zs[r][k - NS + 1]);
   }
   // workgroup-wide OR through four LDS words (st.res is free here).  Not __syncthreads_or: its library implementation
   // rebuilds the flat thread id from threadIdx.y/z, which keeps two more VGPRs alive through the whole kernel.
@@ -723,35 +812,45 @@ __device__ __forceinline__ void merge_sort_item(ST& st, int tid) {
       const int r = e / NF, k = e - r * NF;
       int rank;
       float x;
-      if (k < 64) {                                  // own index + #(z_samples < x)
+      if (k < NS) {                                  // own index + #(z_samples < x)
         x = st.zc[r][k];
         int lb = 0;
+        if constexpr (kPow2) {
 #pragma unroll
-        for (int sft = NI / 2; sft > 0; sft >>= 1) lb += (st.zs[r][lb + sft - 1] < x) ? sft : 0;
-        lb += (st.zs[r][lb] < x) ? 1 : 0;
+          for (int sft = NI / 2; sft > 0; sft >>= 1) lb += (st.zs[r][lb + sft - 1] < x) ? sft : 0;
+          lb += (st.zs[r][lb] < x) ? 1 : 0;
+        } else {
+          int hi = NI;
+          while (lb < hi) { const int mid = (lb + hi) >> 1; if (st.zs[r][NSR_IDX(mid, NI)] < x) lb = mid + 1; else hi = mid; }
+        }
         rank = k + lb;
       } else {                                       // own index + #(z_coarse <= x)
-        x = st.zs[r][k - 64];
+        x = st.zs[r][k - NS];
         int ub = 0;
+        if constexpr (kPow2) {
 #pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) ub += (st.zc[r][ub + sft - 1] <= x) ? sft : 0;
-        ub += (st.zc[r][ub] <= x) ? 1 : 0;
-        rank = (k - 64) + ub;
+          for (int sft = NS / 2; sft > 0; sft >>= 1) ub += (st.zc[r][ub + sft - 1] <= x) ? sft : 0;
+          ub += (st.zc[r][ub] <= x) ? 1 : 0;
+        } else {
+          int hi = NS;
+          while (ub < hi) { const int mid = (ub + hi) >> 1; if (st.zc[r][NSR_IDX(mid, NS)] <= x) ub = mid + 1; else hi = mid; }
+        }
+        rank = (k - NS) + ub;
       }
       st.zf[r][NSR_IDX(rank, NF)] = x;
     }
   } else {
     for (int e = tid; e < NF * R; e += 256) {
       const int r = e / NF, k = e - r * NF;
-      const float x = (k < 64) ? st.zc[r][k] : st.zs[r][k - 64];
+      const float x = (k < NS) ? st.zc[r][k] : st.zs[r][k - NS];
       int rank = 0;
-      for (int j = 0; j < 64; ++j) {
+      for (int j = 0; j < NS; ++j) {
         const float y = st.zc[r][j];
         rank += (y < x) || (y == x && j < k);
       }
       for (int j = 0; j < NI; ++j) {
         const float y = st.zs[r][j];
-        rank += (y < x) || (y == x && (j + 64) < k);
+        rank += (y < x) || (y == x && (j + NS) < k);
       }
       st.zf[r][NSR_IDX(rank, NF)] = x;
     }
@@ -767,19 +866,33 @@ __device__ __forceinline__ float coarse_z(float near_, float far_, float t, int 
 
 // RN:447-459 (perturb > 0): one stratified sample per interval between the mid-points of the coarse depths of both rays of
 // an item; t_rand [rays][64] are the caller's draws.  Called by the whole workgroup once st.zc is complete.
-template <typename ST>
+template <int NS = 64, typename ST>
 __device__ __forceinline__ void perturb_coarse_z(ST& st, const float* t_rand, long long row0, int valid, int tid) {
-  const int r = (tid >> 6) & 1, i = tid & 63;
-  float zn = 0.0f;
-  if (tid < 128) {
-    const float* zr = st.zc[r];
-    const float lower = i > 0 ? 0.5f * (zr[i] + zr[i - 1]) : zr[0];
-    const float upper = i < 63 ? 0.5f * (zr[i + 1] + zr[i]) : zr[63];
-    zn = lower + (upper - lower) * t_rand[(row0 + (r < valid ? r : 0)) * 64 + i];
+  if constexpr (NS == 64) {
+    const int r = (tid >> 6) & 1, i = tid & 63;
+    float zn = 0.0f;
+    if (tid < 128) {
+      const float* zr = st.zc[r];
+      const float lower = i > 0 ? 0.5f * (zr[i] + zr[i - 1]) : zr[0];
+      const float upper = i < 63 ? 0.5f * (zr[i + 1] + zr[i]) : zr[63];
+      zn = lower + (upper - lower) * t_rand[(row0 + (r < valid ? r : 0)) * 64 + i];
+    }
+    __syncthreads();
+    if (tid < 128) st.zc[r][i] = zn;
+    __syncthreads();
+  } else {                                       // N_samples 32 / 128: thread tid owns sample tid % NS of ray tid / NS (2 NS <= 256)
+    const int r = tid / NS, i = tid - r * NS;
+    float zn = 0.0f;
+    if (tid < 2 * NS) {
+      const float* zr = st.zc[r];
+      const float lower = i > 0 ? 0.5f * (zr[i] + zr[i - 1]) : zr[0];
+      const float upper = i < NS - 1 ? 0.5f * (zr[i + 1] + zr[i]) : zr[NS - 1];
+      zn = lower + (upper - lower) * t_rand[(row0 + (r < valid ? r : 0)) * NS + i];
+    }
+    __syncthreads();
+    if (tid < 2 * NS) st.zc[r][i] = zn;
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < 128) st.zc[r][i] = zn;
-  __syncthreads();
 }
 
 // get_rays RH:156-165 for pixel (row, col); cam = {c2w[12], fx, fy, cx, cy}
@@ -940,12 +1053,18 @@ __device__ __forceinline__ void range_poison(const RenderArgs& a, long long ray0
 // (RN:474: 64 + NI fine samples per ray, ceil(2 (64 + NI) / 128) = 2 fine passes per item instead of 3; a wave's 32 points
 // belong to one ray because 64 + NI is a multiple of 32; with NI = 32 the last two waves of the second pass have no points:
 // they run the pass on a repeated point -- the weight ring is consumed in lock-step -- and store nothing).
-template <int MODE, int NI = 128>
+// NS: coarse samples per ray (N_samples, RN:439).  64 = the YCB-V configuration; 32 / 128 (r05): one coarse pass with two idle waves
+// / two coarse passes per item, item state ItemStateBig for 128.
+template <int MODE, int NI = 128, int NS = 64>
 __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap, char* smem) {
   constexpr bool B3 = MODE == kMlpB3;
-  constexpr int NF = 64 + NI;                              // fine samples per ray
+  constexpr int NF = NS + NI;                              // fine samples per ray
   constexpr int NP = (2 * NF + 127) / 128;                 // fine passes per item
-  static_assert(NF % 32 == 0 && NF <= 192, "a wave's points belong to one ray; the item state holds 192 samples per ray");
+  constexpr int NPC = (2 * NS + 127) / 128;                // coarse passes per item
+  constexpr int LNS = NS == 32 ? 5 : (NS == 64 ? 6 : 7);   // N_samples is 32, 64 or 128
+  typedef typename ItemStateFor<NS>::type ST;
+  static_assert((NS == 32 || NS == 64 || NS == 128) && NF % 32 == 0 && NS <= ST::kNS && NF <= ST::kNF,
+                "a wave's points belong to one ray; the item state holds kNS coarse / kNF fine samples per ray");
   const RenderArgs& a_setup = *ap;
 #ifdef NSR_PHASE_TIMING
   long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -959,7 +1078,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   const int lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int j = lane & 31;
-  ItemState& st = *(ItemState*)(smem + kLdsState);
+  ST& st = *(ST*)(smem + kLdsState);
 
   const long long n_rays = a_setup.n_rays;
   if ((long long)blockIdx.x >= queue_items(a_setup)) return;
@@ -967,8 +1086,8 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   int* ovf = (int*)&st.ray[1][14];                       // f16x2: [2] points with NaN network outputs, per ray of the current item
 
   Ring rg;
-  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? 1 + NP : 1, wave, lane);
-  rg.pn1 = 1 + NP;
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, fine ? NPC + NP : NPC, wave, lane);
+  rg.pn0 = NPC; rg.pn1 = NPC + NP;
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
@@ -976,7 +1095,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
   else ring_start(rg, A0, lane);   // weights start streaming while the aux blocks and tables are staged
 
   load_aux(smem, a_setup, tid0);
-  if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
+  if (tid0 < NS) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
   if (tid0 < NI) st.ufine[tid0] = a_setup.ufine[tid0];
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
@@ -991,7 +1110,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
     return v;
   };
   long long packed = next_item();
-  int pass = 0;              // 0 = coarse pass, 1..NP = fine passes of the current item
+  int pass = 0;              // 0 .. NPC - 1 = coarse pass(es), NPC .. NPC + NP - 1 = fine passes of the current item
 #pragma unroll 1
   while (packed != -1ll) {
     const long long item = packed & kItemMask;
@@ -1029,30 +1148,36 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (MODE == kMlpH2 && (tid == 64 || tid == 65)) ovf[tid - 64] = 0;
-      if (tid < 128) {
-        const int r = tid >> 6, i = tid & 63;
+      if (tid < 2 * NS) {
+        const int r = tid >> LNS, i = tid & (NS - 1);
         const float t = st.tcoarse[i];
         const long long rb = ray0 + (r < valid ? r : 0);
         st.zc[r][i] = coarse_z(a.near_rays ? a.near_rays[rb] : near_, a.near_rays ? a.far_rays[rb] : far_, t, a.lindisp);
       }
       __syncthreads();
-      if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);
+      if (a.t_rand) perturb_coarse_z<NS>(st, a.t_rand, ray0, valid, tid);
       NSR_T(0);
     }
 
     // ---- one network pass: 128 points -------------------------------------------------------------
-    //   coarse: wave w -> ray w>>1, samples 32*(w&1) + j              (RN:463-466)
-    //   fine p: point q = 128(p-1) + 32w + j -> ray q/NF, sample q%NF (RN:478-483)
+    //   coarse p: point q = 128 p + 32w + j -> ray q/NS, sample q%NS   (RN:463-466; NS = 64: ray w>>1, sample 32 (w&1) + j)
+    //   fine p:   point q = 128 (p - NPC) + 32w + j -> ray q/NF, sample q%NF (RN:478-483)
     {
       int r, i;
       const float* zsrc;
       float* dst;
       bool real = true;                                    // (NI = 32: the second pass has points for two waves only)
-      if (pass == 0) {
-        r = wave >> 1; i = 32 * (wave & 1) + j;
+      if ((NPC == 1) ? (pass == 0) : (pass < NPC)) {
+        if constexpr (NS == 64) {
+          r = wave >> 1; i = 32 * (wave & 1) + j;
+        } else {
+          int q0 = 128 * pass + 32 * wave;
+          if (2 * NS % 128 != 0 && q0 >= 2 * NS) { q0 = 2 * NS - 32; real = false; }      // (N_samples = 32: two waves have no points)
+          r = q0 >> LNS; i = (q0 & (NS - 1)) + j;
+        }
         zsrc = &st.zc[r][i]; dst = st.rawc[r][i];
       } else {
-        int q0 = 128 * (pass - 1) + 32 * wave;
+        int q0 = 128 * (pass - NPC) + 32 * wave;
         if (2 * NF % 128 != 0 && q0 >= 2 * NF) { q0 = 2 * NF - 32; real = false; }
         r = q0 / NF; i = q0 - r * NF + j;
         zsrc = &st.zf[r][i]; dst = st.rawf[r][i];
@@ -1060,7 +1185,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass<false, MODE>(rg, aux_c + (pass == 0 ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+      mlp_pass<false, MODE>(rg, aux_c + (((NPC == 1) ? (pass == 0) : (pass < NPC)) ? 0 : kAuxFloats), A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
                ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, nullptr, 0, NSR_TPASS);
       if (lane < 32 && real) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
       if constexpr (MODE == kMlpH2) { if (real) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane); }
@@ -1069,13 +1194,20 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 
     const RenderArgs& a = *opaque_s(ap);                  // nothing below may be hoisted above the network pass
     const int tid = opaque_v(tid0);
-    if (pass == 0) {
+    if (NPC > 1 && pass < NPC - 1) {
+      ++pass;                                              // (N_samples = 128: the item's second coarse pass)
+    } else if ((NPC == 1) ? (pass == 0) : (pass < NPC)) {
       __syncthreads();
       if (a.dbg_raw0) {
-        for (int idx = tid; idx < 2 * 256; idx += 256) if (wr(idx >> 8)) a.dbg_raw0[ray0 * 256 + idx] = (&st.rawc[0][0][0])[idx];
+        if constexpr (NS == ST::kNS) {
+          for (int idx = tid; idx < 2 * NS * 4; idx += 256) if (wr(idx >> (LNS + 2))) a.dbg_raw0[ray0 * (NS * 4) + idx] = (&st.rawc[0][0][0])[idx];
+        } else {
+          for (int idx = tid; idx < 2 * NS * 4; idx += 256)
+            if (wr(idx >> (LNS + 2))) a.dbg_raw0[ray0 * (NS * 4) + idx] = (&st.rawc[idx >> (LNS + 2)][0][0])[idx & (NS * 4 - 1)];
+        }
         __syncthreads();
       }
-      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
+      composite<NS, 2, ST::kNS>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
       if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1088,7 +1220,8 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         else if (c == 4) { if (acc_dst) acc_dst[rr] = v; }
       }
       if (a.dbg_w0)
-        for (int idx = tid; idx < 2 * 64; idx += 256) if (wr(idx >> 6)) a.dbg_w0[ray0 * 64 + idx] = (&st.w0[0][0])[idx];
+        for (int idx = tid; idx < 2 * NS; idx += 256)
+          if (wr(idx >> LNS)) a.dbg_w0[ray0 * NS + idx] = NS == ST::kNS ? (&st.w0[0][0])[idx] : st.w0[idx >> LNS][idx & (NS - 1)];
       if (!fine) {
         if (MODE == kMlpH2 && tid == 0) { if (const unsigned m = range_report(a, ovf, item, valid)) range_poison(a, ray0, m); }
         __syncthreads(); packed = next_item(); continue;
@@ -1101,7 +1234,7 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 #else
       int64_t* inds = (int64_t*)a.dbg_inds;
 #endif
-      sample_pdf_item<2, NI>(st, st.ufine, &st.w0[0][1], 64,
+      sample_pdf_item<2, NI, NS>(st, st.ufine, &st.w0[0][1], ST::kNS,
                              [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); },   // RN:473
                              inds ? inds + ray0 * NI : nullptr, NI, tid, valid, a.u_rays, ray0, wmask);
       NSR_T(3);
@@ -1113,22 +1246,23 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
         for (int idx = tid; idx < 2 * 128; idx += 256)      // st.zs rows are 128 apart, the tap's NI
           if (wr(idx >> 7) && (idx & 127) < NI) a.dbg_zs[(ray0 + (idx >> 7)) * NI + (idx & 127)] = (&st.zs[0][0])[idx];
       NSR_T(4);
-      merge_sort_item<2, NI>(st, tid);
+      merge_sort_item<2, NI, NS>(st, tid);
       if (a.dbg_zf)
-        for (int idx = tid; idx < 2 * 192; idx += 256)      // st.zf rows are 192 apart, the tap's NF
-          if (wr(idx / 192) && idx % 192 < NF) a.dbg_zf[(ray0 + idx / 192) * NF + idx % 192] = (&st.zf[0][0])[idx];
+        for (int idx = tid; idx < 2 * ST::kNF; idx += 256)      // st.zf rows are kNF apart, the tap's NF
+          if (wr(idx / ST::kNF) && idx % ST::kNF < NF) a.dbg_zf[(ray0 + idx / ST::kNF) * NF + idx % ST::kNF] = (&st.zf[0][0])[idx];
       NSR_T(5);
-      pass = 1;
-    } else if (pass < NP) {
+      pass = NPC;
+    } else if (pass < NPC + NP - 1) {
       ++pass;
     } else {
       __syncthreads();
       if (a.dbg_raw) {
-        for (int idx = tid; idx < 2 * 768; idx += 256)      // st.rawf rows are 192 x 4 apart, the tap's NF x 4
-          if (wr(idx / 768) && idx % 768 < NF * 4) a.dbg_raw[(ray0 + idx / 768) * (NF * 4) + idx % 768] = (&st.rawf[0][0][0])[idx];
+        for (int idx = tid; idx < 2 * ST::kNF * 4; idx += 256)      // st.rawf rows are kNF x 4 apart, the tap's NF x 4
+          if (wr(idx / (ST::kNF * 4)) && idx % (ST::kNF * 4) < NF * 4)
+            a.dbg_raw[(ray0 + idx / (ST::kNF * 4)) * (NF * 4) + idx % (ST::kNF * 4)] = (&st.rawf[0][0][0])[idx];
         __syncthreads();
       }
-      composite<NF, 2, 192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
+      composite<NF, 2, ST::kNF>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
       if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1187,6 +1321,23 @@ __global__ void __launch_bounds__(256, 1) k_render_b3_n32(const RenderArgs* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render32_body<kMlpB3, 32>(ap, smem);
 }
+
+// r05: the other sample counts of RN:439 / RN:474 the f16x2 handles serve natively (and the bf16x3 kernels their range safety
+// net falls back to): N_importance = 96 (64 + 96 fine samples, three fine passes, the third with two idle waves), N_samples = 32
+// with N_importance = 64 (one coarse pass with two idle waves, two fine passes), N_samples = 128 with N_importance = 128 (two
+// coarse and four fine passes per item, ItemStateBig).
+#define NSR_RENDER_KERNEL(NAME, MODE, NI, NS)                                                        \
+  __global__ void __launch_bounds__(256, 1) NAME(const RenderArgs* __restrict__ ap) {                \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                      \
+    render32_body<MODE, NI, NS>(ap, smem);                                                           \
+  }
+NSR_RENDER_KERNEL(k_render_h2_n96, kMlpH2, 96, 64)
+NSR_RENDER_KERNEL(k_render_b3_n96, kMlpB3, 96, 64)
+NSR_RENDER_KERNEL(k_render_h2_c32_n64, kMlpH2, 64, 32)
+NSR_RENDER_KERNEL(k_render_b3_c32_n64, kMlpB3, 64, 32)
+NSR_RENDER_KERNEL(k_render_h2_c128_n128, kMlpH2, 128, 128)
+NSR_RENDER_KERNEL(k_render_b3_c128_n128, kMlpB3, 128, 128)
+#undef NSR_RENDER_KERNEL
 
 // ------------------------------------------------------------------------------------------------------
 // Backward (input-side VJP) of one network pass.  Same register-chained scheme with W^T as the A operand:
@@ -1377,8 +1528,8 @@ __device__ __forceinline__ void mlp_bwd_pass(Ring& rg, const float* aux, f32x4 (
 // st.rawf holds sigmoid(rgb) and the raw sigma, st.alpha / st.wf / st.tf the forward alpha, weights, T.
 //   dL/dw_i = g . c_i ;  dL/dalpha_i = A_i T_i - (sum_{k>i} A_k w_k) / (1 - alpha_i + 1e-10)
 // Only the suffix sum is serial (one lane per ray, fp32, 8 terms per LDS round trip).
-template <int S = 192>
-__device__ __forceinline__ void composite_bwd(ItemState& st, const float* grgb /* [2][3] in LDS */, int tid) {
+template <int S = 192, typename ST>
+__device__ __forceinline__ void composite_bwd(ST& st, const float* grgb /* [2][3] in LDS */, int tid) {
   float* aw = &st.bwd_scratch[0][0][0];   // [2][S] A_i * w_i, then the exclusive suffix sums
   float* at = aw + 2 * S;                 // [2][S] A_i * T_i
   for (int idx = tid; idx < 2 * S; idx += 256) {
@@ -1461,41 +1612,46 @@ __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) {
 //   pass 4-6    fine backward through the transposed network -> dL/d pts, dL/d viewdir per sample
 //   --          per-ray reduction: dL/d rays_o, dL/d rays_d
 // ------------------------------------------------------------------------------------------------------
-template <int MODE, int NI = 128>
+template <int MODE, int NI = 128, int NS = 64>
 __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp, char* smem) {
   constexpr bool B3 = MODE == kMlpB3;
-  constexpr int NF = 64 + NI;                              // fine samples per ray (see render32_body)
+  constexpr int NF = NS + NI;                              // fine samples per ray (see render32_body)
   constexpr int NP = (2 * NF + 127) / 128;                 // fine passes per item, forward and again backward
-  static_assert(NF % 32 == 0 && NF <= 192, "a wave's points belong to one ray; the item state holds 192 samples per ray");
+  constexpr int NPC = (2 * NS + 127) / 128;                // coarse passes per item
+  constexpr int LNS = NS == 32 ? 5 : (NS == 64 ? 6 : 7);   // N_samples is 32, 64 or 128
+  typedef typename ItemStateFor<NS>::type ST;
+  constexpr int kMaskPasses = NP > 3 ? NP : 3;             // fine forward passes whose relu patterns the scratch holds per workgroup
+  static_assert((NS == 32 || NS == 64 || NS == 128) && NF % 32 == 0 && NS <= ST::kNS && NF <= ST::kNF,
+                "a wave's points belong to one ray; the item state holds kNS coarse / kNF fine samples per ray");
   const VjpArgs& va_setup = *vp;
   const RenderArgs& a_setup = va_setup.r;
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int j = lane & 31;
-  ItemState& st = *(ItemState*)(smem + kLdsState);
+  ST& st = *(ST*)(smem + kLdsState);
 
   const long long n_rays = a_setup.n_rays;
   if ((long long)blockIdx.x >= queue_items(a_setup)) return;
   int* ovf = (int*)&st.ray[1][14];                       // f16x2: [2] points with NaN outputs / gradients, per ray of the item
 
   Ring rg;
-  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, 1 + 2 * NP, wave, lane);
-  rg.pn1 = 1 + NP;
+  ring_init(rg, smem, a_setup.nets, a_setup.net_stride, NPC + 2 * NP, wave, lane);
+  rg.pn0 = NPC; rg.pn1 = NPC + NP;
 
   f32x4 A0[4], A1[4];
   if constexpr (B3) ring_start<kRingSlots, kStreamSlabsB3, kStreamSlabsB3Bwd>(rg, A0, lane);
   else if constexpr (MODE == kMlpH2) ring_start<kRingSlots, kStreamSlabs, kStreamSlabsH2Bwd, kH2RingLag>(rg, A0, lane);
   else ring_start(rg, A0, lane);
   load_aux(smem, a_setup, tid0);
-  if (tid0 < 64) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
+  if (tid0 < NS) st.tcoarse[tid0] = a_setup.tcoarse[tid0];
   if (tid0 < NI) st.ufine[tid0] = a_setup.ufine[tid0];
   __syncthreads();
   const float* aux_c = (const float*)(smem + kLdsAux);
   const float* aux_f = aux_c + kAuxFloats;
   // relu-pattern scratch of this workgroup: a UNIFORM base (scalar registers) + the thread index at each access, so
   // that no per-lane 64-bit address is kept alive across the passes
-  uint4* my_masks = va_setup.mask_scratch + (size_t)blockIdx.x * (3 * 9 * 256);
+  uint4* my_masks = va_setup.mask_scratch + (size_t)blockIdx.x * (kMaskPasses * 9 * 256);
   float* grgb = &st.res[0][0];   // [2][3] cotangent staged here during the backward half (res is free then)
 
   long long* item_slot = (long long*)&st.ray[0][14];     // 8-byte slot in the unused tail of ray 0's block
@@ -1537,27 +1693,33 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         st.ray[tid][12] = a.white_bkgd ? 1.0f : 0.0f;
       }
       if (MODE == kMlpH2 && (tid == 64 || tid == 65)) ovf[tid - 64] = 0;
-      if (tid < 128) {
-        const int r = tid >> 6, i = tid & 63;
+      if (tid < 2 * NS) {
+        const int r = tid >> LNS, i = tid & (NS - 1);
         const float t = st.tcoarse[i];
         const long long rb = ray0 + (r < valid ? r : 0);
         st.zc[r][i] = coarse_z(a.near_rays ? a.near_rays[rb] : near_, a.near_rays ? a.far_rays[rb] : far_, t, a.lindisp);
       }
       __syncthreads();
-      if (a.t_rand) perturb_coarse_z(st, a.t_rand, ray0, valid, tid);
+      if (a.t_rand) perturb_coarse_z<NS>(st, a.t_rand, ray0, valid, tid);
     }
 
-    if (pass <= NP) {
+    if ((NPC == 1) ? (pass <= NP) : (pass < NPC + NP)) {
       // ---- forward passes (coarse, then NP fine with relu capture) ----
       int r, i;
       const float* zsrc;
       float* dst;
       bool real = true;
-      if (pass == 0) {
-        r = wave >> 1; i = 32 * (wave & 1) + j;
+      if ((NPC == 1) ? (pass == 0) : (pass < NPC)) {
+        if constexpr (NS == 64) {
+          r = wave >> 1; i = 32 * (wave & 1) + j;
+        } else {
+          int q0 = 128 * pass + 32 * wave;
+          if (2 * NS % 128 != 0 && q0 >= 2 * NS) { q0 = 2 * NS - 32; real = false; }
+          r = q0 >> LNS; i = (q0 & (NS - 1)) + j;
+        }
         zsrc = &st.zc[r][i]; dst = st.rawc[r][i];
       } else {
-        int q0 = 128 * (pass - 1) + 32 * wave;
+        int q0 = 128 * (pass - NPC) + 32 * wave;
         if (2 * NF % 128 != 0 && q0 >= 2 * NF) { q0 = 2 * NF - 32; real = false; }
         r = q0 / NF; i = q0 - r * NF + j;
         zsrc = &st.zf[r][i]; dst = st.rawf[r][i];
@@ -1565,13 +1727,14 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       const float z = *zsrc;
       const float* ry = st.ray[r];
       float raw[4];
-      mlp_pass<true, MODE>(rg, pass == 0 ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
-                         ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw, my_masks + (pass == 0 ? 0 : (pass - 1)) * (9 * 256), opaque_v(tid0));
+      mlp_pass<true, MODE>(rg, ((NPC == 1) ? (pass == 0) : (pass < NPC)) ? aux_c : aux_f, A0, A1, lane, ry[0] + ry[3] * z, ry[1] + ry[4] * z,
+                         ry[2] + ry[5] * z, ry[6], ry[7], ry[8], raw,
+                         my_masks + (((NPC == 1) ? (pass == 0) : (pass < NPC)) ? 0 : (pass - NPC)) * (9 * 256), opaque_v(tid0));
       if (lane < 32 && real) *(f32x4*)dst = f32x4{raw[0], raw[1], raw[2], raw[3]};
       if constexpr (MODE == kMlpH2) { if (real) range_mark(ovf + r, (raw[0] + raw[1]) + (raw[2] + raw[3]), lane); }
     } else {
       // ---- backward passes: same point mapping as the fine forward pass p = pass - (NP + 1) ----
-      int q0 = 128 * (pass - (NP + 1)) + 32 * wave;
+      int q0 = 128 * (pass - (NPC + NP)) + 32 * wave;
       bool real = true;
       if (2 * NF % 128 != 0 && q0 >= 2 * NF) { q0 = 2 * NF - 32; real = false; }
       const int r = q0 / NF, slot = (q0 - r * NF) >> 5, i = q0 - r * NF + j;
@@ -1579,7 +1742,7 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       const float* ry = st.ray[r];
       const f32x4 g = *(const f32x4*)st.rawf[r][i];
       float dp[3], dv[3];
-      mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - (NP + 1)) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
+      mlp_bwd_pass<MODE>(rg, aux_f, A0, A1, lane, my_masks + (pass - (NPC + NP)) * (9 * 256), opaque_v(tid0), g[0], g[1], g[2], g[3],
                        ry, &st.zf[r][i - j], dp, dv);
       if constexpr (MODE == kMlpH2) { if (real) range_mark(ovf + r, dp[0] + dv[0], lane); }
       if (float* gp = opaque_s(vp)->dbg_gpts) {            // debug tap: the per-sample results of the network backward
@@ -1602,14 +1765,16 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
     const VjpArgs& va = *opaque_s(vp);                    // nothing below may be hoisted above the network passes
     const RenderArgs& a = va.r;
     const int tid = opaque_v(tid0);
-    if (pass == 0) {
+    if (NPC > 1 && pass < NPC - 1) {
+      ++pass;
+    } else if ((NPC == 1) ? (pass == 0) : (pass < NPC)) {
       __syncthreads();
-      composite<64>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
+      composite<NS, 2, ST::kNS>(st, &st.zc[0][0], &st.rawc[0][0][0], &st.w0[0][0], &st.tf[0][0], tid, a.noise0, ray0, valid);
       int64_t* none = nullptr;
-      sample_pdf_item<2, NI>(st, st.ufine, &st.w0[0][1], 64,
+      sample_pdf_item<2, NI, NS>(st, st.ufine, &st.w0[0][1], ST::kNS,
                              [&](int r, int k) { return 0.5f * (st.zc[r][k + 1] + st.zc[r][k]); }, none, NI, tid, valid,
                              a.u_rays, ray0);
-      merge_sort_item<2, NI>(st, tid);
+      merge_sort_item<2, NI, NS>(st, tid);
       if (va.z_fine) {                                       // caller-supplied depths replace the resampled ones
         for (int idx = tid; idx < 2 * NF; idx += 256) {
           const int r = idx / NF, k = idx - r * NF;
@@ -1617,12 +1782,12 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
         }
         __syncthreads();
       }
-      pass = 1;
-    } else if (pass < NP) {
+      pass = NPC;
+    } else if (pass < NPC + NP - 1) {
       ++pass;
-    } else if (pass == NP) {
+    } else if (pass == NPC + NP - 1) {
       __syncthreads();
-      composite<NF, 2, 192>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
+      composite<NF, 2, ST::kNF>(st, &st.zf[0][0], &st.rawf[0][0][0], &st.wf[0][0], &st.tf[0][0], tid, a.noise1, ray0, valid);
       if (tid < 16 && wr(tid >> 3)) {
         const int r = tid >> 3, c = tid & 7;
         const long long rr = ray0 + r;
@@ -1639,10 +1804,11 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
       __syncthreads();
       composite_bwd<NF>(st, grgb, tid);
       if (va.dbg_graw)                                     // debug tap: dL/d raw as the network backward receives it
-        for (int idx = tid; idx < 2 * 768; idx += 256)
-          if (wr(idx / 768) && idx % 768 < NF * 4) va.dbg_graw[(ray0 + idx / 768) * (NF * 4) + idx % 768] = (&st.rawf[0][0][0])[idx];
-      pass = NP + 1;
-    } else if (pass < 2 * NP) {
+        for (int idx = tid; idx < 2 * ST::kNF * 4; idx += 256)
+          if (wr(idx / (ST::kNF * 4)) && idx % (ST::kNF * 4) < NF * 4)
+            va.dbg_graw[(ray0 + idx / (ST::kNF * 4)) * (NF * 4) + idx % (ST::kNF * 4)] = (&st.rawf[0][0][0])[idx];
+      pass = NPC + NP;
+    } else if (pass < NPC + 2 * NP - 1) {
       ++pass;
     } else {
       __syncthreads();
@@ -1730,6 +1896,19 @@ __global__ void __launch_bounds__(256, 1) k_render_vjp_b3_n32(const VjpArgs* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   render_vjp32_body<kMlpB3, 32>(vp, smem);
 }
+
+#define NSR_VJP_KERNEL(NAME, MODE, NI, NS)                                                           \
+  __global__ void __launch_bounds__(256, 1) NAME(const VjpArgs* __restrict__ vp) {                   \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                      \
+    render_vjp32_body<MODE, NI, NS>(vp, smem);                                                       \
+  }
+NSR_VJP_KERNEL(k_render_vjp_h2_n96, kMlpH2, 96, 64)
+NSR_VJP_KERNEL(k_render_vjp_b3_n96, kMlpB3, 96, 64)
+NSR_VJP_KERNEL(k_render_vjp_h2_c32_n64, kMlpH2, 64, 32)
+NSR_VJP_KERNEL(k_render_vjp_b3_c32_n64, kMlpB3, 64, 32)
+NSR_VJP_KERNEL(k_render_vjp_h2_c128_n128, kMlpH2, 128, 128)
+NSR_VJP_KERNEL(k_render_vjp_b3_c128_n128, kMlpB3, 128, 128)
+#undef NSR_VJP_KERNEL
 
 // dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):
 //   g[a][k] = sum_pix grad_d[pix][a] * dirs[pix][k]  (k < 3),  g[a][3] = sum_pix grad_o[pix][a]

@@ -28,7 +28,7 @@ DEFAULT_MLP = "f16x2"
 MLP_MODES = ("fp32", "bf16x3", "f16x2")
 
 
-def _host_tables(n_importance=N_IMPORTANCE, native=False):
+def _host_tables(n_importance=N_IMPORTANCE, native=False, n_samples=N_SAMPLES):
     """The reference builds both linspace tables on the HOST and moves them (RN:439, RH:208); torch's CPU
     linspace is not bit-equal to numpy's, so the same call is made here.
     n_importance < 128 (a divisor of 128): the kernels always draw 128 importance samples, from the 128 uniforms of this
@@ -46,11 +46,13 @@ def _host_tables(n_importance=N_IMPORTANCE, native=False):
         u = torch.cat([u, torch.zeros(N_IMPORTANCE - n)])
     else:
         u = u.repeat_interleave(N_IMPORTANCE // n)
-    return torch.linspace(0., 1., steps=N_SAMPLES).numpy().astype(np.float32), u.numpy().astype(np.float32)
+    return torch.linspace(0., 1., steps=n_samples).numpy().astype(np.float32), u.numpy().astype(np.float32)
 
 
-IMPORTANCE_COUNTS = (0, 1, 2, 4, 8, 16, 32, 64, 128)       # 0 = coarse only; the divisors of the kernels' 128
-NATIVE_IMPORTANCE = (64, 32)       # f16x2 handles: kernels specialised to these counts (k_render_h2_n64 / _n32 and their VJPs)
+IMPORTANCE_COUNTS = (0, 1, 2, 4, 8, 16, 32, 64, 96, 128)   # 0 = coarse only; the divisors of the kernels' 128 (any handle) and 96 (f16x2)
+NATIVE_IMPORTANCE = (96, 64, 32)   # f16x2 handles: kernels specialised to these counts (k_render_h2_n96 / _n64 / _n32 and their VJPs)
+# (N_samples, N_importance) pairs beyond N_samples = 64 that f16x2 handles serve with kernels of their own (r05; RN:439, RN:474)
+NATIVE_COUNTS = ((32, 64), (32, 0), (128, 128), (128, 0))
 
 
 def _fptr(a):
@@ -67,7 +69,8 @@ def _stream_ptr(device):
 
 class NsrModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=N_IMPORTANCE, max_workgroups=0, variant=0,
-                 white_bkgd=False, lindisp=False, chunk=None, schedule=None, mlp=None, range_fallback="bf16x3"):
+                 white_bkgd=False, lindisp=False, chunk=None, schedule=None, mlp=None, range_fallback="bf16x3",
+                 n_samples=N_SAMPLES):
         """sd_*: mappings with the reference's state_dict keys (RH:82-97) -> array-likes (numpy / torch cpu).
         white_bkgd / lindisp: the render options of RN:384-385 / RN:443 (both off in the YCB-V configuration).
         chunk: rays per work-queue chunk of the x16 kernel (None: $NSR_CHUNK, read HERE once, else the library default).
@@ -109,22 +112,28 @@ class NsrModel:
         # the x16 coarse+fine kernels only (the bf16x3 / f16x2 kernels take their items from the per-item queue)
         phases = schedule == "phases" and variant != 32 and n_importance > 0 and mlp == "fp32"
         self.schedule = "phases" if phases else "queue"
-        if n_importance not in IMPORTANCE_COUNTS:
-            raise NotImplementedError("N_importance must be 128, 0 (coarse only) or a divisor of 128 (rendered with duplicated "
-                                      "importance samples, see _host_tables); got %r" % (n_importance,))
+        if n_importance not in IMPORTANCE_COUNTS or (n_importance == 96 and mlp != "f16x2"):
+            raise NotImplementedError("N_importance must be 128, 0 (coarse only), a divisor of 128 (rendered with duplicated "
+                                      "importance samples, see _host_tables) or -- f16x2 handles -- 96; got %r" % (n_importance,))
+        n_samples = int(n_samples)
+        if n_samples != N_SAMPLES and not (mlp == "f16x2" and (n_samples, n_importance) in NATIVE_COUNTS):
+            raise NotImplementedError("N_samples = %r with N_importance = %r: the kernels serve N_samples = 64 with every supported "
+                                      "N_importance and, on f16x2 handles, (N_samples, N_importance) in %s"
+                                      % (n_samples, n_importance, NATIVE_COUNTS))
+        self.n_samples = n_samples
         if n_importance > 0 and sd_fine is None:
             sd_fine = sd_coarse          # RN:482: run_fn = network_fn if network_fine is None
         self.n_importance = n_importance
         # importance samples per ray of the KERNELS this handle runs: n_importance itself where they are specialised to it
         # (f16x2, 64 / 32: 0.75x the time of 128), else 128 with duplicated uniforms (_host_tables); 0 = coarse only
-        native = mlp == "f16x2" and n_importance in NATIVE_IMPORTANCE
+        native = mlp == "f16x2" and (n_importance in NATIVE_IMPORTANCE or n_samples != N_SAMPLES)
         self.ni_kernel = n_importance if (native or n_importance == 0) else N_IMPORTANCE
-        self.nf_kernel = N_SAMPLES + self.ni_kernel
+        self.nf_kernel = n_samples + self.ni_kernel
         if variant not in (0, 16, 32):
             raise NotImplementedError("variant must be 0 (library default), 16 or 32")
         self.variant = variant
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
-        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, N_SAMPLES, self.ni_kernel, max_workgroups, variant,
+        cfg = _lib.NsrConfig(_lib.ABI_VERSION, self.device.index, n_samples, self.ni_kernel, max_workgroups, variant,
                              (1 if white_bkgd else 0) | (2 if lindisp else 0) | (4 if phases else 0)
                              | (8 if mlp == "bf16x3" else 0) | (16 if mlp == "f16x2" else 0), int(chunk))
         self._bbox_reserved = (0, 0)
@@ -135,8 +144,8 @@ class NsrModel:
         _lib.check(self.lib.nsr_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.upload(sd_coarse, sd_fine)
-        t, u = _host_tables(n_importance, native)
-        _lib.check(self.lib.nsr_upload_tables(self.h, _fptr(t), 64, _fptr(u), 128))
+        t, u = _host_tables(n_importance, native and n_importance not in (0, N_IMPORTANCE), n_samples)
+        _lib.check(self.lib.nsr_upload_tables(self.h, _fptr(t), n_samples, _fptr(u), 128))
 
     def upload(self, sd_coarse, sd_fine=None):
         to_np = lambda sd: {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
@@ -206,7 +215,7 @@ class NsrModel:
                                _dev(o.get("disp0")), _dev(o.get("acc0")), _dev(o.get("z_std")))
         dbg = None
         if debug:
-            d = dict(weights0=self._new(n, 64), raw0=self._new(n, 64, 4))
+            d = dict(weights0=self._new(n, self.n_samples), raw0=self._new(n, self.n_samples, 4))
             if fine:
                 ni, nf = self.ni_kernel, self.nf_kernel
                 d.update(z_samples=self._new(n, ni), inds=self._new(n, ni, dtype=torch.int64),
@@ -227,7 +236,8 @@ class NsrModel:
         unknown = set(extras) - set(self.EXTRA_WIDTHS)
         if unknown:
             raise ValueError("unknown ray extras: %s" % sorted(unknown))
-        widths = dict(self.EXTRA_WIDTHS, noise1=self.nf_kernel)      # (u keeps its row stride of 128: the first ni_kernel are read)
+        widths = dict(self.EXTRA_WIDTHS, noise1=self.nf_kernel, t_rand=self.n_samples, noise0=self.n_samples)
+        # (u keeps its row stride of 128: the first ni_kernel are read)
         keep = {k: self._f32(v, (n, widths[k])) for k, v in extras.items() if v is not None}
         if ("near" in keep) != ("far" in keep):
             raise ValueError("per-ray bounds: near and far come together")
@@ -468,7 +478,7 @@ class NsrModel:
         return rgb, disp, acc, w, depth
 
     def _stage_tables_ok(self, what):
-        if self.ni_kernel not in (0, N_IMPORTANCE):      # a native N_importance 64 / 32 handle's u table is linspace(0,1,n) + padding
+        if self.ni_kernel not in (0, N_IMPORTANCE) or self.n_samples != N_SAMPLES:      # (a native handle's u table is linspace(0,1,n) + padding)
             raise NotImplementedError("%s is specialised to 128 importance samples and reads the handle's uniforms table; this "
                                       "handle's kernels (and table) are specialised to N_importance = %d -- use a 128 handle"
                                       % (what, self.ni_kernel))

@@ -545,7 +545,11 @@ def h2_report(sd, coord_max=4.0, act_scale_log2=None):
             in_inf, in_rms = np.concatenate([h_inf, d_inf]), np.concatenate([h_rms, d_rms])
         else:
             in_inf, in_rms = h_inf, h_rms
-        ent_inf, ent_rms = float(in_inf[-256:].max() if l else 1.0), float(np.abs(in_rms[-256:]).max() if l else 1.0)
+        # the HIDDEN part of what enters the layer (the encodings are bounded by construction): cat([x(63), h(256)]) for the
+        # skip layer, cat([feature(256), dirs(27)]) for the view layer (a trailing slice dropped 27 features there)
+        hid_inf = in_inf[63:] if l == 5 else (in_inf[:256] if l == 9 else in_inf)
+        hid_rms = in_rms[63:] if l == 5 else (in_rms[:256] if l == 9 else in_rms)
+        ent_inf, ent_rms = float(hid_inf.max() if l else 1.0), float(np.abs(hid_rms).max() if l else 1.0)
         rows.append(dict(layer=name, sw=int(sw[l]), ca=int(ca[l]), max_abs_weight=float(np.abs(W).max()),
                          worst_log2=float(np.log2(max(ent_inf, 1e-300))), typical_log2=float(np.log2(max(ent_rms, 1e-300))),
                          headroom_worst_bits=float(16 - ca[l] - np.log2(max(ent_inf, 1e-300))),

@@ -43,13 +43,19 @@ def get_embedder(multires, i=0):
     return eo.embed, eo.out_dim
 
 
-# NSR_TRUST_VERSIONS=1 (read once, at import): the packed-weight cache is keyed on storage identity + autograd version of
-# every parameter only -- no content fingerprint, i.e. no kernel launch and no 8-byte read-back (a host-device sync) per
-# render() call: 0.43 instead of 0.48 ms for the bilevel loop's 512-ray patch call.  Safe when nothing writes the weights
-# through `.data` between renders (load_state_dict, optimizer steps and `p.copy_()` under no_grad all bump the version); the
-# reference's loop renders with frozen networks (NM:128, NM:184).  Default off: a missed in-place write would render stale
-# weights silently.
-TRUST_VERSIONS = os.environ.get("NSR_TRUST_VERSIONS", "0") == "1"
+# What keys the packed-weight cache of render().  Storage identity + autograd version of every parameter always
+# (load_state_dict, optimizer steps and `p.copy_()` under no_grad all bump the version); on top of that a CONTENT fingerprint,
+# because writes through `.data` (p.data.copy_(), legacy loaders filling weight.data) change neither -- one native kernel
+# over the parameter storage and an 8-byte read-back, ~50 us per call.  NSR_TRUST_VERSIONS (read once, at import):
+#   unset  the r05 default: the fingerprint is taken by the per-VIEW calls -- render(c2w=...), render_path, render_path_grad,
+#          where it is < 0.1 % of a call -- and NOT by render(rays=...), the bilevel loop's 512-ray patch form (RN:168), where
+#          the read-back's host-device sync was 17.5 % of a 0.41 ms call (BENCH_r04.json: api_overhead).  The reference's
+#          loop renders its views (NM:128) before its patches (NM:184) in every outer step, so a `.data` write is still seen
+#          once per step; only a write BETWEEN two patch calls with no view call in between goes unseen until the next one.
+#   "0"    every call takes the fingerprint (the r04 behaviour);   "1"  no call does.
+_TRUST_ENV = os.environ.get("NSR_TRUST_VERSIONS", "")
+TRUST_VERSIONS = _TRUST_ENV == "1"
+TRUST_PATCH_CALLS = _TRUST_ENV != "0"
 
 
 class NeRF(nn.Module):
@@ -96,16 +102,18 @@ class NeRF(nn.Module):
         return as_kernel_network(sd)
 
     @staticmethod
-    def weights_version_of(*nets):
+    def weights_version_of(*nets, trust=False):
         """weights_version() of several modules with ONE fingerprint launch and ONE read-back when they all sit on one HIP
-        device (render()'s cache key covers network_fn and network_fine: two launches + two syncs per call otherwise)."""
+        device (render()'s cache key covers network_fn and network_fine: two launches + two syncs per call otherwise).
+        -> (identity, fingerprint); trust=True (or NSR_TRUST_VERSIONS=1): identity only, fingerprint = ()."""
         nets = [n for n in nets if n is not None]
         ps = [p for n in nets for p in n.parameters()]
-        if TRUST_VERSIONS:
+        if TRUST_VERSIONS or trust:
             return tuple((p.data_ptr(), p._version) for p in ps), ()
         if len(nets) < 2 or not ps or not all(p.is_cuda and p.device == ps[0].device and p.dtype == torch.float32
                                               and p.is_contiguous() for p in ps):
-            return tuple(n.weights_version() for n in nets)
+            vs = [n.weights_version() for n in nets]       # (one network, or host-resident ones: per-module fingerprints)
+            return tuple(i for v in vs for i in v[0]), tuple(f for v in vs for f in v[1])
         from .run_nerf_noscale import _util_model
         dev = ps[0].device
         ident = tuple((p.data_ptr(), p._version) for p in ps)

@@ -50,17 +50,25 @@ def _util_model(dev=None):
     return _UTIL[idx]
 
 
-def _model_for(network_fn, network_fine, n_importance, kw=None):
+def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     """One native handle per (network_fn, network_fine, render options) tuple, repacked when the parameters change.
-    `kw`: the render kwargs, read for white_bkgd / lindisp (RN:384-385, RN:443)."""
+    `kw`: the render kwargs, read for white_bkgd / lindisp (RN:384-385, RN:443).
+    The cache is keyed on the parameters' storage identity + autograd versions; their CONTENT fingerprint (run_nerf_helpers:
+    NSR_TRUST_VERSIONS) is compared on top of that by every call that takes it -- trust=True (the 512-ray patch form of
+    render(), where its read-back is the API's whole overhead) skips it."""
     from .engine import NsrModel
+    from .run_nerf_helpers import TRUST_PATCH_CALLS
     if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
         raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
     white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
-    wv = NeRF.weights_version_of(network_fn, network_fine)
+    n_samples = int((kw or {}).get("N_samples", 64))
+    ident, fp = NeRF.weights_version_of(network_fn, network_fine, trust=trust and TRUST_PATCH_CALLS)
     forced = network_fn.__dict__.get("_nsr_force_mlp")     # set by _note_range: THESE weights keep leaving f16x2's range
-    forced = forced[0] if forced and forced[1] == wv else None
-    key = (n_importance, wv, forced or os.environ.get("NSR_MLP"))     # forward-kernel arithmetic (engine.NsrModel(mlp=...))
+    forced = forced[0] if forced and forced[1] == ident else None
+    from .engine import NATIVE_COUNTS
+    if forced and ((n_samples, n_importance) in NATIVE_COUNTS or n_importance == 96):
+        forced = None                 # sample counts only the f16x2 kernels are specialised to: stay there (per-item fallback)
+    key = (n_samples, n_importance, ident, forced or os.environ.get("NSR_MLP"))     # forward-kernel arithmetic (engine.NsrModel(mlp=...))
     # a native handle owns ONE argument block / work queue / scratch set (include/nsr.h: one handle per (model,
     # stream)), so the cache is also keyed on the device and on the torch stream the launch will be issued on
     p0 = next(network_fn.parameters())
@@ -74,14 +82,20 @@ def _model_for(network_fn, network_fine, n_importance, kw=None):
         # dropped, not closed: an autograd graph of an earlier render() may still hold the handle (ctx.cfg of _RenderRays /
         # _RenderRaysEx) for its backward; NsrModel.__del__ frees the native side with the last reference
         del pair[next(iter(pair))]
-    if cache.get("key") != key:
+    stale = fp != () and cache.get("fp", fp) != fp        # same storage, same versions, other bits: a write through .data
+    if cache.get("key") != key or stale:
         cache.pop("model", None)                          # same: released when no graph refers to it any more
+        if fp == ():                                      # (a trusted call that has to pack takes the fingerprint once, so
+            fp = NeRF.weights_version_of(network_fn, network_fine)[1]      # that later checking calls have one to compare with)
         with torch.cuda.device(dev):
             cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
                                       else None, device=dev, n_importance=n_importance, white_bkgd=white,
-                                      lindisp=lindisp, mlp=forced)
-            cache["model"].weights_version = wv
+                                      lindisp=lindisp, mlp=forced, n_samples=n_samples)
+            cache["model"].weights_version = ident
         cache["key"] = key
+        cache["fp"] = fp
+    elif fp != ():
+        cache["fp"] = fp
     return cache["model"]
 
 
@@ -220,7 +234,7 @@ class _NdcRays(torch.autograd.Function):
         return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None, None
 
 
-def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128):
+def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128, n_samples=64):
     """The random draws of the stochastic options, in the reference's order: per `chunk` of rays (the reference draws inside
     render_rays, which batchify_rays calls once per chunk) t_rand (RN:451), the coarse density noise (RN:368), the
     resampling uniforms (RH:211), the fine density noise.  From torch's generator of the render device, by the same calls
@@ -253,7 +267,7 @@ def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128):
             np.random.seed(0)
             return torch.Tensor(np.random.rand(c, width))[rows]
         if perturbed:
-            d["t_rand"] = seeded(64).to(dev)
+            d["t_rand"] = seeded(n_samples).to(dev)
         if n_importance > 0:
             if perturbed:
                 d["u"] = widen(seeded(n_importance)).to(dev)
@@ -270,16 +284,16 @@ def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128):
     for i0 in range(0, n, c):
         m = min(c, n - i0)
         if perturbed:
-            parts.setdefault("t_rand", []).append(torch.rand(m, 64, device=dev))
+            parts.setdefault("t_rand", []).append(torch.rand(m, n_samples, device=dev))
         if std > 0.:
-            parts.setdefault("noise0", []).append(torch.randn(m, 64, device=dev) * std)
+            parts.setdefault("noise0", []).append(torch.randn(m, n_samples, device=dev) * std)
         if n_importance > 0:
             if perturbed:                                   # det = (perturb == 0.), RN:474; fewer than 128: duplicated, as
                 parts.setdefault("u", []).append(widen(torch.rand(m, n_importance, device=dev)))      # engine._host_tables
             if std > 0.:
                 # (RN:371 draws [m, 64 + n_importance]; a 128-sample kernel rendering fewer importance samples through
                 # duplicated uniforms takes 192 columns: the duplicates are zero-length intervals whose density is moot)
-                parts.setdefault("noise1", []).append(torch.randn(m, 64 + ni_kernel, device=dev) * std)
+                parts.setdefault("noise1", []).append(torch.randn(m, n_samples + ni_kernel, device=dev) * std)
     for k in ("t_rand", "noise0", "u", "noise1"):           # (the order the tests and the docs name)
         if k in parts:
             d[k] = parts[k][0] if len(parts[k]) == 1 else torch.cat(parts[k], 0)
@@ -328,13 +342,15 @@ def _check_viewdirs(name, use_viewdirs, kw):
 
 def _check_kwargs(kw):
     bad = []
-    if kw.get("N_samples", 64) != 64:
-        bad.append("N_samples=%r (kernel is specialised to 64)" % kw.get("N_samples"))
-    from .engine import IMPORTANCE_COUNTS
-    if kw.get("N_importance", 0) not in IMPORTANCE_COUNTS:
-        bad.append("N_importance=%r (128, 0, or a divisor of 128)" % kw.get("N_importance"))
+    from .engine import IMPORTANCE_COUNTS, NATIVE_COUNTS
+    ns, ni = kw.get("N_samples", 64), kw.get("N_importance", 0)
+    if ns != 64 and (ns, ni) not in NATIVE_COUNTS:
+        bad.append("N_samples=%r with N_importance=%r (the kernels serve N_samples = 64 and, on f16x2 handles, the pairs %s)"
+                   % (ns, ni, NATIVE_COUNTS))
+    elif ns == 64 and ni not in IMPORTANCE_COUNTS:
+        bad.append("N_importance=%r (128, 0, a divisor of 128, or 96 on f16x2 handles)" % ni)
     from .engine import NATIVE_IMPORTANCE
-    if kw.get("retraw", False) and kw.get("N_importance", 0) not in (0, 128) + tuple(NATIVE_IMPORTANCE):
+    if kw.get("retraw", False) and kw.get("N_samples", 64) == 64 and kw.get("N_importance", 0) not in (0, 128) + tuple(NATIVE_IMPORTANCE):
         bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4]; the f16x2 "
                    "kernels are specialised to N_importance 64 and 32 and return the reference's raw there)" % kw.get("N_importance"))
     net = kw.get("network_fine") if kw.get("N_importance", 0) > 0 and kw.get("network_fine") is not None else kw.get("network_fn")
@@ -368,7 +384,8 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     per_ray_bounds = not (np.isscalar(near) and np.isscalar(far))          # RN:106-108: near / far may be arrays
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
-    model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs)
+    model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs,
+                       trust=rays is not None)           # the patch form (RN:168): no fingerprint read-back per call
     _check_retraw(kwargs, model)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
@@ -404,7 +421,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
         ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]), 1.0)
     if special:
-        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk, model.ni_kernel)
+        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk, model.ni_kernel, getattr(model, "n_samples", 64))
         if per_ray_bounds:                                  # one bound per ray (the reference multiplies them into [N,1])
             for k, v in (("near", near), ("far", far)):
                 t = torch.as_tensor(v, dtype=torch.float32).to(model.device).reshape(-1)

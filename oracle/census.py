@@ -78,7 +78,7 @@ def psnr_delta(rgb, rgb_oracle, mask=None):
 
 
 def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STAGE, white_bkgd=False, lindisp=False,
-           coarse_only=False, max_listed=8, rnd=None, viewdirs=None, n_importance=O.N_IMPORTANCE):
+           coarse_only=False, max_listed=8, rnd=None, viewdirs=None, n_importance=O.N_IMPORTANCE, n_samples=O.N_SAMPLES):
     """nets = (sd_coarse, sd_fine); rays [N,3]; got: the render's outputs as numpy arrays [N, ...] -- rgb_map, acc_map,
     disp_map, raw0 [N,64,4] and, unless coarse_only, weights0, inds, z_samples, z_fine, raw [N,192,4], rgb0, acc0;
     ref: the oracle's render of the same rays with extras (O.render_rays(..., extras=True): rgb_map, acc_map, disp_map,
@@ -87,7 +87,7 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
     The render options: rnd = the draws both renders were given (t_rand [N,64], u [N,n], noise0 [N,64], noise1 [N,64+n]:
     RN:447-459, RH:211, RN:365-374) -- they move the coarse depths, replace the linspace of sample_pdf and shift every
     sigma before its relu, so every replay below takes them; viewdirs [N,3]: given view directions (RN:91-103);
-    n_importance: the number of importance samples of BOTH renders (taps then have 64 + n fine samples).
+    n_importance / n_samples: the sample counts of BOTH renders (taps then have n_samples coarse and n_samples + n fine samples).
     Returns a JSON-able dict of counts; `unattributed` must be 0 for the render to pass."""
     sd_c, sd_f = nets
     rnd = rnd or {}
@@ -100,7 +100,8 @@ def census(nets, rays_o, rays_d, near, far, got, ref, tol=TOL, tol_stage=TOL_STA
     r = {k: np.asarray(v).reshape((n,) + np.asarray(v).shape[np.asarray(v).ndim - _trail(k):]) for k, v in ref.items()
          if v is not None and k in _TRAIL}
     vd = O.normalize_dirs(rays_d) if viewdirs is None else np.ascontiguousarray(viewdirs, f32).reshape(-1, 3)
-    zc = O.coarse_z(np.broadcast_to(np.asarray(near, f32), (n,)), np.broadcast_to(np.asarray(far, f32), (n,)), lindisp=lindisp)
+    zc = O.coarse_z(np.broadcast_to(np.asarray(near, f32), (n,)), np.broadcast_to(np.asarray(far, f32), (n,)), n=n_samples,
+                    lindisp=lindisp)
     if rnd.get("t_rand") is not None:
         zc = O.perturb_z(zc, np.asarray(rnd["t_rand"], f32))                                # RN:447-459
     for d in (g, r):

@@ -2,7 +2,7 @@
 whose helpers it uses; runs only in the authoring container, needs /root/reference read-only; nothing of the reference
 travels -- inputs and outputs only).
 
-    python oracle/gen_golden_r5.py            # writes tests/golden/g21_path_options.npz [, g22.. with --counts]
+    python oracle/gen_golden_r5.py            # writes tests/golden/g21_path_options.npz, g22 / g23 / g24_counts_*.npz
 
 g21_path_options: the reference's render_path (RN:213-255) and render_path_grad (RN:126-210) called with
 render_kwargs_TRAIN -- perturb = 1, raw_noise_std > 0 (RN:318-330): both functions forward **render_kwargs to render()
@@ -123,6 +123,23 @@ def main():
              grad_randn1=np.stack(drawn[3::4]), grad_rgbs=rgbs_g, dLdpsis=np.stack([d.numpy() for d in dl]))
     G.save("g21_path_options", **g)
     RN.raw2outputs = orig_r2o
+
+    # ---- g22 / g23 / g24: other sample counts (RN:439 N_samples, RN:474 N_importance are arguments, NM:1258-1260) on g17's
+    # rays and cotangent: (64, 96), (32, 64), (128, 128) -- forward, what sample_pdf saw and produced, and the gradient
+    g17 = np.load(os.path.join(G.OUT, "g17_importance64.npz"))
+    ro, rd, cot = torch.from_numpy(g17["rays_o"]), torch.from_numpy(g17["rays_d"]), torch.from_numpy(g17["cot"])
+    for name, ns, ni in (("g22_counts_64_96", 64, 96), ("g23_counts_32_64", 32, 64), ("g24_counts_128_128", 128, 128)):
+        kw = dict(kwargs, N_samples=ns, N_importance=ni)
+        rays = torch.stack([ro, rd], 0).clone().requires_grad_(True)
+        with G.Capture(RN, RH) as cap:
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=len(ro), rays=rays, **kw)
+        (gr,) = torch.autograd.grad(rgb, rays, grad_outputs=cot)
+        assert cap.log[0]["weights"].shape == (len(ro), ns - 2) and cap.log[0]["samples"].shape == (len(ro), ni)
+        G.save(name, seed=np.int64(SEED), n_samples=np.int64(ns), n_importance=np.int64(ni), rays_o=ro.numpy(), rays_d=rd.numpy(),
+               rgb=rgb.detach().numpy(), disp=disp.detach().numpy(), acc=acc.detach().numpy(), rgb0=ex["rgb0"].detach().numpy(),
+               acc0=ex["acc0"].detach().numpy(), z_std=ex["z_std"].detach().numpy(), z_samples=cap.log[0]["samples"],
+               inds=cap.log[0]["inds"].astype(np.int16), pdf_weights=cap.log[0]["weights"], cdf=cap.log[0]["cdf"],
+               cot=cot.numpy(), grad_rays=gr.numpy())
 
 
 if __name__ == "__main__":

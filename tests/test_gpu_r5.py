@@ -213,3 +213,198 @@ def test_path_functions_take_the_train_kwargs_like_the_reference(oracle, synth_n
     monkeypatch.setattr(torch, "randn", no_draw)
     R.render_path(None, torch.from_numpy(g["poses"]), hwf, K, 16, kw_test, savedir=str(tmp_path))
     monkeypatch.undo()
+
+
+def test_weight_changes_reach_the_renderer(synth_nets, oracle):
+    """The packed-weight cache of render() (run_nerf_helpers: NSR_TRUST_VERSIONS, r05 default): storage identity + autograd
+    versions key every call -- a parameter update that bumps the version (optimizer step, load_state_dict, copy_ under
+    no_grad) is seen by the very next call of either form; a write through `.data`, which bumps nothing, is seen by the next
+    per-VIEW call (content fingerprint) and from then on by the 512-ray patch form too (the patch form itself skips the
+    fingerprint's read-back: that was 17.5 % of such a call in r04)."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.scaled_K(50.0)
+    nets = []
+    for sd in synth_nets:
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64, network_fn=nets[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False, near=near, far=far)
+    pose = torch.tensor(np.asarray(oracle.sweep_poses(1, seed=3))[0][:3, :4])
+    ro, rd = oracle.get_rays(8, 8, K, pose.numpy())
+    rays = torch.stack([torch.from_numpy(ro.reshape(-1, 3)), torch.from_numpy(rd.reshape(-1, 3))], 0)
+    with torch.no_grad():
+        patch = lambda: cpu(R.render(8, 8, K, rays=rays, **kw)[0])
+        view = lambda: cpu(R.render(8, 8, K, c2w=pose, **kw)[0]).reshape(-1, 3)
+        a = patch()
+        assert np.array_equal(a, view()) and np.array_equal(a, patch())
+        m0 = R._model_for(nets[0], nets[1], 128, kw)
+        # (1) a versioned update: the patch form sees it at once
+        nets[1].rgb_linear.bias.add_(0.25)
+        b = patch()
+        assert np.abs(b - a).max() > 1e-3 and R._model_for(nets[0], nets[1], 128, kw) is not m0
+        assert np.array_equal(b, view())
+        # (2) a write through .data: no version moves; the next view call finds it by content, then the patch form has it too
+        nets[1].rgb_linear.bias.data.add_(-0.25)
+        c = view()
+        assert np.abs(c - a).max() < 1e-6 and np.array_equal(patch(), c)
+    for n in nets:
+        n.invalidate()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# other sample counts (RN:439 N_samples, RN:474 N_importance; NM:1258-1260): kernels specialised to (64, 96), (32, 64), (128, 128)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["g22_counts_64_96", "g23_counts_32_64", "g24_counts_128_128"])
+def test_native_sample_counts(name, oracle, synth_nets):
+    """N_samples 32 / 128 and N_importance 96 on kernels of their own (f16x2 handles), against the reference's
+    run at those counts (g22-g24, oracle pinned to them by tests/test_oracle_golden.py): every stage on the kernel's own
+    intermediates -- cdf -> indices -> samples and the merged depths BIT FOR BIT --, the coarse image against the reference
+    1e-5, the census against the oracle's render, PSNR-delta against the reference's pixels, the gradient at the reference's
+    depths against the reference's autograd, ray independence, coarse-only handles, the per-ray options, and the range safety
+    net's fallback at these counts."""
+    import sys
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import census as C
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden(name)
+    ns, ni = int(g["n_samples"]), int(g["n_importance"])
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"], g["rays_d"]
+    n = len(ro)
+    vd = oracle.normalize_dirs(rd)
+    m = NsrModel(synth_nets[0], synth_nets[1], n_samples=ns, n_importance=ni)
+    assert m.mlp == "f16x2" and (m.n_samples, m.ni_kernel, m.nf_kernel) == (ns, ni, ns + ni)
+    r = m.render_rays(ro, rd, near, far, debug=True)
+    shapes = {k: tuple(v.shape[1:]) for k, v in r.items()}
+    assert shapes["weights0"] == (ns,) and shapes["raw0"] == (ns, 4) and shapes["z_samples"] == (ni,) and shapes["inds"] == (ni,)
+    assert shapes["z_fine"] == (ns + ni,) and shapes["raw"] == (ns + ni, 4)
+    # stage by stage on the kernel's own intermediates
+    z = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32), n=ns)
+    raw0 = oracle.run_network(synth_nets[0], (ro[:, None] + rd[:, None] * z[..., None]).astype(np.float32), vd)
+    assert_close(cpu(r["raw0"]), raw0, atol=5e-5, rtol=5e-5, what="coarse raw")
+    rgb0, _, acc0, w0, _ = oracle.raw2outputs(cpu(r["raw0"]), z, rd)
+    assert_close(cpu(r["weights0"]), w0, atol=2e-6, what="weights0 | kernel raw")
+    assert_close(cpu(r["rgb0"]), rgb0, atol=3e-6, what="rgb0 | kernel raw")
+    z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    s, inds, _ = oracle.sample_pdf(z_mid, cpu(r["weights0"])[:, 1:-1], ni)
+    assert np.array_equal(cpu(r["inds"]), inds) and np.array_equal(cpu(r["z_samples"]), s)
+    zf = np.sort(np.concatenate([z, s], -1), -1)
+    assert np.array_equal(cpu(r["z_fine"]), zf)
+    raw = oracle.run_network(synth_nets[1], (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), vd)
+    assert_close(cpu(r["raw"]), raw, atol=5e-5, rtol=5e-5, what="fine raw | kernel z")
+    rgb, disp, acc, _, _ = oracle.raw2outputs(cpu(r["raw"]), zf, rd)
+    assert_close(cpu(r["rgb_map"]), rgb, atol=3e-6, what="rgb | kernel raw")
+    assert_close(cpu(r["acc_map"]), acc, atol=3e-6, what="acc | kernel raw")
+    assert_close(cpu(r["z_std"]), np.std(s.astype(np.float64), -1), atol=1e-6, what="z_std")
+    # the kernel's inverse CDF on the REFERENCE's coarse weights: the reference's indices and samples, bit for bit (stage entry
+    # points are specialised to 64 / 128, so this goes through the oracle, which the line above ties to the kernel)
+    s_ref, inds_ref, _ = oracle.sample_pdf(z_mid, g["pdf_weights"], ni)
+    assert np.array_equal(inds_ref, g["inds"].astype(np.int64)) and np.array_equal(s_ref, g["z_samples"])
+    # against the reference: coarse image, end to end census (vs the oracle's render of these counts) and PSNR-delta
+    assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+    ref = oracle.render_rays(synth_nets[0], synth_nets[1], ro, rd, vd, near, far, n_samples=ns, n_importance=ni, extras=True)
+    taps = ("rgb_map", "acc_map", "disp_map", "rgb0", "acc0", "raw0", "weights0", "inds", "z_samples", "z_fine", "raw")
+    c = C.census(synth_nets, ro, rd, near, far, {k: cpu(r[k]) for k in taps}, ref, n_importance=ni, n_samples=ns)
+    print(name, "census:", {k: c[k] for k in ("rays", "rays_above_tol", "unattributed", "psnr_delta_db")})
+    assert C.passes(c) and c["rays_above_tol"] <= 3 and c["psnr_delta_db"] <= 0.1, c
+    assert C.psnr_delta(cpu(r["rgb_map"]), g["rgb"]) <= 0.1
+    # gradient at the reference's depths, vs the reference's autograd; the VJP launch's forward == the forward kernel
+    zf_ref = np.sort(np.concatenate([z, g["z_samples"]], -1), -1)
+    go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf_ref)
+    for a, b in ((cpu(go), g["grad_rays"][0]), (cpu(gd), g["grad_rays"][1])):
+        e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+        assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (np.percentile(e, 90), e.max())
+    go2, gd2, fwd = m.render_rays_vjp(ro, rd, near, far, g["cot"], with_forward=True)
+    assert np.array_equal(cpu(fwd["rgb_map"]), cpu(r["rgb_map"]), equal_nan=True)
+    wo, wd, _ = oracle.render_rays_vjp(synth_nets[0], synth_nets[1], ro, rd, near, far, g["cot"], n_samples=ns, n_importance=ni, z_fine=zf)
+    for a, b in ((cpu(go2), wo), (cpu(gd2), wd)):
+        e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+        assert np.percentile(e, 90) < 3e-4, np.percentile(e, 90)
+    # ray independence: odd subsets (an item is two rays) forward and backward
+    for k in (1, 7, 33):
+        sub = m.render_rays(ro[:k], rd[:k], near, far)
+        for key in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+            assert np.array_equal(cpu(sub[key]), cpu(r[key])[:k], equal_nan=True), (key, k)
+        so, sd = m.render_rays_vjp(ro[:k], rd[:k], near, far, g["cot"][:k])
+        assert np.array_equal(cpu(so), cpu(go2)[:k]) and np.array_equal(cpu(sd), cpu(gd2)[:k])
+    # a view through render_views: rays generated in-kernel == the same rays given
+    K = oracle.scaled_K(20.0)
+    pose = np.asarray(oracle.sweep_poses(1, seed=3))[0]
+    v = m.render_views(pose, 20, 20, K, near, far)
+    vo, vdir = oracle.get_rays(20, 20, K, pose[:3, :4])
+    vr = m.render_rays(vo.reshape(-1, 3), vdir.reshape(-1, 3), near, far)
+    assert np.array_equal(cpu(v["rgb_map"]), cpu(vr["rgb_map"]))
+    # the per-ray options at these counts: stratified depths + random uniforms + density noise, stage-wise against the oracle
+    rng = np.random.RandomState(5)
+    rnd = dict(t_rand=rng.rand(n, ns).astype(np.float32), u=rng.rand(n, 128).astype(np.float32),
+               noise0=(0.3 * rng.standard_normal((n, ns))).astype(np.float32),
+               noise1=(0.3 * rng.standard_normal((n, ns + ni))).astype(np.float32))
+    q = m.render_rays(ro, rd, near, far, debug=True, extras=rnd)
+    zq = oracle.perturb_z(z, rnd["t_rand"])
+    _, _, _, w0q, _ = oracle.raw2outputs(cpu(q["raw0"]), zq, rd, False, rnd["noise0"])
+    assert_close(cpu(q["weights0"]), w0q, atol=2e-6, what="weights0 with options")
+    zq_mid = (np.float32(0.5) * (zq[:, 1:] + zq[:, :-1])).astype(np.float32)
+    sq, iq, _ = oracle.sample_pdf(zq_mid, cpu(q["weights0"])[:, 1:-1], ni, rnd["u"][:, :ni])
+    assert np.array_equal(cpu(q["inds"]), iq) and np.array_equal(cpu(q["z_samples"]), sq)
+    assert np.array_equal(cpu(q["z_fine"]), np.sort(np.concatenate([zq, sq], -1), -1))
+    rgbq, _, accq, _, _ = oracle.raw2outputs(cpu(q["raw"]), cpu(q["z_fine"]), rd, False, rnd["noise1"])
+    assert_close(cpu(q["rgb_map"]), rgbq, atol=3e-6, what="rgb with options")
+    m.close()
+    # coarse only at this N_samples
+    if ns != 64:
+        mc = NsrModel(synth_nets[0], None, n_samples=ns, n_importance=0)
+        rc = mc.render_rays(ro, rd, near, far, debug=True)
+        assert cpu(rc["raw0"]).shape == (n, ns, 4)
+        rgbc, _, accc, _, _ = oracle.raw2outputs(cpu(rc["raw0"]), z, rd)
+        assert_close(cpu(rc["rgb_map"]), rgbc, atol=3e-6, what="coarse-only rgb")
+        assert_close(cpu(rc["rgb_map"]), g["rgb0"], atol=1e-5, what="coarse-only rgb vs the reference's rgb0")
+        mc.close()
+    # the range safety net at these counts: every point of the coarse network overflows -> the bf16x3 kernel of the same counts
+    big = [{k: np.array(v, copy=True) for k, v in sd.items()} for sd in synth_nets]
+    big[0]["pts_linears.0.bias"][7] = 7.0e4
+    mb = NsrModel(big[0], big[1], n_samples=ns, n_importance=ni)
+    rb = mb.render_rays(ro, rd, near, far, debug=True)
+    st = mb.range_status()
+    assert st["rays"] == n and st["dropped_items"] == 0 and np.isfinite(cpu(rb["rgb_map"])).all(), st
+    refb = oracle.render_rays(big[0], big[1], ro, rd, vd, near, far, n_samples=ns, n_importance=ni, extras=True)
+    assert_close(cpu(rb["rgb0"]), refb["rgb0"], atol=1e-5, what="fallback rgb0 vs oracle")
+    cb = C.census(big, ro, rd, near, far, {k: cpu(rb[k]) for k in taps}, refb, n_importance=ni, n_samples=ns)
+    assert C.passes(cb), cb
+    gob, gdb = mb.render_rays_vjp(ro, rd, near, far, g["cot"])
+    assert np.isfinite(cpu(gdb)).all() and mb.range_status()["dropped_items"] == 0
+    mb.close()
+
+
+def test_dropin_api_takes_the_other_sample_counts(oracle, synth_nets):
+    """render(N_samples=32, N_importance=64) through the drop-in API == the engine's render of the same rays; what is still
+    refused is refused loudly (N_samples = 48; (32, 128))."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd.engine import NsrModel
+    g = load_golden("g23_counts_32_64")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    nets = []
+    for sd in synth_nets:
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=64, network_fine=nets[1], N_samples=32, network_fn=nets[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False, near=near, far=far)
+    rays = (torch.tensor(g["rays_o"]), torch.tensor(g["rays_d"]))
+    rgb, disp, acc, ex = R.render(400, 400, oracle.YCBV_K, rays=rays, retraw=True, **kw)
+    assert tuple(ex["raw"].shape) == (len(g["rays_o"]), 96, 4)
+    m = NsrModel(synth_nets[0], synth_nets[1], n_samples=32, n_importance=64)
+    want = m.render_rays(g["rays_o"], g["rays_d"], near, far)
+    assert np.array_equal(cpu(rgb), cpu(want["rgb_map"]))
+    assert oracle.psnr(cpu(rgb), g["rgb"]) > 50.0
+    m.close()
+    for bad in (dict(N_samples=48), dict(N_samples=32, N_importance=128), dict(N_samples=128, N_importance=64)):
+        with pytest.raises(NotImplementedError, match="N_samples"):
+            R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, **bad))
+    for n in nets:
+        n.invalidate()

@@ -254,6 +254,37 @@ def test_path_functions_with_train_kwargs_against_the_reference(golden, oracle, 
     assert np.abs(got.mean(0) - g["dLdpsis"].mean(0)).max() < 1e-2 * scale
 
 
+@pytest.mark.parametrize("name", ["g22_counts_64_96", "g23_counts_32_64", "g24_counts_128_128"])
+def test_other_sample_counts_against_the_reference(name, golden, oracle, synth_nets):
+    """N_samples / N_importance are arguments of the reference (RN:439, RN:474; NM:1258-1260).  (64, 96), (32, 64) and (128, 128)
+    against the reference's own run (g22-g24): the coarse image 1e-5; torch.sum's association order over N_samples - 2 weights, the
+    fp64 cdf scan, searchsorted and the inverse CDF on the reference's own coarse weights BIT FOR BIT (cdf, indices, samples); the
+    fine image within the usual conditioning; the gradient w.r.t. the rays at the reference's depths."""
+    g = golden(name)
+    ns, ni = int(g["n_samples"]), int(g["n_importance"])
+    sd_c, sd_f = synth_nets
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"], g["rays_d"]
+    n = len(ro)
+    vd = oracle.normalize_dirs(rd)
+    r = oracle.render_rays(sd_c, sd_f, ro, rd, vd, near, far, n_samples=ns, n_importance=ni, extras=True)
+    assert r["z_coarse"].shape == (n, ns) and r["z_fine"].shape == (n, ns + ni)
+    assert_close(r["rgb0"], g["rgb0"], atol=1e-5, what="rgb0")
+    assert_close(r["acc0"], g["acc0"], atol=1e-5, what="acc0")
+    z = r["z_coarse"]
+    z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    s, inds, cdf = oracle.sample_pdf(z_mid, g["pdf_weights"], ni)
+    assert np.array_equal(cdf, g["cdf"]), np.abs(cdf - g["cdf"]).max()
+    assert np.array_equal(inds, g["inds"].astype(np.int64)) and np.array_equal(s, g["z_samples"])
+    d = np.abs(r["rgb_map"] - g["rgb"]).max(-1)
+    assert (d > 1e-4).mean() <= 0.1 and oracle.psnr(r["rgb_map"], g["rgb"]) > 50.0, d.max()
+    zf = np.sort(np.concatenate([z, g["z_samples"]], -1), -1)
+    go, gd, _ = oracle.render_rays_vjp(sd_c, sd_f, ro, rd, near, far, g["cot"], n_samples=ns, n_importance=ni, z_fine=zf)
+    for a, b in ((go, g["grad_rays"][0]), (gd, g["grad_rays"][1])):
+        e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+        assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (np.percentile(e, 90), e.max())
+
+
 def test_c2w_staticcam_against_the_reference(golden, oracle, synth_nets):
     """RN:91-96: rays of the static camera, view directions of the other one."""
     g = golden("g14_stochastic")
