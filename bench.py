@@ -737,8 +737,8 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="validation only: ranks share the visible GPUs round-robin (e.g. --gpus 2 --backend gloo on a "
                          "1-GPU box exercises the N>1 code path end to end; the number is not a scaling result)")
-    ap.add_argument("--pmc-file", default=next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_k_render.json") for r in ("r04", "r03"))
-                                                 if os.path.exists(f)), os.path.join(ROOT, "profiles", "r04", "pmc_k_render.json")))
+    ap.add_argument("--pmc-file", default=next((f for f in (os.path.join(ROOT, "profiles", r, "pmc_k_render.json") for r in ("r05", "r04", "r03"))
+                                                 if os.path.exists(f)), os.path.join(ROOT, "profiles", "r05", "pmc_k_render.json")))
     ap.add_argument("--mlp", choices=MLP_MODES, default=None,
                     help="layer-GEMM arithmetic of the forward kernel (default: the engine's, engine.DEFAULT_MLP / $NSR_MLP)")
     args = ap.parse_args()

@@ -35,9 +35,13 @@ class Embedder:
 
 
 def get_embedder(multires, i=0):
-    """RH:51-66.  Only the log-sampled sin/cos encoding with include_input (i == 0) is supported."""
+    """RH:51-66.  i == 0: the log-sampled sin/cos encoding with include_input; i == -1 (RH:52-53): no encoding -- the
+    reference returns (nn.Identity(), 3), and a NeRF built on 3 + 3 raw input channels is the L = 0 case of
+    as_kernel_network (it reads the leading three columns of each of the kernels' encodings, the rest get zero weights)."""
+    if i == -1:
+        return nn.Identity(), 3
     if i != 0:
-        raise NotImplementedError("i_embed=%r: only the default positional encoding (0) is supported" % (i,))
+        raise NotImplementedError("i_embed=%r: the reference knows 0 (positional encoding) and -1 (none), RH:51-53" % (i,))
     eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
                   log_sampling=True, periodic_fns=[torch.sin, torch.cos])
     return eo.embed, eo.out_dim

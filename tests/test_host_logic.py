@@ -405,6 +405,7 @@ def test_png_roundtrip_and_to8b(tmp_path):
 
 
 def test_api_rejects_unsupported_configurations():
+    import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
     K = [[100., 0, 4], [0, 100., 4], [0, 0, 1]]
     base = dict(H=8, W=8, K=K, c2w=np.eye(4, dtype=np.float32)[:3], ndc=False, use_viewdirs=True,
@@ -428,8 +429,13 @@ def test_api_rejects_unsupported_configurations():
     small = R.NeRF(D=4, W=128, input_ch=39, input_ch_views=15, use_viewdirs=True)       # fits: served as an 8 x 256 network
     assert {k: tuple(v.shape) for k, v in small.native_state_dict().items()} == {k: tuple(v.shape) for k, v in net.state_dict().items()}
     with pytest.raises(NotImplementedError):
-        R.get_embedder(10, -1)
+        R.get_embedder(10, 1)
     assert R.get_embedder(10, 0)[1] == 63 and R.get_embedder(4, 0)[1] == 27
+    # i_embed = -1 (RH:52-53): no encoding -- (Identity, 3), and a NeRF on 3 + 3 raw channels is the L = 0 case of the mapping
+    ident, ch = R.get_embedder(10, -1)
+    assert ch == 3 and torch.equal(ident(torch.arange(6.).reshape(2, 3)), torch.arange(6.).reshape(2, 3))
+    raw_in = R.NeRF(D=8, W=256, input_ch=3, output_ch=5, skips=[4], input_ch_views=3, use_viewdirs=True)
+    assert {k: tuple(v.shape) for k, v in raw_in.native_state_dict().items()} == {k: tuple(v.shape) for k, v in net.state_dict().items()}
 
 
 def test_random_draws_follow_the_references_order():

@@ -52,7 +52,8 @@ if [ -f $T ]; then
   done
 fi
 NSR_MLP=f16x2 timeout 200 python $R/tools/bench_path_grad.py > $O/path_grad_f16x2.json 2> /dev/null
-# r04: the kernels specialised to N_importance 64 / 32 (forward and input gradient), one 400x400 view each
+timeout 200 python $R/tools/bench_api_overhead.py > $O/api_overhead.json 2> /dev/null
+# the kernels specialised to other sample counts (r04: N_importance 64 / 32; r05: 96, N_samples 32 / 128), forward and input gradient
 timeout 200 python - > $O/importance_counts.txt 2>&1 <<PY
 import sys, numpy as np
 sys.path.insert(0, "$R")
@@ -61,8 +62,8 @@ from neural_sim_nerf_amd.engine import NsrModel
 c = S.synth_weights(0); f = S.synth_weights(1000, fine_of=c)
 pose = S.sweep_poses(1, 0)[0]
 cot = np.random.RandomState(1).standard_normal((160000, 3)).astype(np.float32)
-for ni in (128, 64, 32):
-    m = NsrModel(c, f, n_importance=ni)
+for ns, ni in ((64, 128), (64, 96), (64, 64), (64, 32), (32, 64), (128, 128)):
+    m = NsrModel(c, f, n_importance=ni, n_samples=ns)
     t = []
     for _ in range(5):
         m.render_views(pose, 400, 400, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR); t.append(m.last_kernel_ms())
@@ -70,8 +71,8 @@ for ni in (128, 64, 32):
     v = []
     for _ in range(4):
         m.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot); v.append(m.last_kernel_ms())
-    print("N_importance %3d (kernels for %3d): forward %.2f ms, forward + input gradient %.2f ms per 400x400 view (medians after warm-up)"
-          % (ni, m.ni_kernel, float(np.median(t[1:])), float(np.median(v[1:]))))
+    print("N_samples %3d, N_importance %3d (kernels for %3d + %3d): forward %.2f ms, forward + input gradient %.2f ms per 400x400 view (medians after warm-up)"
+          % (ns, ni, m.n_samples, m.ni_kernel, float(np.median(t[1:])), float(np.median(v[1:]))))
     m.close()
 PY
 ls $O

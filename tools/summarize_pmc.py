@@ -88,7 +88,7 @@ for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_b3", "kern
             w = csv.writer(g)
             for r in rows[:1] + [r for r in rows[1:] if r and (r[0].startswith("nsr::") or len(r[0]) < 120)]:
                 w.writerow(r)
-for extra in ("phase_timers.txt", "path_grad_f16x2.json", "importance_counts.txt"):
+for extra in ("phase_timers.txt", "path_grad_f16x2.json", "importance_counts.txt", "api_overhead.json"):
     if os.path.exists(os.path.join(src, extra)):
         os.makedirs(os.path.join(dst, "extra"), exist_ok=True)
         shutil.copy(os.path.join(src, extra), os.path.join(dst, "extra", extra))
