@@ -18,7 +18,10 @@ const char* nsr_probe_last_error(void);
  * workgroup of every CU while the second one runs nothing / a dense fp32 VALU chain / sin-cos / an LDS pointer
  * chase / an fp64 chain (ms = mean duration of the GEMM workgroups; NSR_PROBE_VERBOSE=1 prints the partner's loop
  * rate; partner_prio = 1 raises its priority).  Mode 10: the x32 layer followed by its relu + re-bias epilogue;
- * mode 9: the two-tiles-per-wave 16x16x4 scheme with the epilogue of one tile interleaved into the other tile's MFMAs. */
+ * mode 9: the two-tiles-per-wave 16x16x4 scheme with the epilogue of one tile interleaved into the other tile's MFMAs.
+ * Modes 11..27: the bf16x3 layer and its ablations (tools/probe_bf16x3.py).  Modes 28 / 30 / 29 (r05): the f16x2 layer as the
+ * render kernels run it (gemm_h2<8, 16>: ring, fragment reads, LDS-DMA, split stages) with / without the layer epilogue, and its
+ * MFMAs alone; NSR_PROBE_VERBOSE=1 prints shader cycles per MFMA and the clock of workgroup 0's loop (tools/probe_h2.py). */
 int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms);
 
 #ifdef __cplusplus

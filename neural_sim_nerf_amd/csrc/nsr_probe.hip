@@ -48,7 +48,7 @@ const char* nsr_probe_last_error(void) { return g_perr.c_str(); }
 
 int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   if (!ms) return pfail("nsr_probe: null argument");
-  if (mode < 0 || mode > 27 || iters <= 0) return pfail("nsr_probe: mode in 0..27, iters > 0");
+  if (mode < 0 || mode > 30 || iters <= 0) return pfail("nsr_probe: mode in 0..30, iters > 0");
   NSRP_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   NSRP_HIP(hipGetDeviceProperties(&prop, device));
@@ -76,6 +76,7 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
   NSRP_LDS(nsr::k_probe_b3<11>, lepi); NSRP_LDS(nsr::k_probe_b3<12>, lepi); NSRP_LDS(nsr::k_probe_b3<13>, lepi);
   NSRP_LDS(nsr::k_probe_b3<14>, lepi); NSRP_LDS(nsr::k_probe_b3<15>, lepi); NSRP_LDS(nsr::k_probe_b3<16>, lepi); NSRP_LDS(nsr::k_probe_b3<17>, lepi); NSRP_LDS(nsr::k_probe_b3<18>, lepi);
   NSRP_LDS(nsr::k_probe_b3<19>, lepi); NSRP_LDS(nsr::k_probe_b3<20>, lepi); NSRP_LDS(nsr::k_probe_b3<21>, lepi); NSRP_LDS(nsr::k_probe_b3<22>, lepi); NSRP_LDS(nsr::k_probe_b3<23>, lepi); NSRP_LDS(nsr::k_probe_b3<24>, lepi); NSRP_LDS(nsr::k_probe_b3<25>, lepi); NSRP_LDS(nsr::k_probe_b3<26>, lepi); NSRP_LDS(nsr::k_probe_b3<27>, lepi);
+  NSRP_LDS(nsr::k_probe_h2<28>, lepi); NSRP_LDS(nsr::k_probe_h2<29>, lepi); NSRP_LDS(nsr::k_probe_h2<30>, lepi);
   NSRP_HIP(hipDeviceSynchronize());
   NSRP_HIP(hipEventRecord(ev0, s));
   const dim3 b(256), g1(n_cu), g2(2 * n_cu);
@@ -108,6 +109,9 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
     case 25: hipLaunchKernelGGL(nsr::k_probe_b3<25>, g1, b, lepi, s, wstream, out, iters); break;
     case 26: hipLaunchKernelGGL(nsr::k_probe_b3<26>, g1, b, lepi, s, wstream, out, iters); break;
     case 27: hipLaunchKernelGGL(nsr::k_probe_b3<27>, g1, b, lepi, s, wstream, out, iters); break;
+    case 28: hipLaunchKernelGGL(nsr::k_probe_h2<28>, g1, b, lepi, s, wstream, out, iters); break;
+    case 29: hipLaunchKernelGGL(nsr::k_probe_h2<29>, g1, b, lepi, s, wstream, out, iters); break;
+    case 30: hipLaunchKernelGGL(nsr::k_probe_h2<30>, g1, b, lepi, s, wstream, out, iters); break;
   }
   NSRP_HIP(hipGetLastError());
   NSRP_HIP(hipEventRecord(ev1, s));
@@ -118,7 +122,7 @@ int nsr_probe(int device, int mode, int iters, int partner_prio, float* ms) {
     float cw[2];
     NSRP_HIP(hipMemcpy(cw, out + (size_t)n_cu * 256, sizeof(cw), hipMemcpyDeviceToHost));
     fprintf(stderr, "nsr_probe mode %d: %.0f shader cycles in %.0f ticks of 10 ns -> %.3f GHz, %.2f cycles per MFMA\n", mode,
-            cw[0], cw[1], cw[0] / cw[1] / 10.0, cw[0] / ((double)iters * 768.0));
+            cw[0], cw[1], cw[0] / cw[1] / 10.0, cw[0] / ((double)iters * (mode >= 28 ? 384.0 : 768.0)));
   }
   if (mode >= 4 && mode <= 8) {        // mean duration of the GEMM workgroups (100 MHz ticks -> ms), not the whole kernel
     std::vector<float> host(2 * n_cu);

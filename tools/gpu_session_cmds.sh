@@ -1,4 +1,6 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session H: the native sample counts + the trust change)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session I: the whole GPU suite on the final tree,
+# smoke, then the profile collection of profiles/r05)
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_r5.py -q -m gpu -x --durations=10 > $O/r5_tests.log 2>&1; tail -30 $O/r5_tests.log
-timeout 300 python tools/ab_h2.py --n 8 neural_sim_nerf_amd/csrc/libnsr.so neural_sim_nerf_amd/csrc/libnsr.so 2>&1 | tee $O/ab.txt
+timeout 2400 python -m pytest tests/ -q -m gpu --durations=12 > $O/gpu_suite.log 2>&1; tail -20 $O/gpu_suite.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -5 $O/collect.log
