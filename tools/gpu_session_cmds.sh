@@ -1,6 +1,3 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session I: the whole GPU suite on the final tree,
-# smoke, then the profile collection of profiles/r05)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session J: the isolated f16x2 layer, libnsr_probe modes 28-30)
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -q -m gpu --durations=12 > $O/gpu_suite.log 2>&1; tail -20 $O/gpu_suite.log
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -5 $O/collect.log
+timeout 300 python tools/probe_h2.py 2>&1 | tee $O/probe_h2.txt
