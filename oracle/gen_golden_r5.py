@@ -3,6 +3,7 @@ whose helpers it uses; runs only in the authoring container, needs /root/referen
 travels -- inputs and outputs only).
 
     python oracle/gen_golden_r5.py            # writes tests/golden/g21_path_options.npz, g22 / g23 / g24_counts_*.npz
+    GOLDEN_OUT=/tmp/regen python oracle/gen_golden_r5.py     # ... somewhere else, to check that they reproduce bit for bit
 
 g21_path_options: the reference's render_path (RN:213-255) and render_path_grad (RN:126-210) called with
 render_kwargs_TRAIN -- perturb = 1, raw_noise_std > 0 (RN:318-330): both functions forward **render_kwargs to render()
@@ -28,13 +29,17 @@ import gen_golden as G  # noqa: E402  (import_reference, build_nets, Capture, sa
 
 
 def main():
+    src = G.OUT                                   # g10 / g17 (inputs reused here) are read from the committed fixtures
+    if os.environ.get("GOLDEN_OUT"):              # e.g. GOLDEN_OUT=/tmp/regen: write somewhere else (reproducibility check)
+        G.OUT = os.environ["GOLDEN_OUT"]
+        os.makedirs(G.OUT, exist_ok=True)
     RN, RH, LL = G.import_reference()
     sys.modules["imageio"].imwrite = lambda *a, **k: None        # render_path / render_path_grad write PNGs (RN:206, RN:250)
     torch.manual_seed(0)
     rng = np.random.RandomState(4321)
     SEED = 7
     nets, kwargs, embed_fn, embeddirs_fn = G.build_nets(RN, RH, SEED)
-    g10 = np.load(os.path.join(G.OUT, "g10_path_grad.npz"))
+    g10 = np.load(os.path.join(src, "g10_path_grad.npz"))
 
     sig_last = []
     orig_r2o = RN.raw2outputs
@@ -126,7 +131,7 @@ def main():
 
     # ---- g22 / g23 / g24: other sample counts (RN:439 N_samples, RN:474 N_importance are arguments, NM:1258-1260) on g17's
     # rays and cotangent: (64, 96), (32, 64), (128, 128) -- forward, what sample_pdf saw and produced, and the gradient
-    g17 = np.load(os.path.join(G.OUT, "g17_importance64.npz"))
+    g17 = np.load(os.path.join(src, "g17_importance64.npz"))
     ro, rd, cot = torch.from_numpy(g17["rays_o"]), torch.from_numpy(g17["rays_d"]), torch.from_numpy(g17["cot"])
     for name, ns, ni in (("g22_counts_64_96", 64, 96), ("g23_counts_32_64", 32, 64), ("g24_counts_128_128", 128, 128)):
         kw = dict(kwargs, N_samples=ns, N_importance=ni)

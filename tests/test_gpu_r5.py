@@ -408,3 +408,17 @@ def test_dropin_api_takes_the_other_sample_counts(oracle, synth_nets):
             R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, **bad))
     for n in nets:
         n.invalidate()
+
+
+def test_stage_methods_refuse_handles_of_other_counts(synth_nets):
+    """NsrModel.sample_pdf is specialised to 63 bins / 128 samples and reads the handle's uniforms table; a handle
+    whose kernels (and table) are specialised to other counts must not serve it with a table of padding zeros."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    m = NsrModel(synth_nets[0], synth_nets[1], n_importance=64)
+    with pytest.raises(NotImplementedError, match="specialised"):
+        m.sample_pdf(np.zeros((2, 63), np.float32), np.ones((2, 62), np.float32))
+    m.close()
+    m = NsrModel(synth_nets[0], synth_nets[1])                 # the YCB-V handle serves it
+    s, inds = m.sample_pdf(np.linspace(0.3, 1.9, 63, dtype=np.float32)[None].repeat(2, 0), np.ones((2, 62), np.float32))
+    assert tuple(s.shape) == (2, 128) and (np.diff(cpu(s), axis=1) >= 0).all()
+    m.close()
