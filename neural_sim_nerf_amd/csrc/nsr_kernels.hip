@@ -1224,7 +1224,9 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
           if (wr(idx >> LNS)) a.dbg_w0[ray0 * NS + idx] = NS == ST::kNS ? (&st.w0[0][0])[idx] : st.w0[idx >> LNS][idx & (NS - 1)];
       if (!fine) {
         if (MODE == kMlpH2 && tid == 0) { if (const unsigned m = range_report(a, ovf, item, valid)) range_poison(a, ray0, m); }
-        __syncthreads(); packed = next_item(); continue;
+        __syncthreads();
+        if constexpr (NPC > 1) pass = 0;                   // (N_samples = 128: the next item starts with its first coarse pass)
+        packed = next_item(); continue;
       }
       NSR_T(2);
 

@@ -363,7 +363,23 @@ def test_native_sample_counts(name, oracle, synth_nets):
         rgbc, _, accc, _, _ = oracle.raw2outputs(cpu(rc["raw0"]), z, rd)
         assert_close(cpu(rc["rgb_map"]), rgbc, atol=3e-6, what="coarse-only rgb")
         assert_close(cpu(rc["rgb_map"]), g["rgb0"], atol=1e-5, what="coarse-only rgb vs the reference's rgb0")
+        # many items per workgroup (the persistent loop's pass counter across items): 40 repeats of the rays = 960 items on 256
+        # workgroups, every repeat bit-equal to the first
+        rep = mc.render_rays(np.tile(ro, (40, 1)), np.tile(rd, (40, 1)), near, far)
+        assert np.array_equal(cpu(rep["rgb_map"]).reshape(40, n, 3), np.broadcast_to(cpu(rc["rgb_map"]), (40, n, 3)))
         mc.close()
+    # ... and the same for the coarse + fine handle, forward and input gradient (several items per workgroup)
+    m2 = NsrModel(synth_nets[0], synth_nets[1], n_samples=ns, n_importance=ni)
+    one = m2.render_rays(ro, rd, near, far)
+    rep = m2.render_rays(np.tile(ro, (40, 1)), np.tile(rd, (40, 1)), near, far)
+    for key in ("rgb_map", "disp_map", "acc_map", "rgb0", "z_std"):
+        v = cpu(rep[key])
+        assert np.array_equal(v.reshape((40, n) + v.shape[1:]), np.broadcast_to(cpu(one[key]), (40, n) + v.shape[1:]), equal_nan=True), key
+    g1o, g1d = m2.render_rays_vjp(ro, rd, near, far, g["cot"])
+    gro, grd = m2.render_rays_vjp(np.tile(ro, (40, 1)), np.tile(rd, (40, 1)), near, far, np.tile(g["cot"], (40, 1)))
+    assert np.array_equal(cpu(grd).reshape(40, n, 3), np.broadcast_to(cpu(g1d), (40, n, 3)))
+    assert np.array_equal(cpu(gro).reshape(40, n, 3), np.broadcast_to(cpu(g1o), (40, n, 3)))
+    m2.close()
     # the range safety net at these counts: every point of the coarse network overflows -> the bf16x3 kernel of the same counts
     big = [{k: np.array(v, copy=True) for k, v in sd.items()} for sd in synth_nets]
     big[0]["pts_linears.0.bias"][7] = 7.0e4
