@@ -250,7 +250,8 @@ int nsr_render_rays_vjp(nsr_handle h, const float* d_rays_o, const float* d_rays
 
 /* Debug taps of the input-gradient launch (x32-structured kernels: f16x2, bf16x3 and fp32 `variant` 32 handles; an fp32
  * handle of another variant runs k_render_vjp for a call with taps, like for the extras).  All pointers nullable.
- *   d_relu_masks [ceil(N/2)][3][9][256][4] uint32 (3 = fine passes per item; 2 on an N_importance 64 / 32 handle, whose
+ *   d_relu_masks [ceil(N/2)][3][9][256][4] uint32 (3 = fine passes per item = ceil(2 (n_samples + n_importance) / 128): 2 on
+ *       (64, 64), (64, 32) and (32, 64) handles, 4 on a (128, 128) handle; there the
  *       point mapping is q = 128 p + 32 w + j -> sample q % (64 + n) of ray 2t + q / (64 + n)): the relu patterns the backward pass applied, as captured by the
  *       forward passes of the same launch -- item t = rays 2t, 2t+1; fine pass p of the item covers the 128 points
  *       q = 128 p + 32 w + j (wave w = thread / 64, j = thread % 32) = sample q % 192 of ray 2t + q / 192; layer 0..7 =
