@@ -1,0 +1,136 @@
+/*
+ * nsr_wide.h -- C ABI of the LAYERED renderer inside libnsr.so: the same path as include/nsr.h (render_rays RN:390-501 and its
+ * input-side VJP, RN:168-178) for the configurations the fused kernels are not built for -- a NeRF (RH:70-122) of ANY depth,
+ * width and skip list, any N_samples / N_importance (RN:439, RN:474), with or without view directions.
+ *
+ * (RN = optimization/utils/run_nerf_noscale.py, RH = optimization/utils/run_nerf_helpers.py of the reference.)
+ *
+ * Design: one fp32-MFMA GEMM kernel per network layer over ALL points of a chunk of rays, activations resident
+ * in HBM between the layers (288 GB: a chunk is thousands of rays), the per-ray stages (depths, compositing RN:343-387,
+ * resampling RH:199-243, sort RN:477) as small kernels of their own between them, and for the gradient the same GEMM kernel
+ * on the transposed weights with the relu masks read back from the stored activations.  Nothing here runs on the host CPU
+ * and nothing falls back to another library: a network the fused kernels cannot hold costs layer-by-layer HBM traffic, not
+ * correctness.
+ *
+ * Conventions are those of include/nsr.h: int status (0 = OK, message via nsrw_last_error), caller-owned DEVICE buffers passed
+ * as raw pointers, stream-ordered, no hidden synchronisation in the launch calls, one handle per (model, stream); a handle is
+ * not thread-safe, distinct handles are.  The scratch memory is the CALLER's too: nsrw_workspace_bytes says how much one
+ * chunk of rays needs, the launch calls split the rays into as many chunks as the workspace they are handed allows.
+ */
+#ifndef NSR_WIDE_H_
+#define NSR_WIDE_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct NsrwHandle_* nsrw_handle;
+
+#define NSRW_MAX_SKIPS 16
+#define NSRW_MAX_DEPTH 64
+#define NSRW_MAX_WIDTH 4096
+#define NSRW_MAX_SAMPLES 512         /* N_samples, N_importance (torch.sum's first cascade level: oracle/_torch_sum_lastdim) */
+
+enum { NSRW_FLAG_WHITE_BKGD = 1,     /* RN:384-385 */
+       NSRW_FLAG_LINDISP = 2 };      /* RN:443 */
+
+typedef struct NsrwConfig {
+  int32_t device;
+  int32_t n_samples;                 /* N_samples >= 2 (RN:439) */
+  int32_t n_importance;              /* N_importance >= 0 (RN:474); 0 = coarse only */
+  int32_t flags;
+  int32_t reserved[4];
+} NsrwConfig;
+
+/* One NeRF module (RH:70-97).  input_ch = 3 + 6 multires, input_ch_views = 3 + 6 multires_views (get_embedder RH:51-66;
+ * multires = 0 is i_embed = -1, the identity).  skips: layer indices i whose OUTPUT is concatenated behind the input
+ * encoding (RH:105-106), each < D - 1.  use_viewdirs = 0: outputs = output_linear(h) with output_ch rows (RH:119-120), of
+ * which render_rays reads the first four. */
+typedef struct NsrwNet {
+  int32_t D, W;
+  int32_t multires, multires_views;
+  int32_t use_viewdirs;
+  int32_t output_ch;
+  int32_t n_skips;
+  int32_t skips[NSRW_MAX_SKIPS];
+} NsrwNet;
+
+/* Per-ray inputs of the options beyond the deterministic test-time path, all nullable DEVICE pointers (cf. NsrRayExtras):
+ * viewdirs [N,3] given view directions (c2w_staticcam RN:91-96, ndc RN:101-103); near / far [N] (RN:106-108);
+ * t_rand [N, N_samples] (RN:451), u [N, N_importance] (RH:211), noise0 [N, N_samples] / noise1 [N, N_samples + N_importance]
+ * (RN:365-374, already multiplied by raw_noise_std). */
+typedef struct NsrwExtras {
+  const float* d_viewdirs;
+  const float* d_near;
+  const float* d_far;
+  const float* d_t_rand;
+  const float* d_u;
+  const float* d_noise0;
+  const float* d_noise1;
+} NsrwExtras;
+
+/* Outputs, all nullable DEVICE pointers: the returns of render_rays (RN:488-495) -- rgb [N,3], disp [N], acc [N] of the last
+ * pass, rgb0 / disp0 / acc0 of the coarse pass and z_std [N] when N_importance > 0 -- plus the taps the parity tests read:
+ * raw [N, S, C] of the last pass (retraw; C = 4, or output_ch without view directions), z_vals [N, S] of the last pass,
+ * weights0 [N, N_samples] of the coarse pass, z_samples [N, N_importance], inds int64 [N, N_importance], raw0 [N, N_samples, C]
+ * of the coarse pass when there is a fine one. */
+typedef struct NsrwOut {
+  float* d_rgb;
+  float* d_disp;
+  float* d_acc;
+  float* d_rgb0;
+  float* d_disp0;
+  float* d_acc0;
+  float* d_z_std;
+  float* d_raw;
+  float* d_z_vals;
+  float* d_weights0;
+  float* d_z_samples;
+  int64_t* d_inds;
+  float* d_raw0;
+} NsrwOut;
+
+const char* nsrw_last_error(void);
+
+int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out);
+int nsrw_destroy(nsrw_handle h);
+
+/* Network net_id (0 = network_fn, 1 = network_fine) from HOST memory: the parameters in the module's own order and layout
+ * (torch [out, in] row-major), weight then bias per layer -- pts_linears.0 .. D-1, then with view directions feature_linear,
+ * alpha_linear, views_linears.0, rgb_linear, without them output_linear.  SETUP call: allocates, copies, synchronises. */
+int nsrw_upload_network(nsrw_handle h, int net_id, const NsrwNet* net, const float* weights, size_t n_floats);
+/* Number of floats nsrw_upload_network expects for `net` (0 if the description is invalid; nsrw_last_error says why). */
+size_t nsrw_network_floats(const NsrwNet* net);
+
+/* torch.linspace(0, 1, N_samples) and torch.linspace(0, 1, N_importance) as the HOST's torch computes them (RN:439, RH:208:
+ * ATen's values are not np.linspace's); n_fine may be 0.  SETUP call. */
+int nsrw_upload_tables(nsrw_handle h, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine);
+
+/* Bytes of workspace ONE chunk of `rays` rays needs (with_grad: for nsrw_render_rays_vjp, which keeps every activation of the
+ * fine network).  The launch calls accept any workspace that holds a chunk of at least 64 rays. */
+int nsrw_workspace_bytes(nsrw_handle h, int64_t rays, int with_grad, size_t* bytes);
+
+/* render_rays (RN:390-501) over n_rays rays.  near / far: scalars, overridden per ray by ex->d_near / d_far. */
+int nsrw_render_rays(nsrw_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_,
+                     const NsrwExtras* ex, const NsrwOut* out, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The same forward plus d(sum(rgb * grad_rgb)) / d(rays_o, rays_d) (RN:177; weights frozen, z_samples detached RN:475, so
+ * the gradient flows through the LAST pass only): d_grad_o, d_grad_d [N,3]; d_grad_viewdirs [N,3] iff ex->d_viewdirs is given
+ * (d_grad_d then holds no view-direction term).  out (nullable) receives the forward's results. */
+int nsrw_render_rays_vjp(nsrw_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_,
+                         const NsrwExtras* ex, const float* d_grad_rgb, const NsrwOut* out, float* d_grad_o, float* d_grad_d,
+                         float* d_grad_viewdirs, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* run_network (RN:26-40): d_pts [P,3], d_viewdirs [P,3] (unit length; ignored without view directions) -> d_raw [P, C],
+ * C = 4 or output_ch.  Workspace: nsrw_workspace_bytes(h, ceil(P / max(N_samples + N_importance, 1)), 0) suffices. */
+int nsrw_run_network(nsrw_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts, float* d_raw,
+                     void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Device time of the last launch call (ms; synchronises on its closing event) and the number of chunks it ran. */
+int nsrw_last_ms(nsrw_handle h, float* ms, int* chunks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSR_WIDE_H_ */

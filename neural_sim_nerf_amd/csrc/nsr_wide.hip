@@ -1,0 +1,1290 @@
+// nsr_wide.hip -- the LAYERED renderer (include/nsr_wide.h): render_rays (RN:390-501) and its input-side VJP (RN:168-178) for
+// NeRFs (RH:70-122) of any depth / width / skip list and any sample counts, i.e. everything the fused kernels of
+// nsr_kernels.hip are not specialised to.  A translation unit of its own (its kernels share nothing with the fused ones but the
+// arithmetic they restate), linked into libnsr.so.
+//
+// Shape of the computation.  The rays of a call are cut into chunks of R rays; per chunk
+//   depths -> [encode -> D+3 GEMMs -> composite] (coarse) -> sample_pdf -> sort -> [encode -> GEMMs -> composite] (fine)
+// with every activation matrix [points, width] resident in the caller's workspace (HBM), and for the gradient
+//   composite_bwd -> the same GEMM kernel on the transposed weights, relu masks read from the stored activations
+//   -> encode_bwd + the per-ray reductions.
+// The GEMM (kw_gemm) is fp32 in, fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 out: the reference's arithmetic, no operand
+// splitting, no range to manage.  Every K and N extent is padded to a multiple of 32 with zero weights, so no kernel carries a
+// K tail; M (points) is arbitrary.
+//
+// (RN = optimization/utils/run_nerf_noscale.py, RH = optimization/utils/run_nerf_helpers.py of the reference.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nsr_wide.h"
+
+namespace nsrw {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------------------------------
+// GEMM: C[m][n] = epi( sum_k A[m][k] * Wt[n][k] + bias[n] ), A = [A1 | A2] (two row-major segments: the skip concatenation
+// cat[input_pts, h] RH:105-106 and cat[feature, input_views] RH:113 without materialising them), Wt the packed [Np][K1 + K2]
+// weight (K contiguous), both K extents multiples of 32.
+//   workgroup = 256 threads = 4 waves, tile 128 (M) x TN (N): TN = 128 -> waves 2 x 2, 64 x 64 each (2 x 2 MFMA tiles);
+//   TN = 32 -> waves 4 x 1, 32 x 32 each (tails and the narrow heads).  K advances 32 per stage through double-buffered LDS
+//   tiles [rows][32 + 4] (the +4 makes the 16-byte fragment reads conflict-free: 36 l mod 64 hits every fourth bank once per
+//   16 lanes); one barrier per stage; the next stage's global loads are in flight while the MFMAs of this one issue.
+//   MFMA operand roles: A-operand = activations (lane l: row l % 32, k pair member l / 32), B-operand = weights (column
+//   l % 32), so a lane's 16 accumulators share ONE output column: bias and relu mask cost one load per 16 values and every
+//   store instruction writes two full 128-byte rows.
+//   Workgroup -> tile: blockIdx round-robins over the 8 XCDs (each with its own L2), so the N-tiles of one M-block are
+//   given to ONE XCD back to back: the A tile is read from HBM once and then from that XCD's L2.
+// ------------------------------------------------------------------------------------------------------------------------
+enum { kRelu = 1, kAccum = 2 };
+
+struct GemmArgs {
+  const float* A1; const float* A2;
+  const float* Wt; const float* bias;      // bias nullable
+  float* C;
+  const float* mask;                       // nullable: result kept where mask[m][n] > 0 (relu' of the stored activation), else 0
+  long long M;
+  int lda1, lda2, K1, K2;                  // K2 = 0: one segment
+  int ldc, N;                              // columns n < N are stored
+  int ldm;
+  int n_tiles;                             // N-tiles of this launch
+  int flags;
+};
+
+constexpr int kTM = 128;
+
+// EPI: the epilogue, a compile-time choice (kRelu, kMaskEpi or kAccum; one of them or none), so that a tile's loads of the mask /
+// the old C values are all in flight before the first of them is needed.  KS: K extent of a stage (32, or 16 for three
+// workgroups per CU instead of two).
+enum { kMaskEpi = 4 };
+
+template <int TN, int EPI, int KS>
+__global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs g) {
+  constexpr int MI = TN == 128 ? 2 : 1, NJ = TN == 128 ? 2 : 1, LD = KS + 4;
+  constexpr int AV = KS / 8;                                    // float4 per thread of the A tile (128 x KS)
+  constexpr int BF = TN * KS / 256;                             // floats per thread of the B tile (TN x KS): 16, 8 or 4
+  constexpr int BV = BF / 4;
+  static_assert(BF % 4 == 0, "B tile staging is in float4");
+  __shared__ __attribute__((aligned(16))) float sA[2][kTM][LD];
+  __shared__ __attribute__((aligned(16))) float sB[2][TN][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware tile order
+  const long long bid = blockIdx.x;
+  const int xcd = (int)(bid & 7);
+  const long long j = bid >> 3;
+  const long long mb = (j / g.n_tiles) * 8 + xcd;
+  const int nt = (int)(j % g.n_tiles);
+  const long long m0 = mb * kTM;
+  if (m0 >= g.M) return;
+  const int n0 = nt * TN;
+  const int wm = TN == 128 ? (wave & 1) : wave, wn = TN == 128 ? (wave >> 1) : 0;
+  const int ktot = g.K1 + g.K2;
+  const int stages = ktot / KS, stages1 = g.K1 / KS;
+
+  // global -> register staging: A tile 128 x KS: thread = (row t / 2, KS / 2 floats at (KS / 2) (t % 2))
+  const int arow = tid >> 1, akq = (tid & 1) * (KS / 2);
+  long long am = m0 + arow;
+  if (am >= g.M) am = g.M - 1;                                   // clamped rows are computed and never stored
+  const float* a1p = g.A1 + am * g.lda1 + akq;
+  const float* a2p = g.A2 ? g.A2 + am * g.lda2 + akq : nullptr;
+  // B tile TN x KS: thread = (row t / (256 / TN), BF floats)
+  constexpr int TPR = 256 / TN;                                  // threads per B row
+  const int brow = tid / TPR, bkq = (tid % TPR) * BF;
+  const float* bp = g.Wt + (long long)(n0 + brow) * ktot + bkq;
+  f32x4 ra[AV], rb[BV];
+
+  auto gload = [&](int s) {
+    const float* ap = s < stages1 ? a1p + s * KS : a2p + (s - stages1) * KS;
+#pragma unroll
+    for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
+#pragma unroll
+    for (int v = 0; v < BV; ++v) rb[v] = *reinterpret_cast<const f32x4*>(bp + s * KS + 4 * v);
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < AV; ++v) *reinterpret_cast<f32x4*>(&sA[buf][arow][akq + 4 * v]) = ra[v];
+#pragma unroll
+    for (int v = 0; v < BV; ++v) *reinterpret_cast<f32x4*>(&sB[buf][brow][bkq + 4 * v]) = rb[v];
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int lrow = lane & 31, lk = (lane >> 5) * 4;
+  for (int s = 0; s < stages; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < stages) gload(s + 1);
+#pragma unroll
+    for (int sub = 0; sub < KS / 8; ++sub) {
+      f32x4 fa[MI], fb[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        fa[i] = *reinterpret_cast<const f32x4*>(&sA[buf][wm * (MI * 32) + i * 32 + lrow][sub * 8 + lk]);
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+        fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][sub * 8 + lk]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int jj = 0; jj < NJ; ++jj)
+            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[jj][t], acc[i][jj], 0, 0, 0);
+    }
+    if (s + 1 < stages) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane owns column n, rows 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32 x 32 tile
+  const bool full_rows = m0 + kTM <= g.M;
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int n = n0 + wn * (NJ * 32) + jj * 32 + lrow;
+    const bool ncol = n < g.N;
+    const float b = (g.bias && ncol) ? g.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const long long mt = m0 + wm * (MI * 32) + i * 32 + lk;
+      float aux[16];                                                           // mask values / old C values, loaded together
+      if constexpr (EPI == kMaskEpi || EPI == kAccum) {
+        const float* src = EPI == kMaskEpi ? g.mask : g.C;
+        const int ld = EPI == kMaskEpi ? g.ldm : g.ldc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long m = mt + 8 * (r >> 2) + (r & 3);
+          aux[r] = (ncol && (full_rows || m < g.M)) ? src[m * ld + n] : 0.0f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long m = mt + 8 * (r >> 2) + (r & 3);
+        float v = acc[i][jj][r] + b;
+        if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
+        if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
+        if constexpr (EPI == kAccum) v = aux[r] + v;
+        if (ncol && (full_rows || m < g.M)) g.C[m * g.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// per-ray and per-point stages
+// ------------------------------------------------------------------------------------------------------------------------
+struct RayArgs {                  // one chunk of R rays, first ray = row0 of the call's arrays
+  const float* rays_o; const float* rays_d;      // [N,3] (already offset to the chunk)
+  const float* viewdirs_in;                      // nullable [N,3] (offset)
+  const float* near_in; const float* far_in;     // nullable [N] (offset)
+  float near_, far_;
+  int R, S0, NI, flags;
+  const float* t_tab; const float* u_tab;        // linspace tables
+  const float* t_rand; const float* u_rays; const float* noise0; const float* noise1;   // nullable, offset to the chunk
+  float* vd; float* nrm; float* z0;              // chunk scratch: [R,3], [R], [R,S0]
+};
+
+__device__ __forceinline__ float coarse_z(float near_, float far_, float t, int lindisp) {      // RN:441-443
+  if (lindisp) return 1.0f / (((1.0f / near_) * (1.0f - t)) + ((1.0f / far_) * t));
+  return (near_ * (1.0f - t)) + (far_ * t);
+}
+
+// viewdirs = d / |d| (RN:97-98; torch.norm = sqrt of the sequential fp32 sum of squares), |d| for RN:361, the coarse depths
+// (RN:439-443) and their stratified perturbation (RN:447-459).  One thread per ray.
+__global__ void __launch_bounds__(256) kw_ray_setup(const RayArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const float dx = a.rays_d[r * 3 + 0], dy = a.rays_d[r * 3 + 1], dz = a.rays_d[r * 3 + 2];
+  const float nrm = sqrtf(((dx * dx) + (dy * dy)) + (dz * dz));
+  a.nrm[r] = nrm;
+  if (a.viewdirs_in) {
+    a.vd[r * 3 + 0] = a.viewdirs_in[r * 3 + 0]; a.vd[r * 3 + 1] = a.viewdirs_in[r * 3 + 1]; a.vd[r * 3 + 2] = a.viewdirs_in[r * 3 + 2];
+  } else {
+    a.vd[r * 3 + 0] = dx / nrm; a.vd[r * 3 + 1] = dy / nrm; a.vd[r * 3 + 2] = dz / nrm;
+  }
+  const float nr = a.near_in ? a.near_in[r] : a.near_, fr = a.far_in ? a.far_in[r] : a.far_;
+  const int lindisp = a.flags & NSRW_FLAG_LINDISP;
+  float* z = a.z0 + (long long)r * a.S0;
+  if (!a.t_rand) {
+    for (int i = 0; i < a.S0; ++i) z[i] = coarse_z(nr, fr, a.t_tab[i], lindisp);
+    return;
+  }
+  const float* tr = a.t_rand + (long long)r * a.S0;
+  float prev = coarse_z(nr, fr, a.t_tab[0], lindisp), cur = prev;     // z[i-1], z[i]
+  for (int i = 0; i < a.S0; ++i) {
+    const float next = i + 1 < a.S0 ? coarse_z(nr, fr, a.t_tab[i + 1], lindisp) : cur;
+    const float lower = i > 0 ? 0.5f * (cur + prev) : cur;            // RN:449-450: mids = .5 (z[1:] + z[:-1])
+    const float upper = i + 1 < a.S0 ? 0.5f * (next + cur) : cur;
+    z[i] = lower + (upper - lower) * tr[i];                           // RN:459
+    prev = cur; cur = next;
+  }
+}
+
+// gamma(x) (RH:18-48): fp64 sincos of the fp32 argument 2^l x (the scaling is exact), rounded once: <= 0.5 ulp from the true
+// value, i.e. inside the reference's own libm error.  sin / cos of inf / NaN are NaN, as in torch.
+struct EmbedArgs {
+  const float* rays_o; const float* rays_d;   // rays form: point (r, s) = o + d z[r][s]  (RN:463, RN:478)
+  const float* z; const float* vd;            // [R,S], [R,3]
+  const float* pts; const float* dirs;        // points form (run_network): [P,3] each; used when rays_o == nullptr
+  long long P; int S;
+  int L, Lv;                                  // frequencies; Lv < 0: no direction encoding
+  float* E; int ldE;                          // [P, Ci]
+  float* ED; int ldED;                        // [P, Cv]
+};
+
+// 16 threads per point: thread q writes x (q = 0), band q - 1 (1 <= q <= L) of the position row, and the same for the direction
+// row -- 6 consecutive floats each, so neighbouring threads fill a row front to back; q = 0 also zeroes the padding columns.
+__global__ void __launch_bounds__(256) kw_embed(const EmbedArgs a) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p = gid >> 4;
+  const int q = (int)(gid & 15);
+  if (p >= a.P) return;
+  float x[3], v[3] = {0.0f, 0.0f, 0.0f};
+  if (a.rays_o) {
+    const long long r = p / a.S;
+    const float zz = a.z[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = a.rays_o[r * 3 + c] + a.rays_d[r * 3 + c] * zz;
+    if (a.Lv >= 0)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = a.vd[r * 3 + c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = a.pts[p * 3 + c];
+    if (a.Lv >= 0)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = a.dirs[p * 3 + c];
+  }
+  float* e = a.E + p * a.ldE;
+  if (q == 0) {
+    e[0] = x[0]; e[1] = x[1]; e[2] = x[2];
+    for (int c = 3 + 6 * a.L; c < a.ldE; ++c) e[c] = 0.0f;
+  } else if (q <= a.L) {
+    const float f = ldexpf(1.0f, q - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s, co;
+      sincos((double)(x[c] * f), &s, &co);
+      e[3 + 6 * (q - 1) + c] = (float)s;
+      e[6 + 6 * (q - 1) + c] = (float)co;
+    }
+  }
+  if (a.Lv < 0) return;
+  float* ed = a.ED + p * a.ldED;
+  if (q == 0) {
+    ed[0] = v[0]; ed[1] = v[1]; ed[2] = v[2];
+    for (int c = 3 + 6 * a.Lv; c < a.ldED; ++c) ed[c] = 0.0f;
+  } else if (q <= a.Lv) {
+    const float f = ldexpf(1.0f, q - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s, co;
+      sincos((double)(v[c] * f), &s, &co);
+      ed[3 + 6 * (q - 1) + c] = (float)s;
+      ed[6 + 6 * (q - 1) + c] = (float)co;
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// raw2outputs (RN:343-387), one thread per ray, the reference's operations in its order: dists (last = 1e10) * |d|, sigmoid,
+// alpha = 1 - exp(-relu(sigma + noise) dists), the exclusive transmittance product as torch-CPU's cumprod computes it -- a
+// sequential fp64 product, every prefix rounded to fp32 -- weights, the five weighted sums (sequential fp32), disparity with
+// its NaN case, white background.
+struct CompositeArgs {
+  int R, S, flags;
+  const float* rgb; int ld_rgb;        // raw rgb logits of point p at rgb[p * ld_rgb + 0..2]
+  const float* sigma; int ld_sigma;    // raw density at sigma[p * ld_sigma]
+  const float* z; const float* nrm;    // [R,S], [R]
+  const float* noise;                  // nullable [R,S]
+  float* weights;                      // [R,S]
+  float* rgb_map; float* disp; float* acc;       // nullable outputs [R,3], [R], [R]
+  float* raw_out; int raw_ch;          // nullable [R,S,raw_ch]: the raw the reference returns with retraw (RN:490-491)
+  const float* raw_src; int ld_raw;    // raw_ch channels per point (raw_out given, raw_ch != 4: the output_linear rows)
+};
+
+__global__ void __launch_bounds__(256) kw_composite(const CompositeArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const float* z = a.z + (long long)r * a.S;
+  const float nrm = a.nrm[r];
+  double T = 1.0;
+  float cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, acc = 0.f;
+  for (int i = 0; i < a.S; ++i) {
+    const long long p = (long long)r * a.S + i;
+    float dist = (i < a.S - 1) ? (z[i + 1] - z[i]) : 1e10f;               // RN:358-359
+    dist = dist * nrm;                                                     // RN:361
+    float sg = a.sigma[p * a.ld_sigma];
+    if (a.noise) sg = sg + a.noise[p];                                     // RN:374
+    const float al = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);                 // RN:356
+    const float w = al * (float)T;                                         // RN:376
+    T = T * (double)((1.0f - al) + 1e-10f);
+    a.weights[p] = w;
+    const float* q = a.rgb + p * a.ld_rgb;
+    cr = cr + w * sigmoidf_(q[0]);                                         // RN:363, RN:378
+    cg = cg + w * sigmoidf_(q[1]);
+    cb = cb + w * sigmoidf_(q[2]);
+    depth = depth + w * z[i];                                              // RN:380
+    acc = acc + w;                                                         // RN:382
+    if (a.raw_out) {
+      float* o = a.raw_out + p * a.raw_ch;
+      if (a.raw_src) { for (int c = 0; c < a.raw_ch; ++c) o[c] = a.raw_src[p * a.ld_raw + c]; }
+      else { o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = a.sigma[p * a.ld_sigma]; }
+    }
+  }
+  if (a.rgb_map) {
+    const float qd = depth / acc;
+    const float disp = (qd != qd) ? qd : 1.0f / fmaxf(1e-10f, qd);         // RN:381: 0/0 -> NaN propagates through torch.max
+    if (a.flags & NSRW_FLAG_WHITE_BKGD) {                                   // RN:384-385
+      const float bg = 1.0f - acc;
+      cr = cr + bg; cg = cg + bg; cb = cb + bg;
+    }
+    a.rgb_map[r * 3 + 0] = cr; a.rgb_map[r * 3 + 1] = cg; a.rgb_map[r * 3 + 2] = cb;
+    a.disp[r] = disp; a.acc[r] = acc;
+  }
+}
+
+// sample_pdf (RH:199-243) for bins = mid-points of the coarse depths (RN:473) and the coarse weights[1:-1], one thread per ray:
+// weights + 1e-5, torch.sum in ATen's association order for a contiguous fp32 row (oracle/nerf_oracle.py:_torch_sum_lastdim
+// -- 8 vector lanes x 4 partial vectors, the left-over whole vectors into the first, partials folded 0 += 1, 2, 3, then the
+// scalar tail and the 8 lanes in sequence), pdf, the cdf as a sequential fp64 sum rounded per prefix (torch.cumsum on the CPU),
+// searchsorted(right=True), the gathers, denom < 1e-5 -> 1, the interpolation.  Also z_std = std(z_samples, unbiased=False)
+// (RN:495), fp64 two-pass.
+struct PdfArgs {
+  int R, S0, NI;
+  const float* z0; const float* w0;      // [R,S0] coarse depths and weights
+  const float* u_tab; const float* u_rays;      // [NI] table, or nullable [R,NI] draws
+  float* pdf; float* cdf;                // scratch [R,S0] each
+  float* zs;                             // [R,NI]
+  int64_t* inds;                         // nullable [R,NI]
+  float* z_std;                          // nullable [R]
+};
+
+__global__ void __launch_bounds__(256) kw_sample_pdf(const PdfArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const int NW = a.S0 - 2, NC = a.S0 - 1;
+  const float* z = a.z0 + (long long)r * a.S0;
+  const float* w = a.w0 + (long long)r * a.S0 + 1;
+  float* x = a.pdf + (long long)r * a.S0;
+  float* cdf = a.cdf + (long long)r * a.S0;
+  for (int i = 0; i < NW; ++i) x[i] = w[i] + 1e-5f;                        // RH:201
+  const int nvec = NW / 8, silp = nvec / 4;
+  float ps[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) ps[k][jj] = 0.0f;
+  for (int i = 0; i < silp; ++i)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) ps[k][jj] = ps[k][jj] + x[(i * 4 + k) * 8 + jj];
+  for (int v = silp * 4; v < nvec; ++v)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) ps[0][jj] = ps[0][jj] + x[v * 8 + jj];
+  float total = 0.0f;
+  for (int i = nvec * 8; i < NW; ++i) total = total + x[i];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) total = total + (((ps[0][jj] + ps[1][jj]) + ps[2][jj]) + ps[3][jj]);
+  double run = 0.0;
+  cdf[0] = 0.0f;
+  for (int i = 0; i < NW; ++i) {
+    const float pdf = x[i] / total;                                        // RH:202
+    run = run + (double)pdf;                                               // RH:203
+    cdf[i + 1] = (float)run;
+  }
+  float* zs = a.zs + (long long)r * a.NI;
+  double sum = 0.0;
+  for (int k = 0; k < a.NI; ++k) {
+    const float u = a.u_rays ? a.u_rays[(long long)r * a.NI + k] : a.u_tab[k];
+    int lo = 0, hi = NC;                                                   // RH:227: first index with cdf > u
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    }
+    const int below = max(lo - 1, 0), above = min(lo, NC - 1);             // RH:228-229
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = 0.5f * (z[below + 1] + z[below]), b1 = 0.5f * (z[above + 1] + z[above]);     // RN:473
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.0f;                                       // RH:238-239
+    const float t = (u - c0) / denom;
+    const float s = b0 + t * (b1 - b0);                                    // RH:241
+    zs[k] = s;
+    sum += (double)s;
+    if (a.inds) a.inds[(long long)r * a.NI + k] = (int64_t)lo;
+  }
+  if (a.z_std) {
+    const double mean = sum / a.NI;
+    double var = 0.0;
+    for (int k = 0; k < a.NI; ++k) { const double d = (double)zs[k] - mean; var += d * d; }
+    a.z_std[r] = (float)sqrt(var / a.NI);
+  }
+}
+
+// z_vals, _ = torch.sort(torch.cat([z_vals, z_samples], -1), -1) (RN:477): one wave per ray, exact and stable for ANY input --
+// the rank of an element is the number of elements that sort before it (NaN after every number, ties by position).
+__global__ void __launch_bounds__(64) kw_sort(const float* __restrict__ z0, const float* __restrict__ zs, int S0, int NI,
+                                              float* __restrict__ zf) {
+  extern __shared__ float sz[];
+  const long long r = blockIdx.x;
+  const int S = S0 + NI, lane = threadIdx.x;
+  for (int i = lane; i < S; i += 64) sz[i] = i < S0 ? z0[r * S0 + i] : zs[r * NI + (i - S0)];
+  __syncthreads();
+  for (int i = lane; i < S; i += 64) {
+    const float x = sz[i];
+    const bool xn = x != x;
+    int rank = 0;
+    for (int k = 0; k < S; ++k) {
+      const float y = sz[k];
+      const bool yn = y != y;
+      const bool before = xn ? (!yn || k < i) : (!yn && (y < x || (y == x && k < i)));
+      rank += before ? 1 : 0;
+    }
+    zf[r * S + rank] = x;
+  }
+}
+
+// Backward of the compositing (the last pass's raw2outputs) for the cotangent of rgb_map, one thread per ray, fp32 forward
+// quantities recomputed exactly as kw_composite computed them, derivative arithmetic in fp64:
+//   w_i = alpha_i T_i, T_k (k > i) carries the factor om_i = 1 - alpha_i + 1e-10 -> dL/dalpha_i = A_i T_i - (sum_{k>i} A_k w_k) / om_i
+//   with A_i = g . sigmoid(rgb_i) [- sum g with a white background]; alpha = 1 - exp(-relu(sigma) dz |d|).
+// Writes dL/draw [P,32] (rgb logits, sigma, zero padding: the K extent of the first backward GEMM) and dL/d|d| per ray.
+struct CompositeBwdArgs {
+  int R, S, flags;
+  const float* rgb; int ld_rgb; const float* sigma; int ld_sigma;
+  const float* z; const float* nrm; const float* noise;
+  const float* grad_rgb;              // [R,3]
+  float* draw;                        // [P,32]
+  float* gnorm;                       // [R]
+  float* scr_a; float* scr_t;         // scratch [R,S] each: alpha_i, T_i
+};
+
+__global__ void __launch_bounds__(256) kw_composite_bwd(const CompositeBwdArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.R) return;
+  const float* z = a.z + (long long)r * a.S;
+  const float nrm = a.nrm[r];
+  float* al_s = a.scr_a + (long long)r * a.S;
+  float* t_s = a.scr_t + (long long)r * a.S;
+  double T = 1.0;
+  for (int i = 0; i < a.S; ++i) {
+    const long long p = (long long)r * a.S + i;
+    float dist = (i < a.S - 1) ? (z[i + 1] - z[i]) : 1e10f;
+    dist = dist * nrm;
+    float sg = a.sigma[p * a.ld_sigma];
+    if (a.noise) sg = sg + a.noise[p];
+    const float al = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);
+    al_s[i] = al;
+    t_s[i] = (float)T;
+    T = T * (double)((1.0f - al) + 1e-10f);
+  }
+  const double g0 = a.grad_rgb[r * 3 + 0], g1 = a.grad_rgb[r * 3 + 1], g2 = a.grad_rgb[r * 3 + 2];
+  const double gsum = (a.flags & NSRW_FLAG_WHITE_BKGD) ? (g0 + g1 + g2) : 0.0;
+  double suffix = 0.0, dn = 0.0;
+  for (int i = a.S - 1; i >= 0; --i) {
+    const long long p = (long long)r * a.S + i;
+    const float* q = a.rgb + p * a.ld_rgb;
+    const double c0 = sigmoidf_(q[0]), c1 = sigmoidf_(q[1]), c2 = sigmoidf_(q[2]);
+    const double al = al_s[i], Ti = t_s[i];
+    const double w = (double)(al_s[i] * t_s[i]);
+    const double A = g0 * c0 + g1 * c1 + g2 * c2 - gsum;
+    const double om = (double)((1.0f - al_s[i]) + 1e-10f);
+    const double d_alpha = A * Ti - suffix / om;
+    suffix += A * w;
+    float sg = a.sigma[p * a.ld_sigma];
+    if (a.noise) sg = sg + a.noise[p];
+    const double dz = (i < a.S - 1) ? (double)(z[i + 1] - z[i]) : 1e10;
+    const double e = 1.0 - al;
+    float* o = a.draw + p * 32;
+    o[0] = (float)(w * g0 * c0 * (1.0 - c0));
+    o[1] = (float)(w * g1 * c1 * (1.0 - c1));
+    o[2] = (float)(w * g2 * c2 * (1.0 - c2));
+    o[3] = sg > 0.0f ? (float)(d_alpha * (dz * (double)nrm) * e) : 0.0f;
+    dn += d_alpha * (double)fmaxf(sg, 0.0f) * e * dz;                       // d(dz |d|) / d|d| = dz
+  }
+  a.gnorm[r] = (float)dn;
+}
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, mask);
+  hi = __shfl_xor(hi, mask);
+  return __hiloint2double(hi, lo);
+}
+
+// Backward of the encodings and of pts = o + d z (RN:478), viewdirs = d / |d| (RN:97), dists |d| (RN:361), one wave per ray:
+// lane l owns samples l, l + 64, ...; fp64 throughout (the per-ray sums run over hundreds of samples of either sign).
+struct EmbedBwdArgs {
+  int R, S, L, Lv;
+  const float* rays_o; const float* rays_d; const float* z; const float* vd; const float* nrm; const float* gnorm;
+  const float* GE; int ldE; const float* GED; int ldED;       // dL/d encodings [P, Ci], [P, Cv] (GED nullable)
+  int given_viewdirs;
+  float* grad_o; float* grad_d; float* grad_v;                // [R,3]; grad_v only with given view directions
+};
+
+__device__ __forceinline__ void embed_bwd(const float* G, const double (&x)[3], int L, double (&out)[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[c] = (double)G[c];
+  for (int l = 0; l < L; ++l) {
+    const double f = (double)ldexpf(1.0f, l);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      double s, co;
+      sincos((double)((float)x[c] * (float)f), &s, &co);     // the forward's fp32 argument
+      out[c] += f * ((double)G[3 + 6 * l + c] * co - (double)G[6 + 6 * l + c] * s);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) kw_embed_bwd(const EmbedBwdArgs a) {
+  const long long r = blockIdx.x;
+  const int lane = threadIdx.x;
+  double o[3], d[3], v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[r * 3 + c]; d[c] = a.rays_d[r * 3 + c]; v[c] = a.vd[r * 3 + c]; }
+  double go[3] = {0, 0, 0}, gd[3] = {0, 0, 0}, gv[3] = {0, 0, 0};
+  for (int i = lane; i < a.S; i += 64) {
+    const long long p = r * a.S + i;
+    const float zz = a.z[p];
+    double x[3], gp[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) x[c] = (double)(a.rays_o[r * 3 + c] + a.rays_d[r * 3 + c] * zz);
+    embed_bwd(a.GE + p * a.ldE, x, a.L, gp);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { go[c] += gp[c]; gd[c] += gp[c] * (double)zz; }
+    if (a.GED) {
+      double g2[3];
+      embed_bwd(a.GED + p * a.ldED, v, a.Lv, g2);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gv[c] += g2[c];
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      go[c] += shfl_xor_f64(go[c], m); gd[c] += shfl_xor_f64(gd[c], m); gv[c] += shfl_xor_f64(gv[c], m);
+    }
+  if (lane != 0) return;
+  const double nrm = a.nrm[r], gn = a.gnorm[r];
+  double u[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) u[c] = d[c] / nrm;                       // d|d| / dd = d / |d|
+  if (a.given_viewdirs) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.grad_o[r * 3 + c] = (float)go[c];
+      a.grad_d[r * 3 + c] = (float)(gd[c] + gn * u[c]);
+      if (a.grad_v) a.grad_v[r * 3 + c] = (float)gv[c];
+    }
+  } else {
+    const double dot = gv[0] * u[0] + gv[1] * u[1] + gv[2] * u[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.grad_o[r * 3 + c] = (float)go[c];
+      a.grad_d[r * 3 + c] = (float)(gd[c] + gn * u[c] + (gv[c] - u[c] * dot) / nrm);      // d(d / |d|)
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) kw_copy_rows(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst,
+                                                    long long rows, int cols) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long p = gid / cols;
+  const int c = (int)(gid - p * cols);
+  if (p < rows) dst[p * ld_dst + c] = src[p * ld_src + c];
+}
+
+}  // namespace nsrw
+
+// ------------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+using namespace nsrw;
+
+thread_local std::string g_err;
+
+int fail(const std::string& m) {
+  g_err = m;
+  return 1;
+}
+
+#define NSRW_HIP(expr)                                                                      \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1, dev;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int d) : dev(d) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+#define NSRW_DEVICE(h) DeviceGuard guard_((h)->cfg.device); NSRW_HIP(guard_.err)
+
+inline int pad32(int x) { return (x + 31) / 32 * 32; }
+
+struct Mat {                 // one packed matrix [Np][K1p + K2p] and its (nullable) bias, as offsets into Net::dW
+  size_t w = 0, b = (size_t)-1;
+  int Np = 0, K1p = 0, K2p = 0;
+};
+
+struct Net {
+  NsrwNet d{};
+  bool loaded = false;
+  int in_ch = 0, in_v = 0, Ci = 0, Cv = 0, Wp = 0, W2 = 0, W2p = 0, ldfa = 0, raw_ch = 4;
+  std::vector<char> skip_in;          // skip_in[i]: layer i takes cat[input_pts, h]  (i - 1 in skips)
+  float* dW = nullptr;
+  std::vector<Mat> fwd;               // pts_linears
+  Mat fa, hv, rgb, out;               // [feature | alpha], views_linears.0, rgb_linear / output_linear
+  std::vector<Mat> bwd_h, bwd_e;      // per pts layer: G W_i[:, hidden part] (i >= 1), G W_i[:, encoding part] (layer 0, skip layers)
+  Mat b_rgb, b_feat, b_ed, b_head;
+};
+
+std::string check_net(const NsrwNet& n) {
+  char buf[160];
+  if (n.D < 1 || n.D > NSRW_MAX_DEPTH) { snprintf(buf, sizeof buf, "netdepth %d (1..%d)", n.D, NSRW_MAX_DEPTH); return buf; }
+  if (n.W < 2 || n.W > NSRW_MAX_WIDTH) { snprintf(buf, sizeof buf, "netwidth %d (2..%d)", n.W, NSRW_MAX_WIDTH); return buf; }
+  if (n.multires < 0 || n.multires > 15 || n.multires_views < 0 || n.multires_views > 15) return "multires / multires_views (0..15)";
+  if (n.n_skips < 0 || n.n_skips > NSRW_MAX_SKIPS) return "more skips than NSRW_MAX_SKIPS";
+  for (int i = 0; i < n.n_skips; ++i)
+    if (n.skips[i] < 0 || n.skips[i] >= n.D - 1) {
+      snprintf(buf, sizeof buf, "skip after layer %d of %d (the reference itself fails on a skip behind the last layer, RH:109)", n.skips[i], n.D);
+      return buf;
+    }
+  if (!n.use_viewdirs && (n.output_ch < 4 || n.output_ch > 32)) return "output_ch (4..32) of a network without view directions";
+  return "";
+}
+
+bool is_skip(const NsrwNet& n, int i) {
+  for (int k = 0; k < n.n_skips; ++k) if (n.skips[k] == i) return true;
+  return false;
+}
+
+size_t net_floats(const NsrwNet& n) {
+  const size_t in_ch = 3 + 6 * n.multires, in_v = 3 + 6 * n.multires_views, W = n.W;
+  size_t t = W * in_ch + W;
+  for (int i = 1; i < n.D; ++i) t += W * (W + (is_skip(n, i - 1) ? in_ch : 0)) + W;
+  if (n.use_viewdirs) t += W * W + W + W + 1 + (W / 2) * (W + in_v) + W / 2 + 3 * (W / 2) + 3;
+  else t += (size_t)n.output_ch * W + n.output_ch;
+  return t;
+}
+
+struct Handle {
+  NsrwConfig cfg{};
+  Net net[2];
+  float* d_tab = nullptr;           // [n_samples] t, [n_importance] u
+  bool tables = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int chunks = 0;
+};
+
+// appends a packed [Np][Kp] matrix to `img`; get(n, k) is consulted for n < rows, k < cols only
+template <typename F>
+size_t pack(std::vector<float>& img, int Np, int Kp, F get) {
+  const size_t off = img.size();
+  img.resize(off + (size_t)Np * Kp, 0.0f);
+  for (int n = 0; n < Np; ++n)
+    for (int k = 0; k < Kp; ++k) img[off + (size_t)n * Kp + k] = get(n, k);
+  return off;
+}
+
+size_t pack_bias(std::vector<float>& img, int Np, const float* b, int n_real, int at = 0) {
+  const size_t off = img.size();
+  img.resize(off + Np, 0.0f);
+  for (int n = 0; n < n_real; ++n) img[off + at + n] = b[n];
+  return off;
+}
+
+// Chunk workspace: the same carve runs with base = nullptr to size it.
+struct Carve {
+  char* base; size_t off = 0;
+  explicit Carve(void* b) : base(static_cast<char*>(b)) {}
+  float* f(size_t n) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += (n * sizeof(float) + 255) / 256 * 256;
+    return p;
+  }
+};
+
+struct Chunk {
+  float *vd, *nrm, *z0, *w0, *zs, *zf, *wf, *pdf, *cdf, *gnorm, *scr_a, *scr_t;
+  float *E, *ED, *FA, *HV, *RAW;
+  std::vector<float*> H;
+  float *DRAW, *GV, *G0, *G1, *GEP, *GED;
+};
+
+// floats per point of the forward buffers of `n`
+void carve_chunk(const Handle& h, long long R, bool grad, Carve& c, Chunk& k) {
+  const int S0 = h.cfg.n_samples, NI = h.cfg.n_importance, S1 = NI > 0 ? S0 + NI : 0;
+  const long long Smax = std::max(S0, S1), P = R * Smax;
+  const Net& n0 = h.net[0];
+  const Net& n1 = (NI > 0 && h.net[1].loaded) ? h.net[1] : h.net[0];
+  auto mx = [&](int Net::*f) { return (size_t)std::max(n0.*f, n1.*f); };
+  k.vd = c.f(R * 3); k.nrm = c.f(R); k.gnorm = c.f(R);
+  k.z0 = c.f(R * S0); k.w0 = c.f(R * S0); k.pdf = c.f(R * S0); k.cdf = c.f(R * S0);
+  k.zs = c.f(R * std::max(NI, 1)); k.zf = c.f(R * std::max(S1, 1)); k.wf = c.f(R * std::max(S1, 1));
+  k.E = c.f(P * mx(&Net::Ci)); k.ED = c.f(P * mx(&Net::Cv));
+  k.FA = c.f(P * mx(&Net::ldfa)); k.HV = c.f(P * mx(&Net::W2p)); k.RAW = c.f(P * 32);
+  const Net& last = NI > 0 ? n1 : n0;
+  const int nH = grad ? std::max(2, last.d.D) : 2;
+  k.H.resize(nH);
+  for (int i = 0; i < nH; ++i) k.H[i] = c.f(P * mx(&Net::Wp));
+  if (grad) {
+    const long long Pg = R * (S1 > 0 ? S1 : S0);
+    k.scr_a = c.f(Pg); k.scr_t = c.f(Pg);
+    k.DRAW = c.f(Pg * 32); k.GV = c.f(Pg * last.W2p); k.G0 = c.f(Pg * last.Wp); k.G1 = c.f(Pg * last.Wp);
+    k.GEP = c.f(Pg * last.Ci); k.GED = c.f(Pg * last.Cv);
+  } else {
+    k.scr_a = k.scr_t = k.DRAW = k.GV = k.G0 = k.G1 = k.GEP = k.GED = nullptr;
+  }
+}
+
+int g_gemm_ks = 32;      // K extent of a GEMM stage of the 128-wide kernel (NSRW_GEMM_KS = 16 | 32, read by nsrw_create)
+
+template <int TN, int KS>
+void launch_gemm(hipStream_t st, unsigned grid, const GemmArgs& g, int epi) {
+  switch (epi) {
+    case kRelu: hipLaunchKernelGGL((kw_gemm<TN, kRelu, KS>), dim3(grid), dim3(256), 0, st, g); break;
+    case kMaskEpi: hipLaunchKernelGGL((kw_gemm<TN, kMaskEpi, KS>), dim3(grid), dim3(256), 0, st, g); break;
+    case kAccum: hipLaunchKernelGGL((kw_gemm<TN, kAccum, KS>), dim3(grid), dim3(256), 0, st, g); break;
+    default: hipLaunchKernelGGL((kw_gemm<TN, 0, KS>), dim3(grid), dim3(256), 0, st, g); break;
+  }
+}
+
+int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda1, const float* A2, int lda2, float* C, int ldc,
+         int N, long long M, int flags, const float* mask = nullptr, int ldm = 0, bool with_bias = true) {
+  if (M <= 0) return 0;
+  GemmArgs g{};
+  g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
+  g.bias = (with_bias && m.b != (size_t)-1) ? dW + m.b : nullptr;
+  g.C = C; g.ldc = ldc; g.N = N; g.M = M; g.flags = flags; g.mask = mask; g.ldm = ldm;
+  const int epi = mask ? kMaskEpi : (flags & kAccum) ? kAccum : (flags & kRelu) ? kRelu : 0;     // (never combined: net_*)
+  const long long mblocks = (M + kTM - 1) / kTM, mgroups = (mblocks + 7) / 8;
+  const int full = m.Np / 128, rem = (m.Np % 128) / 32;
+  const int ktot = m.K1p + m.K2p;
+  if (full) {
+    g.Wt = dW + m.w; g.n_tiles = full;
+    const long long grid = mgroups * 8 * full;
+    if (grid > 0x7fffffffll) return fail("nsrw: chunk too large for one GEMM launch");
+    if (g_gemm_ks == 16) launch_gemm<128, 16>(st, (unsigned)grid, g, epi);
+    else launch_gemm<128, 32>(st, (unsigned)grid, g, epi);
+  }
+  if (rem) {
+    GemmArgs t = g;
+    t.Wt = dW + m.w + (size_t)full * 128 * ktot;
+    if (t.bias) t.bias += full * 128;
+    t.C = C + full * 128; t.N = N - full * 128;
+    if (t.mask) t.mask += full * 128;
+    t.n_tiles = rem;
+    if (t.N > 0) {
+      const long long grid = mgroups * 8 * rem;
+      if (grid > 0x7fffffffll) return fail("nsrw: chunk too large for one GEMM launch");
+      launch_gemm<32, 32>(st, (unsigned)grid, t, epi);
+    }
+  }
+  return 0;
+}
+
+// RH:99-122 over P points whose encodings are in k.E / k.ED: leaves the rgb logits in k.RAW (ld 32; all output_linear rows
+// without view directions) and the density at sigma / ld_sigma.  keep: every pts layer's activation stays (k.H[i]).
+int net_forward(hipStream_t st, const Net& n, const Chunk& k, long long P, bool keep, const float** sigma, int* ld_sigma) {
+  const float* h = nullptr;
+  for (int i = 0; i < n.d.D; ++i) {
+    float* out = k.H[keep ? i : (i & 1)];
+    int rc;
+    if (i == 0) rc = gemm(st, n.dW, n.fwd[0], k.E, n.Ci, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
+    else if (n.skip_in[i]) rc = gemm(st, n.dW, n.fwd[i], k.E, n.Ci, h, n.Wp, out, n.Wp, n.Wp, P, kRelu);
+    else rc = gemm(st, n.dW, n.fwd[i], h, n.Wp, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
+    if (rc) return rc;
+    h = out;
+  }
+  if (!n.d.use_viewdirs) {
+    if (gemm(st, n.dW, n.out, h, n.Wp, nullptr, 0, k.RAW, 32, n.d.output_ch, P, 0)) return 1;
+    *sigma = k.RAW + 3; *ld_sigma = 32;
+    return 0;
+  }
+  if (gemm(st, n.dW, n.fa, h, n.Wp, nullptr, 0, k.FA, n.ldfa, n.ldfa, P, 0)) return 1;
+  if (gemm(st, n.dW, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
+  if (gemm(st, n.dW, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, 32, 3, P, 0)) return 1;
+  *sigma = k.FA + n.Wp; *ld_sigma = n.ldfa;
+  return 0;
+}
+
+// Input-side backward of net_forward (activations kept): k.DRAW [P,32] = dL/d(rgb logits, sigma) -> k.GEP [P,Ci], k.GED [P,Cv].
+int net_backward(hipStream_t st, const Net& n, const Chunk& k, long long P) {
+  float* g = k.G0;
+  float* g2 = k.G1;
+  const int D = n.d.D;
+  if (n.d.use_viewdirs) {
+    if (gemm(st, n.dW, n.b_rgb, k.DRAW, 32, nullptr, 0, k.GV, n.W2p, n.W2p, P, 0, k.HV, n.W2p)) return 1;   // (g W_rgb) relu'(views)
+    if (gemm(st, n.dW, n.b_feat, k.GV, n.W2p, nullptr, 0, g2, n.Wp, n.Wp, P, 0)) return 1;                  // dL/d feature
+    if (gemm(st, n.dW, n.b_ed, k.GV, n.W2p, nullptr, 0, k.GED, n.Cv, n.Cv, P, 0)) return 1;                 // dL/d direction encoding
+    if (gemm(st, n.dW, n.b_head, g2, n.Wp, k.DRAW, 32, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;    // feature, alpha -> h_{D-1}
+  } else {
+    if (gemm(st, n.dW, n.b_head, k.DRAW, 32, nullptr, 0, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;
+  }
+  bool first_e = true;
+  for (int i = D - 1; i >= 0; --i) {          // g = dL/d pre-activation of layer i
+    if (i == 0 || n.skip_in[i]) {
+      if (gemm(st, n.dW, n.bwd_e[i], g, n.Wp, nullptr, 0, k.GEP, n.Ci, n.Ci, P, first_e ? 0 : kAccum)) return 1;
+      first_e = false;
+    }
+    if (i > 0) {
+      if (gemm(st, n.dW, n.bwd_h[i], g, n.Wp, nullptr, 0, g2, n.Wp, n.Wp, P, 0, k.H[i - 1], n.Wp)) return 1;
+      std::swap(g, g2);
+    }
+  }
+  return 0;
+}
+
+int check_common(Handle* h, const float* ro, const float* rd, long long n, const NsrwExtras* ex) {
+  if (!h) return fail("nsrw: null handle");
+  if (n < 0) return fail("nsrw: n_rays < 0");
+  if (n > 0 && (!ro || !rd)) return fail("nsrw: null rays");
+  if (!h->net[0].loaded) return fail("nsrw: network 0 not uploaded");
+  if (!h->tables) return fail("nsrw: nsrw_upload_tables not called");
+  if (ex && ex->d_u && h->cfg.n_importance == 0) return fail("nsrw: u draws without N_importance");
+  return 0;
+}
+
+long long chunk_rays(Handle* h, size_t bytes, bool grad, long long n) {
+  // largest R (multiple of 64, <= n rounded up) whose chunk fits `bytes`; 0 if not even 64 rays fit
+  auto need = [&](long long R) { Carve c(nullptr); Chunk k; carve_chunk(*h, R, grad, c, k); return c.off; };
+  if (need(64) > bytes) return 0;
+  long long lo = 64, hi = std::max<long long>(64, (n + 63) / 64 * 64);
+  if (need(hi) <= bytes) return hi;
+  while (hi - lo > 64) {
+    const long long mid = (lo + hi) / 2 / 64 * 64;
+    if (need(mid) <= bytes) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+int render_impl(Handle* h, const float* ro, const float* rd, long long n, float near_, float far_, const NsrwExtras* ex,
+                const float* grad_rgb, const NsrwOut* out, float* grad_o, float* grad_d, float* grad_v, void* ws, size_t ws_bytes,
+                hipStream_t st) {
+  const bool grad = grad_rgb != nullptr;
+  const int S0 = h->cfg.n_samples, NI = h->cfg.n_importance, S1 = NI > 0 ? S0 + NI : 0, SL = NI > 0 ? S1 : S0;
+  const Net& n0 = h->net[0];
+  const Net& n1 = (NI > 0 && h->net[1].loaded) ? h->net[1] : h->net[0];
+  const Net& last = NI > 0 ? n1 : n0;
+  NsrwExtras e{};
+  if (ex) e = *ex;
+  NsrwOut o{};
+  if (out) o = *out;
+  if (n == 0) return 0;
+  if (!ws) return fail("nsrw: null workspace");
+  if ((reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail("nsrw: workspace must be 256-byte aligned");
+  const long long R = chunk_rays(h, ws_bytes, grad, n);
+  if (R == 0) return fail("nsrw: workspace too small for a chunk of 64 rays (nsrw_workspace_bytes)");
+  if ((size_t)S1 * sizeof(float) > 64 * 1024) return fail("nsrw: too many samples per ray for the sort kernel");
+  h->chunks = 0;
+  NSRW_HIP(hipEventRecord(h->ev0, st));
+  for (long long r0 = 0; r0 < n; r0 += R) {
+    const int Rc = (int)std::min<long long>(R, n - r0);
+    Carve c(ws);
+    Chunk k;
+    carve_chunk(*h, R, grad, c, k);
+    const unsigned rb = (Rc + 255) / 256;
+    RayArgs ra{};
+    ra.rays_o = ro + r0 * 3; ra.rays_d = rd + r0 * 3;
+    ra.viewdirs_in = e.d_viewdirs ? e.d_viewdirs + r0 * 3 : nullptr;
+    ra.near_in = e.d_near ? e.d_near + r0 : nullptr; ra.far_in = e.d_far ? e.d_far + r0 : nullptr;
+    ra.near_ = near_; ra.far_ = far_; ra.R = Rc; ra.S0 = S0; ra.NI = NI; ra.flags = h->cfg.flags;
+    ra.t_tab = h->d_tab; ra.u_tab = h->d_tab + S0;
+    ra.t_rand = e.d_t_rand ? e.d_t_rand + r0 * S0 : nullptr;
+    ra.vd = k.vd; ra.nrm = k.nrm; ra.z0 = k.z0;
+    hipLaunchKernelGGL(kw_ray_setup, dim3(rb), dim3(256), 0, st, ra);
+
+    auto encode = [&](const Net& nn, const float* z, int S) {
+      EmbedArgs ea{};
+      ea.rays_o = ra.rays_o; ea.rays_d = ra.rays_d; ea.z = z; ea.vd = k.vd; ea.P = (long long)Rc * S; ea.S = S;
+      ea.L = nn.d.multires; ea.Lv = nn.d.use_viewdirs ? nn.d.multires_views : -1;
+      ea.E = k.E; ea.ldE = nn.Ci; ea.ED = k.ED; ea.ldED = nn.Cv;
+      const long long thr = ea.P * 16;
+      hipLaunchKernelGGL(kw_embed, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, st, ea);
+    };
+    // ---- coarse pass (RN:463-467) ----
+    const float* sigma; int ld_sigma;
+    encode(n0, k.z0, S0);
+    const bool grad_coarse = grad && NI == 0;
+    if (net_forward(st, n0, k, (long long)Rc * S0, grad_coarse, &sigma, &ld_sigma)) return 1;
+    CompositeArgs ca{};
+    ca.R = Rc; ca.S = S0; ca.flags = h->cfg.flags; ca.rgb = k.RAW; ca.ld_rgb = 32; ca.sigma = sigma; ca.ld_sigma = ld_sigma;
+    ca.z = k.z0; ca.nrm = k.nrm; ca.noise = e.d_noise0 ? e.d_noise0 + r0 * S0 : nullptr; ca.weights = k.w0;
+    float* rgb0 = NI > 0 ? o.d_rgb0 : o.d_rgb;
+    float* disp0 = NI > 0 ? o.d_disp0 : o.d_disp;
+    float* acc0 = NI > 0 ? o.d_acc0 : o.d_acc;
+    ca.rgb_map = rgb0 ? rgb0 + r0 * 3 : nullptr; ca.disp = disp0 ? disp0 + r0 : nullptr; ca.acc = acc0 ? acc0 + r0 : nullptr;
+    float* raw_c = NI == 0 ? o.d_raw : o.d_raw0;
+    if (raw_c) {
+      ca.raw_out = raw_c + r0 * S0 * n0.raw_ch; ca.raw_ch = n0.raw_ch;
+      if (!n0.d.use_viewdirs) { ca.raw_src = k.RAW; ca.ld_raw = 32; }
+    }
+    if (ca.rgb_map && !(ca.disp && ca.acc)) return fail("nsrw: rgb / disp / acc outputs of a pass must be given together");
+    hipLaunchKernelGGL(kw_composite, dim3(rb), dim3(256), 0, st, ca);
+    if (o.d_weights0) NSRW_HIP(hipMemcpyAsync(o.d_weights0 + r0 * S0, k.w0, (size_t)Rc * S0 * 4, hipMemcpyDeviceToDevice, st));
+    const float* z_last = k.z0;
+    const float* noise_last = ca.noise;
+    if (NI > 0) {
+      // ---- resampling (RN:473-477) ----
+      PdfArgs pa{};
+      pa.R = Rc; pa.S0 = S0; pa.NI = NI; pa.z0 = k.z0; pa.w0 = k.w0; pa.u_tab = h->d_tab + S0;
+      pa.u_rays = e.d_u ? e.d_u + r0 * NI : nullptr; pa.pdf = k.pdf; pa.cdf = k.cdf; pa.zs = k.zs;
+      pa.inds = o.d_inds ? o.d_inds + r0 * NI : nullptr; pa.z_std = o.d_z_std ? o.d_z_std + r0 : nullptr;
+      hipLaunchKernelGGL(kw_sample_pdf, dim3(rb), dim3(256), 0, st, pa);
+      if (o.d_z_samples) NSRW_HIP(hipMemcpyAsync(o.d_z_samples + r0 * NI, k.zs, (size_t)Rc * NI * 4, hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(kw_sort, dim3((unsigned)Rc), dim3(64), (size_t)S1 * sizeof(float), st, k.z0, k.zs, S0, NI, k.zf);
+      // ---- fine pass (RN:478-485) ----
+      encode(n1, k.zf, S1);
+      if (net_forward(st, n1, k, (long long)Rc * S1, grad, &sigma, &ld_sigma)) return 1;
+      CompositeArgs cf = ca;
+      cf.S = S1; cf.sigma = sigma; cf.ld_sigma = ld_sigma; cf.z = k.zf; cf.noise = e.d_noise1 ? e.d_noise1 + r0 * S1 : nullptr;
+      cf.weights = k.wf;
+      cf.rgb_map = o.d_rgb ? o.d_rgb + r0 * 3 : nullptr; cf.disp = o.d_disp ? o.d_disp + r0 : nullptr;
+      cf.acc = o.d_acc ? o.d_acc + r0 : nullptr;
+      cf.raw_out = nullptr; cf.raw_src = nullptr;
+      if (o.d_raw) {
+        cf.raw_out = o.d_raw + r0 * S1 * last.raw_ch; cf.raw_ch = last.raw_ch;
+        if (!last.d.use_viewdirs) { cf.raw_src = k.RAW; cf.ld_raw = 32; }
+      }
+      if (cf.rgb_map && !(cf.disp && cf.acc)) return fail("nsrw: rgb / disp / acc outputs of a pass must be given together");
+      hipLaunchKernelGGL(kw_composite, dim3(rb), dim3(256), 0, st, cf);
+      z_last = k.zf;
+      noise_last = cf.noise;
+    }
+    if (o.d_z_vals) NSRW_HIP(hipMemcpyAsync(o.d_z_vals + r0 * SL, z_last, (size_t)Rc * SL * 4, hipMemcpyDeviceToDevice, st));
+    if (grad) {
+      const long long P = (long long)Rc * SL;
+      NSRW_HIP(hipMemsetAsync(k.DRAW, 0, (size_t)P * 32 * 4, st));
+      CompositeBwdArgs cb{};
+      cb.R = Rc; cb.S = SL; cb.flags = h->cfg.flags; cb.rgb = k.RAW; cb.ld_rgb = 32; cb.sigma = sigma; cb.ld_sigma = ld_sigma;
+      cb.z = z_last; cb.nrm = k.nrm; cb.noise = noise_last; cb.grad_rgb = grad_rgb + r0 * 3; cb.draw = k.DRAW; cb.gnorm = k.gnorm;
+      cb.scr_a = k.scr_a; cb.scr_t = k.scr_t;
+      hipLaunchKernelGGL(kw_composite_bwd, dim3(rb), dim3(256), 0, st, cb);
+      if (net_backward(st, last, k, P)) return 1;
+      EmbedBwdArgs eb{};
+      eb.R = Rc; eb.S = SL; eb.L = last.d.multires; eb.Lv = last.d.multires_views;
+      eb.rays_o = ra.rays_o; eb.rays_d = ra.rays_d; eb.z = z_last; eb.vd = k.vd; eb.nrm = k.nrm; eb.gnorm = k.gnorm;
+      eb.GE = k.GEP; eb.ldE = last.Ci; eb.GED = last.d.use_viewdirs ? k.GED : nullptr; eb.ldED = last.Cv;
+      eb.given_viewdirs = e.d_viewdirs != nullptr;
+      eb.grad_o = grad_o + r0 * 3; eb.grad_d = grad_d + r0 * 3; eb.grad_v = grad_v ? grad_v + r0 * 3 : nullptr;
+      hipLaunchKernelGGL(kw_embed_bwd, dim3((unsigned)Rc), dim3(64), 0, st, eb);
+    }
+    ++h->chunks;
+  }
+  NSRW_HIP(hipEventRecord(h->ev1, st));
+  h->timed = true;
+  NSRW_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* nsrw_last_error(void) { return g_err.c_str(); }
+
+size_t nsrw_network_floats(const NsrwNet* net) {
+  if (!net) { fail("nsrw_network_floats: null description"); return 0; }
+  const std::string why = check_net(*net);
+  if (!why.empty()) { fail("nsrw: " + why); return 0; }
+  return net_floats(*net);
+}
+
+int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
+  if (!cfg || !out) return fail("nsrw_create: null argument");
+  if (cfg->n_samples < 3 || cfg->n_samples > NSRW_MAX_SAMPLES) return fail("nsrw_create: N_samples must be 3.." + std::to_string(NSRW_MAX_SAMPLES));
+  if (cfg->n_importance < 0 || cfg->n_importance > NSRW_MAX_SAMPLES) return fail("nsrw_create: N_importance must be 0.." + std::to_string(NSRW_MAX_SAMPLES));
+  int count = 0;
+  NSRW_HIP(hipGetDeviceCount(&count));
+  if (cfg->device < 0 || cfg->device >= count) return fail("nsrw_create: no such device");
+  if (const char* ks = getenv("NSRW_GEMM_KS")) g_gemm_ks = atoi(ks) == 16 ? 16 : 32;     // setup call: A/B switch of tools/bench_wide.py
+  Handle* h = new Handle();
+  h->cfg = *cfg;
+  DeviceGuard guard(cfg->device);
+  if (guard.err != hipSuccess) { delete h; return fail("nsrw_create: hipSetDevice failed"); }
+  if (hipMalloc(&h->d_tab, (size_t)(cfg->n_samples + std::max(cfg->n_importance, 1)) * 4) != hipSuccess ||
+      hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    if (h->d_tab) (void)hipFree(h->d_tab);
+    delete h;
+    return fail("nsrw_create: out of device memory");
+  }
+  *out = reinterpret_cast<nsrw_handle>(h);
+  return 0;
+}
+
+int nsrw_destroy(nsrw_handle hh) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h) return 0;
+  DeviceGuard guard(h->cfg.device);
+  for (Net& n : h->net) if (n.dW) (void)hipFree(n.dW);
+  if (h->d_tab) (void)hipFree(h->d_tab);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return 0;
+}
+
+int nsrw_upload_tables(nsrw_handle hh, const float* t_coarse, int n_coarse, const float* u_fine, int n_fine) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h || !t_coarse) return fail("nsrw_upload_tables: null argument");
+  if (n_coarse != h->cfg.n_samples || n_fine != h->cfg.n_importance || (n_fine > 0 && !u_fine))
+    return fail("nsrw_upload_tables: table sizes must be the handle's N_samples / N_importance");
+  NSRW_DEVICE(h);
+  NSRW_HIP(hipMemcpy(h->d_tab, t_coarse, (size_t)n_coarse * 4, hipMemcpyHostToDevice));
+  if (n_fine > 0) NSRW_HIP(hipMemcpy(h->d_tab + n_coarse, u_fine, (size_t)n_fine * 4, hipMemcpyHostToDevice));
+  h->tables = true;
+  return 0;
+}
+
+int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const float* wts, size_t n_floats) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h || !desc || !wts) return fail("nsrw_upload_network: null argument");
+  if (net_id < 0 || net_id > 1) return fail("nsrw_upload_network: net_id must be 0 or 1");
+  const std::string why = check_net(*desc);
+  if (!why.empty()) return fail("nsrw_upload_network: " + why);
+  if (n_floats != net_floats(*desc)) return fail("nsrw_upload_network: expected " + std::to_string(net_floats(*desc)) + " floats, got " + std::to_string(n_floats));
+  Net n;
+  n.d = *desc;
+  const int D = desc->D, W = desc->W;
+  n.in_ch = 3 + 6 * desc->multires; n.in_v = 3 + 6 * desc->multires_views;
+  n.Ci = pad32(n.in_ch); n.Cv = desc->use_viewdirs ? pad32(n.in_v) : 32; n.Wp = pad32(W); n.W2 = W / 2; n.W2p = pad32(std::max(n.W2, 1));
+  n.ldfa = n.Wp + 32;
+  n.raw_ch = desc->use_viewdirs ? 4 : desc->output_ch;
+  n.skip_in.assign(D, 0);
+  for (int i = 1; i < D; ++i) n.skip_in[i] = is_skip(*desc, i - 1);
+  // views of the parameter block
+  std::vector<const float*> Wl(D), Bl(D);
+  std::vector<int> Kin(D);
+  const float* p = wts;
+  for (int i = 0; i < D; ++i) {
+    Kin[i] = i == 0 ? n.in_ch : (n.skip_in[i] ? n.in_ch + W : W);
+    Wl[i] = p; p += (size_t)W * Kin[i];
+    Bl[i] = p; p += W;
+  }
+  const float *Wf = nullptr, *Bf = nullptr, *Wa = nullptr, *Ba = nullptr, *Wv = nullptr, *Bv = nullptr, *Wr = nullptr, *Br = nullptr,
+              *Wo = nullptr, *Bo = nullptr;
+  const int Kv = W + n.in_v;
+  if (desc->use_viewdirs) {
+    Wf = p; p += (size_t)W * W; Bf = p; p += W;
+    Wa = p; p += W; Ba = p; p += 1;
+    Wv = p; p += (size_t)n.W2 * Kv; Bv = p; p += n.W2;
+    Wr = p; p += (size_t)3 * n.W2; Br = p; p += 3;
+  } else {
+    Wo = p; p += (size_t)desc->output_ch * W; Bo = p; p += desc->output_ch;
+  }
+  std::vector<float> img;
+  n.fwd.resize(D); n.bwd_h.resize(D); n.bwd_e.resize(D);
+  const int in_ch = n.in_ch, Ci = n.Ci, Wp = n.Wp;
+  for (int i = 0; i < D; ++i) {
+    Mat& m = n.fwd[i];
+    const float* w = Wl[i];
+    const int K = Kin[i];
+    m.Np = Wp;
+    if (i == 0) {
+      m.K1p = Ci;
+      m.w = pack(img, Wp, Ci, [&](int nn, int kk) { return (nn < W && kk < in_ch) ? w[(size_t)nn * K + kk] : 0.0f; });
+    } else if (n.skip_in[i]) {                      // cat[input_pts, h]: encoding columns first (RH:106)
+      m.K1p = Ci; m.K2p = Wp;
+      m.w = pack(img, Wp, Ci + Wp, [&](int nn, int kk) {
+        if (nn >= W) return 0.0f;
+        if (kk < Ci) return kk < in_ch ? w[(size_t)nn * K + kk] : 0.0f;
+        const int c = kk - Ci;
+        return c < W ? w[(size_t)nn * K + in_ch + c] : 0.0f;
+      });
+    } else {
+      m.K1p = Wp;
+      m.w = pack(img, Wp, Wp, [&](int nn, int kk) { return (nn < W && kk < W) ? w[(size_t)nn * K + kk] : 0.0f; });
+    }
+    m.b = pack_bias(img, Wp, Bl[i], W);
+    // transposed pieces for the backward: out[n'] = sum_k g[k] W_i[k][col(n')]
+    const int hoff = (i > 0 && n.skip_in[i]) ? in_ch : 0;
+    if (i > 0) {
+      Mat& bh = n.bwd_h[i];
+      bh.Np = Wp; bh.K1p = Wp;
+      bh.w = pack(img, Wp, Wp, [&](int nn, int kk) { return (nn < W && kk < W) ? w[(size_t)kk * K + hoff + nn] : 0.0f; });
+    }
+    if (i == 0 || n.skip_in[i]) {
+      Mat& be = n.bwd_e[i];
+      be.Np = Ci; be.K1p = Wp;
+      be.w = pack(img, Ci, Wp, [&](int nn, int kk) { return (nn < in_ch && kk < W) ? w[(size_t)kk * K + nn] : 0.0f; });
+    }
+  }
+  if (desc->use_viewdirs) {
+    const int W2 = n.W2, W2p = n.W2p, Cv = n.Cv, in_v = n.in_v;
+    // [feature_linear rows | alpha_linear at row Wp]
+    n.fa.Np = Wp + 32; n.fa.K1p = Wp;
+    n.fa.w = pack(img, Wp + 32, Wp, [&](int nn, int kk) {
+      if (kk >= W) return 0.0f;
+      if (nn < W) return Wf[(size_t)nn * W + kk];
+      return nn == Wp ? Wa[kk] : 0.0f;
+    });
+    n.fa.b = pack_bias(img, Wp + 32, Bf, W);
+    img[n.fa.b + Wp] = Ba[0];
+    // views_linears.0 on cat[feature, input_views] (RH:113): A1 = FA's feature columns, A2 = direction encoding
+    n.hv.Np = W2p; n.hv.K1p = Wp; n.hv.K2p = Cv;
+    n.hv.w = pack(img, W2p, Wp + Cv, [&](int nn, int kk) {
+      if (nn >= W2) return 0.0f;
+      if (kk < Wp) return kk < W ? Wv[(size_t)nn * Kv + kk] : 0.0f;
+      const int c = kk - Wp;
+      return c < in_v ? Wv[(size_t)nn * Kv + W + c] : 0.0f;
+    });
+    n.hv.b = pack_bias(img, W2p, Bv, W2);
+    n.rgb.Np = 32; n.rgb.K1p = W2p;
+    n.rgb.w = pack(img, 32, W2p, [&](int nn, int kk) { return (nn < 3 && kk < W2) ? Wr[(size_t)nn * W2 + kk] : 0.0f; });
+    n.rgb.b = pack_bias(img, 32, Br, 3);
+    // backward heads
+    n.b_rgb.Np = W2p; n.b_rgb.K1p = 32;
+    n.b_rgb.w = pack(img, W2p, 32, [&](int nn, int kk) { return (nn < W2 && kk < 3) ? Wr[(size_t)kk * W2 + nn] : 0.0f; });
+    n.b_feat.Np = Wp; n.b_feat.K1p = W2p;
+    n.b_feat.w = pack(img, Wp, W2p, [&](int nn, int kk) { return (nn < W && kk < W2) ? Wv[(size_t)kk * Kv + nn] : 0.0f; });
+    n.b_ed.Np = Cv; n.b_ed.K1p = W2p;
+    n.b_ed.w = pack(img, Cv, W2p, [&](int nn, int kk) { return (nn < in_v && kk < W2) ? Wv[(size_t)kk * Kv + W + nn] : 0.0f; });
+    n.b_head.Np = Wp; n.b_head.K1p = Wp; n.b_head.K2p = 32;       // [dL/dfeature | dL/draw]: feature_linear^T, alpha_linear^T at column 3
+    n.b_head.w = pack(img, Wp, Wp + 32, [&](int nn, int kk) {
+      if (nn >= W) return 0.0f;
+      if (kk < Wp) return kk < W ? Wf[(size_t)kk * W + nn] : 0.0f;
+      return kk - Wp == 3 ? Wa[nn] : 0.0f;
+    });
+  } else {
+    const int oc = desc->output_ch;
+    n.out.Np = 32; n.out.K1p = Wp;
+    n.out.w = pack(img, 32, Wp, [&](int nn, int kk) { return (nn < oc && kk < W) ? Wo[(size_t)nn * W + kk] : 0.0f; });
+    n.out.b = pack_bias(img, 32, Bo, oc);
+    n.b_head.Np = Wp; n.b_head.K1p = 32;                            // render_rays reads rows 0..3 of output_linear (RN:363-374)
+    n.b_head.w = pack(img, Wp, 32, [&](int nn, int kk) { return (nn < W && kk < 4) ? Wo[(size_t)kk * W + nn] : 0.0f; });
+  }
+  NSRW_DEVICE(h);
+  NSRW_HIP(hipMalloc(&n.dW, img.size() * sizeof(float)));
+  hipError_t e = hipMemcpy(n.dW, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(n.dW); return fail(std::string("nsrw_upload_network: ") + hipGetErrorString(e)); }
+  Net& slot = h->net[net_id];
+  if (slot.dW) { NSRW_HIP(hipDeviceSynchronize()); (void)hipFree(slot.dW); }
+  slot = n;
+  slot.loaded = true;
+  return 0;
+}
+
+int nsrw_workspace_bytes(nsrw_handle hh, int64_t rays, int with_grad, size_t* bytes) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h || !bytes) return fail("nsrw_workspace_bytes: null argument");
+  if (!h->net[0].loaded) return fail("nsrw_workspace_bytes: network 0 not uploaded");
+  if (rays < 1) rays = 1;
+  const long long R = (rays + 63) / 64 * 64;
+  Carve c(nullptr);
+  Chunk k;
+  carve_chunk(*h, R, with_grad != 0, c, k);
+  *bytes = c.off;
+  return 0;
+}
+
+int nsrw_render_rays(nsrw_handle hh, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_,
+                     const NsrwExtras* ex, const NsrwOut* out, void* ws, size_t ws_bytes, void* stream) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (check_common(h, d_rays_o, d_rays_d, n_rays, ex)) return 1;
+  NSRW_DEVICE(h);
+  return render_impl(h, d_rays_o, d_rays_d, n_rays, near_, far_, ex, nullptr, out, nullptr, nullptr, nullptr, ws, ws_bytes,
+                     static_cast<hipStream_t>(stream));
+}
+
+int nsrw_render_rays_vjp(nsrw_handle hh, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, float near_, float far_,
+                         const NsrwExtras* ex, const float* d_grad_rgb, const NsrwOut* out, float* d_grad_o, float* d_grad_d,
+                         float* d_grad_viewdirs, void* ws, size_t ws_bytes, void* stream) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (check_common(h, d_rays_o, d_rays_d, n_rays, ex)) return 1;
+  if (n_rays > 0 && (!d_grad_rgb || !d_grad_o || !d_grad_d)) return fail("nsrw_render_rays_vjp: null gradient buffer");
+  if (d_grad_viewdirs && !(ex && ex->d_viewdirs)) return fail("nsrw_render_rays_vjp: grad_viewdirs without given view directions");
+  NSRW_DEVICE(h);
+  return render_impl(h, d_rays_o, d_rays_d, n_rays, near_, far_, ex, d_grad_rgb, out, d_grad_o, d_grad_d, d_grad_viewdirs, ws,
+                     ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+int nsrw_run_network(nsrw_handle hh, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts, float* d_raw,
+                     void* ws, size_t ws_bytes, void* stream) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h) return fail("nsrw_run_network: null handle");
+  if (net_id < 0 || net_id > 1 || !h->net[net_id].loaded) return fail("nsrw_run_network: network not uploaded");
+  if (n_pts < 0 || (n_pts > 0 && (!d_pts || !d_raw))) return fail("nsrw_run_network: null argument");
+  const Net& n = h->net[net_id];
+  if (n.d.use_viewdirs && n_pts > 0 && !d_viewdirs) return fail("nsrw_run_network: this network takes view directions");
+  if (n_pts == 0) return 0;
+  if (!ws || (reinterpret_cast<uintptr_t>(ws) & 255) != 0) return fail("nsrw_run_network: workspace must be 256-byte aligned");
+  NSRW_DEVICE(h);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // points per pass: what the workspace holds of [E | ED | FA | HV | RAW | H0 | H1]
+  const size_t per_pt = (size_t)(n.Ci + n.Cv + n.ldfa + n.W2p + 32 + 2 * n.Wp) * 4 + 64;
+  long long PB = (long long)((ws_bytes > 4096 ? ws_bytes - 4096 : 0) / per_pt) / 128 * 128;
+  if (PB < 128) return fail("nsrw_run_network: workspace too small");
+  PB = std::min<long long>(PB, (n_pts + 127) / 128 * 128);
+  Carve c(ws);
+  Chunk k;
+  k.E = c.f(PB * n.Ci); k.ED = c.f(PB * n.Cv); k.FA = c.f(PB * n.ldfa); k.HV = c.f(PB * n.W2p); k.RAW = c.f(PB * 32);
+  k.H = {c.f(PB * n.Wp), c.f(PB * n.Wp)};
+  if (c.off > ws_bytes) return fail("nsrw_run_network: workspace too small");
+  NSRW_HIP(hipEventRecord(h->ev0, st));
+  h->chunks = 0;
+  for (long long p0 = 0; p0 < n_pts; p0 += PB) {
+    const long long P = std::min<long long>(PB, n_pts - p0);
+    EmbedArgs ea{};
+    ea.pts = d_pts + p0 * 3; ea.dirs = d_viewdirs ? d_viewdirs + p0 * 3 : nullptr; ea.P = P; ea.S = 1;
+    ea.L = n.d.multires; ea.Lv = n.d.use_viewdirs ? n.d.multires_views : -1;
+    ea.E = k.E; ea.ldE = n.Ci; ea.ED = k.ED; ea.ldED = n.Cv;
+    hipLaunchKernelGGL(kw_embed, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, st, ea);
+    const float* sigma; int ld_sigma;
+    if (net_forward(st, n, k, P, false, &sigma, &ld_sigma)) return 1;
+    const int C = n.raw_ch;
+    if (n.d.use_viewdirs) {
+      hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P * 3 + 255) / 256)), dim3(256), 0, st, k.RAW, 32, d_raw + p0 * 4, 4, P, 3);
+      hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, sigma, ld_sigma, d_raw + p0 * 4 + 3, 4, P, 1);
+    } else {
+      hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P * C + 255) / 256)), dim3(256), 0, st, k.RAW, 32, d_raw + p0 * C, C, P, C);
+    }
+    ++h->chunks;
+  }
+  NSRW_HIP(hipEventRecord(h->ev1, st));
+  h->timed = true;
+  NSRW_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsrw_last_ms(nsrw_handle hh, float* ms, int* chunks) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h || !ms) return fail("nsrw_last_ms: null argument");
+  if (!h->timed) return fail("nsrw_last_ms: no launch yet");
+  NSRW_DEVICE(h);
+  NSRW_HIP(hipEventSynchronize(h->ev1));
+  NSRW_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));
+  if (chunks) *chunks = h->chunks;
+  return 0;
+}
+
+}  // extern "C"

@@ -65,18 +65,18 @@ TRUST_PATCH_CALLS = _TRUST_ENV != "0"
 class NeRF(nn.Module):
     """RH:70-122: weight container with the reference's parameter names and shapes for the given D / W / input sizes /
     skips / use_viewdirs, so the reference's checkpoints (`network_fn_state_dict` / `network_fine_state_dict`, RN:296-314)
-    load with load_state_dict unchanged.  Shapes that cannot be expressed as the kernels' network are refused (fits_kernel).
-    forward() evaluates the network natively; its input is the reference's [P, 90] embedded tensor, of which
-    only the raw position (columns 0:3) and direction (63:66) are read -- the kernel re-derives the rest."""
+    load with load_state_dict unchanged.  A shape that can be expressed as the fused kernels' 8 x 256 network (fits_kernel) is
+    served by them; every other one -- wider, deeper, more skips -- by the layered renderer (wide.py, include/nsr_wide.h):
+    `self.fused_why_not` is None or the reason.
+    forward() evaluates the network natively; its input is the reference's [P, input_ch + input_ch_views] embedded tensor, of
+    which only the raw position (columns 0:3) and direction (input_ch : input_ch + 3) are read -- the kernels re-derive the rest."""
 
     def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False):
         super().__init__()
-        why = fits_kernel(D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs), output_ch)
+        why = layered_refuses(D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs), output_ch)
         if why:
-            raise NotImplementedError(
-                "the gfx950 kernel is specialised to the 8 x 256 network of configs/nerf_param_ycbv_general.txt (63 + 27 "
-                "inputs, skip after layer 4, use_viewdirs=True) and to the networks that can be written as one exactly "
-                "(run_nerf_helpers.as_kernel_network); this one cannot: " + why)
+            raise NotImplementedError("neither the fused gfx950 kernels nor the layered renderer serve this network: " + why)
+        self.fused_why_not = fits_kernel(D, W, input_ch, input_ch_views, list(skips), bool(use_viewdirs), output_ch)
         self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
         self.skips, self.use_viewdirs = skips, bool(use_viewdirs)
         self.output_ch = int(output_ch)
@@ -100,6 +100,8 @@ class NeRF(nn.Module):
         encoding frequencies, another skip position, use_viewdirs=False) -- the same fused kernels then serve it, forward
         and input gradients, at the full network's price."""
         sd = {k: v.detach() for k, v in self.state_dict().items()}
+        if self.fused_why_not:
+            raise NotImplementedError("this network is served by the layered renderer, not the fused kernels: " + self.fused_why_not)
         if (self.D, self.W, self.input_ch, self.input_ch_views, list(self.skips), self.use_viewdirs) == \
                 (KERNEL_D, KERNEL_W, KERNEL_IN, KERNEL_IN_VIEWS, [KERNEL_SKIP], True):
             return sd
@@ -190,6 +192,11 @@ class NeRF(nn.Module):
             self._native5 = None
             p0 = next(self.parameters())
             dev = p0.device.index if p0.is_cuda else None     # the module's device, not the current one
+            if self.fused_why_not or os.environ.get("NSR_LAYERED") == "1":
+                from .wide import WideModel                   # any shape, all output_linear rows (include/nsr_wide.h)
+                self._native = WideModel({k: v.detach() for k, v in self.state_dict().items()}, None, device=dev, n_importance=0)
+                self._native_key = key
+                return self._native
             self._native = NsrModel(self.native_state_dict(), None, n_importance=0, mlp="fp32", device=dev)   # k_run_network (stage kernel)
             if not self.use_viewdirs and self.output_ch == 5:
                 # RH:95-96 + RN:267: output_linear has FIVE rows when N_importance > 0; render_rays reads rows 0..3, but the
@@ -231,6 +238,25 @@ def _shape_of(sd):
     use_viewdirs = "output_linear.weight" not in sd
     input_ch_views = sd["views_linears.0.weight"].shape[1] - W
     return D, W, input_ch, input_ch_views, skips, use_viewdirs
+
+
+def layered_refuses(D, W, input_ch, input_ch_views, skips, use_viewdirs, output_ch=4):
+    """None if the layered renderer (include/nsr_wide.h: any depth / width / skip list) serves a NeRF of this shape, else why
+    not -- the limits are the header's NSRW_MAX_* and the reference's own (RH:109: a skip behind the last layer fails there)."""
+    if not 1 <= D <= 64:
+        return "netdepth %r (1..64)" % (D,)
+    if not 2 <= W <= 4096:
+        return "netwidth %r (2..4096)" % (W,)
+    if input_ch < 3 or (input_ch - 3) % 6 or input_ch > 3 + 6 * 15:
+        return "input_ch %r (3 + 6 L with L <= 15 frequencies)" % (input_ch,)
+    if use_viewdirs and (input_ch_views < 3 or (input_ch_views - 3) % 6 or input_ch_views > 3 + 6 * 15):
+        return "input_ch_views %r (3 + 6 L with L <= 15 frequencies)" % (input_ch_views,)
+    if not use_viewdirs and not 4 <= output_ch <= 32:
+        return "output_ch %r (4..32)" % (output_ch,)
+    eff = sorted(set(s for s in skips if 0 <= s < D - 1))
+    if len(eff) > 16:
+        return "%d skips (at most 16)" % len(eff)
+    return None
 
 
 def fits_kernel(D, W, input_ch, input_ch_views, skips, use_viewdirs, output_ch=4):

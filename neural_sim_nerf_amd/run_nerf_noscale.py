@@ -68,7 +68,8 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     from .engine import NATIVE_COUNTS
     if forced and ((n_samples, n_importance) in NATIVE_COUNTS or n_importance == 96):
         forced = None                 # sample counts only the f16x2 kernels are specialised to: stay there (per-item fallback)
-    key = (n_samples, n_importance, ident, forced or os.environ.get("NSR_MLP"))     # forward-kernel arithmetic (engine.NsrModel(mlp=...))
+    layered = _layered_why(network_fn, network_fine, n_samples, n_importance, forced or os.environ.get("NSR_MLP"))
+    key = (n_samples, n_importance, ident, "layered" if layered else (forced or os.environ.get("NSR_MLP")))     # which kernels
     # a native handle owns ONE argument block / work queue / scratch set (include/nsr.h: one handle per (model,
     # stream)), so the cache is also keyed on the device and on the torch stream the launch will be issued on
     p0 = next(network_fn.parameters())
@@ -88,15 +89,41 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
         if fp == ():                                      # (a trusted call that has to pack takes the fingerprint once, so
             fp = NeRF.weights_version_of(network_fn, network_fine)[1]      # that later checking calls have one to compare with)
         with torch.cuda.device(dev):
-            cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
-                                      else None, device=dev, n_importance=n_importance, white_bkgd=white,
-                                      lindisp=lindisp, mlp=forced, n_samples=n_samples)
+            if layered:                                   # any network, any sample counts: include/nsr_wide.h
+                from .wide import WideModel
+                own = lambda net: {k: v.detach() for k, v in net.state_dict().items()}
+                cache["model"] = WideModel(own(network_fn), own(network_fine) if network_fine is not None else None, device=dev,
+                                           n_importance=n_importance, white_bkgd=white, lindisp=lindisp, n_samples=n_samples)
+                cache["model"].why_layered = layered
+            else:
+                cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
+                                          else None, device=dev, n_importance=n_importance, white_bkgd=white,
+                                          lindisp=lindisp, mlp=forced, n_samples=n_samples)
             cache["model"].weights_version = ident
         cache["key"] = key
         cache["fp"] = fp
     elif fp != ():
         cache["fp"] = fp
     return cache["model"]
+
+
+def _layered_why(network_fn, network_fine, n_samples, n_importance, mlp=None):
+    """None when the fused kernels serve this (networks, sample counts) pair, else the reason the layered renderer
+    (wide.WideModel: one fp32-MFMA GEMM per layer, activations in HBM) takes it: a network that is not expressible as the
+    kernels' 8 x 256 (NeRF.fused_why_not), or sample counts no fused kernel is built for.  NSR_LAYERED=1 sends everything
+    there (cross-checks of the two renderers against each other)."""
+    from .engine import IMPORTANCE_COUNTS, NATIVE_COUNTS, DEFAULT_MLP
+    if os.environ.get("NSR_LAYERED") == "1":
+        return "NSR_LAYERED=1"
+    for net in (network_fn, network_fine):
+        if net is not None and net.fused_why_not:
+            return net.fused_why_not
+    f16x2 = (mlp or DEFAULT_MLP) == "f16x2"
+    if n_samples == 64 and n_importance in IMPORTANCE_COUNTS and (n_importance != 96 or f16x2):
+        return None
+    if f16x2 and (n_samples, n_importance) in NATIVE_COUNTS:
+        return None
+    return "N_samples=%r with N_importance=%r" % (n_samples, n_importance)
 
 
 _RANGE_SWITCH_FRAC = 0.10         # more than this share of a handle's rays re-rendered by the fallback kernel: use bf16x3 outright
@@ -234,7 +261,7 @@ class _NdcRays(torch.autograd.Function):
         return go.reshape(rays_o.shape), gd.reshape(rays_d.shape), None, None, None, None, None
 
 
-def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128, n_samples=64):
+def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128, n_samples=64, u_width=128):
     """The random draws of the stochastic options, in the reference's order: per `chunk` of rays (the reference draws inside
     render_rays, which batchify_rays calls once per chunk) t_rand (RN:451), the coarse density noise (RN:368), the
     resampling uniforms (RH:211), the fine density noise.  From torch's generator of the render device, by the same calls
@@ -246,10 +273,13 @@ def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128, n_samples=64):
     deterministic resampling uses NUMPY's linspace (a few ulp from torch's); reproduced exactly, side effect included.
     ni_kernel: importance samples per ray of the handle's kernels (NsrModel.ni_kernel): n_importance itself where they are
     specialised to it -- a row of u then holds the n draws followed by padding, the fine noise has 64 + n columns -- else 128
-    with every draw repeated 128 / n times."""
+    with every draw repeated 128 / n times.  u_width: columns of a row of u as the handle reads it (128 for the fused
+    kernels, n_importance for the layered renderer)."""
     native = n_importance > 0 and ni_kernel == n_importance and n_importance != 128
 
-    def widen(u):               # [.., n_importance] -> the [.., 128] row the kernels read
+    def widen(u):               # [.., n_importance] -> the [.., 128] row the fused kernels read
+        if u_width == n_importance:     # the layered renderer reads [.., n_importance] rows as they are
+            return u
         if native:
             return torch.nn.functional.pad(u, (0, 128 - n_importance))
         return u.repeat_interleave(128 // n_importance, dim=-1)
@@ -274,7 +304,7 @@ def _draws(kw, n, n_importance, dev, chunk=None, ni_kernel=128, n_samples=64):
             else:
                 np.random.seed(0)                           # RH:216 reseeds on the deterministic branch too
                 u = widen(torch.Tensor(np.linspace(0., 1., n_importance)))
-                d["u"] = u[None].expand(n, 128).contiguous().to(dev)
+                d["u"] = u[None].expand(n, u.shape[0]).contiguous().to(dev)
         return d
     # the reference draws inside render_rays, i.e. once per `chunk` of rays (batchify_rays RN:43-55), in the order t_rand,
     # coarse noise, u, fine noise: the same calls in the same order here, chunk by chunk, so that a caller who seeds (or
@@ -341,35 +371,31 @@ def _check_viewdirs(name, use_viewdirs, kw):
 
 
 def _check_kwargs(kw):
-    bad = []
-    from .engine import IMPORTANCE_COUNTS, NATIVE_COUNTS
+    """What NO renderer here serves (the fused kernels' own limits are checked on the handle that will run: _check_retraw)."""
     ns, ni = kw.get("N_samples", 64), kw.get("N_importance", 0)
-    if ns != 64 and (ns, ni) not in NATIVE_COUNTS:
-        bad.append("N_samples=%r with N_importance=%r (the kernels serve N_samples = 64 and, on f16x2 handles, the pairs %s)"
-                   % (ns, ni, NATIVE_COUNTS))
-    elif ns == 64 and ni not in IMPORTANCE_COUNTS:
-        bad.append("N_importance=%r (128, 0, a divisor of 128, or 96 on f16x2 handles)" % ni)
-    from .engine import NATIVE_IMPORTANCE
-    if kw.get("retraw", False) and kw.get("N_samples", 64) == 64 and kw.get("N_importance", 0) not in (0, 128) + tuple(NATIVE_IMPORTANCE):
-        bad.append("retraw with N_importance=%r (the fine pass carries duplicated samples: raw would be [N,192,4]; the f16x2 "
-                   "kernels are specialised to N_importance 64 and 32 and return the reference's raw there)" % kw.get("N_importance"))
-    net = kw.get("network_fine") if kw.get("N_importance", 0) > 0 and kw.get("network_fine") is not None else kw.get("network_fn")
-    if kw.get("retraw", False) and not getattr(net, "use_viewdirs", True) and getattr(net, "output_ch", 4) != 4:
-        bad.append("retraw with a use_viewdirs=False network of output_ch=%r (the reference's raw is [N,S,%r]: RN:267, RH:119-120; "
-                   "the fused kernels tap the four channels render_rays reads -- NeRF.evaluate / run_network return all of them)"
-                   % (net.output_ch, net.output_ch))
-    if bad:
-        raise NotImplementedError("render: unsupported option(s): " + ", ".join(bad))
+    from .wide import MAX_SAMPLES
+    if not (isinstance(ns, (int, np.integer)) and 3 <= ns <= MAX_SAMPLES) or not (isinstance(ni, (int, np.integer)) and 0 <= ni <= MAX_SAMPLES):
+        raise NotImplementedError("render: unsupported option(s): N_samples=%r with N_importance=%r (N_samples 3..%d, N_importance "
+                                  "0..%d)" % (ns, ni, MAX_SAMPLES, MAX_SAMPLES))
 
 
 def _check_retraw(kw, model):
-    """retraw wants the reference's [N, 64 + N_importance, 4]: served where the handle's kernels evaluate exactly that many
-    fine samples (128; 64 / 32 on f16x2 handles) -- decided on the handle that will run, not on a guess about it."""
+    """retraw wants the reference's [N, N_samples + N_importance, C]: the layered renderer returns exactly that; a fused handle
+    does where its kernels evaluate exactly that many fine samples (128; 96 / 64 / 32 and the other native counts on f16x2
+    handles) and the network has four output rows -- decided on the handle that will run, not on a guess about it."""
+    if not kw.get("retraw", False) or getattr(model, "mlp", "") == "layered-fp32":
+        return
     n_imp = kw.get("N_importance", 0)
-    if kw.get("retraw", False) and n_imp not in (0, 128) and getattr(model, "ni_kernel", n_imp) != n_imp:
+    if n_imp not in (0, 128) and getattr(model, "ni_kernel", n_imp) != n_imp:
         raise NotImplementedError("render: retraw with N_importance=%r on a %s handle (its fine pass carries duplicated samples: "
-                                  "raw would be [N,192,4]; the f16x2 kernels are specialised to N_importance 64 and 32 and return "
-                                  "the reference's raw there)" % (n_imp, getattr(model, "mlp", "?")))
+                                  "raw would be [N,192,4]; the f16x2 kernels are specialised to N_importance 96, 64 and 32 and return "
+                                  "the reference's raw there; NSR_LAYERED=1 serves any count)" % (n_imp, getattr(model, "mlp", "?")))
+    net = kw.get("network_fine") if n_imp > 0 and kw.get("network_fine") is not None else kw.get("network_fn")
+    if not getattr(net, "use_viewdirs", True) and getattr(net, "output_ch", 4) != 4:
+        raise NotImplementedError("render: retraw with a use_viewdirs=False network of output_ch=%r on the fused kernels (the "
+                                  "reference's raw is [N,S,%r]: RN:267, RH:119-120; they tap the four channels render_rays reads "
+                                  "-- NeRF.evaluate / run_network return all of them, and so does the layered renderer: "
+                                  "NSR_LAYERED=1)" % (net.output_ch, net.output_ch))
 
 
 def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1., use_viewdirs=False,
@@ -421,7 +447,8 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     if ndc:                                                 # RN:101-103 (the reference's callers pass near=0, far=1)
         ro, rd = _NdcRays.apply(ro, rd, model, int(H), int(W), float(K[0][0]), 1.0)
     if special:
-        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk, model.ni_kernel, getattr(model, "n_samples", 64))
+        ex = _draws(kwargs, ro.shape[0], n_imp, model.device, chunk, model.ni_kernel, getattr(model, "n_samples", 64),
+                    getattr(model, "u_width", 128))
         if per_ray_bounds:                                  # one bound per ray (the reference multiplies them into [N,1])
             for k, v in (("near", near), ("far", far)):
                 t = torch.as_tensor(v, dtype=torch.float32).to(model.device).reshape(-1)
@@ -468,9 +495,10 @@ def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False):
     _check_viewdirs(name, kw.pop("use_viewdirs", False), kw)
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
-    if need_fine and n_imp == 0:
-        raise NotImplementedError("%s needs the coarse+fine configuration (N_importance > 0)" % name)
     model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
+    if need_fine and n_imp == 0 and getattr(model, "mlp", "") != "layered-fp32":
+        raise NotImplementedError("%s needs the coarse+fine configuration (N_importance > 0) on the fused kernels (their "
+                                  "input-gradient kernels differentiate the fine pass; NSR_LAYERED=1 serves coarse-only)" % name)
     return H, W, near, far, model, general
 
 

@@ -1,0 +1,330 @@
+"""WideModel: a handle of the LAYERED renderer in libnsr.so (C ABI: include/nsr_wide.h) -- render_rays (RN:390-501) and its
+input-side VJP (RN:168-178) for what the fused kernels are not built for: a NeRF (RH:70-122) of any depth / width / skip
+list, any N_samples / N_importance (RN:439, RN:474).  Same interface as engine.NsrModel where the drop-in API
+(run_nerf_noscale.py) touches it, so `_model_for` can hand out either.
+
+One fp32-MFMA GEMM kernel per layer over a chunk of rays, activations resident in HBM between the layers; torch owns the
+buffers (including the workspace) and the stream, nothing else.  No fallback: without the library or a GPU every call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+MAX_SKIPS = 16
+MAX_SAMPLES = 512
+
+
+class NsrwConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32), ("flags", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
+
+
+class NsrwNet(C.Structure):
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("multires", C.c_int32), ("multires_views", C.c_int32),
+                ("use_viewdirs", C.c_int32), ("output_ch", C.c_int32), ("n_skips", C.c_int32), ("skips", C.c_int32 * MAX_SKIPS)]
+
+
+class NsrwExtras(C.Structure):
+    _fields_ = [("d_viewdirs", C.c_void_p), ("d_near", C.c_void_p), ("d_far", C.c_void_p), ("d_t_rand", C.c_void_p),
+                ("d_u", C.c_void_p), ("d_noise0", C.c_void_p), ("d_noise1", C.c_void_p)]
+
+
+class NsrwOut(C.Structure):
+    _fields_ = [("d_rgb", C.c_void_p), ("d_disp", C.c_void_p), ("d_acc", C.c_void_p), ("d_rgb0", C.c_void_p),
+                ("d_disp0", C.c_void_p), ("d_acc0", C.c_void_p), ("d_z_std", C.c_void_p), ("d_raw", C.c_void_p),
+                ("d_z_vals", C.c_void_p), ("d_weights0", C.c_void_p), ("d_z_samples", C.c_void_p), ("d_inds", C.c_void_p),
+                ("d_raw0", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/nsr_wide.h declares
+SIGNATURES = {
+    "nsrw_last_error": (C.c_char_p, []),
+    "nsrw_create": (C.c_int, [C.POINTER(NsrwConfig), C.POINTER(C.c_void_p)]),
+    "nsrw_destroy": (C.c_int, [C.c_void_p]),
+    "nsrw_upload_network": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(NsrwNet), C.POINTER(C.c_float), C.c_size_t]),
+    "nsrw_network_floats": (C.c_size_t, [C.POINTER(NsrwNet)]),
+    "nsrw_upload_tables": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]),
+    "nsrw_workspace_bytes": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_size_t)]),
+    "nsrw_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.POINTER(NsrwExtras),
+                                   C.POINTER(NsrwOut), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nsrw_render_rays_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float,
+                                       C.POINTER(NsrwExtras), C.c_void_p, C.POINTER(NsrwOut), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nsrw_run_network": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
+    "nsrw_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+}
+
+_bound = None
+
+
+def load():
+    """The nsrw_* entry points of libnsr.so, bound; raises NsrError when the library is missing or stale."""
+    global _bound
+    if _bound is None:
+        lib = _lib.load()
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError:
+                raise _lib.NsrError("libnsr.so does not export %s -- rebuild it (python -c 'import __graft_entry__ as g; g.build()')"
+                                    % name)
+            fn.restype, fn.argtypes = res, args
+        _bound = lib
+    return _bound
+
+
+def check(rc):
+    if rc != 0:
+        raise _lib.NsrError(load().nsrw_last_error().decode("utf-8", "replace"))
+
+
+def _np(v):
+    return (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32)
+
+
+def describe(sd):
+    """State dict with the reference's parameter names (RH:82-97) -> (NsrwNet, flat fp32 parameter block in the order
+    include/nsr_wide.h: nsrw_upload_network names).  The shape is read off the weights (layer i + 1 takes W + input_ch inputs
+    exactly when i is a skip, RH:82-83; `output_linear` present = use_viewdirs=False, RH:95-96)."""
+    a = {k: _np(v) for k, v in sd.items()}
+    D = 1 + max(int(k.split(".")[1]) for k in a if k.startswith("pts_linears."))
+    W, input_ch = a["pts_linears.0.weight"].shape
+    skips = [i for i in range(D - 1) if a["pts_linears.%d.weight" % (i + 1)].shape[1] == W + input_ch]
+    use_viewdirs = "output_linear.weight" not in a
+    if (input_ch - 3) % 6:
+        raise NotImplementedError("input_ch %r is not 3 + 6 L (get_embedder RH:51-66)" % (input_ch,))
+    in_v = a["views_linears.0.weight"].shape[1] - W if "views_linears.0.weight" in a else 3
+    if use_viewdirs and (in_v < 3 or (in_v - 3) % 6):
+        raise NotImplementedError("input_ch_views %r is not 3 + 6 L" % (in_v,))
+    if len(skips) > MAX_SKIPS:
+        raise NotImplementedError("%d skips (at most %d)" % (len(skips), MAX_SKIPS))
+    net = NsrwNet(D, W, (input_ch - 3) // 6, (in_v - 3) // 6 if use_viewdirs else 0, 1 if use_viewdirs else 0,
+                  4 if use_viewdirs else int(a["output_linear.weight"].shape[0]), len(skips),
+                  (C.c_int32 * MAX_SKIPS)(*(skips + [0] * (MAX_SKIPS - len(skips)))))
+    names = ["pts_linears.%d" % i for i in range(D)]
+    names += ["feature_linear", "alpha_linear", "views_linears.0", "rgb_linear"] if use_viewdirs else ["output_linear"]
+    flat = np.concatenate([np.concatenate([a[n + ".weight"].ravel(), a[n + ".bias"].ravel()]) for n in names]).astype(np.float32)
+    return net, np.ascontiguousarray(flat)
+
+
+def _dev(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace_cap_bytes(device):
+    """Upper bound of the workspace a launch call asks torch for: $NSR_WIDE_WORKSPACE_GB, else 16 GiB, and never more than
+    half of what the device has free.  A smaller workspace means more, smaller chunks of rays -- never another result."""
+    cap = int(float(os.environ.get("NSR_WIDE_WORKSPACE_GB", "16")) * (1 << 30))
+    free, _ = torch.cuda.mem_get_info(device)
+    return min(cap, free // 2)              # (the launch calls need room for 64 rays: WideModel._workspace sees to that)
+
+
+class WideModel:
+    mlp = "layered-fp32"
+    variant = 0
+    schedule = "layers"
+
+    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=128, white_bkgd=False, lindisp=False, n_samples=64,
+                 **unused):
+        if not torch.cuda.is_available():
+            raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
+        self.lib = load()
+        if isinstance(device, torch.device):
+            device = device.index
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        n_samples, n_importance = int(n_samples), int(n_importance)
+        if not 3 <= n_samples <= MAX_SAMPLES or not 0 <= n_importance <= MAX_SAMPLES:
+            raise NotImplementedError("N_samples must be 3..%d and N_importance 0..%d (got %r, %r)"
+                                      % (MAX_SAMPLES, MAX_SAMPLES, n_samples, n_importance))
+        self.n_samples, self.n_importance = n_samples, n_importance
+        self.ni_kernel = n_importance
+        self.u_width = n_importance                       # rows of the u draws as nsrw_render_rays reads them
+        self.nf_kernel = n_samples + n_importance
+        self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
+        self.rays_launched = 0
+        self._ws = None
+        self._util = None
+        cfg = NsrwConfig(self.device.index, n_samples, n_importance, (1 if white_bkgd else 0) | (2 if lindisp else 0))
+        h = C.c_void_p()
+        check(self.lib.nsrw_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.upload(sd_coarse, sd_fine)
+        t = torch.linspace(0., 1., steps=n_samples).numpy().astype(np.float32)          # RN:439: on the host, then moved
+        u = torch.linspace(0., 1., steps=max(n_importance, 1)).numpy().astype(np.float32)   # RH:208
+        check(self.lib.nsrw_upload_tables(self.h, t.ctypes.data_as(C.POINTER(C.c_float)), n_samples,
+                                          u.ctypes.data_as(C.POINTER(C.c_float)), n_importance))
+
+    def upload(self, sd_coarse, sd_fine=None):
+        self.nets = []
+        for net_id, sd in enumerate((sd_coarse, sd_fine)):
+            if sd is None:
+                continue
+            net, flat = describe(sd)
+            check(self.lib.nsrw_upload_network(self.h, net_id, C.byref(net), flat.ctypes.data_as(C.POINTER(C.c_float)), flat.size))
+            self.nets.append(net)
+        last = self.nets[-1] if self.n_importance > 0 else self.nets[0]
+        self.raw_ch = 4 if last.use_viewdirs else int(last.output_ch)
+        self.raw_ch0 = 4 if self.nets[0].use_viewdirs else int(self.nets[0].output_ch)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nsrw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _f32(self, x, shape=None):
+        t = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        return t.reshape(shape) if shape is not None else t
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _workspace(self, n_rays, grad):
+        need = C.c_size_t()
+        check(self.lib.nsrw_workspace_bytes(self.h, int(n_rays), 1 if grad else 0, C.byref(need)))
+        want = min(int(need.value), workspace_cap_bytes(self.device))
+        floor = C.c_size_t()
+        check(self.lib.nsrw_workspace_bytes(self.h, 64, 1 if grad else 0, C.byref(floor)))
+        want = max(want, int(floor.value))
+        if self._ws is None or self._ws.numel() < want:
+            self._ws = None                                   # release before asking for the larger one
+            self._ws = torch.empty(want, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _extras(self, extras, n):
+        if not extras or all(v is None for v in extras.values()):
+            return None, None
+        widths = dict(viewdirs=3, near=1, far=1, t_rand=self.n_samples, u=self.n_importance, noise0=self.n_samples,
+                      noise1=self.nf_kernel)
+        unknown = set(extras) - set(widths)
+        if unknown:
+            raise ValueError("unknown ray extras: %s" % sorted(unknown))
+        keep = {k: self._f32(v, (n, widths[k])) for k, v in extras.items() if v is not None}
+        if ("near" in keep) != ("far" in keep):
+            raise ValueError("per-ray bounds: near and far come together")
+        ex = NsrwExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "near", "far", "t_rand", "u", "noise0", "noise1")])
+        return ex, keep
+
+    def _outs(self, n, debug):
+        fine = self.n_importance > 0
+        o = dict(rgb_map=self._new(n, 3), disp_map=self._new(n), acc_map=self._new(n))
+        if fine:
+            o.update(rgb0=self._new(n, 3), disp0=self._new(n), acc0=self._new(n), z_std=self._new(n))
+        d = {}
+        if debug:                                   # engine.NsrModel's tap names
+            d = dict(weights0=self._new(n, self.n_samples), raw0=self._new(n, self.n_samples, self.raw_ch0))
+            if fine:
+                d.update(z_samples=self._new(n, self.n_importance), inds=self._new(n, self.n_importance, dtype=torch.int64),
+                         z_fine=self._new(n, self.nf_kernel), raw=self._new(n, self.nf_kernel, self.raw_ch))
+            else:
+                d.update(z_coarse=self._new(n, self.n_samples))
+            o.update(d)
+        last_raw, last_z = (d.get("raw"), d.get("z_fine")) if fine else (d.get("raw0"), d.get("z_coarse"))
+        out = NsrwOut(_dev(o["rgb_map"]), _dev(o["disp_map"]), _dev(o["acc_map"]), _dev(o.get("rgb0")), _dev(o.get("disp0")),
+                      _dev(o.get("acc0")), _dev(o.get("z_std")), _dev(last_raw), _dev(last_z), _dev(d.get("weights0")),
+                      _dev(d.get("z_samples")), _dev(d.get("inds")), _dev(d.get("raw0")) if fine else None)
+        return o, out
+
+    @property
+    def util(self):
+        """the fused library's handle for the network-free stage kernels (get_rays, pose_grad, ndc_rays)"""
+        if self._util is None:
+            from .run_nerf_noscale import _util_model
+            self._util = _util_model(self.device)
+        return self._util
+
+    # ---- the path -----------------------------------------------------------------------------------
+    def render_rays(self, rays_o, rays_d, near, far, debug=False, extras=None):
+        """render(rays=...) (RN:58-123): rays_o, rays_d [N,3] -> dict of [N,...] tensors on the device (engine.NsrModel's keys;
+        debug adds raw / z_fine / weights0 / z_samples / inds)."""
+        rays_o, rays_d = self._f32(rays_o, (-1, 3)), self._f32(rays_d, (-1, 3))
+        n = rays_o.shape[0]
+        self.rays_launched += n
+        o, out = self._outs(n, debug)
+        ex, keep = self._extras(extras, n)
+        ws = self._workspace(n, False)
+        check(self.lib.nsrw_render_rays(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far), C.byref(ex) if ex else None,
+                                        C.byref(out), _dev(ws), ws.numel(), _stream_ptr(self.device)))
+        return o
+
+    def render_views(self, c2w, H, W, K, near, far, debug=False):
+        """render(c2w=...) for V views: get_rays (RH:156-165) per view on the device, then ONE render_rays call."""
+        c2w = self._f32(c2w)
+        if c2w.dim() == 2:
+            c2w = c2w[None]
+        rays = [self.util.get_rays(int(H), int(W), K, c[:3, :4]) for c in c2w]
+        ro = torch.cat([r[0].reshape(-1, 3) for r in rays], 0)
+        rd = torch.cat([r[1].reshape(-1, 3) for r in rays], 0)
+        return self.render_rays(ro, rd, near, far, debug=debug)
+
+    def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None, extras=None, debug=False):
+        """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each (+ grad_viewdirs with
+        extras["viewdirs"], + the forward's rgb / disp / acc with with_forward)."""
+        if z_fine is not None or debug:
+            raise NotImplementedError("the layered renderer differentiates at its own sample depths and has no relu taps")
+        rays_o, rays_d = self._f32(rays_o, (-1, 3)), self._f32(rays_d, (-1, 3))
+        n = rays_o.shape[0]
+        self.rays_launched += n
+        g = self._f32(grad_rgb, (n, 3))
+        go, gd = self._new(n, 3), self._new(n, 3)
+        fwd, out = None, None
+        if with_forward:
+            fwd = dict(rgb_map=self._new(n, 3), disp_map=self._new(n), acc_map=self._new(n))
+            out = NsrwOut(_dev(fwd["rgb_map"]), _dev(fwd["disp_map"]), _dev(fwd["acc_map"]))
+        ex, keep = self._extras(extras, n)
+        gv = self._new(n, 3) if (keep and "viewdirs" in keep) else None
+        ws = self._workspace(n, True)
+        check(self.lib.nsrw_render_rays_vjp(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
+                                            C.byref(ex) if ex else None, _dev(g), C.byref(out) if out else None, _dev(go), _dev(gd),
+                                            _dev(gv), _dev(ws), ws.numel(), _stream_ptr(self.device)))
+        res = (go, gd) if gv is None else (go, gd, gv)
+        return res + (fwd,) if with_forward else res
+
+    def run_network(self, pts, viewdirs, net_id=0):
+        """run_network (RN:26-40): pts [..,3], viewdirs [..,3] (unit length) -> raw [.., 4 or output_ch]."""
+        shape = tuple(torch.as_tensor(pts).shape[:-1])
+        p = self._f32(pts, (-1, 3))
+        net = self.nets[net_id]
+        v = self._f32(viewdirs, (-1, 3)) if net.use_viewdirs else None
+        ch = 4 if net.use_viewdirs else int(net.output_ch)
+        raw = self._new(p.shape[0], ch)
+        ws = self._workspace(max(1, p.shape[0] // max(self.nf_kernel, 1) + 1), False)
+        check(self.lib.nsrw_run_network(self.h, int(net_id), _dev(p), _dev(v), p.shape[0], _dev(raw), _dev(ws), ws.numel(),
+                                        _stream_ptr(self.device)))
+        return raw.reshape(shape + (ch,))
+
+    # network-free stage kernels: the fused library's
+    def get_rays(self, H, W, K, c2w):
+        return self.util.get_rays(H, W, K, c2w)
+
+    def pose_grad(self, grad_o, grad_d, H, W, K, patch):
+        return self.util.pose_grad(grad_o, grad_d, H, W, K, patch)
+
+    def ndc_rays(self, *a, **k):
+        return self.util.ndc_rays(*a, **k)
+
+    def ndc_rays_vjp(self, *a, **k):
+        return self.util.ndc_rays_vjp(*a, **k)
+
+    def range_status(self):
+        return dict(last_items=0, points=0, rays=0, dropped_items=0)      # fp32 arithmetic: no range to leave
+
+    def last_kernel_ms(self):
+        """(device ms of the last launch call, chunks of rays it ran)"""
+        ms, ch = C.c_float(), C.c_int()
+        check(self.lib.nsrw_last_ms(self.h, C.byref(ms), C.byref(ch)))
+        return float(ms.value), int(ch.value)

@@ -2,7 +2,7 @@
 whose helpers it uses; runs only in the authoring container, needs /root/reference read-only; nothing of the reference
 travels -- inputs and outputs only).
 
-    python oracle/gen_golden_r5.py            # writes tests/golden/g21_path_options.npz, g22 / g23 / g24_counts_*.npz
+    python oracle/gen_golden_r5.py            # writes tests/golden/g21_path_options.npz, g22 / g23 / g24_counts_*.npz, g25_wide_networks.npz
     GOLDEN_OUT=/tmp/regen python oracle/gen_golden_r5.py     # ... somewhere else, to check that they reproduce bit for bit
 
 g21_path_options: the reference's render_path (RN:213-255) and render_path_grad (RN:126-210) called with
@@ -11,6 +11,11 @@ unchanged (RN:233, RN:168), so the stochastic options apply there too.  The refe
 inside render_rays, once per chunk of rays and in the order t_rand, coarse noise, u, fine noise; torch.rand / torch.randn are
 wrapped to RECORD every draw in call order, so that a build fed the same numbers must reproduce the reference's images and
 per-patch psi-gradients.
+
+g25_wide_networks: NeRFs the fused kernels cannot hold (RH:70-97 is generic in D, W, skips; RN:439 / RN:474 in the sample
+counts) -- wider than 256, deeper than 8, two skips, odd widths and sample counts, no view directions, coarse only --
+instantiated from the reference's own class with the oracle's seeded weights (O.synth_weights_shape) and rendered by the
+reference's render(): forward, what sample_pdf saw and produced, run_network on given points, and autograd's d rgb / d rays.
 
 TEST INFRASTRUCTURE ONLY.
 """
@@ -145,6 +150,54 @@ def main():
                acc0=ex["acc0"].detach().numpy(), z_std=ex["z_std"].detach().numpy(), z_samples=cap.log[0]["samples"],
                inds=cap.log[0]["inds"].astype(np.int16), pdf_weights=cap.log[0]["weights"], cdf=cap.log[0]["cdf"],
                cot=cot.numpy(), grad_rays=gr.numpy())
+
+    # ---- g25: networks and sample counts only the layered renderer (include/nsr_wide.h) serves -----------------------------
+    g25 = dict(seed=np.int64(SEED), rays_o=ro.numpy(), rays_d=rd.numpy(), cot=cot.numpy())
+    prng = np.random.RandomState(99)
+    pts = prng.uniform(-1.5, 1.5, (96, 3)).astype(np.float32)
+    dirs = prng.standard_normal((96, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=-1, keepdims=True)
+    g25.update(pts=pts, dirs=dirs)
+    for tag, (D, Wd, L, Lv, skips, uv, ns, ni) in WIDE_CASES.items():
+        sdc = O.synth_weights_shape(SEED + 41, D, Wd, L, Lv, skips, uv)
+        sdf = {k: (v * (1.0 + 0.05 * np.random.RandomState(SEED + 42).standard_normal(v.shape))).astype(np.float32)
+               for k, v in sdc.items()}
+        ef, in_ch = RH.get_embedder(L, 0)
+        edf, in_v = RH.get_embedder(Lv, 0) if uv else (None, 0)
+        nn_ = []
+        for sd in (sdc, sdf):
+            net = RH.NeRF(D=D, W=Wd, input_ch=in_ch, output_ch=5, skips=skips, input_ch_views=in_v, use_viewdirs=uv)
+            net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            nn_.append(net)
+        q = lambda inputs, viewdirs, fn, ef=ef, edf=edf: RN.run_network(inputs, viewdirs, fn, embed_fn=ef, embeddirs_fn=edf,
+                                                                        netchunk=65536)
+        kw = dict(kwargs, network_query_fn=q, network_fn=nn_[0], network_fine=nn_[1] if ni > 0 else None, use_viewdirs=uv,
+                  N_samples=ns, N_importance=ni)
+        with torch.no_grad():
+            net_out = q(torch.from_numpy(pts)[:, None, :], torch.from_numpy(dirs) if uv else None, nn_[0])[:, 0]
+        rays = torch.stack([ro, rd], 0).clone().requires_grad_(True)
+        with G.Capture(RN, RH) as cap:
+            rgb, disp, acc, ex = RN.render(400, 400, O.YCBV_K, chunk=len(ro), rays=rays, **kw)
+        (gr,) = torch.autograd.grad(rgb, rays, grad_outputs=cot)
+        g25.update({tag + "_shape": np.array([D, Wd, L, Lv, int(uv), ns, ni] + list(skips)), tag + "_net_out": net_out.numpy(),
+                    tag + "_rgb": rgb.detach().numpy(), tag + "_disp": disp.detach().numpy(), tag + "_acc": acc.detach().numpy(),
+                    tag + "_grad_rays": gr.numpy()})
+        if ni > 0:
+            assert cap.log[0]["weights"].shape == (len(ro), ns - 2) and cap.log[0]["samples"].shape == (len(ro), ni)
+            g25.update({tag + "_rgb0": ex["rgb0"].detach().numpy(), tag + "_acc0": ex["acc0"].detach().numpy(),
+                        tag + "_disp0": ex["disp0"].detach().numpy(), tag + "_z_std": ex["z_std"].detach().numpy(),
+                        tag + "_z_samples": cap.log[0]["samples"], tag + "_inds": cap.log[0]["inds"].astype(np.int16),
+                        tag + "_pdf_weights": cap.log[0]["weights"], tag + "_cdf": cap.log[0]["cdf"]})
+    G.save("g25_wide_networks", **g25)
+
+
+# tag -> (D, W, multires, multires_views, skips, use_viewdirs, N_samples, N_importance)
+WIDE_CASES = {
+    "a": (10, 384, 10, 4, [4], True, 64, 128),      # wider and deeper than the fused kernels' 8 x 256
+    "b": (6, 300, 6, 2, [1, 3], True, 48, 100),     # two skips, a width that is no multiple of 32, odd sample counts
+    "c": (9, 272, 10, 4, [5], False, 24, 40),       # no view directions (output_linear, 5 rows), a late skip
+    "d": (3, 512, 4, 1, [], True, 20, 0),           # coarse only, no skip
+}
 
 
 if __name__ == "__main__":

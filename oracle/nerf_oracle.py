@@ -242,14 +242,19 @@ def net_shape(sd):
     return D, W, input_ch, input_ch_views, skips, use_viewdirs
 
 
-def mlp(sd, x_embedded, keep=None, all_rows=False):
+def mlp(sd, x_embedded, keep=None, all_rows=False, views=None):
     """RH:99-122 for the network the state dict describes (net_shape): x_embedded [P, 63 + 27] = the FULL encodings
     (10 / 4 frequencies) -> [P, 4] = (rgb logits, sigma).  A network built for fewer frequencies reads the leading
     3 + 6 L columns of each (the encoder emits its bands in increasing order, RH:35-48); a state dict with `output_linear`
-    is the use_viewdirs=False network (RH:95-96, RH:119-120): outputs = output_linear(h), directions ignored."""
+    is the use_viewdirs=False network (RH:95-96, RH:119-120): outputs = output_linear(h), directions ignored.
+    views given: x_embedded is the position encoding alone ([P, input_ch], any number of frequencies) and views the direction
+    encoding [P, input_ch_views]."""
     lin = lambda name, h: (h @ sd[name + ".weight"].T + sd[name + ".bias"]).astype(f32)
     D, W, input_ch, input_ch_views, skips, use_viewdirs = net_shape(sd)
-    pts, views = x_embedded[:, :input_ch], x_embedded[:, IN_CH:IN_CH + max(input_ch_views, 0)]
+    if views is None:
+        pts, views = x_embedded[:, :input_ch], x_embedded[:, IN_CH:IN_CH + max(input_ch_views, 0)]
+    else:
+        pts = x_embedded
     h = pts
     for i in range(D):
         h = np.maximum(lin("pts_linears.%d" % i, h), f32(0))
@@ -337,9 +342,10 @@ def run_network(sd, pts, viewdirs):
     if _BACKEND == "torch":
         return _run_network_torch(sd, pts, viewdirs)
     N, S, _ = pts.shape
-    e = embed(pts.reshape(-1, 3), MULTIRES)
-    ed = embed(np.broadcast_to(viewdirs[:, None, :], pts.shape).reshape(-1, 3), MULTIRES_VIEWS)
-    return mlp(sd, np.concatenate([e, ed], -1)).reshape(N, S, 4)
+    _, _, input_ch, input_ch_views, _, _ = net_shape(sd)         # the network's own frequencies (get_embedder RH:51-66)
+    e = embed(pts.reshape(-1, 3), (input_ch - 3) // 6)
+    ed = embed(np.broadcast_to(viewdirs[:, None, :], pts.shape).reshape(-1, 3), max(input_ch_views - 3, 0) // 6)
+    return mlp(sd, e, views=ed).reshape(N, S, 4)
 
 
 def raw2outputs(raw, z_vals, rays_d, white_bkgd=False, noise=None):
@@ -573,22 +579,23 @@ def sweep_poses(n_views, seed=0):
 # network backward (inputs only)
 # ----------------------------------------------------------------------------------------------
 def _network_forward64(sd, pts, dirs):
-    """fp64 forward of RH:99-122 on fp32 encodings, keeping what the backward needs."""
+    """fp64 forward of RH:99-122 (any shape: net_shape) on fp32 encodings, keeping what the backward needs."""
     W = lambda k: sd[k + ".weight"].astype(f64)
     B = lambda k: sd[k + ".bias"].astype(f64)
-    e_p = embed(pts, MULTIRES).astype(f64)
-    e_d = embed(dirs, MULTIRES_VIEWS).astype(f64)
+    D, _, input_ch, input_ch_views, skips, use_viewdirs = net_shape(sd)
+    e_p = embed(pts, (input_ch - 3) // 6).astype(f64)
     pre = []
     h = e_p
-    for i in range(NET_DEPTH):
+    for i in range(D):
         a = h @ W("pts_linears.%d" % i).T + B("pts_linears.%d" % i)
         pre.append(a)
         h = np.maximum(a, 0)
-        if i == SKIP_AT:
+        if i in skips:
             h = np.concatenate([e_p, h], -1)
-    if "output_linear.weight" in sd:                    # use_viewdirs=False (RH:119-120)
+    if not use_viewdirs:                                # RH:119-120
         out = h @ W("output_linear").T + B("output_linear")
         return dict(pre=pre, av=None, sigma=out[:, 3], rgb_raw=out[:, :3])
+    e_d = embed(dirs, (input_ch_views - 3) // 6).astype(f64)
     sigma = (h @ W("alpha_linear").T + B("alpha_linear"))[:, 0]
     feat = h @ W("feature_linear").T + B("feature_linear")
     av = np.concatenate([feat, e_d], -1) @ W("views_linears.0").T + B("views_linears.0")
@@ -608,10 +615,11 @@ def _embed_bwd(x, G, n_freqs):
 
 def network_vjp(sd, pts, dirs, g_raw, fwd=None, relu_on=None):
     """Input-side VJP of run_network: g_raw [P,4] = dL/d(rgb logits, sigma) -> dL/d pts [P,3], dL/d dirs [P,3]
-    (weights are constants).  Manual backprop of RH:99-122 in float64.
-    relu_on (counterfactual replay, oracle/vjp_census.py): dict(pre=[8 x [P,256] bool], av=[P,128] bool) -- the relu
+    (weights are constants).  Manual backprop of RH:99-122 in float64, for a network of any shape (net_shape).
+    relu_on (counterfactual replay, oracle/vjp_census.py): dict(pre=[D x [P,W] bool], av=[P,W/2] bool) -- the relu
     patterns to apply INSTEAD of the forward's own (pre > 0), i.e. relu' as another evaluation of the forward saw it."""
     W = lambda k: sd[k + ".weight"].astype(f64)
+    D, width, input_ch, input_ch_views, skips, use_viewdirs = net_shape(sd)
     if fwd is None:
         fwd = _network_forward64(sd, pts, dirs)
     pre, av = fwd["pre"], fwd["av"]
@@ -619,20 +627,21 @@ def network_vjp(sd, pts, dirs, g_raw, fwd=None, relu_on=None):
     g_raw = g_raw.astype(f64)
     if av is None:                                      # use_viewdirs=False: outputs = output_linear(h)
         G_h = g_raw @ W("output_linear")[:4]
-        G_ed = np.zeros((pts.shape[0], IN_CH_VIEWS), f64)
+        G_ed = np.zeros((pts.shape[0], 3), f64)
     else:
         G_av = (g_raw[:, :3] @ W("rgb_linear")) * ((av > 0) if relu_on is None else relu_on["av"])
         G_cat = G_av @ W("views_linears.0")
-        G_feat, G_ed = G_cat[:, :NET_WIDTH], G_cat[:, NET_WIDTH:]
+        G_feat, G_ed = G_cat[:, :width], G_cat[:, width:]
         G_h = G_feat @ W("feature_linear") + g_raw[:, 3:4] @ W("alpha_linear")
-    G_ep = np.zeros((pts.shape[0], IN_CH), f64)
-    for i in reversed(range(NET_DEPTH)):
-        if i == SKIP_AT:
-            G_ep += G_h[:, :IN_CH]
-            G_h = G_h[:, IN_CH:]
+    G_ep = np.zeros((pts.shape[0], input_ch), f64)
+    for i in reversed(range(D)):
+        if i in skips:                                  # h after layer i was cat[e_p, relu(pre_i)] (RH:105-106)
+            G_ep += G_h[:, :input_ch]
+            G_h = G_h[:, input_ch:]
         G_h = (G_h * on[i]) @ W("pts_linears.%d" % i)
     G_ep += G_h
-    return _embed_bwd(pts, G_ep, MULTIRES), _embed_bwd(dirs, G_ed, MULTIRES_VIEWS)
+    return (_embed_bwd(pts, G_ep, (input_ch - 3) // 6),
+            _embed_bwd(dirs, G_ed, (input_ch_views - 3) // 6 if use_viewdirs else 0))
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,0 +1,263 @@
+"""GPU tests of the LAYERED renderer (include/nsr_wide.h, neural_sim_nerf_amd/wide.py; run with -m gpu on an MI355X): the same
+path as the fused kernels -- render_rays and its input-side VJP -- for the networks and sample counts they are not built for.
+Parity is the oracle's (pinned to the reference on exactly these cases by tests/test_oracle_golden.py: g25), stage by stage
+on the renderer's own intermediates, end to end through the census and PSNR-delta against the reference's own pixels, and
+the gradient against the oracle's fp64 backprop and the reference's autograd."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden
+from test_oracle_golden import wide_case
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _census():
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import census
+    return census
+
+
+def _rel_rows(a, b):
+    return np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_layered_renderer_stagewise_census_and_gradient(tag, oracle):
+    """g25 a-d: 10 x 384 at (64, 128); 6 x 300 with two skips at (48, 100); 9 x 272 without view directions at (24, 40); a
+    coarse-only 3 x 512 at (20, 0)."""
+    from neural_sim_nerf_amd.wide import WideModel
+    C = _census()
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, tag)
+    fine = ni > 0
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"], g["rays_d"]
+    n = len(ro)
+    vd = oracle.normalize_dirs(rd)
+    m = WideModel(sd_c, sd_f if fine else None, n_samples=ns, n_importance=ni)
+    # run_network on given points against the reference's own outputs
+    want = g[tag + "_net_out"]
+    got = cpu(m.run_network(g["pts"], g["dirs"], 0))
+    assert got.shape == want.shape or got.shape == (len(want), 4)
+    assert_close(got[:, :want.shape[1]], want[:, :got.shape[1]], atol=1e-5 + 2e-6 * np.abs(want).max(), rtol=2e-6, what="run_network")
+    r = m.render_rays(ro, rd, near, far, debug=True)
+    # ---- stage by stage on the renderer's own intermediates
+    z = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32), n=ns)
+    raw0 = oracle.run_network(sd_c, (ro[:, None] + rd[:, None] * z[..., None]).astype(np.float32), vd)
+    k_raw0 = cpu(r["raw0"])[..., :4]
+    assert_close(k_raw0, raw0, atol=5e-5, rtol=5e-5, what="coarse raw")
+    rgb0, disp0, acc0, w0, _ = oracle.raw2outputs(k_raw0, z, rd)
+    assert_close(cpu(r["weights0"]), w0, atol=2e-6, what="weights0 | own raw")
+    assert_close(cpu(r["rgb0"] if fine else r["rgb_map"]), rgb0, atol=3e-6, what="coarse rgb | own raw")
+    assert_close(cpu(r["acc0"] if fine else r["acc_map"]), acc0, atol=3e-6, what="coarse acc | own raw")
+    if not fine:
+        assert np.array_equal(cpu(r["z_coarse"]), z)
+        assert_close(cpu(r["rgb_map"]), g[tag + "_rgb"], atol=1e-5, what="rgb vs reference")
+        assert_close(cpu(r["acc_map"]), g[tag + "_acc"], atol=1e-5, what="acc vs reference")
+        zf = z
+    else:
+        z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+        s, inds, _ = oracle.sample_pdf(z_mid, cpu(r["weights0"])[:, 1:-1], ni)
+        assert np.array_equal(cpu(r["inds"]), inds) and np.array_equal(cpu(r["z_samples"]), s)       # bit for bit
+        zf = np.sort(np.concatenate([z, s], -1), -1)
+        assert np.array_equal(cpu(r["z_fine"]), zf)
+        raw = oracle.run_network(sd_f, (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), vd)
+        k_raw = cpu(r["raw"])[..., :4]
+        assert_close(k_raw, raw, atol=5e-5, rtol=5e-5, what="fine raw | own z")
+        rgb, disp, acc, _, _ = oracle.raw2outputs(k_raw, zf, rd)
+        assert_close(cpu(r["rgb_map"]), rgb, atol=3e-6, what="rgb | own raw")
+        assert_close(cpu(r["acc_map"]), acc, atol=3e-6, what="acc | own raw")
+        with np.errstate(invalid="ignore", divide="ignore"):       # disp = acc / depth (RN:381): a 3e-6 change of acc is 3e-6 / acc of it
+            dd = np.abs(cpu(r["disp_map"]) - disp) / np.abs(disp) * np.clip(acc, 0.0, 1.0)
+        assert np.array_equal(np.isnan(cpu(r["disp_map"])), np.isnan(disp)) and np.nanmax(dd) < 2e-5, np.nanmax(dd)
+        assert_close(cpu(r["z_std"]), np.std(s.astype(np.float64), -1), atol=1e-6, what="z_std")
+        # ---- end to end: coarse image against the reference, census against the oracle's render, PSNR-delta against the
+        # reference's pixels
+        assert_close(cpu(r["rgb0"]), g[tag + "_rgb0"], atol=1e-5, what="rgb0 vs reference")
+        ref = oracle.render_rays(sd_c, sd_f, ro, rd, vd, near, far, n_samples=ns, n_importance=ni, extras=True)
+        taps = ("rgb_map", "acc_map", "disp_map", "rgb0", "acc0", "weights0", "inds", "z_samples", "z_fine")
+        got = {k: cpu(r[k]) for k in taps}
+        got.update(raw0=k_raw0, raw=k_raw)
+        c = C.census((sd_c, sd_f), ro, rd, near, far, got, ref, n_importance=ni, n_samples=ns)
+        print(tag, "census:", {k: c[k] for k in ("rays", "rays_above_tol", "unattributed", "psnr_delta_db")})
+        assert C.passes(c) and c["rays_above_tol"] <= 4 and c["psnr_delta_db"] <= 0.1, c
+        assert C.psnr_delta(cpu(r["rgb_map"]), g[tag + "_rgb"]) <= 0.1
+    # ---- input gradient: against the oracle's fp64 backprop at the renderer's own depths, and against the reference's autograd
+    go, gd, fwd = m.render_rays_vjp(ro, rd, near, far, g["cot"], with_forward=True)
+    assert np.array_equal(cpu(fwd["rgb_map"]), cpu(r["rgb_map"]), equal_nan=True)
+    wo, wd, _ = oracle.render_rays_vjp(sd_c, sd_f if fine else None, ro, rd, near, far, g["cot"], n_samples=ns, n_importance=ni, z_fine=zf)
+    for a, b, what in ((cpu(go), wo, "grad_o"), (cpu(gd), wd, "grad_d")):
+        e = _rel_rows(a, b)
+        print(tag, what, "rel. error per ray: median %.2e  90 %% %.2e  max %.2e" % (np.median(e), np.percentile(e, 90), e.max()))
+        assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (what, np.percentile(e, 90), e.max())
+    for a, b in ((cpu(go), g[tag + "_grad_rays"][0]), (cpu(gd), g[tag + "_grad_rays"][1])):
+        assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-2        # (the reference's depths differ by its own rounding)
+    # ---- chunking never changes a result: the smallest workspace the library accepts (64-ray chunks), ragged ray counts
+    os.environ["NSR_WIDE_WORKSPACE_GB"] = "0.0001"
+    try:
+        m2 = WideModel(sd_c, sd_f if fine else None, n_samples=ns, n_importance=ni)
+        for k in (n, 1, 33):
+            q = m2.render_rays(np.tile(ro, (3, 1))[:k + 96 if k == n else k], np.tile(rd, (3, 1))[:k + 96 if k == n else k], near, far)
+            kk = min(k, n)
+            for key in ("rgb_map", "disp_map", "acc_map") + (("rgb0", "z_std") if fine else ()):
+                assert np.array_equal(cpu(q[key])[:kk], cpu(r[key])[:kk], equal_nan=True), (key, k)
+        q = m2.render_rays(np.tile(ro, (3, 1)), np.tile(rd, (3, 1)), near, far)
+        assert m2.last_kernel_ms()[1] == 3 and np.array_equal(cpu(q["rgb_map"])[2 * n:], cpu(r["rgb_map"]), equal_nan=True)
+        g2o, g2d = m2.render_rays_vjp(np.tile(ro, (3, 1)), np.tile(rd, (3, 1)), near, far, np.tile(g["cot"], (3, 1)))
+        assert np.array_equal(cpu(g2o)[n:2 * n], cpu(go)) and np.array_equal(cpu(g2d)[2 * n:], cpu(gd))
+    finally:
+        del os.environ["NSR_WIDE_WORKSPACE_GB"]
+
+
+def test_layered_renderer_options(oracle):
+    """The per-ray options on the layered renderer (g25 b: two skips, (48, 100) samples): stratified depths, random uniforms,
+    density noise, per-ray bounds, given view directions, white background + lindisp -- stage-wise against the oracle on the
+    renderer's own intermediates, the gradient (incl. dL/d viewdirs) against the oracle's."""
+    from neural_sim_nerf_amd.wide import WideModel
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "b")
+    ro, rd = g["rays_o"], g["rays_d"]
+    n = len(ro)
+    rng = np.random.RandomState(5)
+    near = (oracle.YCBV_NEAR * (1.0 + 0.1 * rng.rand(n))).astype(np.float32)
+    far = (oracle.YCBV_FAR * (1.0 - 0.1 * rng.rand(n))).astype(np.float32)
+    vdirs = rng.standard_normal((n, 3)).astype(np.float32)
+    vdirs /= np.linalg.norm(vdirs, axis=-1, keepdims=True)
+    rnd = dict(t_rand=rng.rand(n, ns).astype(np.float32), u=rng.rand(n, ni).astype(np.float32),
+               noise0=(0.3 * rng.standard_normal((n, ns))).astype(np.float32),
+               noise1=(0.3 * rng.standard_normal((n, ns + ni))).astype(np.float32))
+    for white, lindisp in ((False, False), (True, True)):
+        m = WideModel(sd_c, sd_f, n_samples=ns, n_importance=ni, white_bkgd=white, lindisp=lindisp)
+        q = m.render_rays(ro, rd, 0.0, 0.0, debug=True, extras=dict(rnd, near=near, far=far, viewdirs=vdirs))
+        z = oracle.perturb_z(oracle.coarse_z(near, far, n=ns, lindisp=lindisp), rnd["t_rand"])
+        raw0 = oracle.run_network(sd_c, (ro[:, None] + rd[:, None] * z[..., None]).astype(np.float32), vdirs)
+        assert_close(cpu(q["raw0"]), raw0, atol=5e-5, rtol=5e-5, what="coarse raw with options")
+        rgb0, _, _, w0, _ = oracle.raw2outputs(cpu(q["raw0"]), z, rd, white, rnd["noise0"])
+        assert_close(cpu(q["weights0"]), w0, atol=2e-6, what="weights0 with options")
+        assert_close(cpu(q["rgb0"]), rgb0, atol=3e-6, what="rgb0 with options")
+        z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+        s, inds, _ = oracle.sample_pdf(z_mid, cpu(q["weights0"])[:, 1:-1], ni, u=rnd["u"])
+        assert np.array_equal(cpu(q["inds"]), inds) and np.array_equal(cpu(q["z_samples"]), s)
+        zf = np.sort(np.concatenate([z, s], -1), -1)            # the random uniforms leave z_samples unsorted: a real sort
+        assert np.array_equal(cpu(q["z_fine"]), zf)
+        raw = oracle.run_network(sd_f, (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), vdirs)
+        assert_close(cpu(q["raw"]), raw, atol=5e-5, rtol=5e-5, what="fine raw with options")
+        rgb, _, acc, _, _ = oracle.raw2outputs(cpu(q["raw"]), zf, rd, white, rnd["noise1"])
+        assert_close(cpu(q["rgb_map"]), rgb, atol=3e-6, what="rgb with options")
+        assert_close(cpu(q["acc_map"]), acc, atol=3e-6, what="acc with options")
+        go, gd, gv = m.render_rays_vjp(ro, rd, 0.0, 0.0, g["cot"], extras=dict(rnd, near=near, far=far, viewdirs=vdirs))
+        wo, wd, _, wv = oracle.render_rays_vjp(sd_c, sd_f, ro, rd, near, far, g["cot"], n_samples=ns, n_importance=ni, z_fine=zf,
+                                                white_bkgd=white, lindisp=lindisp, viewdirs=vdirs, noise1=rnd["noise1"])
+        for a, b, what in ((cpu(go), wo, "grad_o"), (cpu(gd), wd, "grad_d"), (cpu(gv), wv, "grad_viewdirs")):
+            e = _rel_rows(a, b)
+            assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (what, np.percentile(e, 90), e.max())
+
+
+def test_layered_and_fused_renderers_agree_on_the_fused_kernels_network(synth_nets, oracle):
+    """The YCB-V network (8 x 256, 64 + 128 samples) through BOTH renderers: two independent implementations of the same path
+    -- fused f16x2 kernels with the network in registers / LDS, and fp32 GEMMs layer by layer through HBM -- agree on every ray
+    within the end-to-end rule (census against the oracle for each; between them: PSNR > 100 dB), and on the input gradient."""
+    from neural_sim_nerf_amd.engine import NsrModel
+    from neural_sim_nerf_amd.wide import WideModel
+    C = _census()
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.scaled_K(40.0)
+    pose = np.asarray(oracle.sweep_poses(1, seed=2))[0]
+    ro, rd = (a.reshape(-1, 3) for a in oracle.get_rays(40, 40, K, pose[:3, :4]))
+    f = NsrModel(synth_nets[0], synth_nets[1])
+    w = WideModel(synth_nets[0], synth_nets[1])
+    a = f.render_views(pose, 40, 40, K, near, far)
+    b = w.render_views(pose, 40, 40, K, near, far, debug=True)
+    d = np.abs(cpu(a["rgb_map"]) - cpu(b["rgb_map"])).max(-1)
+    print("fused vs layered: rays beyond 1e-4: %d of %d, PSNR %.1f dB" % ((d > 1e-4).sum(), d.size, oracle.psnr(cpu(a["rgb_map"]), cpu(b["rgb_map"]))))
+    assert (d > 1e-4).mean() < 0.01 and oracle.psnr(cpu(a["rgb_map"]), cpu(b["rgb_map"])) > 60.0
+    vd = oracle.normalize_dirs(rd)
+    ref = oracle.render_rays(synth_nets[0], synth_nets[1], ro, rd, vd, near, far, extras=True)
+    taps = ("rgb_map", "acc_map", "disp_map", "rgb0", "acc0", "raw0", "weights0", "inds", "z_samples", "z_fine", "raw")
+    c = C.census(synth_nets, ro, rd, near, far, {k: cpu(b[k]) for k in taps}, ref)
+    print("layered census:", {k: c[k] for k in ("rays", "rays_above_tol", "unattributed", "psnr_delta_db")})
+    assert C.passes(c) and c["psnr_delta_db"] <= 0.1, c
+    cot = np.random.RandomState(3).standard_normal((len(ro), 3)).astype(np.float32)
+    fo, fd = f.render_rays_vjp(ro, rd, near, far, cot)
+    wo, wd = w.render_rays_vjp(ro, rd, near, far, cot)
+    for x, y in ((cpu(fo), cpu(wo)), (cpu(fd), cpu(wd))):
+        assert np.median(_rel_rows(x, y)) < 2e-4 and np.linalg.norm(x - y) / np.linalg.norm(y) < 5e-2
+
+
+def test_dropin_api_serves_networks_beyond_the_fused_kernels(oracle, tmp_path):
+    """create_nerf-style modules of a shape the fused kernels cannot hold (10 x 384) and sample counts they are not built for
+    go through render / render_path / render_path_grad unchanged: which renderer took the call, render() against the
+    reference's pixels (g25 a) and its autograd against the reference's, render_path == render per pose, render_path_grad's
+    per-patch dL/dpsi == autograd through render(rays=...) patch by patch (RN:168-181), retraw in the reference's shape,
+    NeRF.forward on the reference's embedded input."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    C = _census()
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "a")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    D, W = oracle.net_shape(sd_c)[:2]
+    nets = []
+    for sd in (sd_c, sd_f):
+        net = R.NeRF(D=D, W=W, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(net.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=ni, network_fine=nets[1], N_samples=ns, network_fn=nets[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False, near=near, far=far)
+    m = R._model_for(nets[0], nets[1], ni, kw)
+    assert m.mlp == "layered-fp32" and "netdepth" in m.why_layered or "netwidth" in m.why_layered
+    rays = torch.stack([torch.from_numpy(g["rays_o"]), torch.from_numpy(g["rays_d"])], 0).to(R.device).requires_grad_(True)
+    rgb, disp, acc, ex = R.render(400, 400, oracle.YCBV_K, chunk=512, rays=rays, retraw=True, **kw)
+    assert ex["raw"].shape == (len(g["rays_o"]), ns + ni, 4) and set(ex) == {"rgb0", "disp0", "acc0", "z_std", "raw"}
+    assert C.psnr_delta(cpu(rgb), g["a_rgb"]) <= 0.1 and (np.abs(cpu(rgb) - g["a_rgb"]).max(-1) > 1e-4).mean() <= 0.1
+    assert_close(cpu(ex["rgb0"]), g["a_rgb0"], atol=1e-5, what="rgb0 vs reference")
+    (gr,) = torch.autograd.grad(rgb, rays, grad_outputs=torch.from_numpy(g["cot"]).to(R.device))
+    assert np.linalg.norm(cpu(gr) - g["a_grad_rays"]) / np.linalg.norm(g["a_grad_rays"]) < 5e-2
+    # NeRF.forward on the reference's [P, 63 + 27] embedded tensor (only the raw coordinates are read)
+    x = np.concatenate([oracle.embed(g["pts"], 10), oracle.embed(g["dirs"], 4)], -1)
+    out = nets[0](torch.from_numpy(x).to(R.device))
+    assert_close(cpu(out), g["a_net_out"][:, :4], atol=1e-5 + 2e-6 * np.abs(g["a_net_out"]).max(), rtol=2e-6, what="NeRF.forward")
+    # render_path / render_path_grad at odd sample counts on a small image, two poses
+    kw2 = dict(kw, N_samples=40, N_importance=72)
+    assert "N_samples=40" in R._layered_why(nets[0], nets[1], 40, 72) or nets[0].fused_why_not
+    Hs, Ks = 12, oracle.scaled_K(400.0 / 12)
+    hwf = [Hs, Hs, Ks[0][0]]
+    poses = torch.tensor(np.asarray(oracle.sweep_poses(2, seed=5)), dtype=torch.float32)
+    rgbs, disps = R.render_path(None, poses, hwf, Ks, 32, kw2, savedir=str(tmp_path), object_id=2)
+    assert rgbs.shape == (2, Hs, Hs, 3) and sorted(os.listdir(tmp_path / "2")) == ["000.png", "001.png"]
+    for i in range(2):
+        one = R.render(Hs, Hs, Ks, chunk=32, c2w=poses[i, :3, :4], **kw2)
+        assert np.array_equal(cpu(one[0]), rgbs[i]) and np.array_equal(cpu(one[1]), disps[i], equal_nan=True)
+    Dm = torch.tensor(np.random.RandomState(3).standard_normal((8, 4, 4)).astype(np.float32) * 0.05)
+    Dm[:, 3] = 0
+    prob = torch.full((8,), 0.125, requires_grad=True)          # a differentiable path psi -> poses (as LL:202-247 provides)
+    gposes = [p + (prob[:, None, None] * Dm).sum(0) * (1.0 + 0.5 * i) for i, p in enumerate(poses)]
+    rng = np.random.RandomState(1)
+    gE = [{"grad_E": [torch.from_numpy(rng.standard_normal((3, Hs, Hs)).astype(np.float32))]} for _ in range(2)]
+    rgbs_g, dl = R.render_path_grad(prob, gposes, hwf, Ks, 32, gE, kw2, savedir=None)
+    n_patches = (Hs * Hs + 31) // 32
+    assert len(dl) == 2 * n_patches and rgbs_g.shape == (2, Hs, Hs, 3)
+    for i in (0, 1):
+        c2w = gposes[i][:3, :4]
+        ro, rdd = R.get_rays(Hs, Hs, Ks, c2w)
+        cot = gE[i]["grad_E"][0].permute(1, 2, 0).reshape(-1, 3)
+        for p in (0, n_patches - 1):
+            sl = slice(32 * p, min(32 * (p + 1), Hs * Hs))
+            batch = torch.stack([ro.reshape(-1, 3)[sl], rdd.reshape(-1, 3)[sl]], 0)
+            rgb_p = R.render(Hs, Hs, Ks, chunk=32, rays=batch, **kw2)[0]
+            (gb,) = torch.autograd.grad(rgb_p, batch, grad_outputs=cot[sl].to(rgb_p.device), retain_graph=True)
+            (gp,) = torch.autograd.grad(batch, prob, grad_outputs=gb.to(batch.device), retain_graph=True)
+            want = gp.detach().cpu().numpy()
+            got = dl[i * n_patches + p].numpy()
+            assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max() + 1e-9, (i, p, got, want)

@@ -23,6 +23,33 @@ def test_cabi_exports_every_declared_symbol():
     assert lib.nsr_abi_version() == _lib.ABI_VERSION
 
 
+def test_layered_renderer_abi_is_exported_and_bound():
+    """include/nsr_wide.h <-> libnsr.so (and its bounds-checked twin) <-> wide.SIGNATURES; nsrw_network_floats (host arithmetic)
+    agrees with the parameter block wide.describe() builds from a state dict, for networks with and without view directions."""
+    import ctypes as C
+    from neural_sim_nerf_amd import wide
+    import nerf_oracle as O
+    hdr = open(os.path.join(ROOT, "include", "nsr_wide.h")).read()
+    declared = set(re.findall(r"\b(nsrw_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(wide.SIGNATURES), declared ^ set(wide.SIGNATURES)
+    lib = wide.load()
+    dbg = os.path.join(ROOT, "neural_sim_nerf_amd", "csrc", "libnsr_debug.so")
+    if os.path.exists(dbg):
+        d = C.CDLL(dbg)
+        for name in declared:
+            assert hasattr(d, name), name
+    for D, W, L, Lv, skips, uv in ((10, 384, 10, 4, [4], True), (6, 300, 6, 2, [1, 3], True), (9, 272, 10, 4, [5], False),
+                                   (1, 2, 0, 0, [], True)):
+        sd = O.synth_weights_shape(3, D, W, L, Lv, skips, uv)
+        net, flat = wide.describe(sd)
+        assert (net.D, net.W, net.multires, net.use_viewdirs, list(net.skips[:net.n_skips])) == (D, W, L, int(uv), skips)
+        assert lib.nsrw_network_floats(C.byref(net)) == flat.size == sum(v.size for k, v in sd.items()
+                                                                           if uv or not k.startswith("views_linears"))
+        assert np.array_equal(flat[:W * (3 + 6 * L)].reshape(W, -1), sd["pts_linears.0.weight"])
+    bad = wide.NsrwNet(8, 256, 10, 4, 1, 4, 1, (C.c_int32 * 16)(7))           # a skip behind the last layer (RH:109 fails there)
+    assert lib.nsrw_network_floats(C.byref(bad)) == 0 and b"skip" in lib.nsrw_last_error()
+
+
 def test_probe_and_debug_libraries_export_their_headers():
     """include/nsr_probe.h <-> libnsr_probe.so; libnsr_debug.so exports the same ABI as libnsr.so (dlopen only: no
     compute without a GPU)."""
@@ -414,18 +441,34 @@ def test_api_rejects_unsupported_configurations():
     # round 3: tests/test_gpu_parity.py, g14, g15)
     net = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
     base["network_fn"] = net
-    for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=32), "N_samples"),
-                     (dict(N_importance=100), "N_importance"),
-                     (dict(N_importance=16, retraw=True), "retraw")):
+    for bad, pat in ((dict(use_viewdirs=False), "use_viewdirs"), (dict(N_samples=2), "N_samples"),
+                     (dict(N_samples=1000), "N_samples"), (dict(N_importance=600), "N_importance")):
         kw = dict(base)
         kw.update(bad)
         with pytest.raises(NotImplementedError, match=pat):
             R.render(**kw)
+    # sample counts no fused kernel is built for, and networks that are not an 8 x 256 in disguise, go to the layered renderer
+    # (wide.WideModel, include/nsr_wide.h) since r05 instead of being refused -- which renderer takes a call, and why:
+    assert R._layered_why(net, net, 64, 128) is None and R._layered_why(net, None, 64, 0) is None
+    assert R._layered_why(net, net, 32, 64) is None and R._layered_why(net, net, 32, 64, "fp32") is not None
+    assert R._layered_why(net, net, 64, 96) is None and "N_importance" in R._layered_why(net, net, 64, 96, "bf16x3")
+    assert "N_samples=32" in R._layered_why(net, net, 32, 128) and "N_importance=100" in R._layered_why(net, net, 64, 100)
+    deep = R.NeRF(D=9, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    assert "netdepth" in deep.fused_why_not and "netdepth" in R._layered_why(net, deep, 64, 128)
+    with pytest.raises(NotImplementedError, match="layered"):
+        deep.native_state_dict()
+    # retraw on a fused handle whose fine pass carries duplicated samples (decided on the handle that will run)
+    class Fused:
+        mlp, ni_kernel = "f16x2", 128
+    with pytest.raises(NotImplementedError, match="retraw"):
+        R._check_retraw(dict(base, N_importance=16, retraw=True), Fused)
+    R._check_retraw(dict(base, N_importance=128, retraw=True), Fused)
     nv = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=0, use_viewdirs=False)
     assert "output_linear.weight" in nv.state_dict() and "alpha_linear.weight" not in nv.state_dict()
     assert set(nv.native_state_dict()) == set(net.state_dict())
-    with pytest.raises(NotImplementedError, match="specialised"):
-        R.NeRF(D=9, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True)
+    for bad in (dict(D=65), dict(W=5000), dict(input_ch=64), dict(input_ch=3 + 6 * 16), dict(input_ch_views=4)):
+        with pytest.raises(NotImplementedError, match="neither"):
+            R.NeRF(**dict(dict(D=8, W=256, input_ch=63, input_ch_views=27, use_viewdirs=True), **bad))
     small = R.NeRF(D=4, W=128, input_ch=39, input_ch_views=15, use_viewdirs=True)       # fits: served as an 8 x 256 network
     assert {k: tuple(v.shape) for k, v in small.native_state_dict().items()} == {k: tuple(v.shape) for k, v in net.state_dict().items()}
     with pytest.raises(NotImplementedError):
@@ -620,9 +663,11 @@ def test_create_nerf_builds_whatever_the_arguments_say(tmp_path, oracle):
     n = test["network_fn"]
     assert not n.use_viewdirs and n.output_linear.weight.shape == (5, 128) and test["use_viewdirs"] is False
     assert n.views_linears[0].weight.shape == (64, 128) and not hasattr(n, "alpha_linear")            # RH:86, RH:95-96
-    a.netwidth = 512
-    with pytest.raises(NotImplementedError, match="netwidth 512"):
-        R.create_nerf(a)
+    a.netwidth = 512                 # wider than the fused kernels: built all the same, served by the layered renderer (r05)
+    _, test, _, _, _ = R.create_nerf(a)
+    n = test["network_fn"]
+    assert n.pts_linears[0].weight.shape == (512, 39) and "netwidth 512" in n.fused_why_not
+    assert "netwidth 512" in R._layered_why(n, test["network_fine"], 64, 128)
 
 
 def test_bench_self_launch_fails_only_on_device_count():

@@ -449,6 +449,62 @@ def test_every_fitting_shape_is_the_same_function_as_an_8x256_network(shape, ora
     assert_close(a, b, atol=2e-6 * max(1.0, np.abs(b).max()), what="mapped network")
 
 
+def wide_case(oracle, g, tag):
+    """(sd_coarse, sd_fine, n_samples, n_importance) of a g25 case: the weights are the oracle's recipe for the seeds the
+    fixture was generated with (oracle/gen_golden_r5.py)."""
+    sh = [int(v) for v in g[tag + "_shape"]]
+    D, W, L, Lv, uv, ns, ni = sh[:7]
+    skips = sh[7:]
+    seed = int(g["seed"])
+    sd_c = oracle.synth_weights_shape(seed + 41, D, W, L, Lv, skips, bool(uv))
+    sd_f = {k: (v * (1.0 + 0.05 * np.random.RandomState(seed + 42).standard_normal(v.shape))).astype(np.float32)
+            for k, v in sd_c.items()}
+    return sd_c, sd_f, ns, ni
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_networks_beyond_the_fused_kernels_against_the_reference(tag, golden, oracle):
+    """g25: NeRFs the fused kernels cannot hold -- 10 x 384, two skips with width 300 and (48, 100) samples, no view directions
+    with a late skip and (24, 40) samples, a coarse-only 3 x 512 -- built from the reference's own class and rendered by the
+    reference.  The oracle (shape-driven mlp, generic sample counts, shape-driven fp64 backprop) is pinned to them: network
+    outputs, the coarse image, cdf / indices / samples on the reference's coarse weights BIT FOR BIT, the fine image within the
+    usual conditioning, autograd's d rgb / d rays at the reference's own depths."""
+    from neural_sim_nerf_amd.run_nerf_helpers import fits_kernel
+    g = golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, tag)
+    shape = oracle.net_shape(sd_c)
+    assert fits_kernel(*shape) or ns not in (32, 64, 128), "the case is meant to be out of the fused kernels' reach"
+    ro, rd = g["rays_o"], g["rays_d"]
+    n = len(ro)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    vd = oracle.normalize_dirs(rd)
+    want = g[tag + "_net_out"][:, :4]
+    got = oracle.run_network(sd_c, g["pts"][:, None, :], g["dirs"])[:, 0]
+    assert_close(got, want, atol=1e-5 + 2e-6 * np.abs(want).max(), rtol=2e-6, what="network outputs")
+    r = oracle.render_rays(sd_c, sd_f if ni else None, ro, rd, vd, near, far, n_samples=ns, n_importance=ni, extras=True)
+    z = r["z_coarse"]
+    assert z.shape == (n, ns)
+    if ni == 0:
+        assert_close(r["rgb_map"], g[tag + "_rgb"], atol=1e-5, what="rgb")
+        assert_close(r["acc_map"], g[tag + "_acc"], atol=1e-5, what="acc")
+        zf = z
+    else:
+        assert_close(r["rgb0"], g[tag + "_rgb0"], atol=1e-5, what="rgb0")
+        assert_close(r["acc0"], g[tag + "_acc0"], atol=1e-5, what="acc0")
+        z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+        s, inds, cdf = oracle.sample_pdf(z_mid, g[tag + "_pdf_weights"], ni)
+        assert np.array_equal(cdf, g[tag + "_cdf"]), np.abs(cdf - g[tag + "_cdf"]).max()
+        assert np.array_equal(inds, g[tag + "_inds"].astype(np.int64)) and np.array_equal(s, g[tag + "_z_samples"])
+        assert_close(np.std(s.astype(np.float64), -1), g[tag + "_z_std"], atol=1e-6, what="z_std")
+        d = np.abs(r["rgb_map"] - g[tag + "_rgb"]).max(-1)
+        assert (d > 1e-4).mean() <= 0.1 and oracle.psnr(r["rgb_map"], g[tag + "_rgb"]) > 50.0, d.max()
+        zf = np.sort(np.concatenate([z, g[tag + "_z_samples"]], -1), -1)
+    go, gd, _ = oracle.render_rays_vjp(sd_c, sd_f if ni else None, ro, rd, near, far, g["cot"], n_samples=ns, n_importance=ni, z_fine=zf)
+    for a, b in ((go, g[tag + "_grad_rays"][0]), (gd, g[tag + "_grad_rays"][1])):
+        e = np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+        assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (np.percentile(e, 90), e.max())
+
+
 def test_networks_that_do_not_fit_are_refused():
     from neural_sim_nerf_amd.run_nerf_helpers import fits_kernel
     assert fits_kernel(8, 256, 63, 27, [4], True) is None and fits_kernel(8, 256, 63, 0, [4], False, 5) is None

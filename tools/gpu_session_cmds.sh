@@ -1,7 +1,7 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session L: the whole GPU suite on the final tree,
-# smoke, then the profile collection of profiles/r05)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session O: timing of the layered renderer)
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -q -m gpu --durations=8 > $O/gpu_suite.log 2>&1; tail -14 $O/gpu_suite.log
-timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-bash tools/collect_profiles.sh > $O/collect.log 2>&1; tail -3 $O/collect.log
-timeout 120 python tools/probe_h2.py > $O/probe_h2.txt 2>&1; tail -3 $O/probe_h2.txt
+timeout 600 python tools/bench_wide.py --cases ycbv,w512,d10w384,small > $O/bench_wide.txt 2>&1; tail -6 $O/bench_wide.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_wide -o wide -- python $GRAFT_REPO_ROOT/tools/bench_wide.py --cases w512 --steps 2 > $O/prof_wide.log 2>&1
+find $O/prof_wide -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_wide_w512.csv
+head -14 $O/kernel_stats_wide_w512.csv | cut -c1-160
