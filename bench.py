@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0.  Objects beside the contract fields:
                     sample (a smaller view of the same scene, ~15 s of CPU work), rank 0, N=1 only;
   parity         -- PSNR / max-abs of the GPU render vs the oracle on that sample, exact-match rate of the indices;
   extra_workloads.handoff -- f-3: device to8b + bbox extraction of 100 images next to the host route (oracle) on 5;
+  extra_workloads.layered -- the layered renderer (include/nsr_wide.h) on the same view, and on an 8 x 512 network;
   extra_workloads.config1 -- BASELINE configs[0] (64x64, 64 coarse samples only): GPU throughput next to the oracle at
                     chunk 512 (the reference's config) and 4096;
   ranks_seen, kernel_ms_per_rank -- what RCCL actually saw (sum of ones over ranks; per-rank kernel time spread).
@@ -321,6 +322,53 @@ def render_options_workload(sd_c, sd_f, c2w, device):
     return {"workload": "400x400 rays, 64+128 samples, perturb + raw_noise_std via NsrRayExtras (kernel ms, HIP events)",
             "deterministic_ms": round(plain, 3), "stochastic_ms": round(stoch, 3), "ratio": round(stoch / plain, 4),
             "extra_hbm_bytes_per_ray": 448 * 4}
+
+
+def layered_workload(sd_c, sd_f, c2w, device, ref):
+    """extra_workloads.layered: the layered renderer (include/nsr_wide.h: one fp32-MFMA GEMM per network layer, activations in
+    HBM) -- what serves the networks and sample counts the fused kernels are not built for.  The SAME view and networks as the
+    main line through it (the price of leaving the fused kernels, and a cross-check of two independent implementations of the
+    path), and a network the fused kernels cannot hold (8 x 512).  Roofline of its GEMM kernel nsrw::kw_gemm: algorithmic fp32
+    FLOP of the network evaluations / HIP-event time of the whole launch call against the fp32-MFMA peak."""
+    from neural_sim_nerf_amd.wide import WideModel
+    pose = torch.as_tensor(c2w[:3, :4])
+    out = {"workload": "one 400x400 view, 64+128 samples, through nsrw_render_rays (HIP-event ms of the launch call, all chunks)",
+           "kernel": "nsrw::kw_gemm<128, *, 16> (fp32 in, v_mfma_f32_32x32x2_f32, fp32 out)", "peak": PEAK_F32_MFMA_TFLOPS}
+
+    def run(model, flop_per_point, launches=2):
+        ro, rd = model.get_rays(H, W, S.YCBV_K, pose)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        o = model.render_rays(ro, rd, S.YCBV_NEAR, S.YCBV_FAR)
+        ms = []
+        for _ in range(launches):
+            o = model.render_rays(ro, rd, S.YCBV_NEAR, S.YCBV_FAR)
+            ms.append(model.last_kernel_ms())
+        t = float(np.mean([m[0] for m in ms]))
+        flop = H * W * 256 * flop_per_point
+        return o, {"ms_per_view": round(t, 2), "chunks_of_rays": ms[-1][1], "Mray_samples_per_s": round(H * W * 192 / t / 1e3, 2),
+                   "achieved": round(flop / t / 1e9, 1), "unit": "TFLOP/s", "frac": round(flop / t / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
+    m = WideModel(sd_c, sd_f, device=device)
+    o, r = run(m, S.FLOP_PER_POINT)
+    a, b = o["rgb_map"], ref["rgb_map"]
+    d = (a - b).abs().max(-1)[0]
+    mse = float(((a - b) ** 2).mean())
+    r["vs_main_line_kernel_same_view"] = {"psnr_db": round(-10.0 * np.log10(max(mse, 1e-30)), 2), "rays": int(d.numel()),
+                                          "rays_rgb_above_1e-4": int((d > 1e-4).sum())}
+    out["ycbv_8x256"] = r
+    m.close()
+    rng = np.random.RandomState(3)
+    wide = {}
+    Wd = 512
+    for name, o_, i_ in [("pts_linears.0", Wd, 63)] + [("pts_linears.%d" % k, Wd, Wd + (63 if k == 5 else 0)) for k in range(1, 8)] + \
+            [("feature_linear", Wd, Wd), ("alpha_linear", 1, Wd), ("views_linears.0", Wd // 2, Wd + 27), ("rgb_linear", 3, Wd // 2)]:
+        bnd = 1.0 / np.sqrt(i_)
+        wide[name + ".weight"] = (rng.uniform(-bnd, bnd, (o_, i_)) * (1.13 if name.startswith("pts") else 25.0 if name == "alpha_linear" else 1.0)).astype(np.float32)
+        wide[name + ".bias"] = rng.uniform(-bnd, bnd, (o_,)).astype(np.float32)
+    m = WideModel(wide, wide, device=device)
+    _, r = run(m, 2 * sum(v.size for k, v in wide.items() if k.endswith(".weight")))
+    out["wide_8x512"] = r
+    m.close()
+    return out
 
 
 def range_stress_workload(sd_c, sd_f, c2w, device, target=0.10):
@@ -894,6 +942,10 @@ def main():
                                            "render_options": render_options_workload(sd_c, sd_f, poses[0], local),
                                            "range_stress": range_stress_workload(sd_c, sd_f, poses[args.warmup], local)}
                 ref = model.render_views(poses_d[args.warmup], H, W, S.YCBV_K, S.YCBV_NEAR, S.YCBV_FAR)
+                try:                 # (a side workload must never cost the main line)
+                    line["extra_workloads"]["layered"] = layered_workload(sd_c, sd_f, poses[args.warmup], local, ref)
+                except Exception as e:                     # noqa: BLE001
+                    line["extra_workloads"]["layered"] = {"error": repr(e)}
                 for mlp in MLP_MODES:
                     if mlp != model.mlp:
                         line["extra_workloads"][mlp] = alt_mlp_workload(mlp, sd_c, sd_f, local, poses[args.warmup], ref,

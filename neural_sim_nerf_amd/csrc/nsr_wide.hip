@@ -77,37 +77,42 @@ __global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs 
   __shared__ __attribute__((aligned(16))) float sA[2][kTM][LD];
   __shared__ __attribute__((aligned(16))) float sB[2][TN][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // XCD-aware tile order
-  const long long bid = blockIdx.x;
-  const int xcd = (int)(bid & 7);
-  const long long j = bid >> 3;
-  const long long mb = (j / g.n_tiles) * 8 + xcd;
-  const int nt = (int)(j % g.n_tiles);
-  const long long m0 = mb * kTM;
-  if (m0 >= g.M) return;
-  const int n0 = nt * TN;
   const int wm = TN == 128 ? (wave & 1) : wave, wn = TN == 128 ? (wave >> 1) : 0;
   const int ktot = g.K1 + g.K2;
   const int stages = ktot / KS, stages1 = g.K1 / KS;
-
-  // global -> register staging: A tile 128 x KS: thread = (row t / 2, KS / 2 floats at (KS / 2) (t % 2))
-  const int arow = tid >> 1, akq = (tid & 1) * (KS / 2);
-  long long am = m0 + arow;
-  if (am >= g.M) am = g.M - 1;                                   // clamped rows are computed and never stored
-  const float* a1p = g.A1 + am * g.lda1 + akq;
-  const float* a2p = g.A2 ? g.A2 + am * g.lda2 + akq : nullptr;
-  // B tile TN x KS: thread = (row t / (256 / TN), BF floats)
-  constexpr int TPR = 256 / TN;                                  // threads per B row
+  const int arow = tid >> 1, akq = (tid & 1) * (KS / 2);        // A tile 128 x KS: thread = (row t / 2, KS / 2 floats)
+  constexpr int TPR = 256 / TN;                                  // B tile TN x KS: thread = (row t / TPR, BF floats)
   const int brow = tid / TPR, bkq = (tid % TPR) * BF;
-  const float* bp = g.Wt + (long long)(n0 + brow) * ktot + bkq;
-  f32x4 ra[AV], rb[BV];
+  const int lrow = lane & 31, lk = (lane >> 5) * 4;
+  const long long mblocks = (g.M + kTM - 1) / kTM;
+  const long long total = ((mblocks + 7) / 8) * 8 * g.n_tiles;   // tile ids; those whose M-block does not exist are skipped
 
-  auto gload = [&](int s) {
-    const float* ap = s < stages1 ? a1p + s * KS : a2p + (s - stages1) * KS;
+  // PERSISTENT over the tiles (grid = what the device holds at once): a workgroup walks tile, tile + grid, ...; the first stage
+  // of its next tile is loaded into registers before the epilogue of this one, so a tile's start-up latency hides behind the
+  // previous tile's stores.  Tile id -> (M-block, N-tile) is XCD-aware: id % 8 = the XCD the id lands on (grid is a multiple
+  // of 8), and the N-tiles of one M-block are consecutive ids of ONE XCD, run by neighbouring workgroups at the same time.
+  struct Tile { long long m0; int n0; const float* a1p; const float* a2p; const float* bp; };
+  auto coords = [&](long long t, Tile& tl) -> bool {
+    const int xcd = (int)(t & 7);
+    const long long j = t >> 3;
+    const long long mb = (j / g.n_tiles) * 8 + xcd;
+    tl.m0 = mb * kTM;
+    if (tl.m0 >= g.M) return false;
+    tl.n0 = (int)(j % g.n_tiles) * TN;
+    long long am = tl.m0 + arow;
+    if (am >= g.M) am = g.M - 1;                                 // clamped rows are computed and never stored
+    tl.a1p = g.A1 + am * g.lda1 + akq;
+    tl.a2p = g.A2 ? g.A2 + am * g.lda2 + akq : nullptr;
+    tl.bp = g.Wt + (long long)(tl.n0 + brow) * ktot + bkq;
+    return true;
+  };
+  f32x4 ra[AV], rb[BV];
+  auto gload = [&](const Tile& tl, int s) {
+    const float* ap = s < stages1 ? tl.a1p + s * KS : tl.a2p + (s - stages1) * KS;
 #pragma unroll
     for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
 #pragma unroll
-    for (int v = 0; v < BV; ++v) rb[v] = *reinterpret_cast<const f32x4*>(bp + s * KS + 4 * v);
+    for (int v = 0; v < BV; ++v) rb[v] = *reinterpret_cast<const f32x4*>(tl.bp + s * KS + 4 * v);
   };
   auto lstore = [&](int buf) {
 #pragma unroll
@@ -116,72 +121,86 @@ __global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs 
     for (int v = 0; v < BV; ++v) *reinterpret_cast<f32x4*>(&sB[buf][brow][bkq + 4 * v]) = rb[v];
   };
 
-  f32x16 acc[MI][NJ];
+  Tile cur, nxt;
+  long long t = blockIdx.x;
+  while (t < total && !coords(t, cur)) t += gridDim.x;
+  if (t >= total) return;
+  gload(cur, 0);
+  while (true) {
+    f32x16 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  const int lrow = lane & 31, lk = (lane >> 5) * 4;
-  for (int s = 0; s < stages; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < stages) gload(s + 1);
-#pragma unroll
-    for (int sub = 0; sub < KS / 8; ++sub) {
-      f32x4 fa[MI], fb[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        fa[i] = *reinterpret_cast<const f32x4*>(&sA[buf][wm * (MI * 32) + i * 32 + lrow][sub * 8 + lk]);
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj)
-        fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][sub * 8 + lk]);
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < stages) gload(cur, s + 1);
+#pragma unroll
+      for (int sub = 0; sub < KS / 8; ++sub) {
+        f32x4 fa[MI], fb[NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
+          fa[i] = *reinterpret_cast<const f32x4*>(&sA[buf][wm * (MI * 32) + i * 32 + lrow][sub * 8 + lk]);
 #pragma unroll
-          for (int jj = 0; jj < NJ; ++jj)
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[jj][t], acc[i][jj], 0, 0, 0);
+        for (int jj = 0; jj < NJ; ++jj)
+          fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][sub * 8 + lk]);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+              acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][tt], fb[jj][tt], acc[i][jj], 0, 0, 0);
+      }
+      if (s + 1 < stages) lstore(buf ^ 1);
+      __syncthreads();
     }
-    if (s + 1 < stages) lstore(buf ^ 1);
-    __syncthreads();
-  }
+    // the next tile's first stage is on its way while this tile's results are stored
+    long long tn = t + gridDim.x;
+    while (tn < total && !coords(tn, nxt)) tn += gridDim.x;
+    const bool more = tn < total;
+    if (more) gload(nxt, 0);
 
-  // epilogue: lane owns column n, rows 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32 x 32 tile
-  const bool full_rows = m0 + kTM <= g.M;
+    // epilogue: lane owns column n, rows 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32 x 32 tile
+    const bool full_rows = cur.m0 + kTM <= g.M;
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) {
-    const int n = n0 + wn * (NJ * 32) + jj * 32 + lrow;
-    const bool ncol = n < g.N;
-    const float b = (g.bias && ncol) ? g.bias[n] : 0.0f;
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int n = cur.n0 + wn * (NJ * 32) + jj * 32 + lrow;
+      const bool ncol = n < g.N;
+      const float b = (g.bias && ncol) ? g.bias[n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const long long mt = m0 + wm * (MI * 32) + i * 32 + lk;
-      float aux[16];                                                           // mask values / old C values, loaded together
-      if constexpr (EPI == kMaskEpi || EPI == kAccum) {
-        const float* src = EPI == kMaskEpi ? g.mask : g.C;
-        const int ld = EPI == kMaskEpi ? g.ldm : g.ldc;
+      for (int i = 0; i < MI; ++i) {
+        const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
+        float* cb = g.C + mt * g.ldc + n;
+        const int rows_left = (int)(g.M - mt < 32 ? g.M - mt : 32);             // rows mt + ro with ro < rows_left exist
+        float aux[16];                                                           // mask values / old C values, loaded together
+        if constexpr (EPI == kMaskEpi || EPI == kAccum) {
+          const float* sb = EPI == kMaskEpi ? g.mask + mt * g.ldm + n : cb;
+          const int ld = EPI == kMaskEpi ? g.ldm : g.ldc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ro = 8 * (r >> 2) + (r & 3);
+            aux[r] = (ncol && (full_rows || ro < rows_left)) ? sb[ro * ld] : 0.0f;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long long m = mt + 8 * (r >> 2) + (r & 3);
-          aux[r] = (ncol && (full_rows || m < g.M)) ? src[m * ld + n] : 0.0f;
+          const int ro = 8 * (r >> 2) + (r & 3);
+          float v = acc[i][jj][r] + b;
+          if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
+          if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
+          if constexpr (EPI == kAccum) v = aux[r] + v;
+          if (ncol && (full_rows || ro < rows_left)) cb[ro * g.ldc] = v;
         }
       }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long m = mt + 8 * (r >> 2) + (r & 3);
-        float v = acc[i][jj][r] + b;
-        if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
-        if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
-        if constexpr (EPI == kAccum) v = aux[r] + v;
-        if (ncol && (full_rows || m < g.M)) g.C[m * g.ldc + n] = v;
-      }
     }
+    if (!more) break;
+    t = tn;
+    cur = nxt;
   }
 }
 
@@ -764,7 +783,10 @@ void carve_chunk(const Handle& h, long long R, bool grad, Carve& c, Chunk& k) {
   }
 }
 
-int g_gemm_ks = 32;      // K extent of a GEMM stage of the 128-wide kernel (NSRW_GEMM_KS = 16 | 32, read by nsrw_create)
+int g_cus = 256;         // compute units of the device (nsrw_create reads the device's own count)
+int g_gemm_ks = 16;      // K extent of a GEMM stage of the 128-wide kernel: 16 = three workgroups per CU (41 KB of LDS each),
+                         // measured 0.76 against 0.665 of the fp32-MFMA peak for 32 / two per CU on an 8 x 512 network
+                         // (profiles/r05/extra/layered_gemm_ab.txt); NSRW_GEMM_KS = 32 (read by nsrw_create) selects the other
 
 template <int TN, int KS>
 void launch_gemm(hipStream_t st, unsigned grid, const GemmArgs& g, int epi) {
@@ -787,12 +809,15 @@ int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda
   const long long mblocks = (M + kTM - 1) / kTM, mgroups = (mblocks + 7) / 8;
   const int full = m.Np / 128, rem = (m.Np % 128) / 32;
   const int ktot = m.K1p + m.K2p;
+  auto grid_for = [&](long long tiles, int per_cu) {         // persistent workgroups: what the device holds at once (a multiple of 8)
+    const long long cap = (long long)g_cus * per_cu / 8 * 8;
+    return (unsigned)std::max<long long>(8, std::min(tiles, cap));
+  };
   if (full) {
     g.Wt = dW + m.w; g.n_tiles = full;
-    const long long grid = mgroups * 8 * full;
-    if (grid > 0x7fffffffll) return fail("nsrw: chunk too large for one GEMM launch");
-    if (g_gemm_ks == 16) launch_gemm<128, 16>(st, (unsigned)grid, g, epi);
-    else launch_gemm<128, 32>(st, (unsigned)grid, g, epi);
+    const long long tiles = mgroups * 8 * full;
+    if (g_gemm_ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, 3), g, epi);
+    else launch_gemm<128, 32>(st, grid_for(tiles, 2), g, epi);
   }
   if (rem) {
     GemmArgs t = g;
@@ -801,11 +826,7 @@ int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda
     t.C = C + full * 128; t.N = N - full * 128;
     if (t.mask) t.mask += full * 128;
     t.n_tiles = rem;
-    if (t.N > 0) {
-      const long long grid = mgroups * 8 * rem;
-      if (grid > 0x7fffffffll) return fail("nsrw: chunk too large for one GEMM launch");
-      launch_gemm<32, 32>(st, (unsigned)grid, t, epi);
-    }
+    if (t.N > 0) launch_gemm<32, 32>(st, grid_for(mgroups * 8 * rem, 3), t, epi);
   }
   return 0;
 }
@@ -1027,7 +1048,11 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
   int count = 0;
   NSRW_HIP(hipGetDeviceCount(&count));
   if (cfg->device < 0 || cfg->device >= count) return fail("nsrw_create: no such device");
-  if (const char* ks = getenv("NSRW_GEMM_KS")) g_gemm_ks = atoi(ks) == 16 ? 16 : 32;     // setup call: A/B switch of tools/bench_wide.py
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
+  }
+  if (const char* ks = getenv("NSRW_GEMM_KS")) g_gemm_ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switch of tools/bench_wide.py
   Handle* h = new Handle();
   h->cfg = *cfg;
   DeviceGuard guard(cfg->device);

@@ -6,12 +6,15 @@ Everything below L1 of SURVEY.md section 1 -- batchify_rays, render_rays, run_ne
 Embedder, the 8x256 MLP -- is ONE persistent gfx950 kernel (csrc/nsr_kernels.hip) reached through the C ABI
 of include/nsr.h.  This file is host glue: argument checking, handle caching, reshapes, PNG side effects.
 
-Unsupported configurations raise NotImplementedError (the reference has no error convention; silently taking a
-different path is worse): networks that cannot be written as the kernels' 8x256 network (run_nerf_helpers.fits_kernel),
-N_samples != 64, N_importance other than 0, 128 or a divisor of 128 (engine._host_tables).  Smaller networks and use_viewdirs=False networks (RH:95-96) run
-on the same kernels through NeRF.native_state_dict.  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one native handle per option pair);
-ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and raw_noise_std>0 (RN:365-374) reach the
-same kernels as per-ray extras (include/nsr.h: NsrRayExtras) -- see _draws for where the random numbers come from.
+Which kernels run a call (`_model_for`): a NeRF that can be written as the kernels' 8x256 network (run_nerf_helpers.fits_kernel;
+smaller networks and use_viewdirs=False networks, RH:95-96, through NeRF.native_state_dict) at sample counts a fused kernel is
+built for (N_samples 64 with N_importance 0 / 128 / 96 / a divisor of 128; (32, 64), (128, 128)) -> the fused kernels
+(engine.NsrModel); every other network or pair of counts -> the layered renderer (wide.WideModel, include/nsr_wide.h: one
+fp32-MFMA GEMM per layer, activations in HBM).  What neither serves raises NotImplementedError (the reference has no error
+convention; silently taking a different path is worse).  white_bkgd (RN:384-385) and lindisp (RN:443) are handle flags (one
+native handle per option pair); ndc=True (RN:101-103), c2w_staticcam (RN:91-96), perturb>0 (RN:447-459, RH:211) and
+raw_noise_std>0 (RN:365-374) reach the kernels as per-ray extras (include/nsr.h: NsrRayExtras, include/nsr_wide.h: NsrwExtras)
+-- see _draws for where the random numbers come from.
 
 `create_nerf` deliberately restates RN:258-340 statement by statement: the args it reads, the kwargs keys, the
 checkpoint keys and the returned 5-tuple ARE the drop-in contract, so there is nothing to redesign there."""

@@ -397,8 +397,8 @@ def test_native_sample_counts(name, oracle, synth_nets):
 
 
 def test_dropin_api_takes_the_other_sample_counts(oracle, synth_nets):
-    """render(N_samples=32, N_importance=64) through the drop-in API == the engine's render of the same rays; what is still
-    refused is refused loudly (N_samples = 48; (32, 128))."""
+    """render(N_samples=32, N_importance=64) through the drop-in API == the engine's render of the same rays; counts without a
+    fused kernel (N_samples = 48; (32, 128); (128, 64)) go to the layered renderer; N_samples = 2 is refused."""
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
     from neural_sim_nerf_amd.engine import NsrModel
@@ -419,9 +419,20 @@ def test_dropin_api_takes_the_other_sample_counts(oracle, synth_nets):
     assert np.array_equal(cpu(rgb), cpu(want["rgb_map"]))
     assert oracle.psnr(cpu(rgb), g["rgb"]) > 50.0
     m.close()
-    for bad in (dict(N_samples=48), dict(N_samples=32, N_importance=128), dict(N_samples=128, N_importance=64)):
-        with pytest.raises(NotImplementedError, match="N_samples"):
-            R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, **bad))
+    # counts without a fused kernel: the layered renderer (include/nsr_wide.h) takes them since r05 -- against the oracle's render
+    ro, rd = g["rays_o"], g["rays_d"]
+    for other in (dict(N_samples=48), dict(N_samples=32, N_importance=128), dict(N_samples=128, N_importance=64)):
+        kw2 = dict(kw, **other)
+        ns, ni = kw2["N_samples"], kw2["N_importance"]
+        assert "N_samples=%d" % ns in R._layered_why(nets[0], nets[1], ns, ni)
+        got = R.render(400, 400, oracle.YCBV_K, rays=rays, **kw2)
+        assert R._model_for(nets[0], nets[1], ni, kw2).mlp == "layered-fp32"
+        ref = oracle.render_rays(synth_nets[0], synth_nets[1], ro, rd, oracle.normalize_dirs(rd), near, far, n_samples=ns, n_importance=ni)
+        d = np.abs(cpu(got[0]) - ref["rgb_map"]).max(-1)
+        assert (d > 1e-4).mean() <= 0.1 and oracle.psnr(cpu(got[0]), ref["rgb_map"]) > 50.0, (other, d.max())
+        assert_close(cpu(got[3]["rgb0"]), ref["rgb0"], atol=1e-5, what="rgb0 %r" % (other,))
+    with pytest.raises(NotImplementedError, match="N_samples"):
+        R.render(400, 400, oracle.YCBV_K, rays=rays, **dict(kw, N_samples=2))
     for n in nets:
         n.invalidate()
 

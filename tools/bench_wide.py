@@ -15,6 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from neural_sim_nerf_amd import synthetic as S  # noqa: E402
 from neural_sim_nerf_amd.wide import WideModel  # noqa: E402
+from bench import PowerSampler  # noqa: E402  (hwmon power / clock of the GPU while the launches run)
 
 PEAK_FP32_MFMA = 157.3
 
@@ -77,17 +78,24 @@ def main():
                "flop_per_point": flop_per_point(sd)}
         for what in ("forward",) + (() if a.no_grad else ("forward+input-gradient",)):
             ms = []
-            for _ in range(a.steps + 1):
+            ps = None
+            for it in range(a.steps + 1):
+                if it == 1:
+                    ps = PowerSampler(m.device.index)
+                    ps.start()
                 if what == "forward":
                     m.render_rays(ro, rd, S.YCBV_NEAR, S.YCBV_FAR)
                 else:
                     m.render_rays_vjp(ro, rd, S.YCBV_NEAR, S.YCBV_FAR, cot)
                 t, chunks = m.last_kernel_ms()
                 ms.append(t)
+            power = ps.stop() if ps else None
             t = float(np.median(ms[1:]))
             f = flop if what == "forward" else flop + n * (ns + ni) * flop_per_point(sd)     # + the fine pass's transposed GEMMs
             res[what] = {"ms_per_view": round(t, 2), "chunks": chunks, "workspace_GB": round(m._ws.numel() / 2 ** 30, 2),
                          "algorithmic_TFLOPs": round(f / t / 1e9, 1), "frac_of_fp32_mfma_peak": round(f / t / 1e9 / PEAK_FP32_MFMA, 3)}
+            if power:
+                res[what]["power_and_clock"] = {k: v for k, v in power.items() if k != "source"}
             if what == "forward":
                 res[what]["Mray_samples_per_s"] = round(n * (ns + ni) / t / 1e3, 2)
         out[name] = res
