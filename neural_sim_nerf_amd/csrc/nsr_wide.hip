@@ -68,8 +68,14 @@ constexpr int kTM = 128;
 enum { kMaskEpi = 4 };
 
 template <int TN, int EPI, int KS>
-__global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs g) {
-  constexpr int MI = TN == 128 ? 2 : 1, NJ = TN == 128 ? 2 : 1, LD = KS + 4;
+__global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs g) {
+  // LDS tile rows: KS = 32: [32 + 4] floats, the padding makes the 16-byte fragment reads and the staging writes conflict-free
+  // (measured: 0 conflicts).  KS = 16: [16] floats, no padding -- the four 16-byte chunks of a row are XOR-swizzled with bits
+  // 2..3 of the row instead (chunk c of row r sits at c ^ ((r >> 2) & 3)): 16 consecutive rows at one chunk index, the
+  // fragment read pattern, and 8 rows x 2 chunks, the staging write pattern, both cover all 64 banks once; 32 KiB per
+  // workgroup instead of 40, i.e. FOUR workgroups per CU.
+  constexpr bool SWZ = KS == 16;
+  constexpr int MI = TN == 128 ? 2 : 1, NJ = TN == 128 ? 2 : 1, LD = SWZ ? KS : KS + 4;
   constexpr int AV = KS / 8;                                    // float4 per thread of the A tile (128 x KS)
   constexpr int BF = TN * KS / 256;                             // floats per thread of the B tile (TN x KS): 16, 8 or 4
   constexpr int BV = BF / 4;
@@ -114,11 +120,12 @@ __global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs 
 #pragma unroll
     for (int v = 0; v < BV; ++v) rb[v] = *reinterpret_cast<const f32x4*>(tl.bp + s * KS + 4 * v);
   };
+  auto col = [](int row, int c4) { return SWZ ? 4 * ((c4 >> 2) ^ ((row >> 2) & 3)) : c4; };      // c4: column, a multiple of 4
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < AV; ++v) *reinterpret_cast<f32x4*>(&sA[buf][arow][akq + 4 * v]) = ra[v];
+    for (int v = 0; v < AV; ++v) *reinterpret_cast<f32x4*>(&sA[buf][arow][col(arow, akq + 4 * v)]) = ra[v];
 #pragma unroll
-    for (int v = 0; v < BV; ++v) *reinterpret_cast<f32x4*>(&sB[buf][brow][bkq + 4 * v]) = rb[v];
+    for (int v = 0; v < BV; ++v) *reinterpret_cast<f32x4*>(&sB[buf][brow][col(brow, bkq + 4 * v)]) = rb[v];
   };
 
   Tile cur, nxt;
@@ -144,10 +151,10 @@ __global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs 
         f32x4 fa[MI], fb[NJ];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(&sA[buf][wm * (MI * 32) + i * 32 + lrow][sub * 8 + lk]);
+          fa[i] = *reinterpret_cast<const f32x4*>(&sA[buf][wm * (MI * 32) + i * 32 + lrow][col(lrow, sub * 8 + lk)]);
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
-          fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][sub * 8 + lk]);
+          fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][col(lrow, sub * 8 + lk)]);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -177,14 +184,13 @@ __global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs 
         const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
         float* cb = g.C + mt * g.ldc + n;
         const int rows_left = (int)(g.M - mt < 32 ? g.M - mt : 32);             // rows mt + ro with ro < rows_left exist
-        float aux[16];                                                           // mask values / old C values, loaded together
-        if constexpr (EPI == kMaskEpi || EPI == kAccum) {
-          const float* sb = EPI == kMaskEpi ? g.mask + mt * g.ldm + n : cb;
-          const int ld = EPI == kMaskEpi ? g.ldm : g.ldc;
+        float aux[16];                                                           // the 16 mask values, loaded together
+        if constexpr (EPI == kMaskEpi) {
+          const float* sb = g.mask + mt * g.ldm + n;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ro = 8 * (r >> 2) + (r & 3);
-            aux[r] = (ncol && (full_rows || ro < rows_left)) ? sb[ro * ld] : 0.0f;
+            aux[r] = (ncol && (full_rows || ro < rows_left)) ? sb[ro * g.ldm] : 0.0f;
           }
         }
 #pragma unroll
@@ -193,8 +199,10 @@ __global__ void __launch_bounds__(256, KS == 16 ? 3 : 2) kw_gemm(const GemmArgs 
           float v = acc[i][jj][r] + b;
           if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
           if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
-          if constexpr (EPI == kAccum) v = aux[r] + v;
-          if (ncol && (full_rows || ro < rows_left)) cb[ro * g.ldc] = v;
+          if (ncol && (full_rows || ro < rows_left)) {
+            if constexpr (EPI == kAccum) v = cb[ro * g.ldc] + v;                 // (narrow outputs only: the encoding's gradient)
+            cb[ro * g.ldc] = v;
+          }
         }
       }
     }
@@ -784,6 +792,7 @@ void carve_chunk(const Handle& h, long long R, bool grad, Carve& c, Chunk& k) {
 }
 
 int g_cus = 256;         // compute units of the device (nsrw_create reads the device's own count)
+int g_wg_per_cu = 4;     // persistent workgroups of the 16-wide-stage kernel per CU (NSRW_GEMM_WGS = 3 | 4 for the A/B)
 int g_gemm_ks = 16;      // K extent of a GEMM stage of the 128-wide kernel: 16 = three workgroups per CU (41 KB of LDS each),
                          // measured 0.76 against 0.665 of the fp32-MFMA peak for 32 / two per CU on an 8 x 512 network
                          // (profiles/r05/extra/layered_gemm_ab.txt); NSRW_GEMM_KS = 32 (read by nsrw_create) selects the other
@@ -816,7 +825,7 @@ int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda
   if (full) {
     g.Wt = dW + m.w; g.n_tiles = full;
     const long long tiles = mgroups * 8 * full;
-    if (g_gemm_ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, 3), g, epi);
+    if (g_gemm_ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, g_wg_per_cu), g, epi);
     else launch_gemm<128, 32>(st, grid_for(tiles, 2), g, epi);
   }
   if (rem) {
@@ -1052,6 +1061,7 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
   }
+  if (const char* w = getenv("NSRW_GEMM_WGS")) g_wg_per_cu = atoi(w) == 3 ? 3 : 4;
   if (const char* ks = getenv("NSRW_GEMM_KS")) g_gemm_ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switch of tools/bench_wide.py
   Handle* h = new Handle();
   h->cfg = *cfg;
