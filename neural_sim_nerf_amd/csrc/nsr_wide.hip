@@ -720,8 +720,18 @@ size_t net_floats(const NsrwNet& n) {
   return t;
 }
 
+// How the 128-wide GEMM kernel is launched: fixed per handle by nsrw_create (a setup call; launch calls read no environment).
+struct GemmCfg {
+  int cus = 256;       // compute units of the handle's device
+  int ks = 16;         // K extent of a stage: 16 = unpadded swizzled LDS tiles, 32 KiB per workgroup, four workgroups per CU --
+                       // measured 0.75 against 0.665 of the fp32-MFMA peak for 32 / two per CU on an 8 x 512 network
+                       // (profiles/r05/extra/layered_gemm_ab.txt); NSRW_GEMM_KS = 32 selects the other (A/B of tools/bench_wide.py)
+  int wgs = 4;         // persistent workgroups per CU of the 16-wide-stage kernel (NSRW_GEMM_WGS = 3 | 4)
+};
+
 struct Handle {
   NsrwConfig cfg{};
+  GemmCfg gemm_cfg;
   Net net[2];
   float* d_tab = nullptr;           // [n_samples] t, [n_importance] u
   bool tables = false;
@@ -791,12 +801,6 @@ void carve_chunk(const Handle& h, long long R, bool grad, Carve& c, Chunk& k) {
   }
 }
 
-int g_cus = 256;         // compute units of the device (nsrw_create reads the device's own count)
-int g_wg_per_cu = 4;     // persistent workgroups of the 16-wide-stage kernel per CU (NSRW_GEMM_WGS = 3 | 4 for the A/B)
-int g_gemm_ks = 16;      // K extent of a GEMM stage of the 128-wide kernel: 16 = three workgroups per CU (41 KB of LDS each),
-                         // measured 0.76 against 0.665 of the fp32-MFMA peak for 32 / two per CU on an 8 x 512 network
-                         // (profiles/r05/extra/layered_gemm_ab.txt); NSRW_GEMM_KS = 32 (read by nsrw_create) selects the other
-
 template <int TN, int KS>
 void launch_gemm(hipStream_t st, unsigned grid, const GemmArgs& g, int epi) {
   switch (epi) {
@@ -807,8 +811,8 @@ void launch_gemm(hipStream_t st, unsigned grid, const GemmArgs& g, int epi) {
   }
 }
 
-int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda1, const float* A2, int lda2, float* C, int ldc,
-         int N, long long M, int flags, const float* mask = nullptr, int ldm = 0, bool with_bias = true) {
+int gemm(const GemmCfg& cfg, hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda1, const float* A2, int lda2,
+         float* C, int ldc, int N, long long M, int flags, const float* mask = nullptr, int ldm = 0, bool with_bias = true) {
   if (M <= 0) return 0;
   GemmArgs g{};
   g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
@@ -819,13 +823,13 @@ int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda
   const int full = m.Np / 128, rem = (m.Np % 128) / 32;
   const int ktot = m.K1p + m.K2p;
   auto grid_for = [&](long long tiles, int per_cu) {         // persistent workgroups: what the device holds at once (a multiple of 8)
-    const long long cap = (long long)g_cus * per_cu / 8 * 8;
+    const long long cap = (long long)cfg.cus * per_cu / 8 * 8;
     return (unsigned)std::max<long long>(8, std::min(tiles, cap));
   };
   if (full) {
     g.Wt = dW + m.w; g.n_tiles = full;
     const long long tiles = mgroups * 8 * full;
-    if (g_gemm_ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, g_wg_per_cu), g, epi);
+    if (cfg.ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, cfg.wgs), g, epi);
     else launch_gemm<128, 32>(st, grid_for(tiles, 2), g, epi);
   }
   if (rem) {
@@ -842,50 +846,51 @@ int gemm(hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda
 
 // RH:99-122 over P points whose encodings are in k.E / k.ED: leaves the rgb logits in k.RAW (ld 32; all output_linear rows
 // without view directions) and the density at sigma / ld_sigma.  keep: every pts layer's activation stays (k.H[i]).
-int net_forward(hipStream_t st, const Net& n, const Chunk& k, long long P, bool keep, const float** sigma, int* ld_sigma) {
+int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P, bool keep, const float** sigma,
+                int* ld_sigma) {
   const float* h = nullptr;
   for (int i = 0; i < n.d.D; ++i) {
     float* out = k.H[keep ? i : (i & 1)];
     int rc;
-    if (i == 0) rc = gemm(st, n.dW, n.fwd[0], k.E, n.Ci, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
-    else if (n.skip_in[i]) rc = gemm(st, n.dW, n.fwd[i], k.E, n.Ci, h, n.Wp, out, n.Wp, n.Wp, P, kRelu);
-    else rc = gemm(st, n.dW, n.fwd[i], h, n.Wp, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
+    if (i == 0) rc = gemm(cfg, st, n.dW, n.fwd[0], k.E, n.Ci, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
+    else if (n.skip_in[i]) rc = gemm(cfg, st, n.dW, n.fwd[i], k.E, n.Ci, h, n.Wp, out, n.Wp, n.Wp, P, kRelu);
+    else rc = gemm(cfg, st, n.dW, n.fwd[i], h, n.Wp, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
     if (rc) return rc;
     h = out;
   }
   if (!n.d.use_viewdirs) {
-    if (gemm(st, n.dW, n.out, h, n.Wp, nullptr, 0, k.RAW, 32, n.d.output_ch, P, 0)) return 1;
+    if (gemm(cfg, st, n.dW, n.out, h, n.Wp, nullptr, 0, k.RAW, 32, n.d.output_ch, P, 0)) return 1;
     *sigma = k.RAW + 3; *ld_sigma = 32;
     return 0;
   }
-  if (gemm(st, n.dW, n.fa, h, n.Wp, nullptr, 0, k.FA, n.ldfa, n.ldfa, P, 0)) return 1;
-  if (gemm(st, n.dW, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
-  if (gemm(st, n.dW, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, 32, 3, P, 0)) return 1;
+  if (gemm(cfg, st, n.dW, n.fa, h, n.Wp, nullptr, 0, k.FA, n.ldfa, n.ldfa, P, 0)) return 1;
+  if (gemm(cfg, st, n.dW, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
+  if (gemm(cfg, st, n.dW, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, 32, 3, P, 0)) return 1;
   *sigma = k.FA + n.Wp; *ld_sigma = n.ldfa;
   return 0;
 }
 
 // Input-side backward of net_forward (activations kept): k.DRAW [P,32] = dL/d(rgb logits, sigma) -> k.GEP [P,Ci], k.GED [P,Cv].
-int net_backward(hipStream_t st, const Net& n, const Chunk& k, long long P) {
+int net_backward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P) {
   float* g = k.G0;
   float* g2 = k.G1;
   const int D = n.d.D;
   if (n.d.use_viewdirs) {
-    if (gemm(st, n.dW, n.b_rgb, k.DRAW, 32, nullptr, 0, k.GV, n.W2p, n.W2p, P, 0, k.HV, n.W2p)) return 1;   // (g W_rgb) relu'(views)
-    if (gemm(st, n.dW, n.b_feat, k.GV, n.W2p, nullptr, 0, g2, n.Wp, n.Wp, P, 0)) return 1;                  // dL/d feature
-    if (gemm(st, n.dW, n.b_ed, k.GV, n.W2p, nullptr, 0, k.GED, n.Cv, n.Cv, P, 0)) return 1;                 // dL/d direction encoding
-    if (gemm(st, n.dW, n.b_head, g2, n.Wp, k.DRAW, 32, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;    // feature, alpha -> h_{D-1}
+    if (gemm(cfg, st, n.dW, n.b_rgb, k.DRAW, 32, nullptr, 0, k.GV, n.W2p, n.W2p, P, 0, k.HV, n.W2p)) return 1;   // (g W_rgb) relu'(views)
+    if (gemm(cfg, st, n.dW, n.b_feat, k.GV, n.W2p, nullptr, 0, g2, n.Wp, n.Wp, P, 0)) return 1;                  // dL/d feature
+    if (gemm(cfg, st, n.dW, n.b_ed, k.GV, n.W2p, nullptr, 0, k.GED, n.Cv, n.Cv, P, 0)) return 1;                 // dL/d direction encoding
+    if (gemm(cfg, st, n.dW, n.b_head, g2, n.Wp, k.DRAW, 32, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;    // feature, alpha -> h_{D-1}
   } else {
-    if (gemm(st, n.dW, n.b_head, k.DRAW, 32, nullptr, 0, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;
+    if (gemm(cfg, st, n.dW, n.b_head, k.DRAW, 32, nullptr, 0, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;
   }
   bool first_e = true;
   for (int i = D - 1; i >= 0; --i) {          // g = dL/d pre-activation of layer i
     if (i == 0 || n.skip_in[i]) {
-      if (gemm(st, n.dW, n.bwd_e[i], g, n.Wp, nullptr, 0, k.GEP, n.Ci, n.Ci, P, first_e ? 0 : kAccum)) return 1;
+      if (gemm(cfg, st, n.dW, n.bwd_e[i], g, n.Wp, nullptr, 0, k.GEP, n.Ci, n.Ci, P, first_e ? 0 : kAccum)) return 1;
       first_e = false;
     }
     if (i > 0) {
-      if (gemm(st, n.dW, n.bwd_h[i], g, n.Wp, nullptr, 0, g2, n.Wp, n.Wp, P, 0, k.H[i - 1], n.Wp)) return 1;
+      if (gemm(cfg, st, n.dW, n.bwd_h[i], g, n.Wp, nullptr, 0, g2, n.Wp, n.Wp, P, 0, k.H[i - 1], n.Wp)) return 1;
       std::swap(g, g2);
     }
   }
@@ -963,7 +968,7 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
     const float* sigma; int ld_sigma;
     encode(n0, k.z0, S0);
     const bool grad_coarse = grad && NI == 0;
-    if (net_forward(st, n0, k, (long long)Rc * S0, grad_coarse, &sigma, &ld_sigma)) return 1;
+    if (net_forward(h->gemm_cfg, st, n0, k, (long long)Rc * S0, grad_coarse, &sigma, &ld_sigma)) return 1;
     CompositeArgs ca{};
     ca.R = Rc; ca.S = S0; ca.flags = h->cfg.flags; ca.rgb = k.RAW; ca.ld_rgb = 32; ca.sigma = sigma; ca.ld_sigma = ld_sigma;
     ca.z = k.z0; ca.nrm = k.nrm; ca.noise = e.d_noise0 ? e.d_noise0 + r0 * S0 : nullptr; ca.weights = k.w0;
@@ -992,7 +997,7 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
       hipLaunchKernelGGL(kw_sort, dim3((unsigned)Rc), dim3(64), (size_t)S1 * sizeof(float), st, k.z0, k.zs, S0, NI, k.zf);
       // ---- fine pass (RN:478-485) ----
       encode(n1, k.zf, S1);
-      if (net_forward(st, n1, k, (long long)Rc * S1, grad, &sigma, &ld_sigma)) return 1;
+      if (net_forward(h->gemm_cfg, st, n1, k, (long long)Rc * S1, grad, &sigma, &ld_sigma)) return 1;
       CompositeArgs cf = ca;
       cf.S = S1; cf.sigma = sigma; cf.ld_sigma = ld_sigma; cf.z = k.zf; cf.noise = e.d_noise1 ? e.d_noise1 + r0 * S1 : nullptr;
       cf.weights = k.wf;
@@ -1017,7 +1022,7 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
       cb.z = z_last; cb.nrm = k.nrm; cb.noise = noise_last; cb.grad_rgb = grad_rgb + r0 * 3; cb.draw = k.DRAW; cb.gnorm = k.gnorm;
       cb.scr_a = k.scr_a; cb.scr_t = k.scr_t;
       hipLaunchKernelGGL(kw_composite_bwd, dim3(rb), dim3(256), 0, st, cb);
-      if (net_backward(st, last, k, P)) return 1;
+      if (net_backward(h->gemm_cfg, st, last, k, P)) return 1;
       EmbedBwdArgs eb{};
       eb.R = Rc; eb.S = SL; eb.L = last.d.multires; eb.Lv = last.d.multires_views;
       eb.rays_o = ra.rays_o; eb.rays_d = ra.rays_d; eb.z = z_last; eb.vd = k.vd; eb.nrm = k.nrm; eb.gnorm = k.gnorm;
@@ -1057,14 +1062,16 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
   int count = 0;
   NSRW_HIP(hipGetDeviceCount(&count));
   if (cfg->device < 0 || cfg->device >= count) return fail("nsrw_create: no such device");
+  GemmCfg gc;
   {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) gc.cus = prop.multiProcessorCount;
   }
-  if (const char* w = getenv("NSRW_GEMM_WGS")) g_wg_per_cu = atoi(w) == 3 ? 3 : 4;
-  if (const char* ks = getenv("NSRW_GEMM_KS")) g_gemm_ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switch of tools/bench_wide.py
+  if (const char* w = getenv("NSRW_GEMM_WGS")) gc.wgs = atoi(w) == 3 ? 3 : 4;
+  if (const char* ks = getenv("NSRW_GEMM_KS")) gc.ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switches of tools/bench_wide.py
   Handle* h = new Handle();
   h->cfg = *cfg;
+  h->gemm_cfg = gc;
   DeviceGuard guard(cfg->device);
   if (guard.err != hipSuccess) { delete h; return fail("nsrw_create: hipSetDevice failed"); }
   if (hipMalloc(&h->d_tab, (size_t)(cfg->n_samples + std::max(cfg->n_importance, 1)) * 4) != hipSuccess ||
@@ -1295,7 +1302,7 @@ int nsrw_run_network(nsrw_handle hh, int net_id, const float* d_pts, const float
     ea.E = k.E; ea.ldE = n.Ci; ea.ED = k.ED; ea.ldED = n.Cv;
     hipLaunchKernelGGL(kw_embed, dim3((unsigned)((P * 16 + 255) / 256)), dim3(256), 0, st, ea);
     const float* sigma; int ld_sigma;
-    if (net_forward(st, n, k, P, false, &sigma, &ld_sigma)) return 1;
+    if (net_forward(h->gemm_cfg, st, n, k, P, false, &sigma, &ld_sigma)) return 1;
     const int C = n.raw_ch;
     if (n.d.use_viewdirs) {
       hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P * 3 + 255) / 256)), dim3(256), 0, st, k.RAW, 32, d_raw + p0 * 4, 4, P, 3);
