@@ -59,7 +59,9 @@ typedef struct NsrwNet {
 /* Per-ray inputs of the options beyond the deterministic test-time path, all nullable DEVICE pointers (cf. NsrRayExtras):
  * viewdirs [N,3] given view directions (c2w_staticcam RN:91-96, ndc RN:101-103); near / far [N] (RN:106-108);
  * t_rand [N, N_samples] (RN:451), u [N, N_importance] (RH:211), noise0 [N, N_samples] / noise1 [N, N_samples + N_importance]
- * (RN:365-374, already multiplied by raw_noise_std). */
+ * (RN:365-374, already multiplied by raw_noise_std); z_fine [N, N_samples + N_importance]: sorted sample depths the fine pass
+ * is to use INSTEAD of its own resampling (z_samples is detached, RN:475: the depths are constants of the gradient -- this is how
+ * the parity tests differentiate at the reference's own depths). */
 typedef struct NsrwExtras {
   const float* d_viewdirs;
   const float* d_near;
@@ -68,6 +70,7 @@ typedef struct NsrwExtras {
   const float* d_u;
   const float* d_noise0;
   const float* d_noise1;
+  const float* d_z_fine;
 } NsrwExtras;
 
 /* Outputs, all nullable DEVICE pointers: the returns of render_rays (RN:488-495) -- rgb [N,3], disp [N], acc [N] of the last

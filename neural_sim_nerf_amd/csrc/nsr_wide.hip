@@ -903,7 +903,7 @@ int check_common(Handle* h, const float* ro, const float* rd, long long n, const
   if (n > 0 && (!ro || !rd)) return fail("nsrw: null rays");
   if (!h->net[0].loaded) return fail("nsrw: network 0 not uploaded");
   if (!h->tables) return fail("nsrw: nsrw_upload_tables not called");
-  if (ex && ex->d_u && h->cfg.n_importance == 0) return fail("nsrw: u draws without N_importance");
+  if (ex && (ex->d_u || ex->d_z_fine) && h->cfg.n_importance == 0) return fail("nsrw: u draws / fine depths without N_importance");
   return 0;
 }
 
@@ -995,6 +995,8 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
       hipLaunchKernelGGL(kw_sample_pdf, dim3(rb), dim3(256), 0, st, pa);
       if (o.d_z_samples) NSRW_HIP(hipMemcpyAsync(o.d_z_samples + r0 * NI, k.zs, (size_t)Rc * NI * 4, hipMemcpyDeviceToDevice, st));
       hipLaunchKernelGGL(kw_sort, dim3((unsigned)Rc), dim3(64), (size_t)S1 * sizeof(float), st, k.z0, k.zs, S0, NI, k.zf);
+      if (e.d_z_fine)          // given depths (constants of the gradient, RN:475) replace the resampled ones for the fine pass
+        NSRW_HIP(hipMemcpyAsync(k.zf, e.d_z_fine + r0 * S1, (size_t)Rc * S1 * 4, hipMemcpyDeviceToDevice, st));
       // ---- fine pass (RN:478-485) ----
       encode(n1, k.zf, S1);
       if (net_forward(h->gemm_cfg, st, n1, k, (long long)Rc * S1, grad, &sigma, &ld_sigma)) return 1;

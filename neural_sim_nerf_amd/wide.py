@@ -29,7 +29,7 @@ class NsrwNet(C.Structure):
 
 class NsrwExtras(C.Structure):
     _fields_ = [("d_viewdirs", C.c_void_p), ("d_near", C.c_void_p), ("d_far", C.c_void_p), ("d_t_rand", C.c_void_p),
-                ("d_u", C.c_void_p), ("d_noise0", C.c_void_p), ("d_noise1", C.c_void_p)]
+                ("d_u", C.c_void_p), ("d_noise0", C.c_void_p), ("d_noise1", C.c_void_p), ("d_z_fine", C.c_void_p)]
 
 
 class NsrwOut(C.Structure):
@@ -208,14 +208,14 @@ class WideModel:
         if not extras or all(v is None for v in extras.values()):
             return None, None
         widths = dict(viewdirs=3, near=1, far=1, t_rand=self.n_samples, u=self.n_importance, noise0=self.n_samples,
-                      noise1=self.nf_kernel)
+                      noise1=self.nf_kernel, z_fine=self.nf_kernel)
         unknown = set(extras) - set(widths)
         if unknown:
             raise ValueError("unknown ray extras: %s" % sorted(unknown))
         keep = {k: self._f32(v, (n, widths[k])) for k, v in extras.items() if v is not None}
         if ("near" in keep) != ("far" in keep):
             raise ValueError("per-ray bounds: near and far come together")
-        ex = NsrwExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "near", "far", "t_rand", "u", "noise0", "noise1")])
+        ex = NsrwExtras(*[_dev(keep.get(k)) for k in ("viewdirs", "near", "far", "t_rand", "u", "noise0", "noise1", "z_fine")])
         return ex, keep
 
     def _outs(self, n, debug):
@@ -273,8 +273,10 @@ class WideModel:
     def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None, extras=None, debug=False):
         """Forward + input-side VJP (RN:168-178): grad_rgb [N,3] -> (grad_rays_o, grad_rays_d) [N,3] each (+ grad_viewdirs with
         extras["viewdirs"], + the forward's rgb / disp / acc with with_forward)."""
-        if z_fine is not None or debug:
-            raise NotImplementedError("the layered renderer differentiates at its own sample depths and has no relu taps")
+        if debug:
+            raise NotImplementedError("the layered renderer has no relu taps")
+        if z_fine is not None:                      # given depths for the fine pass (constants of the gradient, RN:475)
+            extras = dict(extras or {}, z_fine=z_fine)
         rays_o, rays_d = self._f32(rays_o, (-1, 3)), self._f32(rays_d, (-1, 3))
         n = rays_o.shape[0]
         self.rays_launched += n

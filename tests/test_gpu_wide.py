@@ -103,6 +103,13 @@ def test_layered_renderer_stagewise_census_and_gradient(tag, oracle):
         assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (what, np.percentile(e, 90), e.max())
     for a, b in ((cpu(go), g[tag + "_grad_rays"][0]), (cpu(gd), g[tag + "_grad_rays"][1])):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-2        # (the reference's depths differ by its own rounding)
+    if fine:         # ... and AT the reference's own depths (z_samples is detached, RN:475): autograd's numbers, ray by ray
+        zf_ref = np.sort(np.concatenate([z, g[tag + "_z_samples"]], -1), -1)
+        ro_, rd_ = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf_ref)
+        for a, b, what in ((cpu(ro_), g[tag + "_grad_rays"][0], "grad_o"), (cpu(rd_), g[tag + "_grad_rays"][1], "grad_d")):
+            e = _rel_rows(a, b)
+            print(tag, what, "vs the reference's autograd at its depths: median %.2e  90 %% %.2e  max %.2e" % (np.median(e), np.percentile(e, 90), e.max()))
+            assert np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, (what, np.percentile(e, 90), e.max())
     # ---- chunking never changes a result: the smallest workspace the library accepts (64-ray chunks), ragged ray counts
     os.environ["NSR_WIDE_WORKSPACE_GB"] = "0.0001"
     try:
