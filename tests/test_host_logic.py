@@ -100,6 +100,15 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
     assert res["k_render_h2"]["vgpr_count"] + 0 <= 420, res["k_render_h2"]
     # the x32-structured kernels own a whole SIMD's register file (one workgroup per CU); the x16 ones share it two ways
     assert res["k_render_h2"]["vgpr_count"] > 256 and res["k_render16p"]["vgpr_count"] <= 256
+    # the layered renderer (csrc/nsr_wide.hip, a translation unit of its own in the same library): nothing spills, and the
+    # GEMM kernel it launches by default fits FOUR waves per SIMD (128 registers, 32 KiB of LDS per workgroup: DESIGN.md 8)
+    layered = [k for k in res if k.startswith("kw_")]
+    assert {"kw_gemm<128, %d, 16>" % e for e in (0, 1, 2, 4)} <= set(layered) and "kw_composite" in layered and "kw_sort" in layered
+    for k in layered:
+        assert res[k]["vgpr_spill_count"] == 0 and res[k]["private_segment_fixed_size"] == 0, (k, res[k])
+    for e in (0, 1, 2, 4):
+        r = res["kw_gemm<128, %d, 16>" % e]
+        assert r["vgpr_count"] <= 128 and r["group_segment_fixed_size"] == 32768, r
 
 
 def test_header_constants_match_packer():

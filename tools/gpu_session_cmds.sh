@@ -1,3 +1,4 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session W: gradient at the reference's depths)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session X: the whole GPU suite and smoke on the final tree)
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_wide.py -q -x -s 2>&1 | grep -E "autograd|passed|failed|Error|error" | head -30
+timeout 2400 python -m pytest tests/ -q -m gpu --durations=5 > $O/gpu_suite.log 2>&1; tail -9 $O/gpu_suite.log
+timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
