@@ -127,6 +127,38 @@ def test_layered_renderer_stagewise_census_and_gradient(tag, oracle):
         del os.environ["NSR_WIDE_WORKSPACE_GB"]
 
 
+def test_layered_renderer_chunking_at_scale(oracle):
+    """20 000 rays of the 10 x 384 network (g25 a's weights) with a 16 GiB workspace (one or two chunks) and with a 0.5 GiB one
+    (dozens of chunks of other sizes, a ragged last one): forward and input gradient bit for bit -- a ray's result depends on
+    nothing but the ray, whatever the rows of the GEMMs it shares a launch with."""
+    from neural_sim_nerf_amd.wide import WideModel
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "a")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.scaled_K(400.0 / 142)
+    pose = np.asarray(oracle.sweep_poses(1, seed=4))[0]
+    ro, rd = (a.reshape(-1, 3)[:20000] for a in oracle.get_rays(142, 142, K, pose[:3, :4]))
+    cot = np.random.RandomState(0).standard_normal((len(ro), 3)).astype(np.float32)
+    res = []
+    for gb in ("16", "0.5"):
+        os.environ["NSR_WIDE_WORKSPACE_GB"] = gb
+        try:
+            m = WideModel(sd_c, sd_f, n_samples=ns, n_importance=ni)
+            r = m.render_rays(ro, rd, near, far)
+            chunks_f = m.last_kernel_ms()[1]
+            go, gd = m.render_rays_vjp(ro, rd, near, far, cot)
+            res.append((cpu(r["rgb_map"]), cpu(r["disp_map"]), cpu(r["z_std"]), cpu(go), cpu(gd), chunks_f, m.last_kernel_ms()[1]))
+            m.close()
+        finally:
+            del os.environ["NSR_WIDE_WORKSPACE_GB"]
+    a, b = res
+    print("chunks forward / gradient: %d / %d with 16 GiB, %d / %d with 0.5 GiB" % (a[5], a[6], b[5], b[6]))
+    assert b[5] > 4 * a[5] and b[6] > b[5]
+    for x, y in zip(a[:5], b[:5]):
+        assert np.array_equal(x, y, equal_nan=True)
+    assert np.isfinite(a[0]).all() and np.isfinite(a[3]).all() and np.abs(a[3]).max() > 0
+
+
 def test_layered_renderer_options(oracle):
     """The per-ray options on the layered renderer (g25 b: two skips, (48, 100) samples): stratified depths, random uniforms,
     density noise, per-ray bounds, given view directions, white background + lindisp -- stage-wise against the oracle on the
@@ -268,3 +300,54 @@ def test_dropin_api_serves_networks_beyond_the_fused_kernels(oracle, tmp_path):
             want = gp.detach().cpu().numpy()
             got = dl[i * n_patches + p].numpy()
             assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max() + 1e-9, (i, p, got, want)
+
+
+def test_c_host_of_the_layered_renderer(tmp_path, oracle):
+    """The layered renderer's boundary is a C ABI too: examples/c_host_wide.c (plain C + the HIP runtime C API +
+    include/nsr_wide.h; no Python, no torch) describes the 6 x 300 two-skip network of g25 b, uploads the parameters in the
+    modules' own layout, sizes and allocates its workspace itself and renders the 48 golden rays forward and with the input
+    gradient at (48, 100) samples -- every output equals the Python mirror's (wide.WideModel), bit for bit, also when its
+    workspace holds 64 rays only... and when it holds all of them."""
+    import shutil
+    import subprocess
+    from neural_sim_nerf_amd.wide import WideModel, describe
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the ROCm headers")
+    import torch
+    csrc = os.path.join(ROOT, "neural_sim_nerf_amd", "csrc")
+    exe = str(tmp_path / "c_host_wide")
+    subprocess.check_call(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host_wide.c"), "-L" + csrc, "-lnsr", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "b")
+    ro, rd, cot = np.tile(g["rays_o"], (3, 1)), np.tile(g["rays_d"], (3, 1)), np.tile(g["cot"], (3, 1))
+    n = len(ro)
+    near, far = np.float32(oracle.YCBV_NEAR), np.float32(oracle.YCBV_FAR)
+    net, flat_c = describe(sd_c)
+    _, flat_f = describe(sd_f)
+    m = WideModel(sd_c, sd_f, n_samples=ns, n_importance=ni)
+    want = m.render_rays(ro, rd, float(near), float(far))
+    go, gd = m.render_rays_vjp(ro, rd, float(near), float(far), cot)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    for ws_rays in (64, n):
+        hd = np.zeros(32, np.int32)
+        hd[:7] = [net.D, net.W, net.multires, net.multires_views, net.use_viewdirs, net.output_ch, net.n_skips]
+        hd[7:23] = list(net.skips)
+        hd[23:27] = [ns, ni, n, ws_rays]
+        with open(str(tmp_path / "in.bin"), "wb") as f:
+            f.write(hd.tobytes())
+            for a in (flat_c, flat_f, torch.linspace(0., 1., ns).numpy(), torch.linspace(0., 1., ni).numpy(), ro, rd, cot,
+                      np.array([near, far], np.float32)):
+                f.write(np.ascontiguousarray(a, np.float32).tobytes())
+        r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+        print(r.stdout.strip())
+        got = np.fromfile(str(tmp_path / "out.bin"), np.float32)
+        off = 0
+        for key, width in (("rgb_map", 3), ("disp_map", 1), ("acc_map", 1), ("rgb0", 3), ("disp0", 1), ("acc0", 1), ("z_std", 1)):
+            assert np.array_equal(got[off:off + width * n], cpu(want[key]).reshape(-1), equal_nan=True), (ws_rays, key)
+            off += width * n
+        assert np.array_equal(got[off:off + 3 * n], cpu(go).reshape(-1)) and np.array_equal(got[off + 3 * n:], cpu(gd).reshape(-1)), ws_rays
+    m.close()
+

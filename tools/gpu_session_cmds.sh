@@ -1,4 +1,3 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session X: the whole GPU suite and smoke on the final tree)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session Y: chunking at scale, the C host of the layered renderer)
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -q -m gpu --durations=5 > $O/gpu_suite.log 2>&1; tail -9 $O/gpu_suite.log
-timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 600 python -m pytest tests/test_gpu_wide.py -q -x -s -k "scale or c_host" 2>&1 | grep -E "chunks|c_host_wide|passed|failed|Error|error|assert" | head -30
