@@ -329,6 +329,7 @@ __global__ void __launch_bounds__(256) kw_embed(const EmbedArgs a) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float relu_nan(float x) { return (x < 0.0f) ? 0.0f : x; }      // F.relu: a NaN density stays NaN (RN:356)
 
 // raw2outputs (RN:343-387), one thread per ray, the reference's operations in its order: dists (last = 1e10) * |d|, sigmoid,
 // alpha = 1 - exp(-relu(sigma + noise) dists), the exclusive transmittance product as torch-CPU's cumprod computes it -- a
@@ -359,7 +360,7 @@ __global__ void __launch_bounds__(256) kw_composite(const CompositeArgs a) {
     dist = dist * nrm;                                                     // RN:361
     float sg = a.sigma[p * a.ld_sigma];
     if (a.noise) sg = sg + a.noise[p];                                     // RN:374
-    const float al = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);                 // RN:356
+    const float al = 1.0f - expf(-relu_nan(sg) * dist);                    // RN:356
     const float w = al * (float)T;                                         // RN:376
     T = T * (double)((1.0f - al) + 1e-10f);
     a.weights[p] = w;
@@ -517,7 +518,7 @@ __global__ void __launch_bounds__(256) kw_composite_bwd(const CompositeBwdArgs a
     dist = dist * nrm;
     float sg = a.sigma[p * a.ld_sigma];
     if (a.noise) sg = sg + a.noise[p];
-    const float al = 1.0f - expf(-fmaxf(sg, 0.0f) * dist);
+    const float al = 1.0f - expf(-relu_nan(sg) * dist);
     al_s[i] = al;
     t_s[i] = (float)T;
     T = T * (double)((1.0f - al) + 1e-10f);
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(256) kw_composite_bwd(const CompositeBwdArgs a
     o[1] = (float)(w * g1 * c1 * (1.0 - c1));
     o[2] = (float)(w * g2 * c2 * (1.0 - c2));
     o[3] = sg > 0.0f ? (float)(d_alpha * (dz * (double)nrm) * e) : 0.0f;
-    dn += d_alpha * (double)fmaxf(sg, 0.0f) * e * dz;                       // d(dz |d|) / d|d| = dz
+    dn += d_alpha * (double)relu_nan(sg) * e * dz;                       // d(dz |d|) / d|d| = dz
   }
   a.gnorm[r] = (float)dn;
 }

@@ -159,6 +159,31 @@ def test_layered_renderer_chunking_at_scale(oracle):
     assert np.isfinite(a[0]).all() and np.isfinite(a[3]).all() and np.abs(a[3]).max() > 0
 
 
+def test_layered_renderer_nan_rays_stay_nan_and_alone(oracle):
+    """A ray with a NaN origin or an infinite direction renders to NaN (pts -> encodings -> every layer -> relu(sigma), F.relu
+    keeps NaN, RN:356 -> alpha -> weights -> pixel, and disp through torch.max, RN:381), as it does in the reference -- and it
+    is the ONLY ray that does: its neighbours in the same GEMM tiles keep their bits."""
+    from neural_sim_nerf_amd.wide import WideModel
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "b")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"].copy(), g["rays_d"].copy()
+    m = WideModel(sd_c, sd_f, n_samples=ns, n_importance=ni)
+    clean = m.render_rays(ro, rd, near, far)
+    ro[5, 1] = np.nan
+    rd[17, 0] = np.inf
+    bad = m.render_rays(ro, rd, near, far)
+    go, gd = m.render_rays_vjp(ro, rd, near, far, g["cot"])
+    ok = np.ones(len(ro), bool)
+    ok[[5, 17]] = False
+    for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "acc0"):
+        a, b = cpu(bad[k]), cpu(clean[k])
+        assert np.isnan(a[~ok]).all(), k
+        assert np.array_equal(a[ok], b[ok], equal_nan=True), k
+    assert np.isnan(cpu(go)[~ok]).all() and np.isfinite(cpu(go)[ok]).all() and np.isfinite(cpu(gd)[ok]).all()
+    m.close()
+
+
 def test_layered_renderer_options(oracle):
     """The per-ray options on the layered renderer (g25 b: two skips, (48, 100) samples): stratified depths, random uniforms,
     density noise, per-ray bounds, given view directions, white background + lindisp -- stage-wise against the oracle on the
