@@ -1,4 +1,6 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session Z: the layered renderer's tests after the relu-NaN change)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session AB: staggered wave priorities in the layered GEMM)
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_wide.py -q -x 2>&1 | tail -15
-timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for p in 0 1 0 1; do
+  echo "== NSRW_GEMM_STAGGER=$p"
+  NSRW_GEMM_STAGGER=$p timeout 300 python tools/bench_wide.py --cases ycbv,w512 --steps 2 --no-grad 2>&1 | grep -v "^{" | cut -c1-330
+done
