@@ -127,6 +127,16 @@ def workspace_cap_bytes(device):
     return min(cap, free // 2)              # (the launch calls need room for 64 rays: WideModel._workspace sees to that)
 
 
+# ONE workspace per (device, stream), shared by every handle that launches there: a handle's launch calls are stream-ordered, so
+# two handles on one stream can never use it at the same time, and the drop-in API's cache of up to eight handles per module
+# (render options x streams) does not multiply a 16 GiB buffer.  release_workspaces() hands the memory back to torch.
+_WORKSPACES = {}
+
+
+def release_workspaces():
+    _WORKSPACES.clear()
+
+
 class WideModel:
     mlp = "layered-fp32"
     variant = 0
@@ -149,7 +159,7 @@ class WideModel:
         self.nf_kernel = n_samples + n_importance
         self.white_bkgd, self.lindisp = bool(white_bkgd), bool(lindisp)
         self.rays_launched = 0
-        self._ws = None
+        self.workspace_bytes = 0
         self._util = None
         cfg = NsrwConfig(self.device.index, n_samples, n_importance, (1 if white_bkgd else 0) | (2 if lindisp else 0))
         h = C.c_void_p()
@@ -199,10 +209,14 @@ class WideModel:
         floor = C.c_size_t()
         check(self.lib.nsrw_workspace_bytes(self.h, 64, 1 if grad else 0, C.byref(floor)))
         want = max(want, int(floor.value))
-        if self._ws is None or self._ws.numel() < want:
-            self._ws = None                                   # release before asking for the larger one
-            self._ws = torch.empty(want, dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
+        ws = _WORKSPACES.get(key)
+        if ws is None or ws.numel() < want:
+            _WORKSPACES.pop(key, None)                        # release before asking for the larger one
+            ws = None
+            ws = _WORKSPACES[key] = torch.empty(want, dtype=torch.uint8, device=self.device)
+        self.workspace_bytes = want                            # what the launch call is told it may use (<= the shared buffer)
+        return ws, want
 
     def _extras(self, extras, n):
         if not extras or all(v is None for v in extras.values()):
@@ -255,9 +269,9 @@ class WideModel:
         self.rays_launched += n
         o, out = self._outs(n, debug)
         ex, keep = self._extras(extras, n)
-        ws = self._workspace(n, False)
+        ws, nbytes = self._workspace(n, False)
         check(self.lib.nsrw_render_rays(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far), C.byref(ex) if ex else None,
-                                        C.byref(out), _dev(ws), ws.numel(), _stream_ptr(self.device)))
+                                        C.byref(out), _dev(ws), nbytes, _stream_ptr(self.device)))
         return o
 
     def render_views(self, c2w, H, W, K, near, far, debug=False):
@@ -288,10 +302,10 @@ class WideModel:
             out = NsrwOut(_dev(fwd["rgb_map"]), _dev(fwd["disp_map"]), _dev(fwd["acc_map"]))
         ex, keep = self._extras(extras, n)
         gv = self._new(n, 3) if (keep and "viewdirs" in keep) else None
-        ws = self._workspace(n, True)
+        ws, nbytes = self._workspace(n, True)
         check(self.lib.nsrw_render_rays_vjp(self.h, _dev(rays_o), _dev(rays_d), n, float(near), float(far),
                                             C.byref(ex) if ex else None, _dev(g), C.byref(out) if out else None, _dev(go), _dev(gd),
-                                            _dev(gv), _dev(ws), ws.numel(), _stream_ptr(self.device)))
+                                            _dev(gv), _dev(ws), nbytes, _stream_ptr(self.device)))
         res = (go, gd) if gv is None else (go, gd, gv)
         return res + (fwd,) if with_forward else res
 
@@ -303,8 +317,8 @@ class WideModel:
         v = self._f32(viewdirs, (-1, 3)) if net.use_viewdirs else None
         ch = 4 if net.use_viewdirs else int(net.output_ch)
         raw = self._new(p.shape[0], ch)
-        ws = self._workspace(max(1, p.shape[0] // max(self.nf_kernel, 1) + 1), False)
-        check(self.lib.nsrw_run_network(self.h, int(net_id), _dev(p), _dev(v), p.shape[0], _dev(raw), _dev(ws), ws.numel(),
+        ws, nbytes = self._workspace(max(1, p.shape[0] // max(self.nf_kernel, 1) + 1), False)
+        check(self.lib.nsrw_run_network(self.h, int(net_id), _dev(p), _dev(v), p.shape[0], _dev(raw), _dev(ws), nbytes,
                                         _stream_ptr(self.device)))
         return raw.reshape(shape + (ch,))
 

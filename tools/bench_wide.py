@@ -92,7 +92,7 @@ def main():
             power = ps.stop() if ps else None
             t = float(np.median(ms[1:]))
             f = flop if what == "forward" else flop + n * (ns + ni) * flop_per_point(sd)     # + the fine pass's transposed GEMMs
-            res[what] = {"ms_per_view": round(t, 2), "chunks": chunks, "workspace_GB": round(m._ws.numel() / 2 ** 30, 2),
+            res[what] = {"ms_per_view": round(t, 2), "chunks": chunks, "workspace_GB": round(m.workspace_bytes / 2 ** 30, 2),
                          "algorithmic_TFLOPs": round(f / t / 1e9, 1), "frac_of_fp32_mfma_peak": round(f / t / 1e9 / PEAK_FP32_MFMA, 3)}
             if power:
                 res[what]["power_and_clock"] = {k: v for k, v in power.items() if k != "source"}
