@@ -1,4 +1,3 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session AD: the whole GPU suite and smoke on the final tree)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r05 session AE: the layered renderer at W = 1024)
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests/ -q -m gpu --durations=5 > $O/gpu_suite.log 2>&1; tail -9 $O/gpu_suite.log
-timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 200 python tools/bench_wide.py --cases w1024 --steps 1 --no-grad 2>&1 | grep -v "^{" | cut -c1-500
