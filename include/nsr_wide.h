@@ -33,7 +33,10 @@ typedef struct NsrwHandle_* nsrw_handle;
 #define NSRW_MAX_SAMPLES 512         /* N_samples, N_importance (torch.sum's first cascade level: oracle/_torch_sum_lastdim) */
 
 enum { NSRW_FLAG_WHITE_BKGD = 1,     /* RN:384-385 */
-       NSRW_FLAG_LINDISP = 2 };      /* RN:443 */
+       NSRW_FLAG_LINDISP = 2,        /* RN:443 */
+       NSRW_FLAG_MLP_BF16X3 = 4 };   /* r06: the layer GEMMs on bf16 MFMAs, every fp32 operand split exactly into three bf16 pieces, six
+                                      * piece products per product, fp32 accumulate (csrc/nsr_wide_b3.inc): fp32-grade results, fp32's
+                                      * exponent range, 2.67x the matrix-pipe rate of the fp32 MFMAs.  Without the flag: fp32 MFMAs. */
 
 typedef struct NsrwConfig {
   int32_t device;
@@ -132,6 +135,11 @@ int nsrw_run_network(nsrw_handle h, int net_id, const float* d_pts, const float*
 
 /* Device time of the last launch call (ms; synchronises on its closing event) and the number of chunks it ran. */
 int nsrw_last_ms(nsrw_handle h, float* ms, int* chunks);
+
+/* libnsr_debug.so (-DNSR_DEBUG_BOUNDS) checks every global / LDS index of this unit's kernels against its extent; a violation is
+ * recorded, not trapped.  built_with_checks: 1 in that build, 0 in the product library; first_bad_line: 0 = clean, else the source
+ * line of the (highest) failed check -- nsr_wide.hip's line, or 100000 + the line of nsr_wide_b3.inc.  Synchronises the device. */
+int nsrw_debug_bounds_status(int* built_with_checks, unsigned* first_bad_line);
 
 #ifdef __cplusplus
 }

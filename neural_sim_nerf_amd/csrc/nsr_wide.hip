@@ -31,6 +31,20 @@ namespace nsrw {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// `make debug` (-DNSR_DEBUG_BOUNDS, libnsr_debug.so): every global / LDS index the kernels of this unit compute is checked against
+// the extent it must stay inside; a violation records (file tag + source line) in a device word -- no trap (that would take the
+// HSA queue down), the evidence is read back by nsrw_debug_bounds_status().  Release build: nothing.
+#ifdef NSR_DEBUG_BOUNDS
+__device__ unsigned g_wide_violation = 0u;
+#define NSRW_CHECK(cond)                                                                             \
+  do {                                                                                               \
+    if (!(cond)) atomicMax(&nsrw::g_wide_violation, (unsigned)(NSRW_FILE_TAG + __LINE__));           \
+  } while (0)
+#else
+#define NSRW_CHECK(cond) do { } while (0)
+#endif
+#define NSRW_FILE_TAG 0            /* nsr_wide.hip: the line itself; nsr_wide_b3.inc: 100000 + line */
+
 // ------------------------------------------------------------------------------------------------------------------------
 // GEMM: C[m][n] = epi( sum_k A[m][k] * Wt[n][k] + bias[n] ), A = [A1 | A2] (two row-major segments: the skip concatenation
 // cat[input_pts, h] RH:105-106 and cat[feature, input_views] RH:113 without materialising them), Wt the packed [Np][K1 + K2]
@@ -107,6 +121,7 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
     tl.n0 = (int)(j % g.n_tiles) * TN;
     long long am = tl.m0 + arow;
     if (am >= g.M) am = g.M - 1;                                 // clamped rows are computed and never stored
+    NSRW_CHECK(am >= 0 && am < g.M && akq + KS / 2 <= KS && tl.n0 + brow < g.n_tiles * TN);
     tl.a1p = g.A1 + am * g.lda1 + akq;
     tl.a2p = g.A2 ? g.A2 + am * g.lda2 + akq : nullptr;
     tl.bp = g.Wt + (long long)(tl.n0 + brow) * ktot + bkq;
@@ -114,6 +129,7 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
   };
   f32x4 ra[AV], rb[BV];
   auto gload = [&](const Tile& tl, int s) {
+    NSRW_CHECK(s >= 0 && s < stages && (s < stages1 || tl.a2p) && bkq + BF <= KS);
     const float* ap = s < stages1 ? tl.a1p + s * KS : tl.a2p + (s - stages1) * KS;
 #pragma unroll
     for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
@@ -122,6 +138,8 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
   };
   auto col = [](int row, int c4) { return SWZ ? 4 * ((c4 >> 2) ^ ((row >> 2) & 3)) : c4; };      // c4: column, a multiple of 4
   auto lstore = [&](int buf) {
+    NSRW_CHECK((buf == 0 || buf == 1) && arow < kTM && brow < TN && col(arow, akq + 4 * (AV - 1)) + 4 <= LD &&
+               col(brow, bkq + 4 * (BV - 1)) + 4 <= LD);
 #pragma unroll
     for (int v = 0; v < AV; ++v) *reinterpret_cast<f32x4*>(&sA[buf][arow][col(arow, akq + 4 * v)]) = ra[v];
 #pragma unroll
@@ -155,6 +173,8 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj)
           fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][col(lrow, sub * 8 + lk)]);
+        NSRW_CHECK(wm * (MI * 32) + (MI - 1) * 32 + lrow < kTM && wn * (NJ * 32) + (NJ - 1) * 32 + lrow < TN &&
+                   col(lrow, sub * 8 + lk) + 4 <= LD);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -200,6 +220,7 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
           if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
           if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
           if (ncol && (full_rows || ro < rows_left)) {
+            NSRW_CHECK(mt + ro < g.M && n < g.ldc && (EPI != kMaskEpi || n < g.ldm));
             if constexpr (EPI == kAccum) v = cb[ro * g.ldc] + v;                 // (narrow outputs only: the encoding's gradient)
             cb[ro * g.ldc] = v;
           }
@@ -211,6 +232,12 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
     cur = nxt;
   }
 }
+
+#undef NSRW_FILE_TAG
+#define NSRW_FILE_TAG 100000
+#include "nsr_wide_b3.inc"
+#undef NSRW_FILE_TAG
+#define NSRW_FILE_TAG 0
 
 // ------------------------------------------------------------------------------------------------------------------------
 // per-ray and per-point stages
@@ -448,6 +475,7 @@ __global__ void __launch_bounds__(256) kw_sample_pdf(const PdfArgs a) {
       if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
     }
     const int below = max(lo - 1, 0), above = min(lo, NC - 1);             // RH:228-229
+    NSRW_CHECK(lo >= 0 && lo <= NC && below >= 0 && above + 1 < a.S0 && below + 1 < a.S0 && NC < a.S0);
     const float c0 = cdf[below], c1 = cdf[above];
     const float b0 = 0.5f * (z[below + 1] + z[below]), b1 = 0.5f * (z[above + 1] + z[above]);     // RN:473
     float denom = c1 - c0;
@@ -485,6 +513,7 @@ __global__ void __launch_bounds__(64) kw_sort(const float* __restrict__ z0, cons
       const bool before = xn ? (!yn || k < i) : (!yn && (y < x || (y == x && k < i)));
       rank += before ? 1 : 0;
     }
+    NSRW_CHECK(rank >= 0 && rank < S);
     zf[r * S + rank] = x;
   }
 }
@@ -678,6 +707,8 @@ inline int pad32(int x) { return (x + 31) / 32 * 32; }
 struct Mat {                 // one packed matrix [Np][K1p + K2p] and its (nullable) bias, as offsets into Net::dW
   size_t w = 0, b = (size_t)-1;
   int Np = 0, K1p = 0, K2p = 0;
+  size_t wb = 0;             // bf16x3 handles: byte offset of the split image [col-block][k16 block][piece][64][8 bf16] in Net::dWb
+  int ncb = 0;               // ... and its col-blocks (Np / 32 rounded up to an even count; the padding holds zero weights)
 };
 
 struct Net {
@@ -686,6 +717,8 @@ struct Net {
   int in_ch = 0, in_v = 0, Ci = 0, Cv = 0, Wp = 0, W2 = 0, W2p = 0, ldfa = 0, raw_ch = 4;
   std::vector<char> skip_in;          // skip_in[i]: layer i takes cat[input_pts, h]  (i - 1 in skips)
   float* dW = nullptr;
+  char* dWb = nullptr;                // bf16x3 handles: the split images of every matrix (nsr_wide_b3.inc)
+  size_t wb_bytes = 0;
   std::vector<Mat> fwd;               // pts_linears
   Mat fa, hv, rgb, out;               // [feature | alpha], views_linears.0, rgb_linear / output_linear
   std::vector<Mat> bwd_h, bwd_e;      // per pts layer: G W_i[:, hidden part] (i >= 1), G W_i[:, encoding part] (layer 0, skip layers)
@@ -728,6 +761,8 @@ struct GemmCfg {
                        // measured 0.75 against 0.665 of the fp32-MFMA peak for 32 / two per CU on an 8 x 512 network
                        // (profiles/r05/extra/layered_gemm_ab.txt); NSRW_GEMM_KS = 32 selects the other (A/B of tools/bench_wide.py)
   int wgs = 4;         // persistent workgroups per CU of the 16-wide-stage kernel (NSRW_GEMM_WGS = 3 | 4)
+  bool b3 = false;     // NSRW_FLAG_MLP_BF16X3: every GEMM on bf16 MFMAs with three-way split operands (kw_gemm_b3)
+  int b3_wm = 4;       // ... 256-column tiles with 256 rows / 512 threads (4) or 128 rows / 256 threads (2: NSRW_B3_WM = 2)
 };
 
 struct Handle {
@@ -756,6 +791,47 @@ size_t pack_bias(std::vector<float>& img, int Np, const float* b, int n_real, in
   img.resize(off + Np, 0.0f);
   for (int n = 0; n < n_real; ++n) img[off + at + n] = b[n];
   return off;
+}
+
+// fp32 -> nearest-even bf16 (bit pattern); the three round-to-nearest pieces of a weight sum to it exactly
+inline uint16_t bf16_rn(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)((u >> 16) | ((u & 0xffffu) ? 0x40u : 0u));      // inf / NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+inline float bf16_f(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// appends the bf16x3 image of the packed fp32 matrix src [Np][Kp] (Kp a multiple of 16): [col-block][k16 block][piece][lane][8],
+// lane l <-> (column 32 cb + l % 32, k = 16 kb + 8 (l / 32) .. + 7): what one LDS-DMA instruction of kw_gemm_b3 moves is one
+// B fragment of v_mfma_f32_32x32x16_bf16.  Returns the byte offset; *ncb = col-blocks, rounded up to an even count.
+size_t pack_b3(std::vector<uint16_t>& imgb, const float* src, int Np, int Kp, int* ncb) {
+  const int cbs = ((Np + 31) / 32 + 1) / 2 * 2, KB = Kp / 16;
+  const size_t off = imgb.size();
+  imgb.resize(off + (size_t)cbs * KB * 3 * 512, 0);
+  for (int cb = 0; cb < cbs; ++cb)
+    for (int kb = 0; kb < KB; ++kb) {
+      uint16_t* blk = imgb.data() + off + ((size_t)cb * KB + kb) * 3 * 512;
+      for (int l = 0; l < 64; ++l) {
+        const int n = 32 * cb + (l & 31);
+        if (n >= Np) continue;
+        for (int e = 0; e < 8; ++e) {
+          const float w = src[(size_t)n * Kp + 16 * kb + 8 * (l >> 5) + e];
+          const uint16_t p0 = bf16_rn(w);
+          const float r1 = w - bf16_f(p0);
+          const uint16_t p1 = bf16_rn(r1);
+          const uint16_t p2 = bf16_rn(r1 - bf16_f(p1));
+          blk[0 * 512 + l * 8 + e] = p0; blk[1 * 512 + l * 8 + e] = p1; blk[2 * 512 + l * 8 + e] = p2;
+        }
+      }
+    }
+  *ncb = cbs;
+  return off * sizeof(uint16_t);
 }
 
 // Chunk workspace: the same carve runs with base = nullptr to size it.
@@ -812,9 +888,65 @@ void launch_gemm(hipStream_t st, unsigned grid, const GemmArgs& g, int epi) {
   }
 }
 
-int gemm(const GemmCfg& cfg, hipStream_t st, const float* dW, const Mat& m, const float* A1, int lda1, const float* A2, int lda2,
+template <int NJ, int WM>
+void launch_gemm_b3(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi) {
+  switch (epi) {
+    case kRelu: hipLaunchKernelGGL((kw_gemm_b3<NJ, kRelu, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    case kMaskEpi: hipLaunchKernelGGL((kw_gemm_b3<NJ, kMaskEpi, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    case kAccum: hipLaunchKernelGGL((kw_gemm_b3<NJ, kAccum, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    default: hipLaunchKernelGGL((kw_gemm_b3<NJ, 0, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+  }
+}
+
+// bf16x3 handles: the N extent is cut into tiles of 256 columns, then one of 128 and one of 64 for what is left (the image is
+// padded to an even number of 32-column blocks with zero weights; columns >= N are never stored)
+int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const float* bias, const float* A1, int lda1,
+            const float* A2, int lda2, float* C, int ldc, int N, long long M, int epi, const float* mask, int ldm) {
+  GemmB3Args g{};
+  g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
+  g.M = M; g.ldc = ldc; g.ldm = ldm;
+  const int KB = (m.K1p + m.K2p) / 16;
+  int cb = 0;
+  auto part = [&](int nj, int tiles) {
+    // 256-row tiles (one 512-thread workgroup per CU) for the 256-column tiles; the narrow remainders keep 128 rows
+    const bool tall = nj >= 2 && cfg.b3_wm == 4;
+    const int tm = tall ? 256 : 128;
+    const long long mblocks = (M + tm - 1) / tm, mgroups = (mblocks + 7) / 8;
+    GemmB3Args t = g;
+    const size_t boff = (size_t)cb * KB * 3072;
+    t.Wb = net.dWb + m.wb + boff;
+    t.wb_bytes = (unsigned)((size_t)m.ncb * KB * 3072 - boff);
+    t.bias = bias ? bias + cb * 32 : nullptr;
+    t.C = C + cb * 32; t.N = N - cb * 32;
+    t.mask = mask ? mask + cb * 32 : nullptr;
+    t.n_tiles = tiles;
+    if (t.N > 0) {
+      const long long all = mgroups * 8 * tiles;
+      const int per_cu = tall ? (nj == 4 ? 1 : 2) : nj == 4 ? 2 : nj == 2 ? 3 : 4;
+      const unsigned grid = (unsigned)std::max<long long>(8, std::min<long long>(all, (long long)cfg.cus * per_cu / 8 * 8));
+      if (tall && nj == 4) launch_gemm_b3<4, 4>(st, grid, t, epi);
+      else if (tall) launch_gemm_b3<2, 4>(st, grid, t, epi);
+      else if (nj == 4) launch_gemm_b3<4, 2>(st, grid, t, epi);
+      else if (nj == 2) launch_gemm_b3<2, 2>(st, grid, t, epi);
+      else launch_gemm_b3<1, 2>(st, grid, t, epi);
+    }
+    cb += tiles * nj * 2;
+  };
+  if (m.ncb / 8) part(4, m.ncb / 8);
+  if ((m.ncb % 8) / 4) part(2, 1);
+  if ((m.ncb % 4) / 2) part(1, 1);
+  return 0;
+}
+
+int gemm(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const float* A1, int lda1, const float* A2, int lda2,
          float* C, int ldc, int N, long long M, int flags, const float* mask = nullptr, int ldm = 0, bool with_bias = true) {
   if (M <= 0) return 0;
+  const float* dW = net.dW;
+  if (cfg.b3) {
+    const int epi_b3 = mask ? kMaskEpi : (flags & kAccum) ? kAccum : (flags & kRelu) ? kRelu : 0;
+    return gemm_b3(cfg, st, net, m, (with_bias && m.b != (size_t)-1) ? dW + m.b : nullptr, A1, lda1, A2, lda2, C, ldc, N, M, epi_b3,
+                   mask, ldm);
+  }
   GemmArgs g{};
   g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
   g.bias = (with_bias && m.b != (size_t)-1) ? dW + m.b : nullptr;
@@ -853,20 +985,20 @@ int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k
   for (int i = 0; i < n.d.D; ++i) {
     float* out = k.H[keep ? i : (i & 1)];
     int rc;
-    if (i == 0) rc = gemm(cfg, st, n.dW, n.fwd[0], k.E, n.Ci, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
-    else if (n.skip_in[i]) rc = gemm(cfg, st, n.dW, n.fwd[i], k.E, n.Ci, h, n.Wp, out, n.Wp, n.Wp, P, kRelu);
-    else rc = gemm(cfg, st, n.dW, n.fwd[i], h, n.Wp, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
+    if (i == 0) rc = gemm(cfg, st, n, n.fwd[0], k.E, n.Ci, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
+    else if (n.skip_in[i]) rc = gemm(cfg, st, n, n.fwd[i], k.E, n.Ci, h, n.Wp, out, n.Wp, n.Wp, P, kRelu);
+    else rc = gemm(cfg, st, n, n.fwd[i], h, n.Wp, nullptr, 0, out, n.Wp, n.Wp, P, kRelu);
     if (rc) return rc;
     h = out;
   }
   if (!n.d.use_viewdirs) {
-    if (gemm(cfg, st, n.dW, n.out, h, n.Wp, nullptr, 0, k.RAW, 32, n.d.output_ch, P, 0)) return 1;
+    if (gemm(cfg, st, n, n.out, h, n.Wp, nullptr, 0, k.RAW, 32, n.d.output_ch, P, 0)) return 1;
     *sigma = k.RAW + 3; *ld_sigma = 32;
     return 0;
   }
-  if (gemm(cfg, st, n.dW, n.fa, h, n.Wp, nullptr, 0, k.FA, n.ldfa, n.ldfa, P, 0)) return 1;
-  if (gemm(cfg, st, n.dW, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
-  if (gemm(cfg, st, n.dW, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, 32, 3, P, 0)) return 1;
+  if (gemm(cfg, st, n, n.fa, h, n.Wp, nullptr, 0, k.FA, n.ldfa, n.ldfa, P, 0)) return 1;
+  if (gemm(cfg, st, n, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
+  if (gemm(cfg, st, n, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, 32, 3, P, 0)) return 1;
   *sigma = k.FA + n.Wp; *ld_sigma = n.ldfa;
   return 0;
 }
@@ -877,21 +1009,21 @@ int net_backward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& 
   float* g2 = k.G1;
   const int D = n.d.D;
   if (n.d.use_viewdirs) {
-    if (gemm(cfg, st, n.dW, n.b_rgb, k.DRAW, 32, nullptr, 0, k.GV, n.W2p, n.W2p, P, 0, k.HV, n.W2p)) return 1;   // (g W_rgb) relu'(views)
-    if (gemm(cfg, st, n.dW, n.b_feat, k.GV, n.W2p, nullptr, 0, g2, n.Wp, n.Wp, P, 0)) return 1;                  // dL/d feature
-    if (gemm(cfg, st, n.dW, n.b_ed, k.GV, n.W2p, nullptr, 0, k.GED, n.Cv, n.Cv, P, 0)) return 1;                 // dL/d direction encoding
-    if (gemm(cfg, st, n.dW, n.b_head, g2, n.Wp, k.DRAW, 32, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;    // feature, alpha -> h_{D-1}
+    if (gemm(cfg, st, n, n.b_rgb, k.DRAW, 32, nullptr, 0, k.GV, n.W2p, n.W2p, P, 0, k.HV, n.W2p)) return 1;   // (g W_rgb) relu'(views)
+    if (gemm(cfg, st, n, n.b_feat, k.GV, n.W2p, nullptr, 0, g2, n.Wp, n.Wp, P, 0)) return 1;                  // dL/d feature
+    if (gemm(cfg, st, n, n.b_ed, k.GV, n.W2p, nullptr, 0, k.GED, n.Cv, n.Cv, P, 0)) return 1;                 // dL/d direction encoding
+    if (gemm(cfg, st, n, n.b_head, g2, n.Wp, k.DRAW, 32, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;    // feature, alpha -> h_{D-1}
   } else {
-    if (gemm(cfg, st, n.dW, n.b_head, k.DRAW, 32, nullptr, 0, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;
+    if (gemm(cfg, st, n, n.b_head, k.DRAW, 32, nullptr, 0, g, n.Wp, n.Wp, P, 0, k.H[D - 1], n.Wp)) return 1;
   }
   bool first_e = true;
   for (int i = D - 1; i >= 0; --i) {          // g = dL/d pre-activation of layer i
     if (i == 0 || n.skip_in[i]) {
-      if (gemm(cfg, st, n.dW, n.bwd_e[i], g, n.Wp, nullptr, 0, k.GEP, n.Ci, n.Ci, P, first_e ? 0 : kAccum)) return 1;
+      if (gemm(cfg, st, n, n.bwd_e[i], g, n.Wp, nullptr, 0, k.GEP, n.Ci, n.Ci, P, first_e ? 0 : kAccum)) return 1;
       first_e = false;
     }
     if (i > 0) {
-      if (gemm(cfg, st, n.dW, n.bwd_h[i], g, n.Wp, nullptr, 0, g2, n.Wp, n.Wp, P, 0, k.H[i - 1], n.Wp)) return 1;
+      if (gemm(cfg, st, n, n.bwd_h[i], g, n.Wp, nullptr, 0, g2, n.Wp, n.Wp, P, 0, k.H[i - 1], n.Wp)) return 1;
       std::swap(g, g2);
     }
   }
@@ -1072,6 +1204,8 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
   }
   if (const char* w = getenv("NSRW_GEMM_WGS")) gc.wgs = atoi(w) == 3 ? 3 : 4;
   if (const char* ks = getenv("NSRW_GEMM_KS")) gc.ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switches of tools/bench_wide.py
+  gc.b3 = (cfg->flags & NSRW_FLAG_MLP_BF16X3) != 0;
+  if (const char* wm = getenv("NSRW_B3_WM")) gc.b3_wm = atoi(wm) == 2 ? 2 : 4;
   Handle* h = new Handle();
   h->cfg = *cfg;
   h->gemm_cfg = gc;
@@ -1091,7 +1225,10 @@ int nsrw_destroy(nsrw_handle hh) {
   Handle* h = reinterpret_cast<Handle*>(hh);
   if (!h) return 0;
   DeviceGuard guard(h->cfg.device);
-  for (Net& n : h->net) if (n.dW) (void)hipFree(n.dW);
+  for (Net& n : h->net) {
+    if (n.dW) (void)hipFree(n.dW);
+    if (n.dWb) (void)hipFree(n.dWb);
+  }
   if (h->d_tab) (void)hipFree(h->d_tab);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1228,12 +1365,36 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
     n.b_head.Np = Wp; n.b_head.K1p = 32;                            // render_rays reads rows 0..3 of output_linear (RN:363-374)
     n.b_head.w = pack(img, Wp, 32, [&](int nn, int kk) { return (nn < W && kk < 4) ? Wo[(size_t)kk * W + nn] : 0.0f; });
   }
+  // bf16x3 handles: every matrix once more as three bf16 pieces in the layout kw_gemm_b3's LDS-DMA reads (6 bytes per weight)
+  std::vector<uint16_t> imgb;
+  if (h->gemm_cfg.b3) {
+    std::vector<Mat*> all;
+    for (Mat& m : n.fwd) all.push_back(&m);
+    for (Mat& m : n.bwd_h) all.push_back(&m);
+    for (Mat& m : n.bwd_e) all.push_back(&m);
+    for (Mat* m : {&n.fa, &n.hv, &n.rgb, &n.out, &n.b_rgb, &n.b_feat, &n.b_ed, &n.b_head}) all.push_back(m);
+    for (Mat* m : all)
+      if (m->Np > 0) m->wb = pack_b3(imgb, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->ncb);
+    if (imgb.size() * sizeof(uint16_t) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the bf16x3 image");
+  }
   NSRW_DEVICE(h);
-  NSRW_HIP(hipMalloc(&n.dW, img.size() * sizeof(float)));
-  hipError_t e = hipMemcpy(n.dW, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(n.dW); return fail(std::string("nsrw_upload_network: ") + hipGetErrorString(e)); }
+  // (every failure path below frees what this call allocated: ADVICE r05)
+  hipError_t e = hipMalloc(&n.dW, img.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMemcpy(n.dW, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess && !imgb.empty()) {
+    n.wb_bytes = imgb.size() * sizeof(uint16_t);
+    e = hipMalloc(&n.dWb, n.wb_bytes);
+    if (e == hipSuccess) e = hipMemcpy(n.dWb, imgb.data(), n.wb_bytes, hipMemcpyHostToDevice);
+  }
   Net& slot = h->net[net_id];
-  if (slot.dW) { NSRW_HIP(hipDeviceSynchronize()); (void)hipFree(slot.dW); }
+  if (e == hipSuccess && (slot.dW || slot.dWb)) e = hipDeviceSynchronize();      // a launch may still read the images being replaced
+  if (e != hipSuccess) {
+    if (n.dW) (void)hipFree(n.dW);
+    if (n.dWb) (void)hipFree(n.dWb);
+    return fail(std::string("nsrw_upload_network: ") + hipGetErrorString(e));
+  }
+  if (slot.dW) (void)hipFree(slot.dW);
+  if (slot.dWb) (void)hipFree(slot.dWb);
   slot = n;
   slot.loaded = true;
   return 0;
@@ -1318,6 +1479,19 @@ int nsrw_run_network(nsrw_handle hh, int net_id, const float* d_pts, const float
   NSRW_HIP(hipEventRecord(h->ev1, st));
   h->timed = true;
   NSRW_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsrw_debug_bounds_status(int* built_with_checks, unsigned* first_bad_line) {
+  if (!built_with_checks || !first_bad_line) return fail("nsrw_debug_bounds_status: null argument");
+  *first_bad_line = 0;
+#ifdef NSR_DEBUG_BOUNDS
+  *built_with_checks = 1;
+  NSRW_HIP(hipDeviceSynchronize());
+  NSRW_HIP(hipMemcpyFromSymbol(first_bad_line, HIP_SYMBOL(nsrw::g_wide_violation), sizeof(unsigned)));
+#else
+  *built_with_checks = 0;
+#endif
   return 0;
 }
 

@@ -56,7 +56,13 @@ SIGNATURES = {
     "nsrw_run_network": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),
     "nsrw_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "nsrw_debug_bounds_status": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
 }
+
+FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_MLP_BF16X3 = 1, 2, 4
+MLPS = ("bf16x3", "fp32")
+
+DEFAULT_MLP = "fp32"
 
 _bound = None
 
@@ -119,12 +125,17 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def workspace_cap_bytes(device):
-    """Upper bound of the workspace a launch call asks torch for: $NSR_WIDE_WORKSPACE_GB, else 16 GiB, and never more than
-    half of what the device has free.  A smaller workspace means more, smaller chunks of rays -- never another result."""
-    cap = int(float(os.environ.get("NSR_WIDE_WORKSPACE_GB", "16")) * (1 << 30))
+def workspace_cap_env():
+    """Upper bound of the workspace a launch call may use: $NSR_WIDE_WORKSPACE_GB, else 16 GiB.  A smaller workspace means more,
+    smaller chunks of rays -- never another result."""
+    return int(float(os.environ.get("NSR_WIDE_WORKSPACE_GB", "16")) * (1 << 30))
+
+
+def workspace_cap_bytes(device, reusable=0):
+    """... and never more than half of what the device has free (`reusable`: bytes of a buffer that is about to be released).
+    Only consulted when the shared workspace has to GROW (WideModel._workspace): one driver query per growth, not per launch."""
     free, _ = torch.cuda.mem_get_info(device)
-    return min(cap, free // 2)              # (the launch calls need room for 64 rays: WideModel._workspace sees to that)
+    return min(workspace_cap_env(), (free + reusable) // 2)
 
 
 # ONE workspace per (device, stream), shared by every handle that launches there: a handle's launch calls are stream-ordered, so
@@ -138,11 +149,18 @@ def release_workspaces():
 
 
 class WideModel:
-    mlp = "layered-fp32"
     variant = 0
     schedule = "layers"
 
-    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=128, white_bkgd=False, lindisp=False, n_samples=64):
+    def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=128, white_bkgd=False, lindisp=False, n_samples=64,
+                 mlp=None):
+        """mlp: the arithmetic of the layer GEMMs -- "bf16x3" (bf16 MFMAs on three-way split fp32 operands, fp32-grade results at
+        2.67x the matrix-pipe rate: csrc/nsr_wide_b3.inc) or "fp32" (fp32 MFMAs, the strict mode); default $NSR_WIDE_MLP, else
+        DEFAULT_MLP."""
+        mlp = mlp or os.environ.get("NSR_WIDE_MLP") or DEFAULT_MLP
+        if mlp not in MLPS:
+            raise ValueError("mlp must be one of %s (got %r)" % (MLPS, mlp))
+        self.mlp = "layered-" + mlp
         if not torch.cuda.is_available():
             raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
         self.lib = load()
@@ -161,7 +179,10 @@ class WideModel:
         self.rays_launched = 0
         self.workspace_bytes = 0
         self._util = None
-        cfg = NsrwConfig(self.device.index, n_samples, n_importance, (1 if white_bkgd else 0) | (2 if lindisp else 0))
+        self._ws_need = {}                                # (rays, grad) -> bytes one chunk of that many rays needs
+        cfg = NsrwConfig(self.device.index, n_samples, n_importance,
+                         (FLAG_WHITE_BKGD if white_bkgd else 0) | (FLAG_LINDISP if lindisp else 0) |
+                         (FLAG_MLP_BF16X3 if mlp == "bf16x3" else 0))
         h = C.c_void_p()
         check(self.lib.nsrw_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -202,21 +223,36 @@ class WideModel:
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
+    def _need(self, n_rays, grad):
+        """bytes one chunk of n_rays rays needs (cached per handle: the bilevel loop asks for the same 512 rays 313 times a pose)"""
+        key = (int(n_rays), bool(grad))
+        v = self._ws_need.get(key)
+        if v is None:
+            need = C.c_size_t()
+            check(self.lib.nsrw_workspace_bytes(self.h, key[0], 1 if grad else 0, C.byref(need)))
+            v = self._ws_need[key] = int(need.value)
+        return v
+
     def _workspace(self, n_rays, grad):
-        need = C.c_size_t()
-        check(self.lib.nsrw_workspace_bytes(self.h, int(n_rays), 1 if grad else 0, C.byref(need)))
-        want = min(int(need.value), workspace_cap_bytes(self.device))
-        floor = C.c_size_t()
-        check(self.lib.nsrw_workspace_bytes(self.h, 64, 1 if grad else 0, C.byref(floor)))
-        want = max(want, int(floor.value))
+        """(shared workspace of this stream, bytes of it the launch call may use).  A buffer that already holds the call's one
+        chunk -- or is as large as the cap allowed when it was made -- is reused without a driver query (the cap used
+        to be recomputed from mem_get_info on every launch, AFTER the workspace itself had shrunk the free memory)."""
+        floor = self._need(64, grad)
+        need = max(min(self._need(n_rays, grad), workspace_cap_env()), floor)
         key = (self.device.index, torch.cuda.current_stream(self.device).cuda_stream)
-        ws = _WORKSPACES.get(key)
-        if ws is None or ws.numel() < want:
-            _WORKSPACES.pop(key, None)                        # release before asking for the larger one
-            ws = None
-            ws = _WORKSPACES[key] = torch.empty(want, dtype=torch.uint8, device=self.device)
-        self.workspace_bytes = want                            # what the launch call is told it may use (<= the shared buffer)
-        return ws, want
+        ws, capped = _WORKSPACES.get(key, (None, False))
+        have = ws.numel() if ws is not None else 0
+        if have < need and not (capped and have >= floor):
+            want = max(min(need, workspace_cap_bytes(self.device, have)), floor)
+            if want > have:
+                _WORKSPACES.pop(key, None)                     # release before asking for the larger one
+                ws = None
+                ws = torch.empty(want, dtype=torch.uint8, device=self.device)
+                have = want
+            _WORKSPACES[key] = (ws, have < need)               # capped: as large as the device allows -- do not ask again
+        use = min(need, have)
+        self.workspace_bytes = use                             # what the launch call is told it may use (<= the shared buffer)
+        return ws, use
 
     def _extras(self, extras, n):
         if not extras or all(v is None for v in extras.values()):
@@ -336,7 +372,13 @@ class WideModel:
         return self.util.ndc_rays_vjp(*a, **k)
 
     def range_status(self):
-        return dict(last_items=0, points=0, rays=0, dropped_items=0)      # fp32 arithmetic: no range to leave
+        return dict(last_items=0, points=0, rays=0, dropped_items=0)      # fp32 / bf16x3 arithmetic: no range to leave
+
+    def debug_bounds_status(self):
+        """(built_with_checks, first_bad_line): see nsrw_debug_bounds_status / `make debug`."""
+        built, line = C.c_int(), C.c_uint()
+        check(self.lib.nsrw_debug_bounds_status(C.byref(built), C.byref(line)))
+        return bool(built.value), int(line.value)
 
     def last_kernel_ms(self):
         """(device ms of the last launch call, chunks of rays it ran)"""

@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--cases", default="ycbv,w512,d10w384,small")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-grad", action="store_true")
+    ap.add_argument("--mlp", default=None, help="bf16x3 | fp32 (default: the library's)")
     a = ap.parse_args()
     K = S.scaled_K(400.0 / a.hw)
     pose = S.sweep_poses(1, seed=0)[0]
@@ -67,7 +68,7 @@ def main():
     for name in a.cases.split(","):
         D, W, L, Lv, skips, ns, ni = CASES[name]
         sd = net_sd(D, W, L, Lv, skips, 1)
-        m = WideModel(sd, sd, n_samples=ns, n_importance=ni)
+        m = WideModel(sd, sd, n_samples=ns, n_importance=ni, mlp=a.mlp)
         n = a.hw * a.hw
         evals = n * (ns + ns + ni)
         flop = evals * flop_per_point(sd)
@@ -75,7 +76,7 @@ def main():
         ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
         cot = torch.randn(n, 3, device=m.device)
         res = {"network": "%d x %d, skips %s, %d + %d samples" % (D, W, skips, ns, ni), "rays": n,
-               "flop_per_point": flop_per_point(sd)}
+               "flop_per_point": flop_per_point(sd), "mlp": m.mlp}
         for what in ("forward",) + (() if a.no_grad else ("forward+input-gradient",)):
             ms = []
             ps = None
@@ -94,6 +95,8 @@ def main():
             f = flop if what == "forward" else flop + n * (ns + ni) * flop_per_point(sd)     # + the fine pass's transposed GEMMs
             res[what] = {"ms_per_view": round(t, 2), "chunks": chunks, "workspace_GB": round(m.workspace_bytes / 2 ** 30, 2),
                          "algorithmic_TFLOPs": round(f / t / 1e9, 1), "frac_of_fp32_mfma_peak": round(f / t / 1e9 / PEAK_FP32_MFMA, 3)}
+            if m.mlp.endswith("bf16x3"):       # six bf16 piece products per product: ceiling 2500 / 6 TFLOP/s of algorithmic work
+                res[what]["issued_frac_of_bf16_peak"] = round(6 * f / t / 1e9 / 2500.0, 3)
             if power:
                 res[what]["power_and_clock"] = {k: v for k, v in power.items() if k != "source"}
             if what == "forward":

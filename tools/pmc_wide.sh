@@ -12,7 +12,7 @@ SETS=("SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
 i=0
 for set in "${SETS[@]}"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -- python $R/tools/bench_wide.py --cases $CASE --hw $HW --steps 1 --no-grad > $O/pmc_$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/pmc_$i -- python $R/tools/bench_wide.py ${MLP:+--mlp $MLP} --cases $CASE --hw $HW --steps 1 --no-grad > $O/pmc_$i.log 2>&1
 done
 python $R/tools/pmc_wide.py $O > $O/pmc_summary.json 2>&1
 cat $O/pmc_summary.json
