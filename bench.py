@@ -249,6 +249,61 @@ def parity_vs_oracle(model, sample):
                       "the oracle's sample_pdf on the kernel's own coarse weights (the bit-exact stage)" % (side, side)}
 
 
+def trained_workload(device, cpu_setting, side=160):
+    """extra_workloads.trained: the end-to-end census on a TRAINED pair of networks -- trained by the
+    reference's own code against an analytic scene (oracle/train_g26.py; stored in tests/golden/g26_trained.npz with the
+    reference's render of them): sparse, saturated densities (sigma of several hundred, three quarters of the samples in empty
+    space), opaque rays whose resampling denominators sit at the 1e-5 switch -- what the synthetic weight family of the main
+    line does not have.  A side x side view of the fixture's camera, every arithmetic of the fused kernels and of the layered
+    renderer against the oracle's render of the same rays (the oracle leg: checker, never the thing shipped)."""
+    path = os.path.join(ROOT, "tests", "golden", "g26_trained.npz")
+    if not os.path.exists(path):
+        return {"error": "tests/golden/g26_trained.npz is missing"}
+    from neural_sim_nerf_amd.wide import WideModel
+    g = np.load(path)
+    sd_c = {k[2:]: np.asarray(g[k], np.float32) for k in g.files if k.startswith("c.")}
+    sd_f = {k[2:]: np.asarray(g[k], np.float32) for k in g.files if k.startswith("f.")}
+    c2w = np.asarray(g["c2w"], np.float32)
+    O = _oracle()
+    if cpu_setting:
+        O.set_backend(cpu_setting[0])
+        if cpu_setting[1]:
+            torch.set_num_threads(cpu_setting[1])
+    t0 = time.perf_counter()
+    ref = O.render(sd_c, sd_f, side, side, S.scaled_K(400.0 / side), c2w=c2w[:3, :4], near=S.YCBV_NEAR, far=S.YCBV_FAR, chunk=4096,
+                   extras=True)
+    dt = time.perf_counter() - t0
+    O.set_backend("numpy")
+    sig = ref["raw"][..., 3]
+    stats = {"sigma_max": round(float(sig.max()), 1), "sigma_share_above_100": round(float((sig > 100).mean()), 4),
+             "sigma_share_not_positive": round(float((sig <= 0).mean()), 4),
+             "rays_acc_between_0.01_and_0.99": round(float(((ref["acc_map"] > 0.01) & (ref["acc_map"] < 0.99)).mean()), 4)}
+    ref = {k: v.reshape((side * side,) + v.shape[2:]) for k, v in ref.items() if k not in ("raw", "weights", "cdf")}
+    ref["sigma0_last"] = ref.pop("raw0")[:, -1, 3].copy()
+    sample = {"ref": ref, "side": side, "c2w": c2w, "nets": (sd_c, sd_f)}
+    out = {"workload": "%dx%d view of the trained pair (g26: %d Adam steps of the reference's render + img2mse on an analytic textured box), "
+                       "64+128 samples, census against the oracle's render (%.1f s on the host)" % (side, side, int(g["train_steps"]), dt),
+           "network": stats}
+
+    def brief(par, model):
+        c = par["census"]
+        return {"rays": c["rays"], "rays_above_tol": c["rays_above_tol"], "unattributed": c["unattributed"],
+                "cliff_rays": c["cliff_rays"], "index_flip_rays": c["index_flip_rays"], "denom_switch_rays": c["denom_switch_rays"],
+                "illconditioned_shift_rays": c["illconditioned_shift_rays"], "psnr_delta_db": par["psnr_delta_db"],
+                "max_abs_rgb": par["max_abs_rgb"], "max_abs_acc": par["max_abs_acc"], "inds_exact": par["inds_exact_match_rate"],
+                "passes": par["passes"], "range_status": model.range_status()}
+    for mlp in MLP_MODES:
+        m = NsrModel(sd_c, sd_f, device=device, mlp=mlp)
+        out[mlp] = brief(parity_vs_oracle(m, sample), m)
+        m.close()
+    for mlp in ("bf16x3", "fp32"):
+        m = WideModel(sd_c, sd_f, device=device, mlp=mlp)
+        out["layered-" + mlp] = brief(parity_vs_oracle(m, sample), m)
+        m.close()
+    out["passes"] = all(v["passes"] and v["unattributed"] == 0 for k, v in out.items() if isinstance(v, dict) and "passes" in v)
+    return out
+
+
 def api_overhead_workload(sd_c, sd_f, device, reps=60):
     """What the drop-in API costs on top of the engine: run_nerf_noscale.render(c2w=...) of a 64x64 view and render(rays=...)
     of a 512-ray patch (the bilevel loop's call pattern, RN:156-168) against the same launches through NsrModel.  Per call
@@ -285,10 +340,22 @@ def api_overhead_workload(sd_c, sd_f, device, reps=60):
         api_patch = timed(lambda: R.render(side, side, K, chunk=32768, rays=patch, **kw))
         eng_patch = timed(lambda: eng.render_rays(patch[0], patch[1], S.YCBV_NEAR, S.YCBV_FAR))
         fp = timed(lambda: nets[0].weights_version())
+        # ... and the same patch through the LAYERED renderer (sample counts no fused kernel is built for: 40 + 72), drop-in
+        # render(rays=...) against WideModel.render_rays = nsrw_render_rays
+        from neural_sim_nerf_amd.wide import WideModel
+        kwl = dict(kw, N_samples=40, N_importance=72)
+        own = lambda net: {k: v.detach() for k, v in net.state_dict().items()}
+        weng = WideModel(own(nets[0]), own(nets[1]), device=device, n_samples=40, n_importance=72)
+        api_lay = timed(lambda: R.render(side, side, K, chunk=32768, rays=patch, **kwl))
+        eng_lay = timed(lambda: weng.render_rays(patch[0], patch[1], S.YCBV_NEAR, S.YCBV_FAR))
+        weng.close()
     eng.close()
     for n in nets:
         n.invalidate()
     return {"workload": "drop-in API vs engine, 64+128 samples, %d calls each, wall clock per call" % reps,
+            "layered_patch_512": {"api": round(api_lay, 4), "engine": round(eng_lay, 4), "overhead_frac": round(api_lay / eng_lay - 1.0, 4),
+                                  "note": "512 rays at 40 + 72 samples through the layered renderer: render(rays=...) vs WideModel.render_rays"},
+            "weights_check": "every call checked; the patch form reads the fingerprint while its render runs (NSR_TRUST_VERSIONS unset)",
             "view_64x64_ms": {"api": round(api_view, 4), "engine": round(eng_view, 4),
                               "overhead_frac": round(api_view / eng_view - 1.0, 4)},
             "patch_512_rays_ms": {"api": round(api_patch, 4), "engine": round(eng_patch, 4),
@@ -333,7 +400,12 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
     from neural_sim_nerf_amd.wide import WideModel
     pose = torch.as_tensor(c2w[:3, :4])
     out = {"workload": "one 400x400 view, 64+128 samples, through nsrw_render_rays (HIP-event ms of the launch call, all chunks)",
-           "kernel": "nsrw::kw_gemm<128, *, 16> (fp32 in, v_mfma_f32_32x32x2_f32, fp32 out)", "peak": PEAK_F32_MFMA_TFLOPS}
+           "kernel": "nsrw::kw_gemm_b3<4, *, 4> (r06, the default: fp32 in HBM, every operand split exactly into three bf16 pieces, six "
+                     "piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 out); fp32: nsrw::kw_gemm<128, *, 16> "
+                     "(v_mfma_f32_32x32x2_f32)",
+           "peak": PEAK_BF16_MFMA_TFLOPS, "peak_note": "dense bf16 MFMA; `frac` = algorithmic FLOP / time / peak, `issued_frac` = 6 x that "
+           "(six bf16 piece products per fp32 product: the ceiling of `frac` is 1/6 = 0.167, i.e. 417 TFLOP/s of algorithmic work); "
+           "`frac_of_fp32_mfma_peak` puts the same algorithmic rate over the 157.3 TFLOP/s the fp32 MFMAs could reach at most"}
 
     def run(model, flop_per_point, launches=2):
         ro, rd = model.get_rays(H, W, S.YCBV_K, pose)
@@ -345,9 +417,15 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
             ms.append(model.last_kernel_ms())
         t = float(np.mean([m[0] for m in ms]))
         flop = H * W * 256 * flop_per_point
-        return o, {"ms_per_view": round(t, 2), "chunks_of_rays": ms[-1][1], "Mray_samples_per_s": round(H * W * 192 / t / 1e3, 2),
-                   "achieved": round(flop / t / 1e9, 1), "unit": "TFLOP/s", "frac": round(flop / t / 1e9 / PEAK_F32_MFMA_TFLOPS, 4)}
-    m = WideModel(sd_c, sd_f, device=device)
+        tf = flop / t / 1e9
+        r = {"ms_per_view": round(t, 2), "chunks_of_rays": ms[-1][1], "Mray_samples_per_s": round(H * W * 192 / t / 1e3, 2),
+             "achieved": round(tf, 1), "unit": "TFLOP/s", "mlp": model.mlp, "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
+        if model.mlp.endswith("bf16x3"):
+            r.update(frac=round(tf / PEAK_BF16_MFMA_TFLOPS, 4), issued_frac=round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4))
+        else:
+            r.update(frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4), peak=PEAK_F32_MFMA_TFLOPS)
+        return o, r
+    m = WideModel(sd_c, sd_f, device=device, mlp="bf16x3")
     o, r = run(m, S.FLOP_PER_POINT)
     a, b = o["rgb_map"], ref["rgb_map"]
     d = (a - b).abs().max(-1)[0]
@@ -355,6 +433,9 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
     r["vs_main_line_kernel_same_view"] = {"psnr_db": round(-10.0 * np.log10(max(mse, 1e-30)), 2), "rays": int(d.numel()),
                                           "rays_rgb_above_1e-4": int((d > 1e-4).sum())}
     out["ycbv_8x256"] = r
+    m.close()
+    m = WideModel(sd_c, sd_f, device=device, mlp="fp32")
+    _, out["ycbv_8x256_strict_fp32"] = run(m, S.FLOP_PER_POINT, launches=1)
     m.close()
     rng = np.random.RandomState(3)
     wide = {}
@@ -364,9 +445,25 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
         bnd = 1.0 / np.sqrt(i_)
         wide[name + ".weight"] = (rng.uniform(-bnd, bnd, (o_, i_)) * (1.13 if name.startswith("pts") else 25.0 if name == "alpha_linear" else 1.0)).astype(np.float32)
         wide[name + ".bias"] = rng.uniform(-bnd, bnd, (o_,)).astype(np.float32)
-    m = WideModel(wide, wide, device=device)
-    _, r = run(m, 2 * sum(v.size for k, v in wide.items() if k.endswith(".weight")))
+    fpp = 2 * sum(v.size for k, v in wide.items() if k.endswith(".weight"))
+    m = WideModel(wide, wide, device=device, mlp="bf16x3")
+    ps = PowerSampler(device)
+    ps.start()
+    _, r = run(m, fpp)
+    r["power_and_clock"] = ps.stop()
     out["wide_8x512"] = r
+    # forward + input gradient (nsrw_render_rays_vjp): + the fine pass's transposed GEMMs
+    ro, rd = m.get_rays(H, W, S.YCBV_K, pose)
+    cot = torch.ones(H * W, 3, device=ro.device)
+    m.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot)
+    m.render_rays_vjp(ro.reshape(-1, 3), rd.reshape(-1, 3), S.YCBV_NEAR, S.YCBV_FAR, cot)
+    t, ch = m.last_kernel_ms()
+    tf = (H * W * (256 + 192) * fpp) / t / 1e9
+    out["wide_8x512_with_input_gradient"] = {"ms_per_view": round(t, 2), "chunks_of_rays": ch, "achieved": round(tf, 1), "unit": "TFLOP/s",
+                                             "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "issued_frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+    m.close()
+    m = WideModel(wide, wide, device=device, mlp="fp32")
+    _, out["wide_8x512_strict_fp32"] = run(m, fpp, launches=1)
     m.close()
     return out
 
@@ -909,6 +1006,9 @@ def main():
             roof.update({"traffic": traffic, "traffic_source": traffic_source, "traffic_note": traffic_note})
             if world == 1 and model.mlp != "fp32":
                 roof["strict_fp32"] = strict_fp32_line(sd_c, sd_f, local, poses[args.warmup])
+                # (r06: also at the top level of the line -- the figure a reader who takes BASELINE configs[1]'s "fp32" literally wants)
+                line["strict_fp32"] = roof["strict_fp32"]
+            line["power_and_clock_over_the_timed_steps"] = power
             line["range_status"] = model.range_status()      # f16x2 range safety net: all zero = nothing left the fp16 range
             line.update({
                 "value": round(rays * SAMPLES_PER_RAY / dt / 1e6, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -946,6 +1046,10 @@ def main():
                     line["extra_workloads"]["layered"] = layered_workload(sd_c, sd_f, poses[args.warmup], local, ref)
                 except Exception as e:                     # noqa: BLE001
                     line["extra_workloads"]["layered"] = {"error": repr(e)}
+                try:
+                    line["extra_workloads"]["trained"] = trained_workload(local, cpu_setting)
+                except Exception as e:                     # noqa: BLE001
+                    line["extra_workloads"]["trained"] = {"error": repr(e)}
                 for mlp in MLP_MODES:
                     if mlp != model.mlp:
                         line["extra_workloads"][mlp] = alt_mlp_workload(mlp, sd_c, sd_f, local, poses[args.warmup], ref,

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define NSR_ABI_VERSION 4
+#define NSR_ABI_VERSION 5       /* r06: + nsr_get_rays_views (nothing else changed since 4) */
 
 /* Fixed architecture of the path (configs/nerf_param_ycbv_general.txt:12-13; NM:1232-1272). */
 #define NSR_N_SAMPLES     64   /* N_samples    (coarse, RN:439)          */
@@ -303,6 +303,10 @@ int nsr_pose_grad(nsr_handle h, const float* d_grad_o, const float* d_grad_d, in
 /* get_rays (RH:156-165): d_rays_o, d_rays_d [H*W,3] for one c2w [3,4]. */
 int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K9,
                  float* d_rays_o, float* d_rays_d, void* stream);
+/* ... for n_views cameras d_c2w [n_views,3,4] in ONE launch: d_rays_o, d_rays_d [n_views*H*W,3], view-major (r06: what the
+ * layered renderer's render(c2w=...) / render_path feed to nsrw_render_rays; the fused kernels generate their rays themselves). */
+int nsr_get_rays_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9,
+                       float* d_rays_o, float* d_rays_d, void* stream);
 
 /* Embedder.embed (RH:18-48, get_embedder RH:51-66 with i_embed = 0): d_x [n,3] -> d_out [n, 3 + 6*multires] in the
  * reference's channel order [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)].  This is the

@@ -7,7 +7,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NSR_LIB_PATH", os.path.join(_HERE, "csrc", "libnsr.so"))   # override: A/B builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 PACKED_FLOATS = 145 * 4096 + 3328
 
 
@@ -77,6 +77,8 @@ SIGNATURES = {
                                 C.c_int, C.c_void_p, C.c_void_p]),
     "nsr_get_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p,
                                C.c_void_p, C.c_void_p]),
+    "nsr_get_rays_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
     "nsr_to8b": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nsr_find_bbox": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),

@@ -4,7 +4,11 @@
 // caller's stream: every scratch buffer they need is allocated by the setup calls (nsr_create, nsr_upload_weights_bwd,
 // nsr_reserve_bbox), they read no environment variables, they leave the calling thread's current device as they found
 // it, and they can be captured into a hipGraph.
+#define NSR_UNIT_F32 1          // this unit: the host API, the stage kernels, the x32 fp32 kernels (nsr_kernels.hip: "Translation units")
 #include "nsr_kernels.hip"
+extern "C" int nsr_unit_bounds_h2(unsigned* line);
+extern "C" int nsr_unit_bounds_b3(unsigned* line);
+extern "C" int nsr_unit_bounds_x16(unsigned* line);
 #include "nsr_handoff.hip"
 #include "nsr_pose.hip"
 
@@ -788,6 +792,19 @@ int nsr_get_rays(nsr_handle h, const float* d_c2w, int H, int W, const double* K
   return 0;
 }
 
+int nsr_get_rays_views(nsr_handle h, const float* d_c2w, int n_views, int H, int W, const double* K9, float* d_rays_o,
+                       float* d_rays_d, void* stream) {
+  if (h && n_views == 0) return 0;
+  if (!h || !d_c2w || !K9 || !d_rays_o || !d_rays_d) return fail("nsr_get_rays_views: null argument");
+  if (H <= 0 || W <= 0 || n_views < 0 || n_views > 65535) return fail("nsr_get_rays_views: bad image geometry / view count");
+  NSR_DEVICE(h);
+  const int n = H * W;
+  hipLaunchKernelGGL(nsr::k_get_rays, dim3((n + 255) / 256, n_views), dim3(256), 0, (hipStream_t)stream, d_c2w, (float)K9[0],
+                     (float)K9[4], (float)K9[2], (float)K9[5], H, W, d_rays_o, d_rays_d);
+  NSR_HIP(hipGetLastError());
+  return 0;
+}
+
 int nsr_ndc_rays(nsr_handle h, const float* d_rays_o, const float* d_rays_d, int64_t n_rays, int H, int W, double focal,
                  double near_, float* d_o_out, float* d_d_out, void* stream) {
   if (h && n_rays == 0) return 0;
@@ -1074,6 +1091,11 @@ int nsr_debug_bounds_status(nsr_handle h, int* built_with_checks, unsigned* firs
   *built_with_checks = 1;
   NSR_HIP(hipDeviceSynchronize());
   NSR_HIP(hipMemcpyFromSymbol(first_bad_line, HIP_SYMBOL(nsr::g_bounds_violation), sizeof(unsigned)));
+  for (auto unit : {nsr_unit_bounds_h2, nsr_unit_bounds_b3, nsr_unit_bounds_x16}) {      // the other units' copies of the word
+    unsigned line = 0;
+    if (unit(&line) != 0) return fail("nsr_debug_bounds_status: reading a unit's violation word failed");
+    if (line > *first_bad_line) *first_bad_line = line;
+  }
 #else
   *built_with_checks = 0;
 #endif

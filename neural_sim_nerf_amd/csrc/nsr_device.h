@@ -53,7 +53,8 @@ __device__ __forceinline__ f32x16 relu16(f32x16 x) { return clamp_bits16(x, 0); 
 // is clamped -- no wild LDS write, the kernel finishes -- and its source line is recorded in a device word that
 // nsr_debug_bounds_status() reads back.  (A trap would take the whole HSA queue down; this keeps the evidence.)
 #ifdef NSR_DEBUG_BOUNDS
-__device__ unsigned g_bounds_violation = 0u;      // first (highest) offending source line, 0 = clean
+static __device__ unsigned g_bounds_violation = 0u;      // first (highest) offending source line, 0 = clean; one copy per
+                                                         // translation unit (nsr_unit_bounds.inc collects them)
 __device__ __forceinline__ long long checked_index(long long i, long long n, unsigned line) {
   if (i < 0 || i >= n) {
     atomicMax(&g_bounds_violation, line);

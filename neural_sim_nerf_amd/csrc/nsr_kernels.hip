@@ -24,6 +24,35 @@
 #include <stdint.h>
 #include "nsr_device.h"
 
+// Translation units (r06).  This file holds the device code of every fused kernel; libnsr.so compiles it FOUR times, each
+// unit DEFINING its own subset of the __global__ kernels and only declaring the others (their host-side launch stubs are
+// ordinary functions, resolved at link time; no device function is called across units, so no relocatable device code):
+//   nsr_api.hip        NSR_UNIT_F32  the host API, the stage kernels, the x32 fp32 kernels (k_render, k_render_vjp, k_run_network)
+//   nsr_fused_h2.hip   NSR_UNIT_H2   the f16x2 kernels (the default arithmetic): k_render_h2*, k_render_vjp_h2*
+//   nsr_fused_b3.hip   NSR_UNIT_B3   the bf16x3 kernels: k_render_b3*, k_render_vjp_b3*
+//   nsr_fused_x16.hip  NSR_UNIT_X16  the x16 fp32 kernels: k_render16, k_render16p, k_render_vjp16, k_render_vjp16p
+// A unit that defines none of the NSR_UNIT_* macros (libnsr_probe.so) gets everything.
+#if !defined(NSR_UNIT_F32) && !defined(NSR_UNIT_H2) && !defined(NSR_UNIT_B3) && !defined(NSR_UNIT_X16)
+#define NSR_UNIT_F32 1
+#define NSR_UNIT_H2 1
+#define NSR_UNIT_B3 1
+#define NSR_UNIT_X16 1
+#endif
+#ifndef NSR_UNIT_F32
+#define NSR_UNIT_F32 0
+#endif
+#ifndef NSR_UNIT_H2
+#define NSR_UNIT_H2 0
+#endif
+#ifndef NSR_UNIT_B3
+#define NSR_UNIT_B3 0
+#endif
+#ifndef NSR_UNIT_X16
+#define NSR_UNIT_X16 0
+#endif
+#define NSR_CAT_(a, b) a##b
+#define NSR_CAT(a, b) NSR_CAT_(a, b)
+
 namespace nsr {
 
 // Opaque copies: the per-item phases of the persistent kernels index LDS and the argument block with expressions that
@@ -976,12 +1005,14 @@ __device__ __forceinline__ void load_aux(char* smem, const RenderArgs& a, int ti
 // (stream-ordered, no host staging buffer to keep alive), and the render kernel reads its fields with scalar
 // loads at the point of use -- by-value kernel arguments were all preloaded into SGPRs and cost 70 more SGPR
 // spills inside the MFMA passes.
+#if NSR_UNIT_F32     // (launched by the API's unit only)
 __global__ void k_set_args(const RenderArgs a, RenderArgs* dst) {
   *dst = a;
   *a.work_counter = 0ull;
   if (a.ovf_stat) a.ovf_stat[0] = 0u;
   if (a.epoch_counter) dst->epoch = *a.epoch_counter = *a.epoch_counter % 4094u + 1u;
 }
+#endif
 
 // Work queue of the x32-structured kernels: the next item (2 rays) of this launch as  item | write mask << 62  (bit r of
 // the mask: ray r of the item is this launch's to write), or -1 when there is none left.  A fallback launch (item_list)
@@ -1290,56 +1321,34 @@ __device__ __forceinline__ void render32_body(const RenderArgs* __restrict__ ap,
 #undef NSR_TPASS
 }
 
-__global__ void __launch_bounds__(256, 1) k_render(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpF32>(ap, smem);
-}
-// the same kernel with the layer GEMMs on bf16 MFMAs, fp32 operands split three ways (nsr_b3.inc)
-__global__ void __launch_bounds__(256, 1) k_render_b3(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpB3>(ap, smem);
-}
-// ... and on fp16 MFMAs, fp32 operands split two ways with power-of-two range management (nsr_h2.inc)
-__global__ void __launch_bounds__(256, 1) k_render_h2(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpH2>(ap, smem);
-}
-// N_importance = 64 / 32 (RN:474), evaluated at their own 64 + 64 / 64 + 32 fine samples per ray: two fine passes per item
-// instead of three.  f16x2 handles, and the bf16x3 kernels their range safety net falls back to (bf16x3 has fp32's exponent
-// range -- no failure domain -- and fp32-grade error, at 1.7x the fp32-MFMA kernels' speed).
-__global__ void __launch_bounds__(256, 1) k_render_h2_n64(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpH2, 64>(ap, smem);
-}
-__global__ void __launch_bounds__(256, 1) k_render_h2_n32(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpH2, 32>(ap, smem);
-}
-__global__ void __launch_bounds__(256, 1) k_render_b3_n64(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpB3, 64>(ap, smem);
-}
-__global__ void __launch_bounds__(256, 1) k_render_b3_n32(const RenderArgs* __restrict__ ap) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render32_body<kMlpB3, 32>(ap, smem);
-}
-
-// r05: the other sample counts of RN:439 / RN:474 the f16x2 handles serve natively (and the bf16x3 kernels their range safety
-// net falls back to): N_importance = 96 (64 + 96 fine samples, three fine passes, the third with two idle waves), N_samples = 32
-// with N_importance = 64 (one coarse pass with two idle waves, two fine passes), N_samples = 128 with N_importance = 128 (two
-// coarse and four fine passes per item, ItemStateBig).
-#define NSR_RENDER_KERNEL(NAME, MODE, NI, NS)                                                        \
+// The x32 forward kernels: one body, three arithmetics (fp32 MFMAs; bf16 MFMAs on three-way split operands, nsr_b3.inc; fp16
+// MFMAs on two-way split operands with power-of-two range management, nsr_h2.inc) and the sample counts with kernels of their
+// own -- N_importance = 64 / 32 / 96 at N_samples = 64 (two or three fine passes per item), N_samples = 32 with N_importance =
+// 64, N_samples = 128 with N_importance = 128 (ItemStateBig): f16x2 handles, and the bf16x3 kernels their range safety net
+// falls back to (fp32's exponent range -- no failure domain -- and fp32-grade error at 1.7x the fp32-MFMA kernels' speed).
+#define NSR_RENDER_KERNEL_1(NAME, ...)                                                               \
   __global__ void __launch_bounds__(256, 1) NAME(const RenderArgs* __restrict__ ap) {                \
     extern __shared__ __attribute__((aligned(16))) char smem[];                                      \
-    render32_body<MODE, NI, NS>(ap, smem);                                                           \
+    render32_body<__VA_ARGS__>(ap, smem);                                                            \
   }
-NSR_RENDER_KERNEL(k_render_h2_n96, kMlpH2, 96, 64)
-NSR_RENDER_KERNEL(k_render_b3_n96, kMlpB3, 96, 64)
-NSR_RENDER_KERNEL(k_render_h2_c32_n64, kMlpH2, 64, 32)
-NSR_RENDER_KERNEL(k_render_b3_c32_n64, kMlpB3, 64, 32)
-NSR_RENDER_KERNEL(k_render_h2_c128_n128, kMlpH2, 128, 128)
-NSR_RENDER_KERNEL(k_render_b3_c128_n128, kMlpB3, 128, 128)
+#define NSR_RENDER_KERNEL_0(NAME, ...) __global__ void __launch_bounds__(256, 1) NAME(const RenderArgs* __restrict__ ap);
+#define NSR_RENDER_KERNEL(UNIT, NAME, ...) NSR_CAT(NSR_RENDER_KERNEL_, UNIT)(NAME, __VA_ARGS__)
+NSR_RENDER_KERNEL(NSR_UNIT_F32, k_render, kMlpF32)
+NSR_RENDER_KERNEL(NSR_UNIT_B3, k_render_b3, kMlpB3)
+NSR_RENDER_KERNEL(NSR_UNIT_H2, k_render_h2, kMlpH2)
+NSR_RENDER_KERNEL(NSR_UNIT_H2, k_render_h2_n64, kMlpH2, 64)
+NSR_RENDER_KERNEL(NSR_UNIT_H2, k_render_h2_n32, kMlpH2, 32)
+NSR_RENDER_KERNEL(NSR_UNIT_B3, k_render_b3_n64, kMlpB3, 64)
+NSR_RENDER_KERNEL(NSR_UNIT_B3, k_render_b3_n32, kMlpB3, 32)
+NSR_RENDER_KERNEL(NSR_UNIT_H2, k_render_h2_n96, kMlpH2, 96, 64)
+NSR_RENDER_KERNEL(NSR_UNIT_B3, k_render_b3_n96, kMlpB3, 96, 64)
+NSR_RENDER_KERNEL(NSR_UNIT_H2, k_render_h2_c32_n64, kMlpH2, 64, 32)
+NSR_RENDER_KERNEL(NSR_UNIT_B3, k_render_b3_c32_n64, kMlpB3, 64, 32)
+NSR_RENDER_KERNEL(NSR_UNIT_H2, k_render_h2_c128_n128, kMlpH2, 128, 128)
+NSR_RENDER_KERNEL(NSR_UNIT_B3, k_render_b3_c128_n128, kMlpB3, 128, 128)
 #undef NSR_RENDER_KERNEL
+#undef NSR_RENDER_KERNEL_0
+#undef NSR_RENDER_KERNEL_1
 
 // ------------------------------------------------------------------------------------------------------
 // Backward (input-side VJP) of one network pass.  Same register-chained scheme with W^T as the A operand:
@@ -1599,12 +1608,14 @@ struct VjpArgs {
   float* dbg_gpts;          // [N,192,6] per sample: dL/d pts, dL/d viewdirs (output of the network backward)
 };
 
+#if NSR_UNIT_F32
 __global__ void k_set_vjp_args(const VjpArgs a, VjpArgs* dst) {
   *dst = a;
   *a.r.work_counter = 0ull;
   if (a.r.ovf_stat) a.r.ovf_stat[0] = 0u;
   if (a.r.epoch_counter) dst->r.epoch = *a.r.epoch_counter = *a.r.epoch_counter % 4094u + 1u;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // Fused forward + input-gradient kernel (render_path_grad, RN:168-178).  Per item (2 rays):
@@ -1867,51 +1878,33 @@ __device__ __forceinline__ void render_vjp32_body(const VjpArgs* __restrict__ vp
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ void __launch_bounds__(256, 1) k_render_vjp(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpF32>(vp, smem);
-}
-// the same kernel with every GEMM, forward and transposed, on bf16 MFMAs with three-way split operands (nsr_b3.inc)
-__global__ void __launch_bounds__(256, 1) k_render_vjp_b3(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpB3>(vp, smem);
-}
-// ... and on fp16 MFMAs with two-way split operands; the gradients are normalised per point (nsr_h2_bwd.inc)
-__global__ void __launch_bounds__(256, 1) k_render_vjp_h2(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpH2>(vp, smem);
-}
-// N_importance = 64 / 32 (see k_render_h2_n64): two fine forward + two backward passes per item instead of three + three
-__global__ void __launch_bounds__(256, 1) k_render_vjp_h2_n64(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpH2, 64>(vp, smem);
-}
-__global__ void __launch_bounds__(256, 1) k_render_vjp_h2_n32(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpH2, 32>(vp, smem);
-}
-__global__ void __launch_bounds__(256, 1) k_render_vjp_b3_n64(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpB3, 64>(vp, smem);
-}
-__global__ void __launch_bounds__(256, 1) k_render_vjp_b3_n32(const VjpArgs* __restrict__ vp) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  render_vjp32_body<kMlpB3, 32>(vp, smem);
-}
-
-#define NSR_VJP_KERNEL(NAME, MODE, NI, NS)                                                           \
+// The x32 input-gradient kernels, same arithmetics and sample counts (two fine forward + two backward passes per item at
+// N_importance = 64 / 32 instead of three + three; f16x2: the gradients are normalised per point, nsr_h2_bwd.inc).
+#define NSR_VJP_KERNEL_1(NAME, ...)                                                                  \
   __global__ void __launch_bounds__(256, 1) NAME(const VjpArgs* __restrict__ vp) {                   \
     extern __shared__ __attribute__((aligned(16))) char smem[];                                      \
-    render_vjp32_body<MODE, NI, NS>(vp, smem);                                                       \
+    render_vjp32_body<__VA_ARGS__>(vp, smem);                                                        \
   }
-NSR_VJP_KERNEL(k_render_vjp_h2_n96, kMlpH2, 96, 64)
-NSR_VJP_KERNEL(k_render_vjp_b3_n96, kMlpB3, 96, 64)
-NSR_VJP_KERNEL(k_render_vjp_h2_c32_n64, kMlpH2, 64, 32)
-NSR_VJP_KERNEL(k_render_vjp_b3_c32_n64, kMlpB3, 64, 32)
-NSR_VJP_KERNEL(k_render_vjp_h2_c128_n128, kMlpH2, 128, 128)
-NSR_VJP_KERNEL(k_render_vjp_b3_c128_n128, kMlpB3, 128, 128)
+#define NSR_VJP_KERNEL_0(NAME, ...) __global__ void __launch_bounds__(256, 1) NAME(const VjpArgs* __restrict__ vp);
+#define NSR_VJP_KERNEL(UNIT, NAME, ...) NSR_CAT(NSR_VJP_KERNEL_, UNIT)(NAME, __VA_ARGS__)
+NSR_VJP_KERNEL(NSR_UNIT_F32, k_render_vjp, kMlpF32)
+NSR_VJP_KERNEL(NSR_UNIT_B3, k_render_vjp_b3, kMlpB3)
+NSR_VJP_KERNEL(NSR_UNIT_H2, k_render_vjp_h2, kMlpH2)
+NSR_VJP_KERNEL(NSR_UNIT_H2, k_render_vjp_h2_n64, kMlpH2, 64)
+NSR_VJP_KERNEL(NSR_UNIT_H2, k_render_vjp_h2_n32, kMlpH2, 32)
+NSR_VJP_KERNEL(NSR_UNIT_B3, k_render_vjp_b3_n64, kMlpB3, 64)
+NSR_VJP_KERNEL(NSR_UNIT_B3, k_render_vjp_b3_n32, kMlpB3, 32)
+NSR_VJP_KERNEL(NSR_UNIT_H2, k_render_vjp_h2_n96, kMlpH2, 96, 64)
+NSR_VJP_KERNEL(NSR_UNIT_B3, k_render_vjp_b3_n96, kMlpB3, 96, 64)
+NSR_VJP_KERNEL(NSR_UNIT_H2, k_render_vjp_h2_c32_n64, kMlpH2, 64, 32)
+NSR_VJP_KERNEL(NSR_UNIT_B3, k_render_vjp_b3_c32_n64, kMlpB3, 64, 32)
+NSR_VJP_KERNEL(NSR_UNIT_H2, k_render_vjp_h2_c128_n128, kMlpH2, 128, 128)
+NSR_VJP_KERNEL(NSR_UNIT_B3, k_render_vjp_b3_c128_n128, kMlpB3, 128, 128)
 #undef NSR_VJP_KERNEL
+#undef NSR_VJP_KERNEL_0
+#undef NSR_VJP_KERNEL_1
 
+#if NSR_UNIT_F32
 // dL/d c2w[3][4] per patch of P consecutive pixels from dL/d rays (rays are linear in c2w, RH:160-164):
 //   g[a][k] = sum_pix grad_d[pix][a] * dirs[pix][k]  (k < 3),  g[a][3] = sum_pix grad_o[pix][a]
 __global__ void __launch_bounds__(256) k_pose_grad(const float* __restrict__ go, const float* __restrict__ gd,
@@ -1943,6 +1936,7 @@ __global__ void __launch_bounds__(256) k_pose_grad(const float* __restrict__ go,
   }
   if (threadIdx.x < 12) out[blockIdx.x * 12 + threadIdx.x] = (float)red[0][threadIdx.x];
 }
+#endif  // NSR_UNIT_F32
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -1972,6 +1966,7 @@ struct ItemState16 {            // one ray; 7520 bytes
   float res[1][8];
 };
 static_assert(kLds16State + sizeof(ItemState16) <= 81920, "two workgroups must fit in the 160 KiB LDS of a CU");
+#if NSR_UNIT_X16     // (the state structs above and below size the launches: every unit sees them; the code is the x16 unit's)
 
 template <int NG>
 struct BRegs4 {    // previous layer's C fragment (16x16x4): k-step t <-> register (t>>2, t&3)
@@ -2729,6 +2724,7 @@ __device__ __forceinline__ void mlp_bwd_pass16(Ring& rg, const float* aux, f32x4
   }
 }
 
+#endif  // NSR_UNIT_X16
 struct ItemStateV16 {           // one ray; the coarse-phase arrays are dead once the samples are sorted and are reused
   float ray[1][16];
   union {
@@ -2743,6 +2739,7 @@ struct ItemStateV16 {           // one ray; the coarse-phase arrays are dead onc
   float res[1][8];
 };
 static_assert(kLds16State + sizeof(ItemStateV16) <= 81920, "two workgroups must fit in the 160 KiB LDS of a CU");
+#if NSR_UNIT_X16
 
 // Backward of raw2outputs (RN:343-387) for the ray of an x16 item, as composite_bwd: dL/d raw written over st.rawf,
 // dL/d|rays_d| in st.gnorm.  st.rawf holds sigmoid(rgb) and the raw sigma, st.alpha / st.wf / st.tf the forward
@@ -3093,6 +3090,14 @@ __global__ void __launch_bounds__(256, 2) k_render_vjp16p(const VjpArgs* __restr
   render_vjp16_body<true>(vp, smem);
 }
 
+#else    // another unit: the x16 kernels are nsr_fused_x16.hip's
+__global__ void __launch_bounds__(256, 2) k_render16(const RenderArgs* __restrict__ ap);
+__global__ void __launch_bounds__(256, 2) k_render16p(const RenderArgs* __restrict__ ap);
+__global__ void __launch_bounds__(256, 2) k_render_vjp16(const VjpArgs* __restrict__ vp);
+__global__ void __launch_bounds__(256, 2) k_render_vjp16p(const VjpArgs* __restrict__ vp);
+#endif  // NSR_UNIT_X16
+
+#if NSR_UNIT_F32     // the stage kernels live in the API's unit
 // ------------------------------------------------------------------------------------------------------
 // run_network (RN:26-40) as a stage kernel: 128 points per workgroup pass.
 // ------------------------------------------------------------------------------------------------------
@@ -3141,9 +3146,10 @@ __global__ void k_get_rays(const float* __restrict__ c2w, float fx, float fy, fl
   const int pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= H * W) return;
   float o[3], d[3];
-  gen_ray(c2w, fx, fy, cx, cy, pix / W, pix % W, o, d);
+  gen_ray(c2w + 12 * blockIdx.y, fx, fy, cx, cy, pix / W, pix % W, o, d);       // blockIdx.y: the view (nsr_get_rays_views)
+  const long long at = ((long long)blockIdx.y * H * W + pix) * 3;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) { rays_o[pix * 3 + c] = o[c]; rays_d[pix * 3 + c] = d[c]; }
+  for (int c = 0; c < 3; ++c) { rays_o[at + c] = o[c]; rays_d[at + c] = d[c]; }
 }
 
 // ndc_rays (RH:168-186) in torch's fp32 op order: the python scalars -1/(W/(2 focal)), -1/(H/(2 focal)), 2 near, -2 near
@@ -3321,5 +3327,7 @@ __global__ void k_selftest(float* out /*[64][16] + [64][16]*/) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
 }
+
+#endif  // NSR_UNIT_F32
 
 }  // namespace nsr

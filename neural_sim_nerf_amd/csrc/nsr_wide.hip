@@ -59,7 +59,7 @@ __device__ unsigned g_wide_violation = 0u;
 //   Workgroup -> tile: blockIdx round-robins over the 8 XCDs (each with its own L2), so the N-tiles of one M-block are
 //   given to ONE XCD back to back: the A tile is read from HBM once and then from that XCD's L2.
 // ------------------------------------------------------------------------------------------------------------------------
-enum { kRelu = 1, kAccum = 2 };
+enum { kRelu = 1, kAccum = 2, kMaskEpi = 4 };
 
 struct GemmArgs {
   const float* A1; const float* A2;
@@ -79,10 +79,13 @@ constexpr int kTM = 128;
 // EPI: the epilogue, a compile-time choice (kRelu, kMaskEpi or kAccum; one of them or none), so that a tile's loads of the mask /
 // the old C values are all in flight before the first of them is needed.  KS: K extent of a stage (32, or 16 for three
 // workgroups per CU instead of two).
-enum { kMaskEpi = 4 };
+
+// workgroups per CU: 4 at KS = 16 (128 registers), except the mask epilogue, whose 16 mask values on top of the 64 accumulators
+// need more (r06: both epilogue forms in one kernel): 3 (168 registers)
+template <int EPI, int KS> constexpr int gemm_wgs_per_cu() { return KS == 16 ? (EPI == kMaskEpi ? 3 : 4) : 2; }
 
 template <int TN, int EPI, int KS>
-__global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs g) {
+__global__ void __launch_bounds__(256, (gemm_wgs_per_cu<EPI, KS>())) kw_gemm(const GemmArgs g) {
   // LDS tile rows: KS = 32: [32 + 4] floats, the padding makes the 16-byte fragment reads and the staging writes conflict-free
   // (measured: 0 conflicts).  KS = 16: [16] floats, no padding -- the four 16-byte chunks of a row are XOR-swizzled with bits
   // 2..3 of the row instead (chunk c of row r sits at c ^ ((r >> 2) & 3)): 16 consecutive rows at one chunk index, the
@@ -192,37 +195,78 @@ __global__ void __launch_bounds__(256, KS == 16 ? 4 : 2) kw_gemm(const GemmArgs 
     const bool more = tn < total;
     if (more) gload(nxt, 0);
 
-    // epilogue: lane owns column n, rows 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32 x 32 tile
-    const bool full_rows = cur.m0 + kTM <= g.M;
+    // epilogue: lane owns column n, rows 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32 x 32 tile.  A tile that lies inside the
+    // matrix takes the predicate-free form, 16 stores per block back to back (r06: per-row predicates put every store into a
+    // conditional block of its own and hipcc waits vmcnt(0) in front of each -- the stores of a tile serialise on the memory
+    // round trip; found on kw_gemm_b3, profiles/r06/extra/ab_wide_w512.txt).
+    const bool inside = cur.m0 + kTM <= g.M && cur.n0 + TN <= g.N;
+    if (inside) {
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      const int n = cur.n0 + wn * (NJ * 32) + jj * 32 + lrow;
-      const bool ncol = n < g.N;
-      const float b = (g.bias && ncol) ? g.bias[n] : 0.0f;
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int n = cur.n0 + wn * (NJ * 32) + jj * 32 + lrow;
+        float b = 0.0f;
+        if (g.bias) b = g.bias[n];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
-        float* cb = g.C + mt * g.ldc + n;
-        const int rows_left = (int)(g.M - mt < 32 ? g.M - mt : 32);             // rows mt + ro with ro < rows_left exist
-        float aux[16];                                                           // the 16 mask values, loaded together
-        if constexpr (EPI == kMaskEpi) {
-          const float* sb = g.mask + mt * g.ldm + n;
+        for (int i = 0; i < MI; ++i) {
+          const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
+          float* cb = g.C + mt * g.ldc + n;
+          NSRW_CHECK(mt + 27 < g.M && n < g.ldc && n < g.N);
+          constexpr int G = EPI == kAccum ? 4 : 16;                            // rows in flight (register pressure of the kAccum form)
+#pragma unroll
+          for (int r0 = 0; r0 < 16; r0 += G) {
+            float aux[G];
+            if constexpr (EPI == kMaskEpi) {
+              const float* sb = g.mask + mt * g.ldm + n;
+#pragma unroll
+              for (int r = 0; r < G; ++r) aux[r] = sb[(8 * ((r0 + r) >> 2) + ((r0 + r) & 3)) * g.ldm];
+            }
+            if constexpr (EPI == kAccum) {
+#pragma unroll
+              for (int r = 0; r < G; ++r) aux[r] = cb[(8 * ((r0 + r) >> 2) + ((r0 + r) & 3)) * g.ldc];
+            }
+#pragma unroll
+            for (int r = 0; r < G; ++r) {
+              float v = acc[i][jj][r0 + r] + b;
+              if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;             // NaN stays NaN, as through torch's relu
+              if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
+              if constexpr (EPI == kAccum) v = aux[r] + v;
+              cb[(8 * ((r0 + r) >> 2) + ((r0 + r) & 3)) * g.ldc] = v;
+            }
+          }
+        }
+      }
+    } else {
+      const bool full_rows = cur.m0 + kTM <= g.M;
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const int n = cur.n0 + wn * (NJ * 32) + jj * 32 + lrow;
+        const bool ncol = n < g.N;
+        const float b = (g.bias && ncol) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
+          float* cb = g.C + mt * g.ldc + n;
+          const int rows_left = (int)(g.M - mt < 32 ? g.M - mt : 32);             // rows mt + ro with ro < rows_left exist
+          float aux[16];                                                           // the 16 mask values, loaded together
+          if constexpr (EPI == kMaskEpi) {
+            const float* sb = g.mask + mt * g.ldm + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ro = 8 * (r >> 2) + (r & 3);
+              aux[r] = (ncol && (full_rows || ro < rows_left)) ? sb[ro * g.ldm] : 0.0f;
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ro = 8 * (r >> 2) + (r & 3);
-            aux[r] = (ncol && (full_rows || ro < rows_left)) ? sb[ro * g.ldm] : 0.0f;
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = 8 * (r >> 2) + (r & 3);
-          float v = acc[i][jj][r] + b;
-          if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
-          if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
-          if (ncol && (full_rows || ro < rows_left)) {
-            NSRW_CHECK(mt + ro < g.M && n < g.ldc && (EPI != kMaskEpi || n < g.ldm));
-            if constexpr (EPI == kAccum) v = cb[ro * g.ldc] + v;                 // (narrow outputs only: the encoding's gradient)
-            cb[ro * g.ldc] = v;
+            float v = acc[i][jj][r] + b;
+            if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
+            if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
+            if (ncol && (full_rows || ro < rows_left)) {
+              NSRW_CHECK(mt + ro < g.M && n < g.ldc && (EPI != kMaskEpi || n < g.ldm));
+              if constexpr (EPI == kAccum) v = cb[ro * g.ldc] + v;                 // (narrow outputs only: the encoding's gradient)
+              cb[ro * g.ldc] = v;
+            }
           }
         }
       }
@@ -962,7 +1006,7 @@ int gemm(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const
   if (full) {
     g.Wt = dW + m.w; g.n_tiles = full;
     const long long tiles = mgroups * 8 * full;
-    if (cfg.ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, cfg.wgs), g, epi);
+    if (cfg.ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, epi == kMaskEpi ? std::min(cfg.wgs, 3) : cfg.wgs), g, epi);
     else launch_gemm<128, 32>(st, grid_for(tiles, 2), g, epi);
   }
   if (rem) {
@@ -1030,6 +1074,13 @@ int net_backward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& 
   return 0;
 }
 
+// the timing events are skipped while the stream is being captured into a hipGraph (an event recorded under capture cannot be
+// waited on by nsrw_last_ms); everything else a launch call does -- kernels, memset / memcpy nodes -- is capturable
+bool capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 int check_common(Handle* h, const float* ro, const float* rd, long long n, const NsrwExtras* ex) {
   if (!h) return fail("nsrw: null handle");
   if (n < 0) return fail("nsrw: n_rays < 0");
@@ -1072,12 +1123,14 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
   if (R == 0) return fail("nsrw: workspace too small for a chunk of 64 rays (nsrw_workspace_bytes)");
   if ((size_t)S1 * sizeof(float) > 64 * 1024) return fail("nsrw: too many samples per ray for the sort kernel");
   h->chunks = 0;
-  NSRW_HIP(hipEventRecord(h->ev0, st));
+  const bool cap = capturing(st);
+  if (!cap) NSRW_HIP(hipEventRecord(h->ev0, st));
   for (long long r0 = 0; r0 < n; r0 += R) {
     const int Rc = (int)std::min<long long>(R, n - r0);
     Carve c(ws);
     Chunk k;
     carve_chunk(*h, R, grad, c, k);
+    if (c.off > ws_bytes) return fail("nsrw: internal error: the chunk's carve exceeds the workspace");      // (chunk_rays sized it)
     const unsigned rb = (Rc + 255) / 256;
     RayArgs ra{};
     ra.rays_o = ro + r0 * 3; ra.rays_d = rd + r0 * 3;
@@ -1168,8 +1221,8 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
     }
     ++h->chunks;
   }
-  NSRW_HIP(hipEventRecord(h->ev1, st));
-  h->timed = true;
+  if (!cap) NSRW_HIP(hipEventRecord(h->ev1, st));
+  h->timed = !cap;
   NSRW_HIP(hipGetLastError());
   return 0;
 }
@@ -1456,7 +1509,8 @@ int nsrw_run_network(nsrw_handle hh, int net_id, const float* d_pts, const float
   k.E = c.f(PB * n.Ci); k.ED = c.f(PB * n.Cv); k.FA = c.f(PB * n.ldfa); k.HV = c.f(PB * n.W2p); k.RAW = c.f(PB * 32);
   k.H = {c.f(PB * n.Wp), c.f(PB * n.Wp)};
   if (c.off > ws_bytes) return fail("nsrw_run_network: workspace too small");
-  NSRW_HIP(hipEventRecord(h->ev0, st));
+  const bool cap = capturing(st);
+  if (!cap) NSRW_HIP(hipEventRecord(h->ev0, st));
   h->chunks = 0;
   for (long long p0 = 0; p0 < n_pts; p0 += PB) {
     const long long P = std::min<long long>(PB, n_pts - p0);
@@ -1476,8 +1530,8 @@ int nsrw_run_network(nsrw_handle hh, int net_id, const float* d_pts, const float
     }
     ++h->chunks;
   }
-  NSRW_HIP(hipEventRecord(h->ev1, st));
-  h->timed = true;
+  if (!cap) NSRW_HIP(hipEventRecord(h->ev1, st));
+  h->timed = !cap;
   NSRW_HIP(hipGetLastError());
   return 0;
 }
@@ -1498,7 +1552,7 @@ int nsrw_debug_bounds_status(int* built_with_checks, unsigned* first_bad_line) {
 int nsrw_last_ms(nsrw_handle hh, float* ms, int* chunks) {
   Handle* h = reinterpret_cast<Handle*>(hh);
   if (!h || !ms) return fail("nsrw_last_ms: null argument");
-  if (!h->timed) return fail("nsrw_last_ms: no launch yet");
+  if (!h->timed) return fail("nsrw_last_ms: no timed launch yet (launches captured into a hipGraph are not timed)");
   NSRW_DEVICE(h);
   NSRW_HIP(hipEventSynchronize(h->ev1));
   NSRW_HIP(hipEventElapsedTime(ms, h->ev0, h->ev1));

@@ -390,6 +390,19 @@ class NsrModel:
                                          _stream_ptr(self.device)))
         return o, d
 
+    def get_rays_views(self, H, W, K, c2w):
+        """get_rays for V cameras c2w [V, >=3, 4] in one launch: (rays_o, rays_d) [V*H*W, 3] each, view-major."""
+        c2w = self._f32(c2w)
+        if c2w.dim() == 2:
+            c2w = c2w[None]
+        c2w = c2w[:, :3, :4].contiguous()
+        V = int(c2w.shape[0])
+        K9 = (C.c_double * 9)(*[float(K[i][j]) for i in range(3) for j in range(3)])
+        o, d = self._new(V * H * W, 3), self._new(V * H * W, 3)
+        _lib.check(self.lib.nsr_get_rays_views(self.h, _dev(c2w), V, int(H), int(W), K9, _dev(o), _dev(d),
+                                               _stream_ptr(self.device)))
+        return o, d
+
     def sample_pose(self, prob, gumbel, uniform, theta, gumbel_T, radius=1.01, want_jac=True):
         """sample_pose (LL:202-247) on the device in torch's fp32 arithmetic: prob [n_cat] (fp32), recorded noise
         (sample_log lists / arrays, fp64) -> (poses [K,4,4], jac [K,12,n_cat] = d c2w[:3,:4] / d prob or None)."""

@@ -51,15 +51,20 @@ def get_embedder(multires, i=0):
 # (load_state_dict, optimizer steps and `p.copy_()` under no_grad all bump the version); on top of that a CONTENT fingerprint,
 # because writes through `.data` (p.data.copy_(), legacy loaders filling weight.data) change neither -- one native kernel
 # over the parameter storage and an 8-byte read-back, ~50 us per call.  NSR_TRUST_VERSIONS (read once, at import):
-#   unset  the r05 default: the fingerprint is taken by the per-VIEW calls -- render(c2w=...), render_path, render_path_grad,
-#          where it is < 0.1 % of a call -- and NOT by render(rays=...), the bilevel loop's 512-ray patch form (RN:168), where
-#          the read-back's host-device sync was 17.5 % of a 0.41 ms call (BENCH_r04.json: api_overhead).  The reference's
-#          loop renders its views (NM:128) before its patches (NM:184) in every outer step, so a `.data` write is still seen
-#          once per step; only a write BETWEEN two patch calls with no view call in between goes unseen until the next one.
-#   "0"    every call takes the fingerprint (the r04 behaviour);   "1"  no call does.
+#   unset    the r06 default: EVERY call is checked.  The per-view calls -- render(c2w=...), render_path, render_path_grad, where
+#            the check is < 0.1 % of a call -- take the fingerprint before they launch.  render(rays=...), the bilevel loop's
+#            512-ray patch form (RN:168), where waiting for the read-back BEFORE the launch was 17.5 % of a 0.41 ms call
+#            (BENCH_r04.json: api_overhead), enqueues fingerprint kernel -> copy to pinned host memory -> the render, and reads the
+#            fingerprint while the render runs: the device never idles, and a mismatch (a write through `.data` since the
+#            weights were packed) discards that render, repacks and renders again before the call returns -- never a stale pixel
+#            (r05's default left the patch form unchecked, so a caller using only render(rays=...) could render
+#            stale weights for ever);
+#   "0"      every call takes the fingerprint before it launches (the r04 behaviour);
+#   "patch"  the patch form is not checked at all (the r05 default);   "1"  no call is.
 _TRUST_ENV = os.environ.get("NSR_TRUST_VERSIONS", "")
 TRUST_VERSIONS = _TRUST_ENV == "1"
-TRUST_PATCH_CALLS = _TRUST_ENV != "0"
+TRUST_PATCH_CALLS = _TRUST_ENV in ("patch", "1")
+DEFER_PATCH_CHECK = _TRUST_ENV == ""
 
 
 class NeRF(nn.Module):
@@ -132,6 +137,36 @@ class NeRF(nn.Module):
             nets[0].__dict__["_fp_pair_state"] = st
         _util_model(dev).fingerprint(st["table"], st["words"], st["out"])
         return ident, (int(st["out"].item()),)
+
+    @staticmethod
+    def fingerprint_begin(*nets):
+        """Enqueue, on the current stream, the content fingerprint of the modules' parameters (the kernel of weights_version_of)
+        and an asynchronous copy of it to pinned host memory.  -> a token for fingerprint_end, or None when the parameters do
+        not all sit contiguously on one HIP device (the caller then checks synchronously)."""
+        nets = [n for n in nets if n is not None]
+        ps = [p for n in nets for p in n.parameters()]
+        if not ps or not all(p.is_cuda and p.device == ps[0].device and p.dtype == torch.float32 and p.is_contiguous() for p in ps):
+            return None
+        from .run_nerf_noscale import _util_model
+        dev = ps[0].device
+        ptrs = tuple(p.data_ptr() for p in ps)
+        st = nets[0].__dict__.get("_fp_async_state")
+        if st is None or st["ptrs"] != ptrs or st["dev"] != dev:
+            st = {"ptrs": ptrs, "dev": dev, "table": torch.tensor(ptrs, dtype=torch.int64, device=dev),
+                  "words": torch.tensor([p.numel() for p in ps], dtype=torch.int64, device=dev),
+                  "out": torch.zeros(1, dtype=torch.int64, device=dev), "host": torch.zeros(1, dtype=torch.int64).pin_memory(),
+                  "event": torch.cuda.Event()}
+            nets[0].__dict__["_fp_async_state"] = st
+        _util_model(dev).fingerprint(st["table"], st["words"], st["out"])
+        st["host"].copy_(st["out"], non_blocking=True)
+        st["event"].record(torch.cuda.current_stream(dev))
+        return st
+
+    @staticmethod
+    def fingerprint_end(token):
+        """The fingerprint fingerprint_begin enqueued (waits for THAT kernel only, not for what was enqueued behind it)."""
+        token["event"].synchronize()
+        return (int(token["host"][0]),)
 
     def weights_version(self):
         """Key of the packed-weight cache: storage identity + autograd version of every parameter (catches

@@ -57,15 +57,15 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     """One native handle per (network_fn, network_fine, render options) tuple, repacked when the parameters change.
     `kw`: the render kwargs, read for white_bkgd / lindisp (RN:384-385, RN:443).
     The cache is keyed on the parameters' storage identity + autograd versions; their CONTENT fingerprint (run_nerf_helpers:
-    NSR_TRUST_VERSIONS) is compared on top of that by every call that takes it -- trust=True (the 512-ray patch form of
-    render(), where its read-back is the API's whole overhead) skips it."""
+    NSR_TRUST_VERSIONS) is compared on top of that by every call that takes it -- trust=True skips it: render() passes that
+    for its 512-ray patch form, whose fingerprint it reads AFTER the launch (deferred check), or not at all when
+    NSR_TRUST_VERSIONS says so."""
     from .engine import NsrModel
-    from .run_nerf_helpers import TRUST_PATCH_CALLS
     if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
         raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
     white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
     n_samples = int((kw or {}).get("N_samples", 64))
-    ident, fp = NeRF.weights_version_of(network_fn, network_fine, trust=trust and TRUST_PATCH_CALLS)
+    ident, fp = NeRF.weights_version_of(network_fn, network_fine, trust=trust)
     forced = network_fn.__dict__.get("_nsr_force_mlp")     # set by _note_range: THESE weights keep leaving f16x2's range
     forced = forced[0] if forced and forced[1] == ident else None
     from .engine import NATIVE_COUNTS
@@ -107,6 +107,7 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
         cache["fp"] = fp
     elif fp != ():
         cache["fp"] = fp
+    cache["model"].weights_fp = cache.get("fp", ())       # what render()'s deferred check of the patch form compares with
     return cache["model"]
 
 
@@ -386,7 +387,7 @@ def _check_retraw(kw, model):
     """retraw wants the reference's [N, N_samples + N_importance, C]: the layered renderer returns exactly that; a fused handle
     does where its kernels evaluate exactly that many fine samples (128; 96 / 64 / 32 and the other native counts on f16x2
     handles) and the network has four output rows -- decided on the handle that will run, not on a guess about it."""
-    if not kw.get("retraw", False) or getattr(model, "mlp", "") == "layered-fp32":
+    if not kw.get("retraw", False) or getattr(model, "mlp", "").startswith("layered-"):
         return
     n_imp = kw.get("N_importance", 0)
     if n_imp not in (0, 128) and getattr(model, "ni_kernel", n_imp) != n_imp:
@@ -410,11 +411,27 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     ndc (RN:101-103), c2w_staticcam (RN:91-96), perturb > 0 (RN:447-459, RH:211) and raw_noise_std > 0 (RN:365-374) go
     through the per-ray extras of the native renderer (include/nsr.h: NsrRayExtras); see _draws for the random stream."""
     _check_viewdirs("render", use_viewdirs, kwargs)
-    per_ray_bounds = not (np.isscalar(near) and np.isscalar(far))          # RN:106-108: near / far may be arrays
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
-    model = _model_for(kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None, n_imp, kwargs,
-                       trust=rays is not None)           # the patch form (RN:168): no fingerprint read-back per call
+    from .run_nerf_helpers import DEFER_PATCH_CHECK, TRUST_PATCH_CALLS
+    net_c, net_f = kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None
+    # the patch form (RN:168): the content fingerprint is enqueued AHEAD of the render and read while the render runs
+    # (run_nerf_helpers: NSR_TRUST_VERSIONS); a mismatch renders again from repacked weights before this call returns
+    token = NeRF.fingerprint_begin(net_c, net_f) if (rays is not None and DEFER_PATCH_CHECK and isinstance(net_c, NeRF)) else None
+    model = _model_for(net_c, net_f, n_imp, kwargs, trust=rays is not None and (token is not None or TRUST_PATCH_CALLS))
+    if token is not None:
+        ret = _render_with(model, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, kwargs)
+        if model.weights_fp not in ((), NeRF.fingerprint_end(token)):       # written through .data since they were packed
+            model = _model_for(net_c, net_f, n_imp, kwargs)
+            ret = _render_with(model, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, kwargs)
+        return ret
+    return _render_with(model, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, kwargs)
+
+
+def _render_with(model, H, W, K, chunk, rays, c2w, ndc, near, far, use_viewdirs, c2w_staticcam, kwargs):
+    """render() on the handle `model` (see there)."""
+    per_ray_bounds = not (np.isscalar(near) and np.isscalar(far))          # RN:106-108: near / far may be arrays
+    n_imp = kwargs.get("N_importance", 0)
     _check_retraw(kwargs, model)
     retraw = bool(kwargs.get("retraw", False))
     fine = n_imp > 0
@@ -499,7 +516,7 @@ def _path_setup(name, hwf, render_factor, render_kwargs, need_fine=False):
     _check_kwargs(kw)
     n_imp = kw.get("N_importance", 0)
     model = _model_for(kw["network_fn"], kw.get("network_fine", None) if n_imp > 0 else None, n_imp, kw)
-    if need_fine and n_imp == 0 and getattr(model, "mlp", "") != "layered-fp32":
+    if need_fine and n_imp == 0 and not getattr(model, "mlp", "").startswith("layered-"):
         raise NotImplementedError("%s needs the coarse+fine configuration (N_importance > 0) on the fused kernels (their "
                                   "input-gradient kernels differentiate the fine pass; NSR_LAYERED=1 serves coarse-only)" % name)
     return H, W, near, far, model, general

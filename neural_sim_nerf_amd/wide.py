@@ -62,7 +62,7 @@ SIGNATURES = {
 FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_MLP_BF16X3 = 1, 2, 4
 MLPS = ("bf16x3", "fp32")
 
-DEFAULT_MLP = "fp32"
+DEFAULT_MLP = "bf16x3"          # r06: same parity bounds as the fp32 MFMAs (tests/test_gpu_wide.py runs every case on both), 1.7x their speed
 
 _bound = None
 
@@ -311,13 +311,9 @@ class WideModel:
         return o
 
     def render_views(self, c2w, H, W, K, near, far, debug=False):
-        """render(c2w=...) for V views: get_rays (RH:156-165) per view on the device, then ONE render_rays call."""
-        c2w = self._f32(c2w)
-        if c2w.dim() == 2:
-            c2w = c2w[None]
-        rays = [self.util.get_rays(int(H), int(W), K, c[:3, :4]) for c in c2w]
-        ro = torch.cat([r[0].reshape(-1, 3) for r in rays], 0)
-        rd = torch.cat([r[1].reshape(-1, 3) for r in rays], 0)
+        """render(c2w=...) for V views: get_rays (RH:156-165) for all of them in ONE launch into one buffer (nsr_get_rays_views;
+        r05 ran a launch per view and concatenated), then ONE render_rays call."""
+        ro, rd = self.util.get_rays_views(int(H), int(W), K, self._f32(c2w))
         return self.render_rays(ro, rd, near, far, debug=debug)
 
     def render_rays_vjp(self, rays_o, rays_d, near, far, grad_rgb, with_forward=False, z_fine=None, extras=None, debug=False):

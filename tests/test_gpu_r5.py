@@ -216,13 +216,16 @@ def test_path_functions_take_the_train_kwargs_like_the_reference(oracle, synth_n
 
 
 def test_weight_changes_reach_the_renderer(synth_nets, oracle):
-    """The packed-weight cache of render() (run_nerf_helpers: NSR_TRUST_VERSIONS, r05 default): storage identity + autograd
+    """The packed-weight cache of render() (run_nerf_helpers: NSR_TRUST_VERSIONS, r06 default): storage identity + autograd
     versions key every call -- a parameter update that bumps the version (optimizer step, load_state_dict, copy_ under
-    no_grad) is seen by the very next call of either form; a write through `.data`, which bumps nothing, is seen by the next
-    per-VIEW call (content fingerprint) and from then on by the 512-ray patch form too (the patch form itself skips the
-    fingerprint's read-back: that was 17.5 % of such a call in r04)."""
+    no_grad) is seen by the very next call of either form -- and so is a write through `.data`, which bumps nothing: per-view
+    calls compare the content fingerprint before they launch, the 512-ray patch form reads it while its render runs and
+    renders again when it differs (a caller that ONLY uses render(rays=...) never got the check in r05).  Also
+    through autograd, and on the layered renderer."""
     import torch
     import neural_sim_nerf_amd.run_nerf_noscale as R
+    import neural_sim_nerf_amd.run_nerf_helpers as RHm
+    assert RHm.DEFER_PATCH_CHECK and not RHm.TRUST_PATCH_CALLS and not RHm.TRUST_VERSIONS       # (the suite runs with the default)
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     K = oracle.scaled_K(50.0)
     nets = []
@@ -235,21 +238,39 @@ def test_weight_changes_reach_the_renderer(synth_nets, oracle):
     pose = torch.tensor(np.asarray(oracle.sweep_poses(1, seed=3))[0][:3, :4])
     ro, rd = oracle.get_rays(8, 8, K, pose.numpy())
     rays = torch.stack([torch.from_numpy(ro.reshape(-1, 3)), torch.from_numpy(rd.reshape(-1, 3))], 0)
-    with torch.no_grad():
-        patch = lambda: cpu(R.render(8, 8, K, rays=rays, **kw)[0])
-        view = lambda: cpu(R.render(8, 8, K, c2w=pose, **kw)[0]).reshape(-1, 3)
-        a = patch()
-        assert np.array_equal(a, view()) and np.array_equal(a, patch())
-        m0 = R._model_for(nets[0], nets[1], 128, kw)
-        # (1) a versioned update: the patch form sees it at once
-        nets[1].rgb_linear.bias.add_(0.25)
-        b = patch()
-        assert np.abs(b - a).max() > 1e-3 and R._model_for(nets[0], nets[1], 128, kw) is not m0
-        assert np.array_equal(b, view())
-        # (2) a write through .data: no version moves; the next view call finds it by content, then the patch form has it too
-        nets[1].rgb_linear.bias.data.add_(-0.25)
-        c = view()
-        assert np.abs(c - a).max() < 1e-6 and np.array_equal(patch(), c)
+    for kwx in (kw, dict(kw, N_samples=40, N_importance=72)):                    # the fused kernels, the layered renderer
+        with torch.no_grad():
+            patch = lambda: cpu(R.render(8, 8, K, rays=rays, **kwx)[0])
+            view = lambda: cpu(R.render(8, 8, K, c2w=pose, **kwx)[0]).reshape(-1, 3)
+            a = patch()
+            assert np.array_equal(a, view()) and np.array_equal(a, patch())
+            m0 = R._model_for(nets[0], nets[1], kwx["N_importance"], kwx)
+            # (1) a versioned update: the patch form sees it at once
+            nets[1].rgb_linear.bias.add_(0.25)
+            b = patch()
+            assert np.abs(b - a).max() > 1e-3 and R._model_for(nets[0], nets[1], kwx["N_importance"], kwx) is not m0
+            assert np.array_equal(b, view())
+            # (2) a write through .data: no version moves; the very next PATCH call finds it by content (no view call in between)
+            nets[1].rgb_linear.bias.data.add_(-0.25)
+            c = patch()
+            assert np.abs(c - a).max() < 1e-6 and np.array_equal(patch(), c) and np.array_equal(view(), c)
+            # (3) ... and a patch-only caller keeps being checked: another .data write, two patch calls
+            nets[0].alpha_linear.bias.data.add_(0.5)
+            d = patch()
+            assert np.abs(d - c).max() > 1e-4 and np.array_equal(patch(), d)
+            nets[0].alpha_linear.bias.data.add_(-0.5)
+            assert np.array_equal(patch(), c)
+        # (4) the same through autograd: the gradient comes from the repacked weights as well
+        r1 = rays.clone().requires_grad_(True)
+        g1 = torch.autograd.grad(R.render(8, 8, K, rays=r1, **kwx)[0].sum(), r1)[0]
+        saved = nets[1].rgb_linear.weight.data.clone()
+        nets[1].rgb_linear.weight.data.mul_(1.5)
+        r2 = rays.clone().requires_grad_(True)
+        g2 = torch.autograd.grad(R.render(8, 8, K, rays=r2, **kwx)[0].sum(), r2)[0]
+        nets[1].rgb_linear.weight.data.copy_(saved)
+        r3 = rays.clone().requires_grad_(True)
+        g3 = torch.autograd.grad(R.render(8, 8, K, rays=r3, **kwx)[0].sum(), r3)[0]
+        assert (g1 - g2).abs().max() > 1e-6 and torch.equal(g1, g3)
     for n in nets:
         n.invalidate()
 
@@ -426,7 +447,7 @@ def test_dropin_api_takes_the_other_sample_counts(oracle, synth_nets):
         ns, ni = kw2["N_samples"], kw2["N_importance"]
         assert "N_samples=%d" % ns in R._layered_why(nets[0], nets[1], ns, ni)
         got = R.render(400, 400, oracle.YCBV_K, rays=rays, **kw2)
-        assert R._model_for(nets[0], nets[1], ni, kw2).mlp == "layered-fp32"
+        assert R._model_for(nets[0], nets[1], ni, kw2).mlp.startswith("layered-")
         ref = oracle.render_rays(synth_nets[0], synth_nets[1], ro, rd, oracle.normalize_dirs(rd), near, far, n_samples=ns, n_importance=ni)
         d = np.abs(cpu(got[0]) - ref["rgb_map"]).max(-1)
         assert (d > 1e-4).mean() <= 0.1 and oracle.psnr(cpu(got[0]), ref["rgb_map"]) > 50.0, (other, d.max())
