@@ -333,8 +333,8 @@ __global__ void __launch_bounds__(256) kw_ray_setup(const RayArgs a) {
   }
 }
 
-// gamma(x) (RH:18-48): fp64 sincos of the fp32 argument 2^l x (the scaling is exact), rounded once: <= 0.5 ulp from the true
-// value, i.e. inside the reference's own libm error.  sin / cos of inf / NaN are NaN, as in torch.
+// gamma(x) (RH:18-48): sin / cos of the fp32 argument 2^l x (the scaling is exact) by sincos_enc: <= 1 ulp from the true value,
+// i.e. inside the reference's own libm error.  sin / cos of inf / NaN are NaN, as in torch.
 struct EmbedArgs {
   const float* rays_o; const float* rays_d;   // rays form: point (r, s) = o + d z[r][s]  (RN:463, RN:478)
   const float* z; const float* vd;            // [R,S], [R,3]
@@ -344,6 +344,36 @@ struct EmbedArgs {
   float* E; int ldE;                          // [P, Ci]
   float* ED; int ldED;                        // [P, Cv]
 };
+
+// sin and cos of the fp32 argument a for the encodings.  |a| < 2^24 (every scene: 2^14 |x| < 2^24 means |x| < 1024): ONE fp64
+// range reduction -- t = a * 2 / pi has >= 24 spare bits, the split into quadrant and fraction is exact -- and the Cephes
+// single-precision minimax polynomials on [-pi / 4, pi / 4] (1 ulp), as the fused kernels' enc_trig (nsr_kernels.hip); ~30 VALU
+// for the pair where the fp64 library sincos costs several hundred (r06: kw_embed was 2-9 % of a layered render).  Beyond that,
+// and for inf / NaN: the fp64 library routine, rounded once, as before.
+__device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
+  if (!(fabsf(a) < 16777216.0f)) {
+    double sd, cd;
+    sincos((double)a, &sd, &cd);
+    s = (float)sd; c = (float)cd;
+    return;
+  }
+  const double kMagic = 6755399441055744.0;                 // 1.5 * 2^52: t + kMagic holds rint(t) in its low word
+  const double t = (double)a * 0.63661977236758134308;      // a * 2 / pi
+  const double tm = t + kMagic;
+  const int n = __double2loint(tm);
+  const double f = t - (tm - kMagic);                       // [-0.5, 0.5], exact
+  const float r = (float)(f * 1.57079632679489661923);
+  const float z = r * r;
+  float ps = __builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+  ps = __builtin_fmaf(ps, z, -1.6666654611e-1f);
+  ps = __builtin_fmaf(ps * z, r, r);
+  float pc = __builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(pc, z, 4.166664568298827e-2f);
+  pc = __builtin_fmaf(pc * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
+  const float vs = (n & 1) ? pc : ps, vc = (n & 1) ? ps : pc;              // sin(a) = sin(r + n pi/2), cos(a) = sin(r + (n + 1) pi/2)
+  s = __uint_as_float(__float_as_uint(vs) ^ ((unsigned)(n & 2) << 30));
+  c = __uint_as_float(__float_as_uint(vc) ^ ((unsigned)((n + 1) & 2) << 30));
+}
 
 // 16 threads per point: thread q writes x (q = 0), band q - 1 (1 <= q <= L) of the position row, and the same for the direction
 // row -- 6 consecutive floats each, so neighbouring threads fill a row front to back; q = 0 also zeroes the padding columns.
@@ -375,12 +405,7 @@ __global__ void __launch_bounds__(256) kw_embed(const EmbedArgs a) {
   } else if (q <= a.L) {
     const float f = ldexpf(1.0f, q - 1);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      double s, co;
-      sincos((double)(x[c] * f), &s, &co);
-      e[3 + 6 * (q - 1) + c] = (float)s;
-      e[6 + 6 * (q - 1) + c] = (float)co;
-    }
+    for (int c = 0; c < 3; ++c) sincos_enc(x[c] * f, e[3 + 6 * (q - 1) + c], e[6 + 6 * (q - 1) + c]);
   }
   if (a.Lv < 0) return;
   float* ed = a.ED + p * a.ldED;
@@ -390,12 +415,7 @@ __global__ void __launch_bounds__(256) kw_embed(const EmbedArgs a) {
   } else if (q <= a.Lv) {
     const float f = ldexpf(1.0f, q - 1);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      double s, co;
-      sincos((double)(v[c] * f), &s, &co);
-      ed[3 + 6 * (q - 1) + c] = (float)s;
-      ed[6 + 6 * (q - 1) + c] = (float)co;
-    }
+    for (int c = 0; c < 3; ++c) sincos_enc(v[c] * f, ed[3 + 6 * (q - 1) + c], ed[6 + 6 * (q - 1) + c]);
   }
 }
 
@@ -759,12 +779,13 @@ struct Net {
   NsrwNet d{};
   bool loaded = false;
   int in_ch = 0, in_v = 0, Ci = 0, Cv = 0, Wp = 0, W2 = 0, W2p = 0, ldfa = 0, raw_ch = 4;
+  int ldraw = 32;                     // row length of the raw outputs: 4 = [r g b sigma] dense (view directions), else 32
   std::vector<char> skip_in;          // skip_in[i]: layer i takes cat[input_pts, h]  (i - 1 in skips)
   float* dW = nullptr;
   char* dWb = nullptr;                // bf16x3 handles: the split images of every matrix (nsr_wide_b3.inc)
   size_t wb_bytes = 0;
   std::vector<Mat> fwd;               // pts_linears
-  Mat fa, hv, rgb, out;               // [feature | alpha], views_linears.0, rgb_linear / output_linear
+  Mat fa, al, hv, rgb, out;           // feature_linear, alpha_linear, views_linears.0, rgb_linear / output_linear
   std::vector<Mat> bwd_h, bwd_e;      // per pts layer: G W_i[:, hidden part] (i >= 1), G W_i[:, encoding part] (layer 0, skip layers)
   Mat b_rgb, b_feat, b_ed, b_head;
 };
@@ -1040,10 +1061,13 @@ int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k
     *sigma = k.RAW + 3; *ld_sigma = 32;
     return 0;
   }
+  // the raw outputs of a point are FOUR dense floats [r g b sigma] (r06: rows of 32 with 3 + 1 useful values made every per-ray
+  // kernel fetch two 128-byte lines per point): alpha_linear writes column 3, rgb_linear columns 0..2
   if (gemm(cfg, st, n, n.fa, h, n.Wp, nullptr, 0, k.FA, n.ldfa, n.ldfa, P, 0)) return 1;
+  if (gemm(cfg, st, n, n.al, h, n.Wp, nullptr, 0, k.RAW + 3, n.ldraw, 1, P, 0)) return 1;
   if (gemm(cfg, st, n, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
-  if (gemm(cfg, st, n, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, 32, 3, P, 0)) return 1;
-  *sigma = k.FA + n.Wp; *ld_sigma = n.ldfa;
+  if (gemm(cfg, st, n, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, n.ldraw, 3, P, 0)) return 1;
+  *sigma = k.RAW + 3; *ld_sigma = n.ldraw;
   return 0;
 }
 
@@ -1156,7 +1180,7 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
     const bool grad_coarse = grad && NI == 0;
     if (net_forward(h->gemm_cfg, st, n0, k, (long long)Rc * S0, grad_coarse, &sigma, &ld_sigma)) return 1;
     CompositeArgs ca{};
-    ca.R = Rc; ca.S = S0; ca.flags = h->cfg.flags; ca.rgb = k.RAW; ca.ld_rgb = 32; ca.sigma = sigma; ca.ld_sigma = ld_sigma;
+    ca.R = Rc; ca.S = S0; ca.flags = h->cfg.flags; ca.rgb = k.RAW; ca.ld_rgb = n0.ldraw; ca.sigma = sigma; ca.ld_sigma = ld_sigma;
     ca.z = k.z0; ca.nrm = k.nrm; ca.noise = e.d_noise0 ? e.d_noise0 + r0 * S0 : nullptr; ca.weights = k.w0;
     float* rgb0 = NI > 0 ? o.d_rgb0 : o.d_rgb;
     float* disp0 = NI > 0 ? o.d_disp0 : o.d_disp;
@@ -1187,7 +1211,7 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
       encode(n1, k.zf, S1);
       if (net_forward(h->gemm_cfg, st, n1, k, (long long)Rc * S1, grad, &sigma, &ld_sigma)) return 1;
       CompositeArgs cf = ca;
-      cf.S = S1; cf.sigma = sigma; cf.ld_sigma = ld_sigma; cf.z = k.zf; cf.noise = e.d_noise1 ? e.d_noise1 + r0 * S1 : nullptr;
+      cf.S = S1; cf.ld_rgb = n1.ldraw; cf.sigma = sigma; cf.ld_sigma = ld_sigma; cf.z = k.zf; cf.noise = e.d_noise1 ? e.d_noise1 + r0 * S1 : nullptr;
       cf.weights = k.wf;
       cf.rgb_map = o.d_rgb ? o.d_rgb + r0 * 3 : nullptr; cf.disp = o.d_disp ? o.d_disp + r0 : nullptr;
       cf.acc = o.d_acc ? o.d_acc + r0 : nullptr;
@@ -1206,7 +1230,7 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
       const long long P = (long long)Rc * SL;
       NSRW_HIP(hipMemsetAsync(k.DRAW, 0, (size_t)P * 32 * 4, st));
       CompositeBwdArgs cb{};
-      cb.R = Rc; cb.S = SL; cb.flags = h->cfg.flags; cb.rgb = k.RAW; cb.ld_rgb = 32; cb.sigma = sigma; cb.ld_sigma = ld_sigma;
+      cb.R = Rc; cb.S = SL; cb.flags = h->cfg.flags; cb.rgb = k.RAW; cb.ld_rgb = last.ldraw; cb.sigma = sigma; cb.ld_sigma = ld_sigma;
       cb.z = z_last; cb.nrm = k.nrm; cb.noise = noise_last; cb.grad_rgb = grad_rgb + r0 * 3; cb.draw = k.DRAW; cb.gnorm = k.gnorm;
       cb.scr_a = k.scr_a; cb.scr_t = k.scr_t;
       hipLaunchKernelGGL(kw_composite_bwd, dim3(rb), dim3(256), 0, st, cb);
@@ -1313,7 +1337,8 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
   const int D = desc->D, W = desc->W;
   n.in_ch = 3 + 6 * desc->multires; n.in_v = 3 + 6 * desc->multires_views;
   n.Ci = pad32(n.in_ch); n.Cv = desc->use_viewdirs ? pad32(n.in_v) : 32; n.Wp = pad32(W); n.W2 = W / 2; n.W2p = pad32(std::max(n.W2, 1));
-  n.ldfa = n.Wp + 32;
+  n.ldfa = n.Wp;
+  n.ldraw = desc->use_viewdirs ? 4 : 32;
   n.raw_ch = desc->use_viewdirs ? 4 : desc->output_ch;
   n.skip_in.assign(D, 0);
   for (int i = 1; i < D; ++i) n.skip_in[i] = is_skip(*desc, i - 1);
@@ -1376,15 +1401,13 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
   }
   if (desc->use_viewdirs) {
     const int W2 = n.W2, W2p = n.W2p, Cv = n.Cv, in_v = n.in_v;
-    // [feature_linear rows | alpha_linear at row Wp]
-    n.fa.Np = Wp + 32; n.fa.K1p = Wp;
-    n.fa.w = pack(img, Wp + 32, Wp, [&](int nn, int kk) {
-      if (kk >= W) return 0.0f;
-      if (nn < W) return Wf[(size_t)nn * W + kk];
-      return nn == Wp ? Wa[kk] : 0.0f;
-    });
-    n.fa.b = pack_bias(img, Wp + 32, Bf, W);
-    img[n.fa.b + Wp] = Ba[0];
+    // feature_linear, and alpha_linear as a matrix of its own (row 0; its one output column goes to the raw block, net_forward)
+    n.fa.Np = Wp; n.fa.K1p = Wp;
+    n.fa.w = pack(img, Wp, Wp, [&](int nn, int kk) { return (nn < W && kk < W) ? Wf[(size_t)nn * W + kk] : 0.0f; });
+    n.fa.b = pack_bias(img, Wp, Bf, W);
+    n.al.Np = 32; n.al.K1p = Wp;
+    n.al.w = pack(img, 32, Wp, [&](int nn, int kk) { return (nn == 0 && kk < W) ? Wa[kk] : 0.0f; });
+    n.al.b = pack_bias(img, 32, Ba, 1);
     // views_linears.0 on cat[feature, input_views] (RH:113): A1 = FA's feature columns, A2 = direction encoding
     n.hv.Np = W2p; n.hv.K1p = Wp; n.hv.K2p = Cv;
     n.hv.w = pack(img, W2p, Wp + Cv, [&](int nn, int kk) {
@@ -1425,7 +1448,7 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
     for (Mat& m : n.fwd) all.push_back(&m);
     for (Mat& m : n.bwd_h) all.push_back(&m);
     for (Mat& m : n.bwd_e) all.push_back(&m);
-    for (Mat* m : {&n.fa, &n.hv, &n.rgb, &n.out, &n.b_rgb, &n.b_feat, &n.b_ed, &n.b_head}) all.push_back(m);
+    for (Mat* m : {&n.fa, &n.al, &n.hv, &n.rgb, &n.out, &n.b_rgb, &n.b_feat, &n.b_ed, &n.b_head}) all.push_back(m);
     for (Mat* m : all)
       if (m->Np > 0) m->wb = pack_b3(imgb, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->ncb);
     if (imgb.size() * sizeof(uint16_t) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the bf16x3 image");
@@ -1522,9 +1545,8 @@ int nsrw_run_network(nsrw_handle hh, int net_id, const float* d_pts, const float
     const float* sigma; int ld_sigma;
     if (net_forward(h->gemm_cfg, st, n, k, P, false, &sigma, &ld_sigma)) return 1;
     const int C = n.raw_ch;
-    if (n.d.use_viewdirs) {
-      hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P * 3 + 255) / 256)), dim3(256), 0, st, k.RAW, 32, d_raw + p0 * 4, 4, P, 3);
-      hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, sigma, ld_sigma, d_raw + p0 * 4 + 3, 4, P, 1);
+    if (n.d.use_viewdirs) {          // the raw block IS [P, 4] = [r g b sigma]
+      NSRW_HIP(hipMemcpyAsync(d_raw + p0 * 4, k.RAW, (size_t)P * 4 * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {
       hipLaunchKernelGGL(kw_copy_rows, dim3((unsigned)((P * C + 255) / 256)), dim3(256), 0, st, k.RAW, 32, d_raw + p0 * C, C, P, C);
     }

@@ -38,6 +38,13 @@ def synth_nets(oracle):
     return sd_c, oracle.synth_weights(seed + 1000, fine_of=sd_c)
 
 
+def trained_pair(g):
+    """(coarse, fine) state dicts of tests/golden/g26_trained.npz: a pair TRAINED by the reference's own code (oracle/train_g26.py)"""
+    sd_c = {k[2:]: np.asarray(g[k], np.float32) for k in g.files if k.startswith("c.")}
+    sd_f = {k[2:]: np.asarray(g[k], np.float32) for k in g.files if k.startswith("f.")}
+    return sd_c, sd_f
+
+
 def assert_close(a, b, atol=0.0, rtol=0.0, what=""):
     a = np.asarray(a)
     b = np.asarray(b)

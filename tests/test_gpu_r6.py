@@ -1,0 +1,156 @@
+"""GPU tests added in round 6 (run with -m gpu on an MI355X): parity on a TRAINED pair of networks.
+
+Every other fixture uses one synthetic weight family (nn.Linear-uniform init, scaled).  tests/golden/g26_trained.npz holds a
+pair trained by the reference's OWN code on an analytic textured box (oracle/train_g26.py) and the reference's render of it:
+densities of several hundred, four fifths of the samples in empty space, opaque rays whose empty resampling bins sit at the
+1e-5 denominator switch (RH:238-239), hidden activations an order of magnitude beyond the synthetic family's -- what drives the
+three discontinuities of the path and f16x2's range.  tests/test_oracle_golden.py pins the oracle to the reference on it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, census_ref, load_golden, trained_pair
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+KERNELS = ["f16x2", "bf16x3", "fp32", "x32", "layered-bf16x3", "layered-fp32"]
+
+
+def cpu(t):
+    return t.detach().cpu().numpy()
+
+
+def _census_mod():
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+    import census
+    return census
+
+
+def _model(kernel, sd_c, sd_f):
+    if kernel.startswith("layered-"):
+        from neural_sim_nerf_amd.wide import WideModel
+        return WideModel(sd_c, sd_f, mlp=kernel[len("layered-"):])
+    from neural_sim_nerf_amd.engine import NsrModel
+    return NsrModel(sd_c, sd_f, variant=32) if kernel == "x32" else NsrModel(sd_c, sd_f, mlp=kernel)
+
+
+def _rel_rows(a, b):
+    return np.linalg.norm(a - b, axis=1) / (np.linalg.norm(b, axis=1) + 1e-12)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_trained_network_stagewise_census_and_gradient(kernel, oracle):
+    """The 40 x 40 view of g26 on every arithmetic of the fused kernels and of the layered renderer: (1) stage by stage against
+    the oracle on the kernel's own intermediates -- network outputs relative to their size (sigma reaches several hundred),
+    coarse weights 2e-6, cdf -> indices -> samples and the merged depths BIT FOR BIT, pixels 3e-6; (2) END TO END against the
+    reference's own render: every ray beyond 1e-4 attributed (oracle/census.py), PSNR-delta <= 0.1 dB, and the counts printed
+    next to the synthetic family's; (3) the input gradient at the reference's own depths against the reference's autograd;
+    (4) f16x2: how many points left the fp16 range (they are re-rendered on bf16 MFMAs inside the call) and the pack-time
+    head-room of this network."""
+    C = _census_mod()
+    g = load_golden("g26_trained")
+    sd_c, sd_f = trained_pair(g)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = g["K40"].tolist()
+    ro, rd = oracle.get_rays(40, 40, K, g["c2w"][:3, :4])
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    n = len(ro)
+    vd = oracle.normalize_dirs(rd)
+    m = _model(kernel, sd_c, sd_f)
+    r = m.render_views(g["c2w"], 40, 40, K, near, far, debug=True)
+    # ---- (1) stage by stage on the kernel's own intermediates
+    z = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32))
+    raw0 = oracle.run_network(sd_c, (ro[:, None] + rd[:, None] * z[..., None]).astype(np.float32), vd)
+    k_raw0 = cpu(r["raw0"])
+    # fp32-grade: 5e-5 absolute on outputs of order 1 (the synthetic family's bound), relative on the large densities
+    assert_close(k_raw0, raw0, atol=5e-5, rtol=2e-5, what="coarse raw")
+    rgb0, _, acc0, w0, _ = oracle.raw2outputs(k_raw0, z, rd)
+    assert_close(cpu(r["weights0"]), w0, atol=2e-6, what="weights0 | own raw")
+    assert_close(cpu(r["rgb0"]), rgb0, atol=3e-6, what="rgb0 | own raw")
+    z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+    s, inds, _ = oracle.sample_pdf(z_mid, cpu(r["weights0"])[:, 1:-1])
+    assert np.array_equal(cpu(r["inds"]), inds) and np.array_equal(cpu(r["z_samples"]), s)       # bit for bit
+    zf = np.sort(np.concatenate([z, s], -1), -1)
+    assert np.array_equal(cpu(r["z_fine"]), zf)
+    raw = oracle.run_network(sd_f, (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), vd)
+    k_raw = cpu(r["raw"])
+    assert_close(k_raw, raw, atol=5e-5, rtol=2e-5, what="fine raw | own z")
+    rgb, _, acc, _, _ = oracle.raw2outputs(k_raw, zf, rd)
+    assert_close(cpu(r["rgb_map"]), rgb, atol=3e-6, what="rgb | own raw")
+    assert_close(cpu(r["acc_map"]), acc, atol=3e-6, what="acc | own raw")
+    # ---- (2) end to end against the REFERENCE's render of these weights
+    taps = ("rgb_map", "acc_map", "disp_map", "rgb0", "acc0", "raw0", "weights0", "inds", "z_samples", "z_fine", "raw")
+    c = C.census((sd_c, sd_f), ro, rd, near, far, {k: cpu(r[k]) for k in taps}, census_ref(g))
+    inds_eq = float((cpu(r["inds"]) == g["inds"].astype(np.int64)).mean())
+    print("%s on the TRAINED pair vs the reference: %s, inds equal to the reference's end to end: %.6f, max |rgb| %.2e |acc| %.2e"
+          % (kernel, {k: c[k] for k in ("rays", "rays_above_tol", "cliff_rays", "index_flip_rays", "denom_switch_rays",
+                                        "illconditioned_shift_rays", "unattributed", "psnr_delta_db")}, inds_eq,
+             np.abs(cpu(r["rgb_map"]) - g["rgb"]).max(), np.abs(cpu(r["acc_map"]) - g["acc"]).max()))
+    assert C.passes(c) and c["unattributed"] == 0 and c["psnr_delta_db"] <= 0.1, c
+    assert c["rays_above_tol"] <= 0.05 * c["rays"], c
+    assert C.psnr_delta(cpu(r["rgb_map"]), g["rgb"]) <= 0.1
+    assert_close(cpu(r["rgb0"]), g["rgb0"], atol=1e-5, what="coarse image vs the reference")
+    # ---- (3) the input gradient AT the reference's own depths (z_samples is detached, RN:475) against its autograd
+    gro, grd = g["grad_rays_in"]
+    zg = oracle.coarse_z(np.full(len(gro), near, np.float32), np.full(len(gro), far, np.float32))
+    zf_ref = np.sort(np.concatenate([zg, g["grad_z_samples"]], -1), -1)
+    out = m.render_rays_vjp(gro, grd, near, far, g["cot"], z_fine=zf_ref)
+    for a, b, what in ((cpu(out[0]), g["grad_rays"][0], "grad_o"), (cpu(out[1]), g["grad_rays"][1], "grad_d")):
+        e = _rel_rows(a, b)
+        print("%s %s vs the reference's autograd: median %.2e  90 %% %.2e  max %.2e" % (kernel, what, np.median(e), np.percentile(e, 90), e.max()))
+        assert np.isfinite(a).all() and np.percentile(e, 90) < 3e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2, \
+            (what, np.percentile(e, 90), e.max())
+    # ---- (4) the range of f16x2 on a trained network
+    st = m.range_status()
+    if kernel == "f16x2":
+        from neural_sim_nerf_amd import pack
+        for name, sd in (("coarse", sd_c), ("fine", sd_f)):
+            rep = pack.h2_report(sd)
+            rows = rep["layers"] if isinstance(rep, dict) and "layers" in rep else rep
+            print("f16x2 pack-time head-room of the trained %s network (bits, typical / worst case): %s" % (
+                name, [(round(float(x.get("headroom_typical", np.nan)), 1), round(float(x.get("headroom_worst", np.nan)), 1))
+                       for x in rows] if isinstance(rows, (list, tuple)) else rows))
+        print("f16x2 range status on the trained pair (points / rays re-rendered on bf16 MFMAs, dropped):", st)
+        assert st["dropped_items"] == 0
+    else:
+        assert st["points"] == 0 and st["dropped_items"] == 0, st
+    m.close()
+
+
+def test_trained_network_through_the_dropin_api(oracle):
+    """The same pair loaded the way the reference's consumers load a checkpoint (load_state_dict on NeRF modules, RN:296-314)
+    and rendered through render(c2w=...) / render(rays=...) + autograd: the reference's pixels within the end-to-end rule, its
+    gradient direction, no range warning that drops anything."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    C = _census_mod()
+    g = load_golden("g26_trained")
+    sd_c, sd_f = trained_pair(g)
+    nets = []
+    for sd in (sd_c, sd_f):
+        net = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nets.append(net.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64, network_fn=nets[0],
+              use_viewdirs=True, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False, near=oracle.YCBV_NEAR, far=oracle.YCBV_FAR)
+    with torch.no_grad():
+        rgb, disp, acc, ex = R.render(40, 40, g["K40"].tolist(), chunk=512, c2w=torch.from_numpy(g["c2w"][:3, :4]), **kw)
+    d = np.abs(cpu(rgb).reshape(-1, 3) - g["rgb"]).max(-1)
+    print("drop-in render of the trained pair vs the reference: %d of 1600 rays beyond 1e-4, PSNR-delta %.4f dB"
+          % ((d > 1e-4).sum(), C.psnr_delta(cpu(rgb).reshape(-1, 3), g["rgb"])))
+    assert C.psnr_delta(cpu(rgb).reshape(-1, 3), g["rgb"]) <= 0.1 and (d > 1e-4).mean() <= 0.05
+    assert_close(cpu(ex["rgb0"]).reshape(-1, 3), g["rgb0"], atol=1e-5, what="rgb0 vs reference")
+    rays = torch.from_numpy(g["grad_rays_in"]).to(R.device).requires_grad_(True)
+    rgb_p = R.render(40, 40, g["K40"].tolist(), chunk=128, rays=rays, **kw)[0]
+    (gr,) = torch.autograd.grad(rgb_p, rays, grad_outputs=torch.from_numpy(g["cot"]).to(R.device))
+    assert C.psnr_delta(cpu(rgb_p), g["grad_rgb"]) <= 0.1
+    rel = np.linalg.norm(cpu(gr) - g["grad_rays"]) / np.linalg.norm(g["grad_rays"])
+    print("drop-in autograd vs the reference's (own depths on both sides): relative difference %.3e" % rel)
+    assert rel < 0.2          # (the depths are each side's own: a flipped resampling index moves a ray's gradient; direction and size agree)
+    for n_ in nets:
+        n_.invalidate()
