@@ -296,7 +296,7 @@ def trained_workload(device, cpu_setting, side=160):
         m = NsrModel(sd_c, sd_f, device=device, mlp=mlp)
         out[mlp] = brief(parity_vs_oracle(m, sample), m)
         m.close()
-    for mlp in ("bf16x3", "fp32"):
+    for mlp in ("bf16x3", "fp32", "f16x2"):
         m = WideModel(sd_c, sd_f, device=device, mlp=mlp)
         out["layered-" + mlp] = brief(parity_vs_oracle(m, sample), m)
         m.close()

@@ -773,6 +773,8 @@ struct Mat {                 // one packed matrix [Np][K1p + K2p] and its (nulla
   int Np = 0, K1p = 0, K2p = 0;
   size_t wb = 0;             // bf16x3 handles: byte offset of the split image [col-block][k16 block][piece][64][8 bf16] in Net::dWb
   int ncb = 0;               // ... and its col-blocks (Np / 32 rounded up to an even count; the padding holds zero weights)
+  size_t wh = 0;             // f16x2 handles: byte offset of the two-piece fp16 image (same layout, 2 KiB per block) in Net::dWh
+  float cscale = 1.0f;       // ... and 2^-sw, which undoes the image's weight scale in the epilogue
 };
 
 struct Net {
@@ -784,6 +786,8 @@ struct Net {
   float* dW = nullptr;
   char* dWb = nullptr;                // bf16x3 handles: the split images of every matrix (nsr_wide_b3.inc)
   size_t wb_bytes = 0;
+  char* dWh = nullptr;                // f16x2 handles: the scaled two-piece fp16 images of the FORWARD matrices (kw_gemm_h2)
+  size_t wh_bytes = 0;
   std::vector<Mat> fwd;               // pts_linears
   Mat fa, al, hv, rgb, out;           // feature_linear, alpha_linear, views_linears.0, rgb_linear / output_linear
   std::vector<Mat> bwd_h, bwd_e;      // per pts layer: G W_i[:, hidden part] (i >= 1), G W_i[:, encoding part] (layer 0, skip layers)
@@ -828,6 +832,13 @@ struct GemmCfg {
   int wgs = 4;         // persistent workgroups per CU of the 16-wide-stage kernel (NSRW_GEMM_WGS = 3 | 4)
   bool b3 = false;     // NSRW_FLAG_MLP_BF16X3: every GEMM on bf16 MFMAs with three-way split operands (kw_gemm_b3)
   int b3_wm = 4;       // ... 256-column tiles with 256 rows / 512 threads (4) or 128 rows / 256 threads (2: NSRW_B3_WM = 2)
+  // NSRW_FLAG_MLP_F16X2 (b3 is set as well: it is the re-run arithmetic and the backward's).  A forward network pass runs on
+  // kw_gemm_h2 (two fp16 pieces, three products); an activation that leaves fp16's range sets d_range[0], and the same pass
+  // follows on kw_gemm_b3 in launches that return at once unless the flag is set (net_forward).
+  bool h2 = false;
+  unsigned* d_range = nullptr;          // device: [0] flag of the pass in flight, [1] passes run, [2] passes re-run on bf16x3
+  bool use_h2 = false;                  // (per call, net_forward) this chain runs on kw_gemm_h2
+  const unsigned* run_if = nullptr;     // (per call, net_forward) this chain's launches are conditional on *run_if
 };
 
 struct Handle {
@@ -837,6 +848,7 @@ struct Handle {
   float* d_tab = nullptr;           // [n_samples] t, [n_importance] u
   bool tables = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  unsigned* d_range = nullptr;      // GemmCfg::d_range
   bool timed = false;
   int chunks = 0;
 };
@@ -896,6 +908,37 @@ size_t pack_b3(std::vector<uint16_t>& imgb, const float* src, int Np, int Kp, in
       }
     }
   *ncb = cbs;
+  return off * sizeof(uint16_t);
+}
+
+// f16x2: the image of src scaled by 2^sw -- sw the power of two that puts the largest |entry| into [2^14, 2^15), 0 for a zero
+// matrix -- as two round-to-nearest fp16 pieces in pack_b3's layout (2 KiB per (col-block, k16 block)).  *cscale = 2^-sw.
+size_t pack_h2(std::vector<uint16_t>& imgh, const float* src, int Np, int Kp, float* cscale) {
+  const int cbs = ((Np + 31) / 32 + 1) / 2 * 2, KB = Kp / 16;
+  float amax = 0.0f;
+  for (size_t i = 0; i < (size_t)Np * Kp; ++i) if (std::isfinite(src[i])) amax = std::max(amax, std::fabs(src[i]));
+  int sw = 0;
+  if (amax > 0.0f) { int e; (void)std::frexp(amax, &e); sw = 15 - e; }        // amax = f 2^e, f in [0.5, 1): amax 2^sw in [2^14, 2^15)
+  sw = std::max(-100, std::min(100, sw));
+  const float up = std::ldexp(1.0f, sw);
+  *cscale = std::ldexp(1.0f, -sw);
+  const size_t off = imgh.size();
+  imgh.resize(off + (size_t)cbs * KB * 2 * 512, 0);
+  auto bits = [](_Float16 v) { uint16_t u; memcpy(&u, &v, 2); return u; };
+  for (int cb = 0; cb < cbs; ++cb)
+    for (int kb = 0; kb < KB; ++kb) {
+      uint16_t* blk = imgh.data() + off + ((size_t)cb * KB + kb) * 2 * 512;
+      for (int l = 0; l < 64; ++l) {
+        const int n = 32 * cb + (l & 31);
+        if (n >= Np) continue;
+        for (int e = 0; e < 8; ++e) {
+          const float w = src[(size_t)n * Kp + 16 * kb + 8 * (l >> 5) + e] * up;       // exact (a non-finite weight stays non-finite)
+          const _Float16 p0 = (_Float16)w;
+          const _Float16 p1 = (_Float16)(w - (float)p0);
+          blk[0 * 512 + l * 8 + e] = bits(p0); blk[1 * 512 + l * 8 + e] = bits(p1);
+        }
+      }
+    }
   return off * sizeof(uint16_t);
 }
 
@@ -963,6 +1006,12 @@ void launch_gemm_b3(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi)
   }
 }
 
+template <int NJ, int WM>
+void launch_gemm_h2(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi) {      // (forward chains only: no mask / accumulate)
+  if (epi == kRelu) hipLaunchKernelGGL((kw_gemm_h2<NJ, kRelu, WM>), dim3(grid), dim3(128 * WM), 0, st, g);
+  else hipLaunchKernelGGL((kw_gemm_h2<NJ, 0, WM>), dim3(grid), dim3(128 * WM), 0, st, g);
+}
+
 // bf16x3 handles: the N extent is cut into tiles of 256 columns, then one of 128 and one of 64 for what is left (the image is
 // padded to an even number of 32-column blocks with zero weights; columns >= N are never stored)
 int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const float* bias, const float* A1, int lda1,
@@ -970,6 +1019,9 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
   GemmB3Args g{};
   g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
   g.M = M; g.ldc = ldc; g.ldm = ldm;
+  const bool h2 = cfg.use_h2 && (epi == 0 || epi == kRelu);
+  const int kfrag = h2 ? 2048 : 3072;                               // bytes of one (col-block, k16 block) of the image
+  g.cscale = h2 ? m.cscale : 1.0f; g.range_flag = cfg.d_range; g.run_if = cfg.run_if;
   const int KB = (m.K1p + m.K2p) / 16;
   int cb = 0;
   auto part = [&](int nj, int tiles) {
@@ -978,9 +1030,9 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
     const int tm = tall ? 256 : 128;
     const long long mblocks = (M + tm - 1) / tm, mgroups = (mblocks + 7) / 8;
     GemmB3Args t = g;
-    const size_t boff = (size_t)cb * KB * 3072;
-    t.Wb = net.dWb + m.wb + boff;
-    t.wb_bytes = (unsigned)((size_t)m.ncb * KB * 3072 - boff);
+    const size_t boff = (size_t)cb * KB * kfrag;
+    t.Wb = (h2 ? net.dWh + m.wh : net.dWb + m.wb) + boff;
+    t.wb_bytes = (unsigned)((size_t)m.ncb * KB * kfrag - boff);
     t.bias = bias ? bias + cb * 32 : nullptr;
     t.C = C + cb * 32; t.N = N - cb * 32;
     t.mask = mask ? mask + cb * 32 : nullptr;
@@ -989,7 +1041,13 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
       const long long all = mgroups * 8 * tiles;
       const int per_cu = tall ? (nj == 4 ? 1 : 2) : nj == 4 ? 2 : nj == 2 ? 3 : 4;
       const unsigned grid = (unsigned)std::max<long long>(8, std::min<long long>(all, (long long)cfg.cus * per_cu / 8 * 8));
-      if (tall && nj == 4) launch_gemm_b3<4, 4>(st, grid, t, epi);
+      if (h2) {
+        if (tall && nj == 4) launch_gemm_h2<4, 4>(st, grid, t, epi);
+        else if (tall) launch_gemm_h2<2, 4>(st, grid, t, epi);
+        else if (nj == 4) launch_gemm_h2<4, 2>(st, grid, t, epi);
+        else if (nj == 2) launch_gemm_h2<2, 2>(st, grid, t, epi);
+        else launch_gemm_h2<1, 2>(st, grid, t, epi);
+      } else if (tall && nj == 4) launch_gemm_b3<4, 4>(st, grid, t, epi);
       else if (tall) launch_gemm_b3<2, 4>(st, grid, t, epi);
       else if (nj == 4) launch_gemm_b3<4, 2>(st, grid, t, epi);
       else if (nj == 2) launch_gemm_b3<2, 2>(st, grid, t, epi);
@@ -1044,8 +1102,8 @@ int gemm(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const
 
 // RH:99-122 over P points whose encodings are in k.E / k.ED: leaves the rgb logits in k.RAW (ld 32; all output_linear rows
 // without view directions) and the density at sigma / ld_sigma.  keep: every pts layer's activation stays (k.H[i]).
-int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P, bool keep, const float** sigma,
-                int* ld_sigma) {
+int net_forward_chain(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P, bool keep, const float** sigma,
+                      int* ld_sigma) {
   const float* h = nullptr;
   for (int i = 0; i < n.d.D; ++i) {
     float* out = k.H[keep ? i : (i & 1)];
@@ -1068,6 +1126,28 @@ int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k
   if (gemm(cfg, st, n, n.hv, k.FA, n.ldfa, k.ED, n.Cv, k.HV, n.W2p, n.W2p, P, kRelu)) return 1;
   if (gemm(cfg, st, n, n.rgb, k.HV, n.W2p, nullptr, 0, k.RAW, n.ldraw, 3, P, 0)) return 1;
   *sigma = k.RAW + 3; *ld_sigma = n.ldraw;
+  return 0;
+}
+
+// the bookkeeping of one f16x2 network pass: counts it, counts its re-run, clears the flag for the next pass
+__global__ void kw_range_tally(unsigned* r) {
+  if (threadIdx.x == 0) {
+    r[1] += 1u;
+    if (r[0]) { r[2] += 1u; r[0] = 0u; }
+  }
+}
+
+int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P, bool keep, const float** sigma,
+                int* ld_sigma) {
+  if (!cfg.h2 || P <= 0) return net_forward_chain(cfg, st, n, k, P, keep, sigma, ld_sigma);
+  // f16x2: the pass on fp16 MFMAs; then the same pass on bf16x3 in launches that are empty unless an activation left fp16's
+  // range (its inputs -- the encodings -- are untouched, every buffer it writes is written again); then the tally
+  GemmCfg c = cfg;
+  c.use_h2 = true;
+  if (net_forward_chain(c, st, n, k, P, keep, sigma, ld_sigma)) return 1;
+  c.use_h2 = false; c.run_if = cfg.d_range;
+  if (net_forward_chain(c, st, n, k, P, keep, sigma, ld_sigma)) return 1;
+  hipLaunchKernelGGL(kw_range_tally, dim3(1), dim3(64), 0, st, cfg.d_range);
   return 0;
 }
 
@@ -1281,7 +1361,8 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
   }
   if (const char* w = getenv("NSRW_GEMM_WGS")) gc.wgs = atoi(w) == 3 ? 3 : 4;
   if (const char* ks = getenv("NSRW_GEMM_KS")) gc.ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switches of tools/bench_wide.py
-  gc.b3 = (cfg->flags & NSRW_FLAG_MLP_BF16X3) != 0;
+  gc.h2 = (cfg->flags & NSRW_FLAG_MLP_F16X2) != 0;
+  gc.b3 = gc.h2 || (cfg->flags & NSRW_FLAG_MLP_BF16X3) != 0;
   if (const char* wm = getenv("NSRW_B3_WM")) gc.b3_wm = atoi(wm) == 2 ? 2 : 4;
   Handle* h = new Handle();
   h->cfg = *cfg;
@@ -1289,12 +1370,28 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
   DeviceGuard guard(cfg->device);
   if (guard.err != hipSuccess) { delete h; return fail("nsrw_create: hipSetDevice failed"); }
   if (hipMalloc(&h->d_tab, (size_t)(cfg->n_samples + std::max(cfg->n_importance, 1)) * 4) != hipSuccess ||
+      hipMalloc(&h->d_range, 4 * sizeof(unsigned)) != hipSuccess || hipMemset(h->d_range, 0, 4 * sizeof(unsigned)) != hipSuccess ||
       hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
     if (h->d_tab) (void)hipFree(h->d_tab);
+    if (h->d_range) (void)hipFree(h->d_range);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
     delete h;
     return fail("nsrw_create: out of device memory");
   }
+  h->gemm_cfg.d_range = h->d_range;
   *out = reinterpret_cast<nsrw_handle>(h);
+  return 0;
+}
+
+int nsrw_range_status(nsrw_handle hh, unsigned long long* passes, unsigned long long* passes_rerun) {
+  Handle* h = reinterpret_cast<Handle*>(hh);
+  if (!h) return fail("nsrw_range_status: null handle");
+  NSRW_DEVICE(h);
+  unsigned r[4] = {0, 0, 0, 0};
+  NSRW_HIP(hipDeviceSynchronize());
+  NSRW_HIP(hipMemcpy(r, h->d_range, sizeof r, hipMemcpyDeviceToHost));
+  if (passes) *passes = r[1];
+  if (passes_rerun) *passes_rerun = r[2];
   return 0;
 }
 
@@ -1305,8 +1402,10 @@ int nsrw_destroy(nsrw_handle hh) {
   for (Net& n : h->net) {
     if (n.dW) (void)hipFree(n.dW);
     if (n.dWb) (void)hipFree(n.dWb);
+    if (n.dWh) (void)hipFree(n.dWh);
   }
   if (h->d_tab) (void)hipFree(h->d_tab);
+  if (h->d_range) (void)hipFree(h->d_range);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   delete h;
@@ -1453,6 +1552,15 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
       if (m->Np > 0) m->wb = pack_b3(imgb, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->ncb);
     if (imgb.size() * sizeof(uint16_t) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the bf16x3 image");
   }
+  // f16x2 handles: the forward matrices also as scaled two-piece fp16 images (4 bytes per weight) for kw_gemm_h2
+  std::vector<uint16_t> imgh;
+  if (h->gemm_cfg.h2) {
+    std::vector<Mat*> fw;
+    for (Mat& m : n.fwd) fw.push_back(&m);
+    for (Mat* m : {&n.fa, &n.al, &n.hv, &n.rgb, &n.out}) fw.push_back(m);
+    for (Mat* m : fw)
+      if (m->Np > 0) m->wh = pack_h2(imgh, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->cscale);
+  }
   NSRW_DEVICE(h);
   // (every failure path below frees what this call allocated: ADVICE r05)
   hipError_t e = hipMalloc(&n.dW, img.size() * sizeof(float));
@@ -1462,15 +1570,22 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
     e = hipMalloc(&n.dWb, n.wb_bytes);
     if (e == hipSuccess) e = hipMemcpy(n.dWb, imgb.data(), n.wb_bytes, hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && !imgh.empty()) {
+    n.wh_bytes = imgh.size() * sizeof(uint16_t);
+    e = hipMalloc(&n.dWh, n.wh_bytes);
+    if (e == hipSuccess) e = hipMemcpy(n.dWh, imgh.data(), n.wh_bytes, hipMemcpyHostToDevice);
+  }
   Net& slot = h->net[net_id];
   if (e == hipSuccess && (slot.dW || slot.dWb)) e = hipDeviceSynchronize();      // a launch may still read the images being replaced
   if (e != hipSuccess) {
     if (n.dW) (void)hipFree(n.dW);
     if (n.dWb) (void)hipFree(n.dWb);
+    if (n.dWh) (void)hipFree(n.dWh);
     return fail(std::string("nsrw_upload_network: ") + hipGetErrorString(e));
   }
   if (slot.dW) (void)hipFree(slot.dW);
   if (slot.dWb) (void)hipFree(slot.dWb);
+  if (slot.dWh) (void)hipFree(slot.dWh);
   slot = n;
   slot.loaded = true;
   return 0;

@@ -57,10 +57,11 @@ SIGNATURES = {
                                    C.c_void_p]),
     "nsrw_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "nsrw_debug_bounds_status": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
+    "nsrw_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
 }
 
-FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_MLP_BF16X3 = 1, 2, 4
-MLPS = ("bf16x3", "fp32")
+FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_MLP_BF16X3, FLAG_MLP_F16X2 = 1, 2, 4, 8
+MLPS = ("bf16x3", "fp32", "f16x2")
 
 DEFAULT_MLP = "bf16x3"          # r06: same parity bounds as the fp32 MFMAs (tests/test_gpu_wide.py runs every case on both), 1.7x their speed
 
@@ -155,8 +156,9 @@ class WideModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=128, white_bkgd=False, lindisp=False, n_samples=64,
                  mlp=None):
         """mlp: the arithmetic of the layer GEMMs -- "bf16x3" (bf16 MFMAs on three-way split fp32 operands, fp32-grade results at
-        2.67x the matrix-pipe rate: csrc/nsr_wide_b3.inc) or "fp32" (fp32 MFMAs, the strict mode); default $NSR_WIDE_MLP, else
-        DEFAULT_MLP."""
+        2.67x the matrix-pipe rate: csrc/nsr_wide_b3.inc), "fp32" (fp32 MFMAs, the strict mode) or "f16x2" (the forward network
+        passes on fp16 MFMAs with two-piece operands -- the fused default kernel's arithmetic -- a pass that leaves fp16's range is
+        re-run on bf16x3 inside the call, the gradient GEMMs are bf16x3); default $NSR_WIDE_MLP, else DEFAULT_MLP."""
         mlp = mlp or os.environ.get("NSR_WIDE_MLP") or DEFAULT_MLP
         if mlp not in MLPS:
             raise ValueError("mlp must be one of %s (got %r)" % (MLPS, mlp))
@@ -182,7 +184,7 @@ class WideModel:
         self._ws_need = {}                                # (rays, grad) -> bytes one chunk of that many rays needs
         cfg = NsrwConfig(self.device.index, n_samples, n_importance,
                          (FLAG_WHITE_BKGD if white_bkgd else 0) | (FLAG_LINDISP if lindisp else 0) |
-                         (FLAG_MLP_BF16X3 if mlp == "bf16x3" else 0))
+                         (FLAG_MLP_BF16X3 if mlp == "bf16x3" else 0) | (FLAG_MLP_F16X2 if mlp == "f16x2" else 0))
         h = C.c_void_p()
         check(self.lib.nsrw_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -368,7 +370,15 @@ class WideModel:
         return self.util.ndc_rays_vjp(*a, **k)
 
     def range_status(self):
-        return dict(last_items=0, points=0, rays=0, dropped_items=0)      # fp32 / bf16x3 arithmetic: no range to leave
+        """fp32 / bf16x3: no range to leave.  f16x2: `passes` network passes launched so far, `passes_rerun` of them re-run on
+        bf16x3 because an activation reached fp16's largest number; nothing is ever dropped.  (The keys of NsrModel.range_status
+        are kept: `points` / `rays` stay 0 -- the unit of the layered renderer's safety net is a pass over a chunk of rays.)"""
+        out = dict(last_items=0, points=0, rays=0, dropped_items=0, passes=0, passes_rerun=0)
+        if self.mlp == "layered-f16x2":
+            a, b = C.c_ulonglong(), C.c_ulonglong()
+            check(self.lib.nsrw_range_status(self.h, C.byref(a), C.byref(b)))
+            out["passes"], out["passes_rerun"] = int(a.value), int(b.value)
+        return out
 
     def debug_bounds_status(self):
         """(built_with_checks, first_bad_line): see nsrw_debug_bounds_status / `make debug`."""

@@ -33,6 +33,7 @@ def _rel_rows(a, b):
 
 
 MLPS = ["bf16x3", "fp32"]          # the two arithmetics of the layer GEMMs (wide.WideModel(mlp=...)): every parity bound is the same
+MLPS3 = MLPS + ["f16x2"]           # ... and the forward passes on fp16 MFMAs with two-piece operands (r06), same bounds again
 
 
 def _wide(mlp):
@@ -41,7 +42,7 @@ def _wide(mlp):
     return lambda *a, **k: WideModel(*a, mlp=mlp, **k)
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 @pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_layered_renderer_stagewise_census_and_gradient(tag, mlp, oracle):
     """g25 a-d: 10 x 384 at (64, 128); 6 x 300 with two skips at (48, 100); 9 x 272 without view directions at (24, 40); a
@@ -113,6 +114,8 @@ def test_layered_renderer_stagewise_census_and_gradient(tag, mlp, oracle):
         assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (what, np.percentile(e, 90), e.max())
     for a, b in ((cpu(go), g[tag + "_grad_rays"][0]), (cpu(gd), g[tag + "_grad_rays"][1])):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 5e-2        # (the reference's depths differ by its own rounding)
+    st = m.range_status()
+    assert st["passes_rerun"] == 0 and st["dropped_items"] == 0 and (st["passes"] > 0) == (mlp == "f16x2"), st
     if fine:         # ... and AT the reference's own depths (z_samples is detached, RN:475): autograd's numbers, ray by ray
         zf_ref = np.sort(np.concatenate([z, g[tag + "_z_samples"]], -1), -1)
         ro_, rd_ = m.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf_ref)
@@ -170,7 +173,7 @@ def test_layered_renderer_chunking_at_scale(mlp, oracle):
     assert np.isfinite(a[0]).all() and np.isfinite(a[3]).all() and np.abs(a[3]).max() > 0
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 def test_layered_renderer_nan_rays_stay_nan_and_alone(mlp, oracle):
     """A ray with a NaN origin or an infinite direction renders to NaN (pts -> encodings -> every layer -> relu(sigma), F.relu
     keeps NaN, RN:356 -> alpha -> weights -> pixel, and disp through torch.max, RN:381), as it does in the reference -- and it
@@ -192,7 +195,13 @@ def test_layered_renderer_nan_rays_stay_nan_and_alone(mlp, oracle):
     for k in ("rgb_map", "disp_map", "acc_map", "rgb0", "acc0"):
         a, b = cpu(bad[k]), cpu(clean[k])
         assert np.isnan(a[~ok]).all(), k
-        assert np.array_equal(a[ok], b[ok], equal_nan=True), k
+        if mlp == "f16x2":      # the infinite ray leaves fp16's range: its passes are run again on bf16x3, whose bits the neighbours then carry
+            assert np.isfinite(a[ok]).all() and (np.abs(a[ok] - b[ok]) > 1e-5).mean() < 0.02 and np.abs(a[ok] - b[ok]).max() < 5e-3, k
+        else:
+            assert np.array_equal(a[ok], b[ok], equal_nan=True), k
+    if mlp == "f16x2":
+        st = m.range_status()
+        assert st["passes_rerun"] >= 1 and st["passes"] > st["passes_rerun"], st
     assert np.isnan(cpu(go)[~ok]).all() and np.isfinite(cpu(go)[ok]).all() and np.isfinite(cpu(gd)[ok]).all()
     m.close()
 
@@ -242,7 +251,7 @@ def test_layered_renderer_options(mlp, oracle):
             assert np.percentile(e, 90) < 1e-4 and np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-2, (what, np.percentile(e, 90), e.max())
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 def test_layered_and_fused_renderers_agree_on_the_fused_kernels_network(mlp, synth_nets, oracle):
     """The YCB-V network (8 x 256, 64 + 128 samples) through BOTH renderers: two independent implementations of the same path
     -- fused f16x2 kernels with the network in registers / LDS, and GEMMs layer by layer through HBM (fp32 MFMAs / bf16x3) -- agree
@@ -408,7 +417,7 @@ def _edge_case(oracle):
     return sd_c, sd_f, np.ascontiguousarray(ro[:61]), np.ascontiguousarray(rd[:61])
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 def test_layered_renderer_edge_shapes(mlp, oracle):
     """W = 34, N_samples = 3, N_importance = 512, 61 rays (a ragged last GEMM tile at every tile height), and run_network on
     1 / 127 / 129 / 257 points of two networks: stage by stage against the oracle, indices and samples bit for bit, the input
@@ -457,7 +466,7 @@ def test_layered_renderer_edge_shapes(mlp, oracle):
     mb.close()
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 def test_layered_launch_is_graph_capturable_and_replays_bit_identically(mlp, oracle):
     """include/nsr_wide.h: the launch calls only enqueue work (kernels, memset / memcpy nodes; the timing events are skipped
     under capture), so nsrw_render_rays and nsrw_render_rays_vjp can be captured into a hipGraph: the replay equals the eager
@@ -497,6 +506,64 @@ def test_layered_launch_is_graph_capturable_and_replays_bit_identically(mlp, ora
         for x, y in zip(got, eager[it % 2]):
             assert np.array_equal(x, y, equal_nan=True), it
     m.close()
+
+
+def test_layered_f16x2_pass_that_leaves_the_fp16_range_is_rerun_on_bf16x3(oracle):
+    """NSRW_FLAG_MLP_F16X2's safety net.  A coarse network whose layer-2 bias sends one hidden unit to 7e4 on every point: the
+    activations entering layer 3 leave fp16's range (65504), kw_gemm_h2 raises the flag, and the whole coarse pass runs again on
+    bf16x3 inside the same call -- the coarse outputs, the resampling indices and the fine depths are then the bf16x3 handle's BIT
+    FOR BIT; the fine pass (in range) stays on fp16 MFMAs.  Counted per pass: one re-run per chunk of rays, none dropped; and the
+    call stays capturable (no host round trip: the re-run's launches are conditional on a device flag)."""
+    import torch
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "b")
+    sd_c = {k: v.copy() for k, v in sd_c.items()}
+    sd_c["pts_linears.2.bias"][5] += 7.0e4
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd, cot = np.tile(g["rays_o"], (4, 1)), np.tile(g["rays_d"], (4, 1)), np.tile(g["cot"], (4, 1))
+    os.environ["NSR_WIDE_WORKSPACE_GB"] = "0.0001"        # the smallest workspace the library accepts: chunks of 64 rays
+    try:
+        h2, b3 = (_wide(mlp)(sd_c, sd_f, n_samples=ns, n_importance=ni) for mlp in ("f16x2", "bf16x3"))
+        a, b = h2.render_rays(ro, rd, near, far, debug=True), b3.render_rays(ro, rd, near, far, debug=True)
+        chunks = h2.last_kernel_ms()[1]
+        st = h2.range_status()
+        assert chunks >= 2 and st["passes"] == 2 * chunks and st["passes_rerun"] == chunks and st["dropped_items"] == 0, (chunks, st)
+        for k in ("rgb0", "acc0", "weights0", "raw0", "inds", "z_samples", "z_fine"):
+            assert np.array_equal(cpu(a[k]), cpu(b[k]), equal_nan=True), k
+        assert np.isfinite(cpu(a["rgb_map"])).all() and not np.array_equal(cpu(a["raw"]), cpu(b["raw"]))      # the fine pass ran on fp16 MFMAs
+        assert_close(cpu(a["raw"]), cpu(b["raw"]), atol=5e-5, rtol=5e-5, what="fine raw: f16x2 vs bf16x3 at the same depths")
+        assert_close(cpu(a["rgb_map"]), cpu(b["rgb_map"]), atol=3e-6, what="rgb: f16x2 vs bf16x3 at the same depths")
+        # against the oracle, like any other network
+        vd = oracle.normalize_dirs(rd)
+        z = oracle.coarse_z(np.full(len(ro), near, np.float32), np.full(len(ro), far, np.float32), n=ns)
+        raw0 = oracle.run_network(sd_c, (ro[:, None] + rd[:, None] * z[..., None]).astype(np.float32), vd)
+        assert_close(cpu(a["raw0"])[..., :4], raw0, atol=5e-5, rtol=5e-5, what="coarse raw of the re-run pass")
+        # the gradient call: forward re-run as well, gradient GEMMs on bf16x3 -> the bf16x3 handle's numbers at the same depths
+        go, gd = h2.render_rays_vjp(ro, rd, near, far, cot)
+        wo, wd = b3.render_rays_vjp(ro, rd, near, far, cot)
+        for x, y in ((cpu(go), cpu(wo)), (cpu(gd), cpu(wd))):
+            assert np.isfinite(x).all() and np.percentile(_rel_rows(x, y), 90) < 1e-4
+        # under capture
+        dev = h2.device
+        to, td = (torch.as_tensor(np.ascontiguousarray(x), device=dev) for x in (ro, rd))
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            h2.render_rays(to, td, near, far)
+            torch.cuda.synchronize(dev)
+            before = h2.range_status()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=s):
+                r = h2.render_rays(to, td, near, far)
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        after = h2.range_status()
+        assert after["passes_rerun"] - before["passes_rerun"] == chunks, (before, after)
+        assert np.array_equal(cpu(r["rgb_map"]), cpu(a["rgb_map"]), equal_nan=True)
+        h2.close()
+        b3.close()
+    finally:
+        del os.environ["NSR_WIDE_WORKSPACE_GB"]
 
 
 def test_two_layered_handles_on_two_streams(oracle):

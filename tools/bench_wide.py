@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--cases", default="ycbv,w512,d10w384,small")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-grad", action="store_true")
-    ap.add_argument("--mlp", default=None, help="bf16x3 | fp32 (default: the library's)")
+    ap.add_argument("--mlp", default=None, help="bf16x3 | fp32 | f16x2 (default: the library's)")
     a = ap.parse_args()
     K = S.scaled_K(400.0 / a.hw)
     pose = S.sweep_poses(1, seed=0)[0]
@@ -97,10 +97,14 @@ def main():
                          "algorithmic_TFLOPs": round(f / t / 1e9, 1), "frac_of_fp32_mfma_peak": round(f / t / 1e9 / PEAK_FP32_MFMA, 3)}
             if m.mlp.endswith("bf16x3"):       # six bf16 piece products per product: ceiling 2500 / 6 TFLOP/s of algorithmic work
                 res[what]["issued_frac_of_bf16_peak"] = round(6 * f / t / 1e9 / 2500.0, 3)
+            if m.mlp.endswith("f16x2") and what == "forward":       # three fp16 piece products per product (the gradient GEMMs are bf16x3)
+                res[what]["issued_frac_of_fp16_peak"] = round(3 * f / t / 1e9 / 2500.0, 3)
             if power:
                 res[what]["power_and_clock"] = {k: v for k, v in power.items() if k != "source"}
             if what == "forward":
                 res[what]["Mray_samples_per_s"] = round(n * (ns + ni) / t / 1e3, 2)
+        if m.mlp.endswith("f16x2"):
+            res["range_status"] = m.range_status()
         out[name] = res
         print(name, json.dumps(res), flush=True)
         m.close()

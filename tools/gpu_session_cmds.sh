@@ -1,9 +1,12 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session K: compact raw layout + fast encodings)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session M: whole GPU suite + smoke + bench)
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_wide.py -q -m gpu 2>&1 | tail -6
-cd /tmp && export TMPDIR=/tmp
-for c in ycbv small; do
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$c -- python $GRAFT_REPO_ROOT/tools/bench_wide.py --mlp bf16x3 --cases $c --steps 2 > $O/ks_$c.log 2>&1
-grep "^$c" $O/ks_$c.log | cut -c1-400
-f=$(ls $O/ks_$c/*/*_kernel_stats.csv | head -1); cut -c1-130 $f | grep -v "kw_gemm" | head -9
-done
+timeout 1500 python -m pytest tests -q -m gpu --durations=15 2>&1 | tail -40
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.err
+python - <<PY
+import json
+d = json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in ("value", "ms_per_step", "dtype")}, d["roofline"]["frac"], d["roofline"]["issued_frac"])
+print(json.dumps(d["extra_workloads"].get("trained"))[:3000])
+print(json.dumps(d["extra_workloads"].get("api_overhead"))[:1500])
+PY
