@@ -196,7 +196,10 @@ def test_layered_renderer_nan_rays_stay_nan_and_alone(mlp, oracle):
         a, b = cpu(bad[k]), cpu(clean[k])
         assert np.isnan(a[~ok]).all(), k
         if mlp == "f16x2":      # the infinite ray leaves fp16's range: its passes are run again on bf16x3, whose bits the neighbours then carry
-            assert np.isfinite(a[ok]).all() and (np.abs(a[ok] - b[ok]) > 1e-5).mean() < 0.02 and np.abs(a[ok] - b[ok]).max() < 5e-3, k
+            fin = np.isfinite(b[ok])                       # (disp of an empty ray is 0 / 0 in the reference too, RN:381)
+            assert np.array_equal(np.isfinite(a[ok]), fin), k
+            dlt = np.abs(a[ok][fin] - b[ok][fin])
+            assert (dlt > 1e-5).mean() < 0.02 and dlt.max() < 5e-3, (k, dlt.max())
         else:
             assert np.array_equal(a[ok], b[ok], equal_nan=True), k
     if mlp == "f16x2":
