@@ -37,11 +37,11 @@ enum { NSRW_FLAG_WHITE_BKGD = 1,     /* RN:384-385 */
        NSRW_FLAG_MLP_BF16X3 = 4,     /* r06: the layer GEMMs on bf16 MFMAs, every fp32 operand split exactly into three bf16 pieces, six
                                       * piece products per product, fp32 accumulate (csrc/nsr_wide_b3.inc): fp32-grade results, fp32's
                                       * exponent range, 2.67x the matrix-pipe rate of the fp32 MFMAs.  Without a flag: fp32 MFMAs. */
-       NSRW_FLAG_MLP_F16X2 = 8 };    /* r06: the FORWARD network passes on fp16 MFMAs, every fp32 operand as two fp16 pieces, three piece
-                                      * products (the arithmetic of the fused default kernel, csrc/nsr_h2.inc: |error| <= 2^-22 per
-                                      * product, weights pre-scaled per matrix); a pass in which an activation reaches fp16's
-                                      * largest number is run again on bf16x3 inside the same call (nsrw_range_status counts them),
-                                      * so the results never depend on the range.  The gradient GEMMs stay on bf16x3. */
+       NSRW_FLAG_MLP_F16X2 = 8 };    /* r06: the layer GEMMs on fp16 MFMAs, every fp32 operand as two fp16 pieces, three piece products
+                                      * (the arithmetic of the fused default kernel, csrc/nsr_h2.inc: |error| <= 2^-22 per product;
+                                      * weights pre-scaled per matrix, gradients normalised per point).  A network pass -- forward or
+                                      * backward -- in which a value reaches fp16's largest number is run again on bf16x3 inside the
+                                      * same call (nsrw_range_status counts them), so no result depends on the range. */
 
 typedef struct NsrwConfig {
   int32_t device;
@@ -138,8 +138,8 @@ int nsrw_render_rays_vjp(nsrw_handle h, const float* d_rays_o, const float* d_ra
 int nsrw_run_network(nsrw_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts, float* d_raw,
                      void* d_workspace, size_t workspace_bytes, void* stream);
 
-/* NSRW_FLAG_MLP_F16X2 handles: network passes launched so far and how many of them were re-run on bf16x3 because an activation left
- * fp16's range (both 0 for the other arithmetics).  Synchronises the device. */
+/* NSRW_FLAG_MLP_F16X2 handles: network passes (forward and backward) launched so far and how many of them were re-run on bf16x3
+ * because an activation or a gradient left fp16's range (both 0 for the other arithmetics).  Synchronises the device. */
 int nsrw_range_status(nsrw_handle h, unsigned long long* passes, unsigned long long* passes_rerun);
 
 /* Device time of the last launch call (ms; synchronises on its closing event) and the number of chunks it ran. */

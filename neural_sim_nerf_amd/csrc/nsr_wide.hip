@@ -595,7 +595,21 @@ struct CompositeBwdArgs {
   float* draw;                        // [P,32]
   float* gnorm;                       // [R]
   float* scr_a; float* scr_t;         // scratch [R,S] each: alpha_i, T_i
+  float* gscale;                      // nullable [P]: f16x2 handles -- the row leaves NORMALISED, gscale[p] undoes it (kw_embed_bwd)
 };
+
+// f16x2 gradient GEMMs (csrc/nsr_h2_bwd.inc has the reasoning): the backward chain is LINEAR in a point's dL/d raw, whose size is
+// whatever the cotangent and the compositing weights make it (1e-12 for an occluded sample, 1e+3 for a summed loss) -- no
+// upload-time scale can fit it into fp16.  So every point's four inputs are multiplied by s = 2^(7 - floor(log2 max|.|)) (exact),
+// the chain runs on gradients of magnitude ~2^7 (2^9 of head-room; a point that outgrows it raises the range flag and the chain is
+// re-run on bf16x3), and kw_embed_bwd multiplies what comes out by 1 / s.  0 / denormal-small / inf / NaN rows stay as they are.
+__device__ __forceinline__ float grad_norm_scale(float g0, float g1, float g2, float g3, float& inv) {
+  const float m = fmaxf(fmaxf(fabsf(g0), fabsf(g1)), fmaxf(fabsf(g2), fabsf(g3)));
+  const unsigned ef = (__float_as_uint(m) >> 23) & 0xffu;
+  const bool ok = ef >= 8u && ef <= 253u;
+  inv = ok ? __uint_as_float((ef - 7u) << 23) : 1.0f;                  // 2^(ef - 127 - 7)
+  return ok ? __uint_as_float((254u - ef + 7u) << 23) : 1.0f;          // 2^(127 - ef + 7)
+}
 
 __global__ void __launch_bounds__(256) kw_composite_bwd(const CompositeBwdArgs a) {
   const int r = blockIdx.x * 256 + threadIdx.x;
@@ -634,10 +648,17 @@ __global__ void __launch_bounds__(256) kw_composite_bwd(const CompositeBwdArgs a
     const double dz = (i < a.S - 1) ? (double)(z[i + 1] - z[i]) : 1e10;
     const double e = 1.0 - al;
     float* o = a.draw + p * 32;
-    o[0] = (float)(w * g0 * c0 * (1.0 - c0));
-    o[1] = (float)(w * g1 * c1 * (1.0 - c1));
-    o[2] = (float)(w * g2 * c2 * (1.0 - c2));
-    o[3] = sg > 0.0f ? (float)(d_alpha * (dz * (double)nrm) * e) : 0.0f;
+    float o0 = (float)(w * g0 * c0 * (1.0 - c0));
+    float o1 = (float)(w * g1 * c1 * (1.0 - c1));
+    float o2 = (float)(w * g2 * c2 * (1.0 - c2));
+    float o3 = sg > 0.0f ? (float)(d_alpha * (dz * (double)nrm) * e) : 0.0f;
+    if (a.gscale) {
+      float inv;
+      const float sc = grad_norm_scale(o0, o1, o2, o3, inv);
+      o0 *= sc; o1 *= sc; o2 *= sc; o3 *= sc;
+      a.gscale[p] = inv;
+    }
+    o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
     dn += d_alpha * (double)relu_nan(sg) * e * dz;                       // d(dz |d|) / d|d| = dz
   }
   a.gnorm[r] = (float)dn;
@@ -658,6 +679,7 @@ struct EmbedBwdArgs {
   const float* GE; int ldE; const float* GED; int ldED;       // dL/d encodings [P, Ci], [P, Cv] (GED nullable)
   int given_viewdirs;
   float* grad_o; float* grad_d; float* grad_v;                // [R,3]; grad_v only with given view directions
+  const float* gscale;                                        // nullable [P]: 1 / s of the point's normalised chain (kw_composite_bwd)
 };
 
 __device__ __forceinline__ void embed_bwd(const float* G, const double (&x)[3], int L, double (&out)[3]) {
@@ -688,13 +710,14 @@ __global__ void __launch_bounds__(64) kw_embed_bwd(const EmbedBwdArgs a) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) x[c] = (double)(a.rays_o[r * 3 + c] + a.rays_d[r * 3 + c] * zz);
     embed_bwd(a.GE + p * a.ldE, x, a.L, gp);
+    const double un = a.gscale ? (double)a.gscale[p] : 1.0;             // (a power of two: exact)
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { go[c] += gp[c]; gd[c] += gp[c] * (double)zz; }
+    for (int c = 0; c < 3; ++c) { go[c] += gp[c] * un; gd[c] += gp[c] * un * (double)zz; }
     if (a.GED) {
       double g2[3];
       embed_bwd(a.GED + p * a.ldED, v, a.Lv, g2);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gv[c] += g2[c];
+      for (int c = 0; c < 3; ++c) gv[c] += g2[c] * un;
     }
   }
 #pragma unroll
@@ -786,7 +809,7 @@ struct Net {
   float* dW = nullptr;
   char* dWb = nullptr;                // bf16x3 handles: the split images of every matrix (nsr_wide_b3.inc)
   size_t wb_bytes = 0;
-  char* dWh = nullptr;                // f16x2 handles: the scaled two-piece fp16 images of the FORWARD matrices (kw_gemm_h2)
+  char* dWh = nullptr;                // f16x2 handles: the scaled two-piece fp16 images of every matrix (kw_gemm_h2)
   size_t wh_bytes = 0;
   std::vector<Mat> fwd;               // pts_linears
   Mat fa, al, hv, rgb, out;           // feature_linear, alpha_linear, views_linears.0, rgb_linear / output_linear
@@ -957,7 +980,7 @@ struct Chunk {
   float *vd, *nrm, *z0, *w0, *zs, *zf, *wf, *pdf, *cdf, *gnorm, *scr_a, *scr_t;
   float *E, *ED, *FA, *HV, *RAW;
   std::vector<float*> H;
-  float *DRAW, *GV, *G0, *G1, *GEP, *GED;
+  float *DRAW, *GV, *G0, *G1, *GEP, *GED, *gscale;
 };
 
 // floats per point of the forward buffers of `n`
@@ -978,11 +1001,11 @@ void carve_chunk(const Handle& h, long long R, bool grad, Carve& c, Chunk& k) {
   for (int i = 0; i < nH; ++i) k.H[i] = c.f(P * mx(&Net::Wp));
   if (grad) {
     const long long Pg = R * (S1 > 0 ? S1 : S0);
-    k.scr_a = c.f(Pg); k.scr_t = c.f(Pg);
+    k.scr_a = c.f(Pg); k.scr_t = c.f(Pg); k.gscale = c.f(Pg);
     k.DRAW = c.f(Pg * 32); k.GV = c.f(Pg * last.W2p); k.G0 = c.f(Pg * last.Wp); k.G1 = c.f(Pg * last.Wp);
     k.GEP = c.f(Pg * last.Ci); k.GED = c.f(Pg * last.Cv);
   } else {
-    k.scr_a = k.scr_t = k.DRAW = k.GV = k.G0 = k.G1 = k.GEP = k.GED = nullptr;
+    k.scr_a = k.scr_t = k.DRAW = k.GV = k.G0 = k.G1 = k.GEP = k.GED = k.gscale = nullptr;
   }
 }
 
@@ -1007,9 +1030,13 @@ void launch_gemm_b3(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi)
 }
 
 template <int NJ, int WM>
-void launch_gemm_h2(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi) {      // (forward chains only: no mask / accumulate)
-  if (epi == kRelu) hipLaunchKernelGGL((kw_gemm_h2<NJ, kRelu, WM>), dim3(grid), dim3(128 * WM), 0, st, g);
-  else hipLaunchKernelGGL((kw_gemm_h2<NJ, 0, WM>), dim3(grid), dim3(128 * WM), 0, st, g);
+void launch_gemm_h2(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi) {
+  switch (epi) {
+    case kRelu: hipLaunchKernelGGL((kw_gemm_h2<NJ, kRelu, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    case kMaskEpi: hipLaunchKernelGGL((kw_gemm_h2<NJ, kMaskEpi, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    case kAccum: hipLaunchKernelGGL((kw_gemm_h2<NJ, kAccum, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    default: hipLaunchKernelGGL((kw_gemm_h2<NJ, 0, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+  }
 }
 
 // bf16x3 handles: the N extent is cut into tiles of 256 columns, then one of 128 and one of 64 for what is left (the image is
@@ -1019,7 +1046,7 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
   GemmB3Args g{};
   g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
   g.M = M; g.ldc = ldc; g.ldm = ldm;
-  const bool h2 = cfg.use_h2 && (epi == 0 || epi == kRelu);
+  const bool h2 = cfg.use_h2;
   const int kfrag = h2 ? 2048 : 3072;                               // bytes of one (col-block, k16 block) of the image
   g.cscale = h2 ? m.cscale : 1.0f; g.range_flag = cfg.d_range; g.run_if = cfg.run_if;
   const int KB = (m.K1p + m.K2p) / 16;
@@ -1152,7 +1179,7 @@ int net_forward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k
 }
 
 // Input-side backward of net_forward (activations kept): k.DRAW [P,32] = dL/d(rgb logits, sigma) -> k.GEP [P,Ci], k.GED [P,Cv].
-int net_backward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P) {
+int net_backward_chain(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P) {
   float* g = k.G0;
   float* g2 = k.G1;
   const int D = n.d.D;
@@ -1175,6 +1202,20 @@ int net_backward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& 
       std::swap(g, g2);
     }
   }
+  return 0;
+}
+
+// f16x2: the chain on fp16 MFMAs over the per-point NORMALISED gradients (kw_composite_bwd), then -- in launches that are empty
+// unless a gradient left fp16's range -- once more on bf16x3 from the same inputs (k.DRAW and the stored activations are read
+// only; the first write of k.GEP does not accumulate), then the tally
+int net_backward(const GemmCfg& cfg, hipStream_t st, const Net& n, const Chunk& k, long long P) {
+  if (!cfg.h2 || P <= 0) return net_backward_chain(cfg, st, n, k, P);
+  GemmCfg c = cfg;
+  c.use_h2 = true;
+  if (net_backward_chain(c, st, n, k, P)) return 1;
+  c.use_h2 = false; c.run_if = cfg.d_range;
+  if (net_backward_chain(c, st, n, k, P)) return 1;
+  hipLaunchKernelGGL(kw_range_tally, dim3(1), dim3(64), 0, st, cfg.d_range);
   return 0;
 }
 
@@ -1312,14 +1353,14 @@ int render_impl(Handle* h, const float* ro, const float* rd, long long n, float 
       CompositeBwdArgs cb{};
       cb.R = Rc; cb.S = SL; cb.flags = h->cfg.flags; cb.rgb = k.RAW; cb.ld_rgb = last.ldraw; cb.sigma = sigma; cb.ld_sigma = ld_sigma;
       cb.z = z_last; cb.nrm = k.nrm; cb.noise = noise_last; cb.grad_rgb = grad_rgb + r0 * 3; cb.draw = k.DRAW; cb.gnorm = k.gnorm;
-      cb.scr_a = k.scr_a; cb.scr_t = k.scr_t;
+      cb.scr_a = k.scr_a; cb.scr_t = k.scr_t; cb.gscale = h->gemm_cfg.h2 ? k.gscale : nullptr;
       hipLaunchKernelGGL(kw_composite_bwd, dim3(rb), dim3(256), 0, st, cb);
       if (net_backward(h->gemm_cfg, st, last, k, P)) return 1;
       EmbedBwdArgs eb{};
       eb.R = Rc; eb.S = SL; eb.L = last.d.multires; eb.Lv = last.d.multires_views;
       eb.rays_o = ra.rays_o; eb.rays_d = ra.rays_d; eb.z = z_last; eb.vd = k.vd; eb.nrm = k.nrm; eb.gnorm = k.gnorm;
       eb.GE = k.GEP; eb.ldE = last.Ci; eb.GED = last.d.use_viewdirs ? k.GED : nullptr; eb.ldED = last.Cv;
-      eb.given_viewdirs = e.d_viewdirs != nullptr;
+      eb.given_viewdirs = e.d_viewdirs != nullptr; eb.gscale = cb.gscale;
       eb.grad_o = grad_o + r0 * 3; eb.grad_d = grad_d + r0 * 3; eb.grad_v = grad_v ? grad_v + r0 * 3 : nullptr;
       hipLaunchKernelGGL(kw_embed_bwd, dim3((unsigned)Rc), dim3(64), 0, st, eb);
     }
@@ -1552,14 +1593,17 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
       if (m->Np > 0) m->wb = pack_b3(imgb, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->ncb);
     if (imgb.size() * sizeof(uint16_t) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the bf16x3 image");
   }
-  // f16x2 handles: the forward matrices also as scaled two-piece fp16 images (4 bytes per weight) for kw_gemm_h2
+  // f16x2 handles: ... and as scaled two-piece fp16 images (4 bytes per weight) for kw_gemm_h2
   std::vector<uint16_t> imgh;
   if (h->gemm_cfg.h2) {
-    std::vector<Mat*> fw;
-    for (Mat& m : n.fwd) fw.push_back(&m);
-    for (Mat* m : {&n.fa, &n.al, &n.hv, &n.rgb, &n.out}) fw.push_back(m);
-    for (Mat* m : fw)
+    std::vector<Mat*> all;
+    for (Mat& m : n.fwd) all.push_back(&m);
+    for (Mat& m : n.bwd_h) all.push_back(&m);
+    for (Mat& m : n.bwd_e) all.push_back(&m);
+    for (Mat* m : {&n.fa, &n.al, &n.hv, &n.rgb, &n.out, &n.b_rgb, &n.b_feat, &n.b_ed, &n.b_head}) all.push_back(m);
+    for (Mat* m : all)
       if (m->Np > 0) m->wh = pack_h2(imgh, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->cscale);
+    if (imgh.size() * sizeof(uint16_t) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the f16x2 image");
   }
   NSRW_DEVICE(h);
   // (every failure path below frees what this call allocated: ADVICE r05)

@@ -156,9 +156,9 @@ class WideModel:
     def __init__(self, sd_coarse, sd_fine=None, device=None, n_importance=128, white_bkgd=False, lindisp=False, n_samples=64,
                  mlp=None):
         """mlp: the arithmetic of the layer GEMMs -- "bf16x3" (bf16 MFMAs on three-way split fp32 operands, fp32-grade results at
-        2.67x the matrix-pipe rate: csrc/nsr_wide_b3.inc), "fp32" (fp32 MFMAs, the strict mode) or "f16x2" (the forward network
-        passes on fp16 MFMAs with two-piece operands -- the fused default kernel's arithmetic -- a pass that leaves fp16's range is
-        re-run on bf16x3 inside the call, the gradient GEMMs are bf16x3); default $NSR_WIDE_MLP, else DEFAULT_MLP."""
+        2.67x the matrix-pipe rate: csrc/nsr_wide_b3.inc), "fp32" (fp32 MFMAs, the strict mode) or "f16x2" (fp16 MFMAs with
+        two-piece operands -- the fused default kernel's arithmetic; a network pass that leaves fp16's range is re-run on bf16x3
+        inside the call); default $NSR_WIDE_MLP, else DEFAULT_MLP."""
         mlp = mlp or os.environ.get("NSR_WIDE_MLP") or DEFAULT_MLP
         if mlp not in MLPS:
             raise ValueError("mlp must be one of %s (got %r)" % (MLPS, mlp))
