@@ -392,19 +392,21 @@ def render_options_workload(sd_c, sd_f, c2w, device):
 
 
 def layered_workload(sd_c, sd_f, c2w, device, ref):
-    """extra_workloads.layered: the layered renderer (include/nsr_wide.h: one fp32-MFMA GEMM per network layer, activations in
-    HBM) -- what serves the networks and sample counts the fused kernels are not built for.  The SAME view and networks as the
-    main line through it (the price of leaving the fused kernels, and a cross-check of two independent implementations of the
-    path), and a network the fused kernels cannot hold (8 x 512).  Roofline of its GEMM kernel nsrw::kw_gemm: algorithmic fp32
-    FLOP of the network evaluations / HIP-event time of the whole launch call against the fp32-MFMA peak."""
+    """extra_workloads.layered: the layered renderer (include/nsr_wide.h: one MFMA GEMM per network layer, activations in HBM)
+    -- what serves the networks and sample counts the fused kernels are not built for.  The SAME view and networks as the main
+    line through it (the price of leaving the fused kernels, and a cross-check of two independent implementations of the
+    path), and a network the fused kernels cannot hold (8 x 512), on each of its three arithmetics.  Roofline of its GEMM
+    kernels: algorithmic fp32 FLOP of the network evaluations / HIP-event time of the whole launch call (per-ray stages
+    included) against the dense MFMA peak of the datatype issued."""
     from neural_sim_nerf_amd.wide import WideModel
     pose = torch.as_tensor(c2w[:3, :4])
     out = {"workload": "one 400x400 view, 64+128 samples, through nsrw_render_rays (HIP-event ms of the launch call, all chunks)",
-           "kernel": "nsrw::kw_gemm_b3<4, *, 4> (r06, the default: fp32 in HBM, every operand split exactly into three bf16 pieces, six "
-                     "piece products on v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 out); fp32: nsrw::kw_gemm<128, *, 16> "
+           "kernel": "nsrw::kw_gemm_h2<4, *, 4> (r06, the default: fp32 in HBM, every operand as two fp16 pieces, three piece products on "
+                     "v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 out; a pass that leaves fp16's range is re-run on bf16x3 inside the "
+                     "call); bf16x3: nsrw::kw_gemm_b3<4, *, 4> (three bf16 pieces, six products, no range); fp32: nsrw::kw_gemm<128, *, 16> "
                      "(v_mfma_f32_32x32x2_f32)",
-           "peak": PEAK_BF16_MFMA_TFLOPS, "peak_note": "dense bf16 MFMA; `frac` = algorithmic FLOP / time / peak, `issued_frac` = 6 x that "
-           "(six bf16 piece products per fp32 product: the ceiling of `frac` is 1/6 = 0.167, i.e. 417 TFLOP/s of algorithmic work); "
+           "peak": PEAK_BF16_MFMA_TFLOPS, "peak_note": "dense fp16 = bf16 MFMA; `frac` = algorithmic FLOP / time / peak, `issued_frac` = 3 x "
+           "(f16x2) or 6 x (bf16x3) that -- the piece products actually issued: the ceiling of `frac` is 1/3 resp. 1/6; "
            "`frac_of_fp32_mfma_peak` puts the same algorithmic rate over the 157.3 TFLOP/s the fp32 MFMAs could reach at most"}
 
     def run(model, flop_per_point, launches=2):
@@ -422,10 +424,13 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
              "achieved": round(tf, 1), "unit": "TFLOP/s", "mlp": model.mlp, "frac_of_fp32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
         if model.mlp.endswith("bf16x3"):
             r.update(frac=round(tf / PEAK_BF16_MFMA_TFLOPS, 4), issued_frac=round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4))
+        elif model.mlp.endswith("f16x2"):
+            r.update(frac=round(tf / PEAK_BF16_MFMA_TFLOPS, 4), issued_frac=round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                     range_status=model.range_status())
         else:
             r.update(frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4), peak=PEAK_F32_MFMA_TFLOPS)
         return o, r
-    m = WideModel(sd_c, sd_f, device=device, mlp="bf16x3")
+    m = WideModel(sd_c, sd_f, device=device, mlp="f16x2")
     o, r = run(m, S.FLOP_PER_POINT)
     a, b = o["rgb_map"], ref["rgb_map"]
     d = (a - b).abs().max(-1)[0]
@@ -434,9 +439,10 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
                                           "rays_rgb_above_1e-4": int((d > 1e-4).sum())}
     out["ycbv_8x256"] = r
     m.close()
-    m = WideModel(sd_c, sd_f, device=device, mlp="fp32")
-    _, out["ycbv_8x256_strict_fp32"] = run(m, S.FLOP_PER_POINT, launches=1)
-    m.close()
+    for mlp, key in (("bf16x3", "ycbv_8x256_bf16x3"), ("fp32", "ycbv_8x256_strict_fp32")):
+        m = WideModel(sd_c, sd_f, device=device, mlp=mlp)
+        _, out[key] = run(m, S.FLOP_PER_POINT, launches=1)
+        m.close()
     rng = np.random.RandomState(3)
     wide = {}
     Wd = 512
@@ -446,7 +452,7 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
         wide[name + ".weight"] = (rng.uniform(-bnd, bnd, (o_, i_)) * (1.13 if name.startswith("pts") else 25.0 if name == "alpha_linear" else 1.0)).astype(np.float32)
         wide[name + ".bias"] = rng.uniform(-bnd, bnd, (o_,)).astype(np.float32)
     fpp = 2 * sum(v.size for k, v in wide.items() if k.endswith(".weight"))
-    m = WideModel(wide, wide, device=device, mlp="bf16x3")
+    m = WideModel(wide, wide, device=device, mlp="f16x2")
     ps = PowerSampler(device)
     ps.start()
     _, r = run(m, fpp)
@@ -460,11 +466,13 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
     t, ch = m.last_kernel_ms()
     tf = (H * W * (256 + 192) * fpp) / t / 1e9
     out["wide_8x512_with_input_gradient"] = {"ms_per_view": round(t, 2), "chunks_of_rays": ch, "achieved": round(tf, 1), "unit": "TFLOP/s",
-                                             "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "issued_frac": round(6 * tf / PEAK_BF16_MFMA_TFLOPS, 4)}
+                                             "frac": round(tf / PEAK_BF16_MFMA_TFLOPS, 4), "issued_frac": round(3 * tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                                             "range_status": m.range_status()}
     m.close()
-    m = WideModel(wide, wide, device=device, mlp="fp32")
-    _, out["wide_8x512_strict_fp32"] = run(m, fpp, launches=1)
-    m.close()
+    for mlp, key in (("bf16x3", "wide_8x512_bf16x3"), ("fp32", "wide_8x512_strict_fp32")):
+        m = WideModel(wide, wide, device=device, mlp=mlp)
+        _, out[key] = run(m, fpp, launches=1)
+        m.close()
     return out
 
 

@@ -69,10 +69,13 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     forced = network_fn.__dict__.get("_nsr_force_mlp")     # set by _note_range: THESE weights keep leaving f16x2's range
     forced = forced[0] if forced and forced[1] == ident else None
     from .engine import NATIVE_COUNTS
+    forced_any = forced
     if forced and ((n_samples, n_importance) in NATIVE_COUNTS or n_importance == 96):
         forced = None                 # sample counts only the f16x2 kernels are specialised to: stay there (per-item fallback)
     layered = _layered_why(network_fn, network_fine, n_samples, n_importance, forced or os.environ.get("NSR_MLP"))
-    key = (n_samples, n_importance, ident, "layered" if layered else (forced or os.environ.get("NSR_MLP")))     # which kernels
+    if layered:
+        forced = forced_any           # (the layered renderer has every arithmetic at every sample count)
+    key = (n_samples, n_importance, ident, ("layered", forced) if layered else (forced or os.environ.get("NSR_MLP")))     # which kernels
     # a native handle owns ONE argument block / work queue / scratch set (include/nsr.h: one handle per (model,
     # stream)), so the cache is also keyed on the device and on the torch stream the launch will be issued on
     p0 = next(network_fn.parameters())
@@ -96,7 +99,8 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
                 from .wide import WideModel
                 own = lambda net: {k: v.detach() for k, v in net.state_dict().items()}
                 cache["model"] = WideModel(own(network_fn), own(network_fine) if network_fine is not None else None, device=dev,
-                                           n_importance=n_importance, white_bkgd=white, lindisp=lindisp, n_samples=n_samples)
+                                           n_importance=n_importance, white_bkgd=white, lindisp=lindisp, n_samples=n_samples,
+                                           mlp=forced)
                 cache["model"].why_layered = layered
             else:
                 cache["model"] = NsrModel(_native_sd(network_fn), _native_sd(network_fine) if network_fine is not None
@@ -141,6 +145,20 @@ def _note_range(model, network_fn=None):
     sends more than a tenth of its rays down that route pays for both kernels: its later handles are built with the bf16x3
     kernels (`_model_for` reads the mark), which is the same arithmetic without the detour -- 157 against 94 Mray-samples/s
     for the fp32-MFMA kernels r04 switched to."""
+    if getattr(model, "mlp", None) == "layered-f16x2":
+        # the layered renderer's unit is a network PASS over a chunk of rays, re-run on bf16x3 as a whole (include/nsr_wide.h)
+        st = model.range_status()
+        if st["passes_rerun"] and not getattr(model, "_range_warned", False):
+            import warnings
+            model._range_warned = True
+            switch = network_fn is not None and st["passes_rerun"] > _RANGE_SWITCH_FRAC * max(1, st["passes"])
+            if switch:
+                network_fn.__dict__["_nsr_force_mlp"] = (_RANGE_SWITCH_MLP, getattr(model, "weights_version", None))
+            warnings.warn("neural_sim_nerf_amd: %d of %d network passes of the layered renderer left the fp16 range of its f16x2 GEMMs "
+                          "and were run again on bf16x3 inside the call (the results are that arithmetic's).%s"
+                          % (st["passes_rerun"], st["passes"], "  This network now gets the bf16x3 GEMMs outright." if switch else
+                             "  NSR_WIDE_MLP=bf16x3 selects them outright."), RuntimeWarning)
+        return
     if getattr(model, "mlp", None) != "f16x2":
         return
     st = model.range_status()

@@ -63,7 +63,8 @@ SIGNATURES = {
 FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_MLP_BF16X3, FLAG_MLP_F16X2 = 1, 2, 4, 8
 MLPS = ("bf16x3", "fp32", "f16x2")
 
-DEFAULT_MLP = "bf16x3"          # r06: same parity bounds as the fp32 MFMAs (tests/test_gpu_wide.py runs every case on both), 1.7x their speed
+DEFAULT_MLP = "f16x2"           # r06: the fused default kernel's arithmetic; same parity bounds as the fp32 MFMAs and bf16x3 (tests/test_gpu_wide.py
+                                # runs every case on all three), 2.6x / 1.5x their speed; never range-dependent (re-run on bf16x3)
 
 _bound = None
 

@@ -119,6 +119,12 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 98304, r
         r = res["kw_gemm_b3<4, %d, 2>" % e]
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 73728, r
+    # r06: the same kernel body on two fp16 pieces (kw_gemm_h2, the layered default): two thirds of the LDS, the same occupancy
+    h2 = [k for k in layered if k.startswith("kw_gemm_h2<")]
+    assert {"kw_gemm_h2<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(h2), h2
+    for e in (0, 1, 2, 4):
+        r = res["kw_gemm_h2<4, %d, 4>" % e]
+        assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 65536, r
 
 
 def test_header_constants_match_packer():
