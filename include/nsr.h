@@ -385,9 +385,9 @@ int nsr_schedule_stats(nsr_handle h, unsigned* recomputed_rays);
  * outputs / gradients were NaN, *rays = rays rendered again by the fp32 kernel, *dropped_items = items that could not be:
  * EVERY OUTPUT OF THEIR REPORTED RAYS IS NaN (never a finite number computed from out-of-range activations).  An item is
  * dropped only (a) by a launch CAPTURED into a hipGraph that is larger than the list was when the capture began (a capture
- * cannot allocate: call nsr_reserve_range first), (b) by an input-gradient launch without nsr_upload_weights_bwd (no fp32
- * transposed stream to fall back to), or (c) when the device is out of memory for the list.  Any pointer may be NULL.  All
- * zero for other handles.  Synchronises the device. */
+ * cannot allocate: call nsr_reserve_range first) or (b) by an input-gradient launch without nsr_upload_weights_bwd (no fp32
+ * transposed stream to fall back to).  (A launch that cannot get memory for its list FAILS: r06.)  Any pointer may be NULL.
+ * All zero for other handles.  Synchronises the device. */
 int nsr_range_status(nsr_handle h, unsigned* last_items, unsigned* points, unsigned* rays, unsigned* dropped_items);
 
 /* SETUP call: make the safety net's list large enough for launches of up to n_rays rays (8 bytes per 2 rays).  EAGER launch

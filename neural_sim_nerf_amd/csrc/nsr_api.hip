@@ -433,8 +433,9 @@ static bool use_x16(nsr_handle h) { return h->cfg.variant != 32; }
 // Grows geometrically; the outgrown list is RETIRED, never freed while the handle lives (see nsr_handle_s::retired), and
 // nothing synchronises.  Not while the stream is capturing (no allocation inside a capture): a captured launch larger
 // than the list keeps the present capacity, and the kernel stores NaN into the rays of the items it cannot list
-// (range_poison) -- call nsr_reserve_range before capturing to avoid that.  An allocation failure is not an error either:
-// same NaN semantics, counted by nsr_range_status.
+// (range_poison) -- call nsr_reserve_range before capturing to avoid that.  The allocation itself runs in the thread's RELAXED
+// capture mode (hipThreadExchangeStreamCaptureMode, as torch's caching allocator does): a capture in progress on ANOTHER stream
+// or thread in global mode is not invalidated by it.  An allocation failure IS an error of the launch call.
 static int ensure_range(nsr_handle h, long long n_rays, bool capturing) {
   if (!h->d_ovf_items) return 0;
   if (n_rays > kMaxRaysH2) return fail("f16x2 handles take at most 2^33 - 2 rays per launch");
@@ -444,10 +445,18 @@ static int ensure_range(nsr_handle h, long long n_rays, bool capturing) {
   if (want < items) want = items;
   if (want > 0xFFFFFFFFull) want = 0xFFFFFFFFull;
   unsigned long long* grown = nullptr;
-  if (hipMalloc(&grown, sizeof(unsigned long long) * want) != hipSuccess) {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  hipError_t e = hipMalloc(&grown, sizeof(unsigned long long) * want);
+  if (e != hipSuccess && want != items) {
     (void)hipGetLastError();
-    if (want == items || hipMalloc(&grown, sizeof(unsigned long long) * items) != hipSuccess) { (void)hipGetLastError(); return 0; }
     want = items;
+    e = hipMalloc(&grown, sizeof(unsigned long long) * want);
+  }
+  (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail("out of device memory for the f16x2 range list of this launch (nsr_reserve_range)");
   }
   h->retired.push_back(h->d_ovf_items);
   h->d_ovf_items = grown;

@@ -121,6 +121,11 @@ class NsrModel:
                                       "N_importance and, on f16x2 handles, (N_samples, N_importance) in %s"
                                       % (n_samples, n_importance, NATIVE_COUNTS))
         self.n_samples = n_samples
+        if mlp == "f16x2" and range_fallback == "fp32" and (n_importance not in (0, N_IMPORTANCE) or n_samples != N_SAMPLES):
+            # the fp32 kernels exist for (64, 128) and (64, 0) only; without the bf16x3 images such a handle would
+            # have NO fallback and drop every out-of-range ray to NaN
+            raise NotImplementedError("range_fallback='fp32' serves N_samples = 64 with N_importance = 128 or 0 only (got %r, %r): "
+                                      "use the default 'bf16x3'" % (n_samples, n_importance))
         if n_importance > 0 and sd_fine is None:
             sd_fine = sd_coarse          # RN:482: run_fn = network_fn if network_fine is None
         self.n_importance = n_importance
@@ -534,7 +539,7 @@ class NsrModel:
         """f16x2 range safety net (include/nsr.h: nsr_range_status): dict(last_items, points, rays, dropped_items) --
         items (2 rays) the last launch handed to its fp32 fallback; cumulative network evaluations with NaN outputs /
         gradients, rays re-rendered by the fp32 kernel, items that could not be (their rays hold NaN; only a launch captured
-        into a graph before reserve_range, or an out-of-memory list, gets there).  Synchronises the device."""
+        into a graph before reserve_range gets there).  Synchronises the device."""
         v = [C.c_uint() for _ in range(4)]
         _lib.check(self.lib.nsr_range_status(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("last_items", "points", "rays", "dropped_items"), (int(x.value) for x in v)))

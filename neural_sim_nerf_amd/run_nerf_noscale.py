@@ -171,8 +171,8 @@ def _note_range(model, network_fn=None):
         import warnings
         model._range_warned = True
         dropped = ("" if not st["dropped_items"] else
-                   "; %d items (2 rays each) could NOT be -- a launch captured into a graph before NsrModel.reserve_range, or "
-                   "no memory for the list -- and every output of their out-of-range rays is NaN" % st["dropped_items"])
+                   "; %d items (2 rays each) could NOT be -- a launch captured into a graph before NsrModel.reserve_range "
+                   "-- and every output of their out-of-range rays is NaN" % st["dropped_items"])
         warnings.warn("neural_sim_nerf_amd: %d network evaluations left the fp16 range of the f16x2 kernels; %d of %d rays were "
                       "rendered again by the bf16x3 kernel%s.%s"
                       % (st["points"], st["rays"], model.rays_launched, dropped,
