@@ -1,4 +1,10 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session Q: ablations of kw_gemm_h2, then the whole GPU suite)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session S: staggered workgroup starts, A/B)
 cd $GRAFT_REPO_ROOT
-MLP=f16x2 bash tools/ab_wide.sh $O/ab_wide_h2_w512.txt w512
-timeout 1800 python -m pytest tests -q -m gpu --durations=12 2>&1 | tail -25
+for rnd in 1 2; do
+for x in shipped STAGGER; do
+lib=$GRAFT_REPO_ROOT/neural_sim_nerf_amd/csrc/ab/libnsr_wide_$x.so; [ $x = shipped ] && lib=$GRAFT_REPO_ROOT/neural_sim_nerf_amd/csrc/libnsr.so
+for c in w512 ycbv w1024; do
+echo "$x: $(NSR_LIB_PATH=$lib timeout 300 python tools/bench_wide.py --mlp f16x2 --cases $c --steps 2 --no-grad 2>/dev/null | grep "^$c" | cut -c1-90,150-420)"
+done
+done
+done 2>&1 | tee $O/stagger.txt
