@@ -138,6 +138,17 @@ int nsrw_render_rays_vjp(nsrw_handle h, const float* d_rays_o, const float* d_ra
 int nsrw_run_network(nsrw_handle h, int net_id, const float* d_pts, const float* d_viewdirs, int64_t n_pts, float* d_raw,
                      void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* Stage entries that need no handle (stream-ordered launch calls on `device`; they restore the caller's current device).
+ * nsrw_sample_pdf = sample_pdf (RH:199-243) for ANY bin and sample count: d_bins [N, n_bins], d_weights [N, n_bins - 1], the
+ * uniforms d_u -- [n_samples] shared by all rows (det=True: the HOST's torch.linspace(0, 1, n_samples), RH:208) or, u_per_row != 0,
+ * [N, n_samples] (det=False: the caller's torch.rand, RH:211; the library has no generator) -> d_samples [N, n_samples], d_inds
+ * (nullable) int64 [N, n_samples] = searchsorted(cdf, u, right=True) (RH:227).  d_scratch: 2 N (n_bins + 1) floats.  Bit-exact
+ * against the reference: torch.sum's association order, fp64-accumulate cdf.
+ * nsrw_embed_vjp = the VJP of Embedder.embed (RH:39-48): d_x [P,3], d_grad_out [P, 3 + 6 multires] -> d_grad_x [P,3]. */
+int nsrw_sample_pdf(int device, const float* d_bins, const float* d_weights, int64_t n_rows, int n_bins, const float* d_u,
+                    int u_per_row, int n_samples, float* d_samples, int64_t* d_inds, float* d_scratch, void* stream);
+int nsrw_embed_vjp(int device, const float* d_x, const float* d_grad_out, int64_t n_points, int multires, float* d_grad_x, void* stream);
+
 /* NSRW_FLAG_MLP_F16X2 handles: network passes (forward and backward) launched so far and how many of them were re-run on bf16x3
  * because an activation or a gradient left fp16's range (both 0 for the other arithmetics).  Synchronises the device. */
 int nsrw_range_status(nsrw_handle h, unsigned long long* passes, unsigned long long* passes_rerun);

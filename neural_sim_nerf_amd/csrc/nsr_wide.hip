@@ -493,6 +493,7 @@ struct PdfArgs {
   float* zs;                             // [R,NI]
   int64_t* inds;                         // nullable [R,NI]
   float* z_std;                          // nullable [R]
+  const float* bins;                     // nullable: the stage entry nsrw_sample_pdf -- bins [R,S0-1] GIVEN (z0 unused), w0 = weights [R,S0-2]
 };
 
 __global__ void __launch_bounds__(256) kw_sample_pdf(const PdfArgs a) {
@@ -500,7 +501,8 @@ __global__ void __launch_bounds__(256) kw_sample_pdf(const PdfArgs a) {
   if (r >= a.R) return;
   const int NW = a.S0 - 2, NC = a.S0 - 1;
   const float* z = a.z0 + (long long)r * a.S0;
-  const float* w = a.w0 + (long long)r * a.S0 + 1;
+  const float* w = a.bins ? a.w0 + (long long)r * NW : a.w0 + (long long)r * a.S0 + 1;
+  const float* bn = a.bins ? a.bins + (long long)r * NC : nullptr;
   float* x = a.pdf + (long long)r * a.S0;
   float* cdf = a.cdf + (long long)r * a.S0;
   for (int i = 0; i < NW; ++i) x[i] = w[i] + 1e-5f;                        // RH:201
@@ -541,7 +543,8 @@ __global__ void __launch_bounds__(256) kw_sample_pdf(const PdfArgs a) {
     const int below = max(lo - 1, 0), above = min(lo, NC - 1);             // RH:228-229
     NSRW_CHECK(lo >= 0 && lo <= NC && below >= 0 && above + 1 < a.S0 && below + 1 < a.S0 && NC < a.S0);
     const float c0 = cdf[below], c1 = cdf[above];
-    const float b0 = 0.5f * (z[below + 1] + z[below]), b1 = 0.5f * (z[above + 1] + z[above]);     // RN:473
+    const float b0 = bn ? bn[below] : 0.5f * (z[below + 1] + z[below]);     // RN:473
+    const float b1 = bn ? bn[above] : 0.5f * (z[above + 1] + z[above]);
     float denom = c1 - c0;
     if (denom < 1e-5f) denom = 1.0f;                                       // RH:238-239
     const float t = (u - c0) / denom;
@@ -754,6 +757,28 @@ __global__ void __launch_bounds__(256) kw_copy_rows(const float* __restrict__ sr
   const long long p = gid / cols;
   const int c = (int)(gid - p * cols);
   if (p < rows) dst[p * ld_dst + c] = src[p * ld_src + c];
+}
+
+// VJP of Embedder.embed (RH:39-48) alone: gx[c] = g[c] + sum_l 2^l (g_sin[l][c] cos(2^l x_c) - g_cos[l][c] sin(2^l x_c)), the
+// trigonometric values at the forward's own fp32 arguments, the sum in fp64 rounded once.  One thread per point.
+__global__ void __launch_bounds__(256) kw_embed_vjp(const float* __restrict__ x, const float* __restrict__ g, long long P, int L,
+                                                    float* __restrict__ gx) {
+  const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int C = 3 + 6 * L;
+  const float* gp = g + p * C;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xc = x[p * 3 + c];
+    double acc = (double)gp[c];
+    for (int l = 0; l < L; ++l) {
+      const float f = ldexpf(1.0f, l);
+      float sn, cs;
+      sincos_enc(xc * f, sn, cs);
+      acc += (double)f * ((double)gp[3 + 6 * l + c] * (double)cs - (double)gp[6 + 6 * l + c] * (double)sn);
+    }
+    gx[p * 3 + c] = (float)acc;
+  }
 }
 
 }  // namespace nsrw
@@ -1727,6 +1752,37 @@ int nsrw_debug_bounds_status(int* built_with_checks, unsigned* first_bad_line) {
 #else
   *built_with_checks = 0;
 #endif
+  return 0;
+}
+
+int nsrw_sample_pdf(int device, const float* d_bins, const float* d_weights, int64_t n_rows, int n_bins, const float* d_u,
+                    int u_per_row, int n_samples, float* d_samples, int64_t* d_inds, float* d_scratch, void* stream) {
+  if (!d_bins || !d_weights || !d_u || !d_samples || !d_scratch) return fail("nsrw_sample_pdf: null argument");
+  if (n_rows < 0 || n_rows > 0x7fffffffll) return fail("nsrw_sample_pdf: 0 .. 2^31 - 1 rows");
+  if (n_bins < 2 || n_bins > NSRW_MAX_SAMPLES || n_samples < 1 || n_samples > NSRW_MAX_SAMPLES)
+    return fail("nsrw_sample_pdf: 2.." + std::to_string(NSRW_MAX_SAMPLES) + " bins, 1.." + std::to_string(NSRW_MAX_SAMPLES) + " samples");
+  if (n_rows == 0) return 0;
+  DeviceGuard guard_(device);
+  NSRW_HIP(guard_.err);
+  PdfArgs pa{};
+  pa.R = (int)n_rows; pa.S0 = n_bins + 1; pa.NI = n_samples; pa.z0 = d_bins; pa.w0 = d_weights; pa.bins = d_bins;
+  pa.u_tab = u_per_row ? nullptr : d_u; pa.u_rays = u_per_row ? d_u : nullptr;
+  pa.pdf = d_scratch; pa.cdf = d_scratch + (size_t)n_rows * (n_bins + 1);
+  pa.zs = d_samples; pa.inds = d_inds; pa.z_std = nullptr;
+  hipLaunchKernelGGL(kw_sample_pdf, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), pa);
+  NSRW_HIP(hipGetLastError());
+  return 0;
+}
+
+int nsrw_embed_vjp(int device, const float* d_x, const float* d_grad_out, int64_t n_points, int multires, float* d_grad_x, void* stream) {
+  if (!d_x || !d_grad_out || !d_grad_x) return fail("nsrw_embed_vjp: null argument");
+  if (n_points < 0 || multires < 0 || multires > 15) return fail("nsrw_embed_vjp: n_points >= 0, multires 0..15");
+  if (n_points == 0) return 0;
+  DeviceGuard guard_(device);
+  NSRW_HIP(guard_.err);
+  hipLaunchKernelGGL(kw_embed_vjp, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_x, d_grad_out,
+                     (long long)n_points, multires, d_grad_x);
+  NSRW_HIP(hipGetLastError());
   return 0;
 }
 

@@ -16,9 +16,30 @@ mse2psnr = lambda x: -10. * torch.log(x) / torch.log(torch.tensor([10.], device=
 to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)                                       # RH:14 (truncation)
 
 
+class _Embed(torch.autograd.Function):
+    """Embedder.embed with its input gradient: forward nsr_embed, backward nsrw_embed_vjp (both native; RH:39-48)."""
+
+    @staticmethod
+    def forward(ctx, x, num_freqs):
+        from .run_nerf_noscale import _util_model
+        m = _util_model(x.device if x.is_cuda else None)
+        ctx.num_freqs = num_freqs
+        ctx.was_cuda = x.is_cuda
+        xd = m._f32(x.detach())
+        ctx.save_for_backward(xd)
+        return m.embed(xd, num_freqs)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .wide import embed_vjp
+        (xd,) = ctx.saved_tensors
+        gx = embed_vjp(xd, g.contiguous(), ctx.num_freqs)
+        return (gx if ctx.was_cuda else gx.cpu()), None
+
+
 class Embedder:
     """RH:18-48.  Inside render() the encoding is evaluated in registers by the fused kernels; embed() exposes
-    the same device code as a stand-alone op (nsr_embed), forward only."""
+    the same device code as a stand-alone op (nsr_embed), differentiable in its input (r06: nsrw_embed_vjp)."""
 
     def __init__(self, **kwargs):
         self.kwargs = kwargs
@@ -26,9 +47,8 @@ class Embedder:
         self.out_dim = (d if kwargs["include_input"] else 0) + d * 2 * kwargs["num_freqs"]
 
     def embed(self, inputs):
-        if torch.is_tensor(inputs) and inputs.requires_grad:
-            raise NotImplementedError("Embedder.embed is forward-only here; gradients w.r.t. points flow through "
-                                      "render(rays=...) (nsr_render_rays_vjp)")
+        if torch.is_tensor(inputs) and inputs.requires_grad and torch.is_grad_enabled():
+            return _Embed.apply(inputs, self.kwargs["num_freqs"])
         from .run_nerf_noscale import _util_model
         dev = inputs.device if torch.is_tensor(inputs) and inputs.is_cuda else None
         return _util_model(dev).embed(inputs, self.kwargs["num_freqs"])
@@ -98,6 +118,37 @@ class NeRF(nn.Module):
         self._native = None
         self._native_key = None
         self._native5 = None                                 # use_viewdirs=False with output_ch = 5: see evaluate()
+
+    @staticmethod
+    def adopt(module):
+        """A drop-in NeRF that SHARES the parameters of a foreign module with the reference's layout (RH:70-97: attributes D, W,
+        input_ch, input_ch_views, skips, use_viewdirs and the layers pts_linears / views_linears / feature_linear / alpha_linear /
+        rgb_linear or output_linear) -- e.g. an instance of the reference's own class.  The wrapper holds the SAME nn.Linear
+        modules, so an optimizer step or load_state_dict on the foreign module is seen here (the weight fingerprint reads the
+        shared storage); it is cached on the foreign module.  None and drop-in modules pass through."""
+        if module is None or isinstance(module, NeRF):
+            return module
+        cached = module.__dict__.get("_nsr_adopted")
+        if cached is not None and cached.pts_linears is getattr(module, "pts_linears", None):
+            return cached
+        need = ("D", "W", "input_ch", "input_ch_views", "skips", "use_viewdirs", "pts_linears", "views_linears")
+        missing = [n for n in need if not hasattr(module, n)]
+        if missing:
+            raise NotImplementedError("network_fn / network_fine: %s is neither a neural_sim_nerf_amd NeRF nor a module with the "
+                                      "reference's NeRF layout (RH:70-97; missing %s)" % (type(module).__name__, ", ".join(missing)))
+        use_viewdirs = bool(module.use_viewdirs)
+        output_ch = 4 if use_viewdirs else int(module.output_linear.out_features)
+        mine = NeRF(D=int(module.D), W=int(module.W), input_ch=int(module.input_ch), input_ch_views=int(module.input_ch_views),
+                    output_ch=output_ch, skips=list(module.skips), use_viewdirs=use_viewdirs)
+        names = ("pts_linears", "views_linears") + (("feature_linear", "alpha_linear", "rgb_linear") if use_viewdirs else ("output_linear",))
+        for n in names:
+            theirs = getattr(module, n)
+            want = [tuple(p.shape) for p in getattr(mine, n).parameters()]
+            if [tuple(p.shape) for p in theirs.parameters()] != want:
+                raise NotImplementedError("network_fn / network_fine: layer %s of %s does not have the reference's shapes" % (n, type(module).__name__))
+            setattr(mine, n, theirs)                       # the SAME modules: shared Parameters
+        module.__dict__["_nsr_adopted"] = mine             # (not registered as a submodule of the foreign module)
+        return mine
 
     def native_state_dict(self):
         """The weights in the architecture the kernels are built for (as_kernel_network): this module's own state dict
@@ -410,9 +461,23 @@ def ndc_rays(H, W, focal, near, rays_o, rays_d):
 
 
 def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
-    """RH:199-243, deterministic branch only, native kernel."""
-    if not det or pytest or N_samples != 128:
-        raise NotImplementedError("sample_pdf: only det=True, N_samples=128 (perturb=0, RN:474) is supported")
-    from .run_nerf_noscale import _util_model
-    samples, _ = _util_model(bins.device).sample_pdf(bins, weights)
+    """RH:199-243 on the native kernel (nsrw_sample_pdf: any bin / sample count up to 512, bit-exact cdf -> indices -> samples).
+    The uniforms are drawn HERE exactly where and how the reference draws them -- det: torch.linspace(0, 1, N_samples) on the
+    host (RH:208); else torch.rand of the reference's shape (RH:211), on the bins' device; pytest: numpy's generator reseeded
+    with 0 (RH:214-222) -- the library itself has no generator.  Forward only, like the reference's use of it (RN:475 detaches)."""
+    from .wide import sample_pdf as _native
+    bins = torch.as_tensor(bins)
+    lead = list(bins.shape[:-1])
+    if pytest:
+        np.random.seed(0)
+        if det:
+            u = np.broadcast_to(np.linspace(0., 1., N_samples), lead + [N_samples])
+        else:
+            u = np.random.rand(*(lead + [N_samples]))
+        u = torch.as_tensor(np.ascontiguousarray(u), dtype=torch.float32)
+    elif det:
+        u = torch.linspace(0., 1., steps=N_samples)
+    else:
+        u = torch.rand(lead + [N_samples], device=bins.device if bins.is_cuda else None)
+    samples, _ = _native(bins.detach(), torch.as_tensor(weights).detach(), u)
     return samples

@@ -61,8 +61,7 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     for its 512-ray patch form, whose fingerprint it reads AFTER the launch (deferred check), or not at all when
     NSR_TRUST_VERSIONS says so."""
     from .engine import NsrModel
-    if not isinstance(network_fn, NeRF) or (network_fine is not None and not isinstance(network_fine, NeRF)):
-        raise NotImplementedError("network_fn / network_fine must be neural_sim_nerf_amd NeRF modules (create_nerf)")
+    network_fn, network_fine = NeRF.adopt(network_fn), NeRF.adopt(network_fine)     # (a module with the reference's layout: shared weights)
     white, lindisp = bool((kw or {}).get("white_bkgd", False)), bool((kw or {}).get("lindisp", False))
     n_samples = int((kw or {}).get("N_samples", 64))
     ident, fp = NeRF.weights_version_of(network_fn, network_fine, trust=trust)
@@ -72,7 +71,8 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     forced_any = forced
     if forced and ((n_samples, n_importance) in NATIVE_COUNTS or n_importance == 96):
         forced = None                 # sample counts only the f16x2 kernels are specialised to: stay there (per-item fallback)
-    layered = _layered_why(network_fn, network_fine, n_samples, n_importance, forced or os.environ.get("NSR_MLP"))
+    layered = _layered_why(network_fn, network_fine, n_samples, n_importance, forced or os.environ.get("NSR_MLP"),
+                           retraw=bool((kw or {}).get("retraw", False)))
     if layered:
         forced = forced_any           # (the layered renderer has every arithmetic at every sample count)
     key = (n_samples, n_importance, ident, ("layered", forced) if layered else (forced or os.environ.get("NSR_MLP")))     # which kernels
@@ -115,7 +115,7 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
     return cache["model"]
 
 
-def _layered_why(network_fn, network_fine, n_samples, n_importance, mlp=None):
+def _layered_why(network_fn, network_fine, n_samples, n_importance, mlp=None, retraw=False):
     """None when the fused kernels serve this (networks, sample counts) pair, else the reason the layered renderer
     (wide.WideModel: one fp32-MFMA GEMM per layer, activations in HBM) takes it: a network that is not expressible as the
     kernels' 8 x 256 (NeRF.fused_why_not), or sample counts no fused kernel is built for.  NSR_LAYERED=1 sends everything
@@ -127,6 +127,17 @@ def _layered_why(network_fn, network_fine, n_samples, n_importance, mlp=None):
         if net is not None and net.fused_why_not:
             return net.fused_why_not
     f16x2 = (mlp or DEFAULT_MLP) == "f16x2"
+    if retraw:
+        # RN:490-491: raw is [N, N_samples + N_importance, C].  The fused kernels return that where they evaluate exactly those
+        # samples and the network has four output rows; elsewhere (duplicated importance samples, use_viewdirs=False with
+        # output_ch != 4) the layered renderer does (r06; r05 refused)
+        from .engine import NATIVE_IMPORTANCE
+        last = network_fine if (n_importance > 0 and network_fine is not None) else network_fn
+        if not last.use_viewdirs and last.output_ch != 4:
+            return "retraw of a use_viewdirs=False network with output_ch=%d" % last.output_ch
+        if n_samples == 64 and n_importance in IMPORTANCE_COUNTS and n_importance not in (0, 128) and \
+                not (f16x2 and (n_importance in NATIVE_IMPORTANCE or n_importance == 96)):
+            return "retraw with N_importance=%d (the %s kernels render it with duplicated samples)" % (n_importance, mlp or DEFAULT_MLP)
     if n_samples == 64 and n_importance in IMPORTANCE_COUNTS and (n_importance != 96 or f16x2):
         return None
     if f16x2 and (n_samples, n_importance) in NATIVE_COUNTS:
@@ -432,7 +443,7 @@ def render(H, W, K, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far
     _check_kwargs(kwargs)
     n_imp = kwargs.get("N_importance", 0)
     from .run_nerf_helpers import DEFER_PATCH_CHECK, TRUST_PATCH_CALLS
-    net_c, net_f = kwargs["network_fn"], kwargs.get("network_fine", None) if n_imp > 0 else None
+    net_c, net_f = NeRF.adopt(kwargs["network_fn"]), NeRF.adopt(kwargs.get("network_fine", None) if n_imp > 0 else None)
     # the patch form (RN:168): the content fingerprint is enqueued AHEAD of the render and read while the render runs
     # (run_nerf_helpers: NSR_TRUST_VERSIONS); a mismatch renders again from repacked weights before this call returns
     token = NeRF.fingerprint_begin(net_c, net_f) if (rays is not None and DEFER_PATCH_CHECK and isinstance(net_c, NeRF)) else None

@@ -58,6 +58,9 @@ SIGNATURES = {
     "nsrw_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "nsrw_debug_bounds_status": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
     "nsrw_range_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+    "nsrw_sample_pdf": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "nsrw_embed_vjp": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
 }
 
 FLAG_WHITE_BKGD, FLAG_LINDISP, FLAG_MLP_BF16X3, FLAG_MLP_F16X2 = 1, 2, 4, 8
@@ -138,6 +141,51 @@ def workspace_cap_bytes(device, reusable=0):
     Only consulted when the shared workspace has to GROW (WideModel._workspace): one driver query per growth, not per launch."""
     free, _ = torch.cuda.mem_get_info(device)
     return min(workspace_cap_env(), (free + reusable) // 2)
+
+
+def _cuda_f32(x, device=None):
+    t = torch.as_tensor(x, dtype=torch.float32)
+    if not t.is_cuda:
+        if not torch.cuda.is_available():
+            raise _lib.NsrError("no HIP device visible: the render path has no CPU fallback")
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    return t.contiguous()
+
+
+def sample_pdf(bins, weights, u):
+    """nsrw_sample_pdf: sample_pdf (RH:199-243) for any bin / sample count.  bins [..., B], weights [..., B - 1]; u: [S] (shared by
+    all rows: det=True) or [..., S] (det=False).  -> (samples [..., S] float32, inds [..., S] int64) on the device."""
+    lib = load()
+    bins = _cuda_f32(bins)
+    dev = bins.device
+    weights, u = _cuda_f32(weights, dev), _cuda_f32(u, dev)
+    lead, B = tuple(bins.shape[:-1]), int(bins.shape[-1])
+    if tuple(weights.shape) != lead + (B - 1,):
+        raise ValueError("sample_pdf: weights must be bins' shape with one entry less (got %r, %r)" % (tuple(bins.shape), tuple(weights.shape)))
+    S = int(u.shape[-1])
+    per_row = u.dim() > 1
+    if per_row and tuple(u.shape[:-1]) != lead:
+        raise ValueError("sample_pdf: per-row uniforms must have bins' leading shape")
+    if not 2 <= B <= MAX_SAMPLES or not 1 <= S <= MAX_SAMPLES:
+        raise NotImplementedError("sample_pdf: 2..%d bins and 1..%d samples (got %d, %d)" % (MAX_SAMPLES, MAX_SAMPLES, B, S))
+    n = int(np.prod(lead)) if lead else 1
+    samples = torch.empty(lead + (S,), dtype=torch.float32, device=dev)
+    inds = torch.empty(lead + (S,), dtype=torch.int64, device=dev)
+    scratch = torch.empty(2 * n * (B + 1), dtype=torch.float32, device=dev)
+    check(lib.nsrw_sample_pdf(dev.index, _dev(bins), _dev(weights), n, B, _dev(u), 1 if per_row else 0, S, _dev(samples), _dev(inds),
+                              _dev(scratch), _stream_ptr(dev)))
+    return samples, inds
+
+
+def embed_vjp(x, grad_out, multires):
+    """nsrw_embed_vjp: d(sum(embed(x) * grad_out)) / dx for x [..., 3], grad_out [..., 3 + 6 multires]."""
+    lib = load()
+    x = _cuda_f32(x)
+    g = _cuda_f32(grad_out, x.device)
+    gx = torch.empty_like(x)
+    n = x.numel() // 3
+    check(lib.nsrw_embed_vjp(x.device.index, _dev(x), _dev(g), n, int(multires), _dev(gx), _stream_ptr(x.device)))
+    return gx
 
 
 # ONE workspace per (device, stream), shared by every handle that launches there: a handle's launch calls are stream-ordered, so

@@ -466,8 +466,11 @@ def test_noviewdirs_network(mlp, oracle):
     assert tuple(out.shape) == (8, 1, 5)
     assert_close(cpu(out).reshape(-1, 5), oracle.mlp(sd_c, np.concatenate([e, np.zeros((8, 27), np.float32)], -1), all_rows=True),
                  atol=5e-5, rtol=5e-5, what="run_network(viewdirs=None)")
-    with pytest.raises(NotImplementedError, match="retraw"):
-        R.render(400, 400, oracle.YCBV_K, rays=rays, retraw=True, **kw)
+    # retraw of a five-row network (RN:267, RH:119-120: raw is [N, S, 5]): r05 refused it on the fused kernels, since r06 the call
+    # goes to the layered renderer, which returns every output row
+    raw5r = R.render(400, 400, oracle.YCBV_K, rays=rays.detach(), retraw=True, **kw)[3]["raw"]
+    assert tuple(raw5r.shape) == (rays.shape[1], 192, 5)
+    assert R._model_for(nets[0], nets[1], kw["N_importance"], dict(kw, retraw=True)).mlp.startswith("layered-")
     # the fifth row against the REFERENCE's own raw (g15 keeps all five channels of its first 16 rays)
     z15 = oracle.coarse_z(np.full(64, near, np.float32), np.full(64, far, np.float32))
     zf15 = np.sort(np.concatenate([z15, g["z_samples"]], -1), -1)[:16]
@@ -614,8 +617,13 @@ def test_fewer_importance_samples(oracle, synth_nets):
     # retraw: the specialised kernels return the reference's [N, 64 + 64, 4] raw; 16 (duplicated samples) still refuses
     raw = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **kw)[3]["raw"]
     assert tuple(raw.shape) == (len(ro), 128, 4) and np.array_equal(cpu(raw), want_raw)
-    with pytest.raises(NotImplementedError, match="retraw"):
-        R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **dict(kw, N_importance=16))
+    # 16 importance samples: the fused kernels render them as 128 with duplicates, so a retraw call goes to the layered renderer
+    # (r06; r05 refused) and returns the reference's [N, 64 + 16, 4]
+    kw16 = dict(kw, N_importance=16)
+    rgb16r, _, _, ex16 = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **kw16)
+    assert tuple(ex16["raw"].shape) == (len(ro), 80, 4) and R._model_for(nets[0], nets[1], 16, dict(kw16, retraw=True)).mlp.startswith("layered-")
+    rgb16 = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), **kw16)[0]          # (fused, duplicated samples)
+    assert oracle.psnr(cpu(rgb16r), cpu(rgb16)) > 50.0
     # N_importance = 100 has no fused kernel: since r05 the layered renderer takes the call (tests/test_gpu_wide.py) instead of a refusal
     kw100 = dict(kw, N_importance=100)
     rgb100, _, _, ex100 = R.render(400, 400, oracle.YCBV_K, rays=(torch.tensor(ro), torch.tensor(rd)), retraw=True, **kw100)

@@ -153,3 +153,128 @@ def test_trained_network_through_the_dropin_api(oracle):
     assert rel < 0.2          # (the depths are each side's own: a flipped resampling index moves a ray's gradient; direction and size agree)
     for n_ in nets:
         n_.invalidate()
+
+
+def test_module_level_sample_pdf_any_counts_and_both_branches(oracle):
+    """run_nerf_helpers.sample_pdf (RH:199-243) as a function of its own: any bin / sample count, det=True, det=False (torch.rand of
+    the reference's shape, drawn by the wrapper) and pytest=True (numpy's generator reseeded with 0, RH:214-222).  r05 served
+    63 bins / 128 samples / det=True only.  Against the oracle (pinned to the reference's sample_pdf: g5, g6, g14, g22-g26) BIT FOR BIT."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_helpers as H
+    from neural_sim_nerf_amd import wide
+    rng = np.random.RandomState(5)
+    for n_bins, n_smp, rows in ((63, 128, 300), (47, 100, 65), (2, 7, 5), (200, 512, 33), (511, 1, 4)):
+        bins = np.sort(rng.uniform(0.3, 1.9, (rows, n_bins)).astype(np.float32), -1)
+        w = rng.uniform(0, 1, (rows, n_bins - 1)).astype(np.float32) ** 4
+        w[0] = 0.0                                                   # (all-zero weights: uniform pdf, RH:201)
+        if n_bins > 8:
+            w[1, :] = 0.0
+            w[1, 3] = 1.0                                            # a spike: most bins empty, denominators at the 1e-5 switch
+        want, want_i, _ = oracle.sample_pdf(bins, w, n_smp)
+        got = H.sample_pdf(torch.tensor(bins), torch.tensor(w), n_smp, det=True)
+        assert got.is_cuda and np.array_equal(cpu(got), want), (n_bins, n_smp)
+        s2, i2 = wide.sample_pdf(bins, w, oracle.torch_linspace01(n_smp))
+        assert np.array_equal(cpu(i2), want_i) and np.array_equal(cpu(s2), want)
+        # det=False: the wrapper draws torch.rand(rows, n_smp) on the bins' device exactly once
+        torch.manual_seed(11)
+        got = H.sample_pdf(torch.tensor(bins, device="cuda"), torch.tensor(w, device="cuda"), n_smp, det=False)
+        torch.manual_seed(11)
+        u = torch.rand([rows, n_smp], device="cuda")
+        want_u, _, _ = oracle.sample_pdf(bins, w, n_smp, u=cpu(u))
+        assert np.array_equal(cpu(got), want_u), (n_bins, n_smp)
+        # pytest=True: numpy's draws
+        got = H.sample_pdf(torch.tensor(bins), torch.tensor(w), n_smp, det=False, pytest=True)
+        np.random.seed(0)
+        want_p, _, _ = oracle.sample_pdf(bins, w, n_smp, u=np.random.rand(rows, n_smp).astype(np.float32))
+        assert np.array_equal(cpu(got), want_p)
+    # leading batch dimensions like the reference's [..., n_bins]
+    bins = np.sort(rng.uniform(0.3, 1.9, (3, 5, 20)).astype(np.float32), -1)
+    w = rng.uniform(0, 1, (3, 5, 19)).astype(np.float32)
+    got = H.sample_pdf(torch.tensor(bins), torch.tensor(w), 9, det=True)
+    assert tuple(got.shape) == (3, 5, 9)
+    assert np.array_equal(cpu(got).reshape(15, 9), oracle.sample_pdf(bins.reshape(15, 20), w.reshape(15, 19), 9)[0])
+    with pytest.raises(NotImplementedError):
+        H.sample_pdf(torch.zeros(2, 600), torch.zeros(2, 599), 8, det=True)
+
+
+def test_embedder_is_differentiable(oracle):
+    """Embedder.embed (RH:39-48) with requires_grad input: forward = the native encoding, backward = nsrw_embed_vjp; against
+    autograd through a float64 torch restatement of the same function (r05 refused a differentiable embed)."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_helpers as H
+    rng = np.random.RandomState(3)
+    for L in (10, 4, 0):
+        fn, out_dim = H.get_embedder(L, 0) if L else (None, 3)
+        if fn is None:
+            continue
+        x = torch.tensor((rng.rand(257, 3).astype(np.float32) - 0.5) * 3.0, device="cuda", requires_grad=True)
+        g = torch.tensor(rng.standard_normal((257, out_dim)).astype(np.float32), device="cuda")
+        y = fn(x)
+        assert y.requires_grad and tuple(y.shape) == (257, out_dim)
+        assert_close(cpu(y), oracle.embed(cpu(x), L), atol=2.5e-7, what="embed forward")
+        (gx,) = torch.autograd.grad(y, x, grad_outputs=g)
+        x64 = x.detach().double().cpu().requires_grad_(True)
+        parts = [x64]
+        for l in range(L):
+            a = (x.detach() * np.float32(2.0 ** l)).double().cpu()                # the forward's own fp32 argument
+            a = a + (x64 - x64.detach()) * (2.0 ** l)                               # ... differentiable in x
+            parts += [torch.sin(a), torch.cos(a)]
+        (want,) = torch.autograd.grad(torch.cat(parts, -1), x64, grad_outputs=g.double().cpu())
+        scale = np.abs(cpu(want)).max()
+        assert np.abs(cpu(gx) - cpu(want)).max() <= 1e-6 * scale, (L, np.abs(cpu(gx) - cpu(want)).max(), scale)
+        # a CPU input gets a CPU gradient back; no_grad / detached inputs take the plain forward
+        xc = x.detach().cpu().requires_grad_(True)
+        (gc,) = torch.autograd.grad(fn(xc), xc, grad_outputs=g)
+        assert not gc.is_cuda and np.array_equal(cpu(gc), cpu(gx))
+        with torch.no_grad():
+            assert not fn(x).requires_grad
+
+
+def test_a_module_of_the_references_own_class_layout_is_adopted(oracle):
+    """network_fn / network_fine that are NOT neural_sim_nerf_amd modules but have the reference's layout (RH:70-97) -- what a
+    caller holds who built the networks with the reference's own class -- are served through a wrapper SHARING their parameters
+    (NeRF.adopt; r05 refused them): same pixels as the drop-in module, and a weight update on the foreign module is seen."""
+    import torch
+    import torch.nn as nn
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+
+    class Foreign(nn.Module):                                        # the attribute / layer names of RH:70-97, nothing else
+        def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, skips=(4,)):
+            super().__init__()
+            self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = D, W, input_ch, input_ch_views, list(skips), True
+            self.pts_linears = nn.ModuleList([nn.Linear(input_ch, W)] + [nn.Linear(W + input_ch if i in skips else W, W) for i in range(D - 1)])
+            self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+            self.feature_linear, self.alpha_linear, self.rgb_linear = nn.Linear(W, W), nn.Linear(W, 1), nn.Linear(W // 2, 3)
+
+    sd_c = oracle.synth_weights(0)
+    sd_f = oracle.synth_weights(1000, fine_of=sd_c)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    K = oracle.scaled_K(20.0)
+    pose = torch.as_tensor(np.asarray(oracle.sweep_poses(1, seed=4))[0][:3, :4])
+    foreign, ours = [], []
+    for sd in (sd_c, sd_f):
+        f = Foreign()
+        f.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        foreign.append(f.to(R.device))
+        n = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=27, use_viewdirs=True)
+        n.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        ours.append(n.to(R.device))
+    kw = dict(network_query_fn=None, perturb=False, N_importance=128, N_samples=64, use_viewdirs=True, white_bkgd=False,
+              raw_noise_std=0., ndc=False, lindisp=False, near=near, far=far)
+    with torch.no_grad():
+        a = R.render(20, 20, K, c2w=pose, network_fn=foreign[0], network_fine=foreign[1], **kw)[0]
+        b = R.render(20, 20, K, c2w=pose, network_fn=ours[0], network_fine=ours[1], **kw)[0]
+    assert np.array_equal(cpu(a), cpu(b), equal_nan=True)
+    ad = R.NeRF.adopt(foreign[1])
+    assert ad is R.NeRF.adopt(foreign[1]) and ad.rgb_linear.weight is foreign[1].rgb_linear.weight
+    with torch.no_grad():                                              # an update of the FOREIGN module's weights ...
+        foreign[1].rgb_linear.bias.add_(0.5)
+        ours[1].rgb_linear.bias.add_(0.5)
+        a2 = R.render(20, 20, K, c2w=pose, network_fn=foreign[0], network_fine=foreign[1], **kw)[0]
+        b2 = R.render(20, 20, K, c2w=pose, network_fn=ours[0], network_fine=ours[1], **kw)[0]
+    assert np.array_equal(cpu(a2), cpu(b2), equal_nan=True) and not np.array_equal(cpu(a2), cpu(a))      # ... is rendered
+    with pytest.raises(NotImplementedError, match="reference's NeRF layout"):
+        R.render(20, 20, K, c2w=pose, network_fn=nn.Linear(3, 4).to(R.device), network_fine=None, **dict(kw, N_importance=0))
+    for n_ in ours:
+        n_.invalidate()
+

@@ -488,6 +488,11 @@ def test_api_rejects_unsupported_configurations():
     with pytest.raises(NotImplementedError, match="retraw"):
         R._check_retraw(dict(base, N_importance=16, retraw=True), Fused)
     R._check_retraw(dict(base, N_importance=128, retraw=True), Fused)
+    # ... which the drop-in API no longer reaches (r06): a retraw call the fused kernels cannot answer in the reference's shape goes to
+    # the layered renderer
+    assert "retraw" in R._layered_why(net, net, 64, 16, retraw=True) and R._layered_why(net, net, 64, 16) is None
+    assert R._layered_why(net, net, 64, 64, retraw=True) is None and R._layered_why(net, net, 64, 128, retraw=True) is None
+    assert "retraw" in R._layered_why(net, net, 64, 64, "bf16x3", retraw=True)
     nv = R.NeRF(D=8, W=256, input_ch=63, output_ch=5, skips=[4], input_ch_views=0, use_viewdirs=False)
     assert "output_linear.weight" in nv.state_dict() and "alpha_linear.weight" not in nv.state_dict()
     assert set(nv.native_state_dict()) == set(net.state_dict())

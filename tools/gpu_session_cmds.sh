@@ -1,10 +1,7 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session S: staggered workgroup starts, A/B)
-cd $GRAFT_REPO_ROOT
-for rnd in 1 2; do
-for x in shipped STAGGER; do
-lib=$GRAFT_REPO_ROOT/neural_sim_nerf_amd/csrc/ab/libnsr_wide_$x.so; [ $x = shipped ] && lib=$GRAFT_REPO_ROOT/neural_sim_nerf_amd/csrc/libnsr.so
-for c in w512 ycbv w1024; do
-echo "$x: $(NSR_LIB_PATH=$lib timeout 300 python tools/bench_wide.py --mlp f16x2 --cases $c --steps 2 --no-grad 2>/dev/null | grep "^$c" | cut -c1-90,150-420)"
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session T: kernel stats of the layered f16x2 forward)
+cd /tmp && export TMPDIR=/tmp
+for c in ycbv small w512; do
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$c -- python $GRAFT_REPO_ROOT/tools/bench_wide.py --mlp f16x2 --cases $c --steps 2 --no-grad > $O/ks_$c.log 2>&1
+grep "^$c" $O/ks_$c.log | cut -c1-300
+f=$(ls $O/ks_$c/*/*_kernel_stats.csv | head -1); cut -c1-150 $f | head -24
 done
-done
-done 2>&1 | tee $O/stagger.txt
