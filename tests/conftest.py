@@ -65,28 +65,3 @@ def census_ref(g):
     return dict(rgb_map=flat(g["rgb"], 1), acc_map=flat(g["acc"], 0), disp_map=flat(g["disp"], 0),
                 rgb0=flat(g["rgb0"], 1), acc0=flat(g["acc0"], 0), sigma0_last=g["sigma0_last"],
                 pdf_weights=g["pdf_weights"], inds=g["inds"], z_samples=g["z_samples"])
-
-
-def oracle_render_parallel(sd_c, sd_f, ro, rd, near, far, K, threads=32, workers=None):
-    """The oracle's render of many rays on the host, rays cut over as many PROCESSES of `threads` torch threads as the machine has
-    cores for (at most 6): one process does not scale past ~32 threads (measured on the GPU box: 64 threads were slower than 32),
-    several do.  Rays are independent in the oracle, so the pieces concatenate to what one call returns.  Workers are plain
-    subprocesses of tests/oracle_render_job.py (no dependence on how the calling interpreter was started)."""
-    import subprocess
-    import tempfile
-    if workers is None:
-        workers = max(1, min(6, (os.cpu_count() or 1) // threads))
-    threads = min(threads, os.cpu_count() or 1)
-    cuts = np.linspace(0, len(ro), workers + 1).astype(int)
-    with tempfile.TemporaryDirectory() as tmp:
-        np.savez(os.path.join(tmp, "nets.npz"), **{"c." + k: v for k, v in sd_c.items()}, **{"f." + k: v for k, v in sd_f.items()})
-        procs = []
-        for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
-            np.savez(os.path.join(tmp, "job%d.npz" % i), ro=ro[a:b], rd=rd[a:b], near=near, far=far, K=np.asarray(K, np.float64))
-            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "oracle_render_job.py"), tmp, str(i), str(threads)],
-                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-        for i, pr in enumerate(procs):
-            out, _ = pr.communicate(timeout=1800)
-            assert pr.returncode == 0, out[-3000:]
-        parts = [dict(np.load(os.path.join(tmp, "out%d.npz" % i))) for i in range(workers)]
-    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}

@@ -1884,15 +1884,25 @@ def test_census_on_the_baseline_config_views_against_the_reference(oracle, synth
 def oracle_full_view(oracle, synth_nets):
     """BASELINE configs[1] itself: a full 400x400 view, 64+128 -- the kernels and the oracle render all 160 000 rays (r06, VERDICT
     r05 #7: the default kernel is held to the whole view again; the other kernels to a random quarter of it, `sel`).  About
-    half a minute of host time on the GPU box's cores: conftest.oracle_render_parallel, several processes of 32 torch threads)."""
+    two minutes of host time per GPU-suite run: the box gives a job about 32 cores' worth of CPU -- 64 threads, or six processes of
+    32, were no faster (sessions r06Q / r06U)."""
     import torch
     near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
     pose = np.asarray(oracle.sweep_poses(1, seed=11))[0]
     ro, rd = oracle.get_rays(400, 400, oracle.YCBV_K, pose[:3, :4])
     sel = np.sort(np.random.RandomState(11).choice(160000, 40000, replace=False))
     ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
-    from conftest import oracle_render_parallel
-    ref = oracle_render_parallel(synth_nets[0], synth_nets[1], ro, rd, near, far, oracle.YCBV_K)
+    oracle.set_backend("torch")
+    old = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        ref = oracle.render(synth_nets[0], synth_nets[1], 400, 400, oracle.YCBV_K, rays=(ro, rd), near=near, far=far,
+                            chunk=8192, extras=True)
+    finally:
+        oracle.set_backend("numpy")
+        torch.set_num_threads(old)
+    ref = {k: v for k, v in ref.items() if k not in ("raw", "weights", "cdf")}        # 0.7 GB the census does not read
+    ref["sigma0_last"] = ref.pop("raw0")[:, -1, 3].copy()
     return pose, ro, rd, ref, sel
 
 

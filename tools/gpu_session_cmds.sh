@@ -1,7 +1,4 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session T: kernel stats of the layered f16x2 forward)
-cd /tmp && export TMPDIR=/tmp
-for c in ycbv small w512; do
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks_$c -- python $GRAFT_REPO_ROOT/tools/bench_wide.py --mlp f16x2 --cases $c --steps 2 --no-grad > $O/ks_$c.log 2>&1
-grep "^$c" $O/ks_$c.log | cut -c1-300
-f=$(ls $O/ks_$c/*/*_kernel_stats.csv | head -1); cut -c1-150 $f | head -24
-done
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session U: the API pieces r05 refused)
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_gpu_r6.py -q -m gpu -x -k "sample_pdf or embedder or adopted" 2>&1 | tail -30
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "noviewdirs or importance or census_full" --durations=5 2>&1 | tail -30
