@@ -712,3 +712,43 @@ def test_bench_self_launch_fails_only_on_device_count():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "--gpus 2: only %d HIP device(s) visible" % torch.cuda.device_count() in (r.stderr + r.stdout)
+
+
+def test_adopting_a_module_with_the_references_layout():
+    """NeRF.adopt (r06): a module of a FOREIGN class with the reference's attribute and layer names (RH:70-97) is wrapped by a
+    drop-in NeRF that holds the same nn.Linear modules -- shared Parameters, so the weight fingerprint and the packer read what
+    the caller's optimizer writes; anything else is refused by name."""
+    import torch
+    import torch.nn as nn
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+
+    class Foreign(nn.Module):
+        def __init__(self, use_viewdirs):
+            super().__init__()
+            self.D, self.W, self.input_ch, self.input_ch_views, self.skips, self.use_viewdirs = 3, 40, 15, 9, [1], use_viewdirs
+            self.pts_linears = nn.ModuleList([nn.Linear(15, 40), nn.Linear(40, 40), nn.Linear(55, 40)])
+            self.views_linears = nn.ModuleList([nn.Linear(49, 20)])
+            if use_viewdirs:
+                self.feature_linear, self.alpha_linear, self.rgb_linear = nn.Linear(40, 40), nn.Linear(40, 1), nn.Linear(20, 3)
+            else:
+                self.output_linear = nn.Linear(40, 5)
+
+    for uv in (True, False):
+        f = Foreign(uv)
+        a = R.NeRF.adopt(f)
+        assert isinstance(a, R.NeRF) and a is R.NeRF.adopt(f) and R.NeRF.adopt(a) is a and R.NeRF.adopt(None) is None
+        assert (a.D, a.W, a.input_ch, a.input_ch_views, list(a.skips), a.use_viewdirs, a.output_ch) == (3, 40, 15, 9, [1], uv, 4 if uv else 5)
+        assert set(a.state_dict()) == set(f.state_dict())
+        for k, v in f.state_dict().items():
+            assert a.state_dict()[k].data_ptr() == v.data_ptr(), k                 # the SAME storage
+        with torch.no_grad():
+            f.pts_linears[1].bias.add_(1.0)
+        assert torch.equal(a.pts_linears[1].bias, f.pts_linears[1].bias)
+        assert "_nsr_adopted" not in dict(f.named_modules()) and len(list(f.parameters())) == len(list(a.parameters()))
+    with pytest.raises(NotImplementedError, match="reference's NeRF layout"):
+        R.NeRF.adopt(nn.Linear(3, 4))
+    bad = Foreign(True)
+    bad.alpha_linear = nn.Linear(40, 2)
+    with pytest.raises(NotImplementedError, match="alpha_linear"):
+        R.NeRF.adopt(bad)
+

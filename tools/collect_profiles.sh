@@ -76,3 +76,18 @@ for ns, ni in ((64, 128), (64, 96), (64, 64), (64, 32), (32, 64), (128, 128)):
     m.close()
 PY
 ls $O
+# ---- the layered renderer (r06): one 400x400 view per network and arithmetic (whole launch calls), kernel stats of the default arithmetic
+# forward + input gradient, PMC passes over its GEMM kernels at 200x200 (counters summed over all dispatches of the run)
+cd $R
+for mlp in f16x2 bf16x3 fp32; do
+  timeout 900 python tools/bench_wide.py --mlp $mlp --cases ycbv,w512,d10w384,small,w1024 --steps 2 2>/dev/null | grep -v "^{" > $O/layered_bench_$mlp.txt
+done
+cd /tmp
+for c in ycbv w512; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_layered_$c -- python $R/tools/bench_wide.py --mlp f16x2 --cases $c --steps 2 > $O/stats_layered_$c.log 2>&1
+done
+cd $R
+MLP=f16x2 bash tools/pmc_wide.sh $O/layered_pmc_f16x2_w512 w512 200 > /dev/null 2>&1
+MLP=f16x2 bash tools/pmc_wide.sh $O/layered_pmc_f16x2_ycbv ycbv 200 > /dev/null 2>&1
+MLP=bf16x3 bash tools/pmc_wide.sh $O/layered_pmc_bf16x3_w512 w512 200 > /dev/null 2>&1
+ls $O

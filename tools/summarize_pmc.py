@@ -88,6 +88,30 @@ for sub, name in (("stats", "kernel_stats_bench_steps3.csv"), ("stats_b3", "kern
             w = csv.writer(g)
             for r in rows[:1] + [r for r in rows[1:] if r and (r[0].startswith("nsr::") or len(r[0]) < 120)]:
                 w.writerow(r)
+for sub, name in (("stats_layered_ycbv", "kernel_stats_layered_8x256_f16x2.csv"), ("stats_layered_w512", "kernel_stats_layered_8x512_f16x2.csv")):
+    for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1:]:
+        rows = list(csv.reader(open(f)))
+        with open(os.path.join(dst, name), "w", newline="") as g:
+            w = csv.writer(g)
+            for r in rows[:1] + [r for r in rows[1:] if r and ("nsrw" in r[0] or "nsr::" in r[0] or len(r[0]) < 120)]:
+                w.writerow(r)
+os.makedirs(os.path.join(dst, "extra"), exist_ok=True)
+for mlp in ("f16x2", "bf16x3", "fp32"):
+    f = os.path.join(src, "layered_bench_%s.txt" % mlp)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "extra", "layered_bench_%s.txt" % mlp))
+lp = {}
+for tag in ("f16x2_w512", "f16x2_ycbv", "bf16x3_w512"):
+    f = os.path.join(src, "layered_pmc_%s" % tag, "pmc_summary.json")
+    if os.path.exists(f):
+        try:
+            lp[tag] = {k: v for k, v in json.load(open(f)).items() if "kw_" in k}
+        except Exception as e:          # (a failed pass leaves a traceback there)
+            lp[tag] = {"error": repr(e)}
+if lp:
+    json.dump({"note": "tools/pmc_wide.sh: separate rocprofv3 --pmc passes (counters + kernel trace only) over tools/bench_wide.py at 200x200, "
+                       "one forward view; per kernel of the layered renderer the counters are summed over ALL its dispatches of the run",
+               "runs": lp}, open(os.path.join(dst, "extra", "layered_pmc.json"), "w"), indent=1)
 for extra in ("phase_timers.txt", "path_grad_f16x2.json", "importance_counts.txt", "api_overhead.json"):
     if os.path.exists(os.path.join(src, extra)):
         os.makedirs(os.path.join(dst, "extra"), exist_ok=True)
