@@ -375,47 +375,67 @@ __device__ __forceinline__ void sincos_enc(float a, float& s, float& c) {
   c = __uint_as_float(__float_as_uint(vc) ^ ((unsigned)((n + 1) & 2) << 30));
 }
 
-// 16 threads per point: thread q writes x (q = 0), band q - 1 (1 <= q <= L) of the position row, and the same for the direction
-// row -- 6 consecutive floats each, so neighbouring threads fill a row front to back; q = 0 also zeroes the padding columns.
+// 16 threads per point, 16 points per workgroup: thread q computes x (q = 0) or band q - 1 (1 <= q <= L) of the position row and the
+// same of the direction row into LDS; the workgroup then writes its 16 consecutive rows of E (and of ED) -- one contiguous piece of
+// memory -- 16 bytes per thread, padding columns included (r06: the rows used to be written 24 strided bytes per thread, twelve
+// dword stores each; the kernel was 4-15 % of a layered render).
+constexpr int kEmbedLdMax = 96;          // pad32(3 + 6 * 15)
 __global__ void __launch_bounds__(256) kw_embed(const EmbedArgs a) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long p = gid >> 4;
-  const int q = (int)(gid & 15);
-  if (p >= a.P) return;
-  float x[3], v[3] = {0.0f, 0.0f, 0.0f};
-  if (a.rays_o) {
-    const long long r = p / a.S;
-    const float zz = a.z[p];
+  __shared__ __attribute__((aligned(16))) float sE[16 * kEmbedLdMax];
+  __shared__ __attribute__((aligned(16))) float sD[16 * kEmbedLdMax];
+  const int tid = threadIdx.x;
+  const long long p0 = (long long)blockIdx.x * 16;
+  const int lp = tid >> 4, q = tid & 15;
+  const long long p = p0 + lp;
+  const int nE = 16 * a.ldE / 4, nD = a.Lv >= 0 ? 16 * a.ldED / 4 : 0;          // float4s of the workgroup's rows
+  for (int t = tid; t < nE; t += 256) reinterpret_cast<f32x4*>(sE)[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t = tid; t < nD; t += 256) reinterpret_cast<f32x4*>(sD)[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  __syncthreads();
+  if (p < a.P) {
+    float x[3], v[3] = {0.0f, 0.0f, 0.0f};
+    if (a.rays_o) {
+      const long long r = p / a.S;
+      const float zz = a.z[p];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) x[c] = a.rays_o[r * 3 + c] + a.rays_d[r * 3 + c] * zz;
-    if (a.Lv >= 0)
+      for (int c = 0; c < 3; ++c) x[c] = a.rays_o[r * 3 + c] + a.rays_d[r * 3 + c] * zz;
+      if (a.Lv >= 0)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = a.vd[r * 3 + c];
-  } else {
+        for (int c = 0; c < 3; ++c) v[c] = a.vd[r * 3 + c];
+    } else {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) x[c] = a.pts[p * 3 + c];
-    if (a.Lv >= 0)
+      for (int c = 0; c < 3; ++c) x[c] = a.pts[p * 3 + c];
+      if (a.Lv >= 0)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) v[c] = a.dirs[p * 3 + c];
+        for (int c = 0; c < 3; ++c) v[c] = a.dirs[p * 3 + c];
+    }
+    float* e = sE + lp * a.ldE;
+    NSRW_CHECK(a.ldE <= kEmbedLdMax && a.ldED <= kEmbedLdMax && 3 + 6 * a.L <= a.ldE);
+    if (q == 0) {
+      e[0] = x[0]; e[1] = x[1]; e[2] = x[2];
+    } else if (q <= a.L) {
+      const float f = ldexpf(1.0f, q - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sincos_enc(x[c] * f, e[3 + 6 * (q - 1) + c], e[6 + 6 * (q - 1) + c]);
+    }
+    if (a.Lv >= 0) {
+      float* ed = sD + lp * a.ldED;
+      if (q == 0) {
+        ed[0] = v[0]; ed[1] = v[1]; ed[2] = v[2];
+      } else if (q <= a.Lv) {
+        const float f = ldexpf(1.0f, q - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sincos_enc(v[c] * f, ed[3 + 6 * (q - 1) + c], ed[6 + 6 * (q - 1) + c]);
+      }
+    }
   }
-  float* e = a.E + p * a.ldE;
-  if (q == 0) {
-    e[0] = x[0]; e[1] = x[1]; e[2] = x[2];
-    for (int c = 3 + 6 * a.L; c < a.ldE; ++c) e[c] = 0.0f;
-  } else if (q <= a.L) {
-    const float f = ldexpf(1.0f, q - 1);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) sincos_enc(x[c] * f, e[3 + 6 * (q - 1) + c], e[6 + 6 * (q - 1) + c]);
-  }
-  if (a.Lv < 0) return;
-  float* ed = a.ED + p * a.ldED;
-  if (q == 0) {
-    ed[0] = v[0]; ed[1] = v[1]; ed[2] = v[2];
-    for (int c = 3 + 6 * a.Lv; c < a.ldED; ++c) ed[c] = 0.0f;
-  } else if (q <= a.Lv) {
-    const float f = ldexpf(1.0f, q - 1);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) sincos_enc(v[c] * f, ed[3 + 6 * (q - 1) + c], ed[6 + 6 * (q - 1) + c]);
+  __syncthreads();
+  const long long rows = a.P - p0 < 16 ? a.P - p0 : 16;
+  const int mE = (int)(rows * a.ldE / 4), mD = a.Lv >= 0 ? (int)(rows * a.ldED / 4) : 0;
+  f32x4* gE = reinterpret_cast<f32x4*>(a.E + p0 * a.ldE);
+  for (int t = tid; t < mE; t += 256) gE[t] = reinterpret_cast<const f32x4*>(sE)[t];
+  if (mD) {
+    f32x4* gD = reinterpret_cast<f32x4*>(a.ED + p0 * a.ldED);
+    for (int t = tid; t < mD; t += 256) gD[t] = reinterpret_cast<const f32x4*>(sD)[t];
   }
 }
 
