@@ -5,10 +5,11 @@
  *
  * (RN = optimization/utils/run_nerf_noscale.py, RH = optimization/utils/run_nerf_helpers.py of the reference.)
  *
- * Design: one fp32-MFMA GEMM kernel per network layer over ALL points of a chunk of rays, activations resident
- * in HBM between the layers (288 GB: a chunk is thousands of rays), the per-ray stages (depths, compositing RN:343-387,
- * resampling RH:199-243, sort RN:477) as small kernels of their own between them, and for the gradient the same GEMM kernel
- * on the transposed weights with the relu masks read back from the stored activations.  Nothing here runs on the host CPU
+ * Design: one MFMA GEMM kernel per network layer over ALL points of a chunk of rays -- on fp16 MFMAs with two-piece
+ * operands, on bf16 MFMAs with three-piece operands or on fp32 MFMAs (NsrwConfig.flags), fp32 in HBM and fp32-grade results in
+ * every case -- activations resident in HBM between the layers (288 GB: a chunk is thousands of rays), the per-ray stages (depths,
+ * compositing RN:343-387, resampling RH:199-243, sort RN:477) as small kernels of their own between them, and for the gradient the
+ * same GEMM kernel on the transposed weights with the relu masks read back from the stored activations.  Nothing here runs on the host CPU
  * and nothing falls back to another library: a network the fused kernels cannot hold costs layer-by-layer HBM traffic, not
  * correctness.
  *

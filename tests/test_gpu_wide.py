@@ -569,6 +569,40 @@ def test_layered_f16x2_pass_that_leaves_the_fp16_range_is_rerun_on_bf16x3(oracle
         del os.environ["NSR_WIDE_WORKSPACE_GB"]
 
 
+def test_layered_f16x2_gradient_over_twelve_orders_of_magnitude(oracle):
+    """The gradient GEMMs of an f16x2 handle run on per-point NORMALISED gradients (kw_composite_bwd scales a point's dL/d raw to
+    [2^7, 2^8), kw_embed_bwd undoes it: the chain is linear).  Cotangents between 1e-6 and 1e+6 per ray in ONE launch: per-ray
+    error against the oracle's fp64 backprop at the same depths like the bf16x3 handle's; a zero cotangent gives exactly zero; a
+    power-of-two multiple of the cotangent scales the gradient exactly; nothing is re-run."""
+    g = load_golden("g25_wide_networks")
+    sd_c, sd_f, ns, ni = wide_case(oracle, g, "b")
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    ro, rd = g["rays_o"], g["rays_d"]
+    rng = np.random.RandomState(12)
+    amp = np.exp(rng.uniform(np.log(1e-6), np.log(1e6), (len(ro), 1))).astype(np.float32)
+    cot = (g["cot"] * amp).astype(np.float32)
+    cot[7] = 0.0
+    h2, b3 = (_wide(mlp)(sd_c, sd_f, n_samples=ns, n_importance=ni) for mlp in ("f16x2", "bf16x3"))
+    zf = cpu(b3.render_rays(ro, rd, near, far, debug=True)["z_fine"])
+    wo, wd, _ = oracle.render_rays_vjp(sd_c, sd_f, ro, rd, near, far, cot, n_samples=ns, n_importance=ni, z_fine=zf)
+    want = np.concatenate([wo, wd], 1)
+    errs = {}
+    for name, m in (("f16x2", h2), ("bf16x3", b3)):
+        go, gd = m.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf)
+        got = np.concatenate([cpu(go), cpu(gd)], 1)
+        assert np.isfinite(got).all() and not got[7].any(), name
+        ok = np.arange(len(ro)) != 7
+        errs[name] = _rel_rows(got[ok], want[ok])
+        print("layered-%s, cotangents 1e-6 .. 1e+6: per-ray error median %.2e  90 %% %.2e  max %.2e" % (name, np.median(errs[name]), np.percentile(errs[name], 90), errs[name].max()))
+    assert np.median(errs["f16x2"]) <= max(3.0 * np.median(errs["bf16x3"]), 2e-6) and np.percentile(errs["f16x2"], 90) < 1e-4, errs
+    a1 = np.concatenate([cpu(x) for x in h2.render_rays_vjp(ro, rd, near, far, g["cot"], z_fine=zf)], 1)
+    a2 = np.concatenate([cpu(x) for x in h2.render_rays_vjp(ro, rd, near, far, (g["cot"] * np.float32(2.0 ** -9)).astype(np.float32), z_fine=zf)], 1)
+    assert np.array_equal(a2, a1 * np.float32(2.0 ** -9))
+    assert h2.range_status()["passes_rerun"] == 0
+    h2.close()
+    b3.close()
+
+
 def test_two_layered_handles_on_two_streams(oracle):
     """One handle per (model, stream): two handles -- one per arithmetic -- launched back to back on two streams, each with
     its stream's own workspace, give what each gives alone."""
