@@ -403,8 +403,8 @@ def layered_workload(sd_c, sd_f, c2w, device, ref):
     out = {"workload": "one 400x400 view, 64+128 samples, through nsrw_render_rays (HIP-event ms of the launch call, all chunks)",
            "kernel": "nsrw::kw_gemm_h2<4, *, 4> (r06, the default: fp32 in HBM, every operand as two fp16 pieces, three piece products on "
                      "v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 out; a pass that leaves fp16's range is re-run on bf16x3 inside the "
-                     "call); bf16x3: nsrw::kw_gemm_b3<4, *, 4> (three bf16 pieces, six products, no range); fp32: nsrw::kw_gemm<128, *, 16> "
-                     "(v_mfma_f32_32x32x2_f32)",
+                     "call); bf16x3: nsrw::kw_gemm_b3<4, *, 4> (three bf16 pieces, six products, no range); fp32: nsrw::kw_gemm_f32<4, *, 4> "
+                     "(the same kernel body on v_mfma_f32_32x32x2_f32: the strict mode)",
            "peak": PEAK_BF16_MFMA_TFLOPS, "peak_note": "dense fp16 = bf16 MFMA; `frac` = algorithmic FLOP / time / peak, `issued_frac` = 3 x "
            "(f16x2) or 6 x (bf16x3) that -- the piece products actually issued: the ceiling of `frac` is 1/3 resp. 1/6; "
            "`frac_of_fp32_mfma_peak` puts the same algorithmic rate over the 157.3 TFLOP/s the fp32 MFMAs could reach at most"}

@@ -47,238 +47,17 @@ __device__ unsigned g_wide_violation = 0u;
 
 // ------------------------------------------------------------------------------------------------------------------------
 // GEMM: C[m][n] = epi( sum_k A[m][k] * Wt[n][k] + bias[n] ), A = [A1 | A2] (two row-major segments: the skip concatenation
-// cat[input_pts, h] RH:105-106 and cat[feature, input_views] RH:113 without materialising them), Wt the packed [Np][K1 + K2]
-// weight (K contiguous), both K extents multiples of 32.
-//   workgroup = 256 threads = 4 waves, tile 128 (M) x TN (N): TN = 128 -> waves 2 x 2, 64 x 64 each (2 x 2 MFMA tiles);
-//   TN = 32 -> waves 4 x 1, 32 x 32 each (tails and the narrow heads).  K advances 32 per stage through double-buffered LDS
-//   tiles [rows][32 + 4] (the +4 makes the 16-byte fragment reads conflict-free: 36 l mod 64 hits every fourth bank once per
-//   16 lanes); one barrier per stage; the next stage's global loads are in flight while the MFMAs of this one issue.
-//   MFMA operand roles: A-operand = activations (lane l: row l % 32, k pair member l / 32), B-operand = weights (column
-//   l % 32), so a lane's 16 accumulators share ONE output column: bias and relu mask cost one load per 16 values and every
-//   store instruction writes two full 128-byte rows.
-//   Workgroup -> tile: blockIdx round-robins over the 8 XCDs (each with its own L2), so the N-tiles of one M-block are
-//   given to ONE XCD back to back: the A tile is read from HBM once and then from that XCD's L2.
+// cat[input_pts, h] RH:105-106 and cat[feature, input_views] RH:113 without materialising them), both K extents multiples of 32.
+// ONE kernel body for the three arithmetics (nsr_wide_b3.inc: gemm_split_body -> kw_gemm_h2 / kw_gemm_b3 / kw_gemm_f32): weights as an
+// LDS image moved by LDS-DMA, activations staged through registers, 256 x 256 tiles in 512-thread workgroups, persistent tiles with
+// the next tile's first stages in flight, XCD-aware tile order (the N-tiles of one M-block go to ONE XCD back to back: an A tile
+// is read from HBM once and then from that XCD's L2).  MFMA operand roles: A-operand = activations, B-operand = weights, so a
+// lane's 16 accumulators share ONE output column: bias and relu mask cost one load per 16 values and every store instruction
+// writes two full 128-byte rows.  (r05's separate fp32 kernel kw_gemm -- 128 x 128 tiles, XOR-swizzled register-staged LDS tiles --
+// was retired in r06: the shared body on fp32 MFMAs is 9-12 % faster, profiles/r06/extra/layered_fp32_ab.txt.)
 // ------------------------------------------------------------------------------------------------------------------------
 enum { kRelu = 1, kAccum = 2, kMaskEpi = 4 };
 
-struct GemmArgs {
-  const float* A1; const float* A2;
-  const float* Wt; const float* bias;      // bias nullable
-  float* C;
-  const float* mask;                       // nullable: result kept where mask[m][n] > 0 (relu' of the stored activation), else 0
-  long long M;
-  int lda1, lda2, K1, K2;                  // K2 = 0: one segment
-  int ldc, N;                              // columns n < N are stored
-  int ldm;
-  int n_tiles;                             // N-tiles of this launch
-  int flags;
-};
-
-constexpr int kTM = 128;
-
-// EPI: the epilogue, a compile-time choice (kRelu, kMaskEpi or kAccum; one of them or none), so that a tile's loads of the mask /
-// the old C values are all in flight before the first of them is needed.  KS: K extent of a stage (32, or 16 for three
-// workgroups per CU instead of two).
-
-// workgroups per CU: 4 at KS = 16 (128 registers), except the mask epilogue, whose 16 mask values on top of the 64 accumulators
-// need more (r06: both epilogue forms in one kernel): 3 (168 registers)
-template <int EPI, int KS> constexpr int gemm_wgs_per_cu() { return KS == 16 ? (EPI == kMaskEpi ? 3 : 4) : 2; }
-
-template <int TN, int EPI, int KS>
-__global__ void __launch_bounds__(256, (gemm_wgs_per_cu<EPI, KS>())) kw_gemm(const GemmArgs g) {
-  // LDS tile rows: KS = 32: [32 + 4] floats, the padding makes the 16-byte fragment reads and the staging writes conflict-free
-  // (measured: 0 conflicts).  KS = 16: [16] floats, no padding -- the four 16-byte chunks of a row are XOR-swizzled with bits
-  // 2..3 of the row instead (chunk c of row r sits at c ^ ((r >> 2) & 3)): 16 consecutive rows at one chunk index, the
-  // fragment read pattern, and 8 rows x 2 chunks, the staging write pattern, both cover all 64 banks once; 32 KiB per
-  // workgroup instead of 40, i.e. FOUR workgroups per CU.
-  constexpr bool SWZ = KS == 16;
-  constexpr int MI = TN == 128 ? 2 : 1, NJ = TN == 128 ? 2 : 1, LD = SWZ ? KS : KS + 4;
-  constexpr int AV = KS / 8;                                    // float4 per thread of the A tile (128 x KS)
-  constexpr int BF = TN * KS / 256;                             // floats per thread of the B tile (TN x KS): 16, 8 or 4
-  constexpr int BV = BF / 4;
-  static_assert(BF % 4 == 0, "B tile staging is in float4");
-  __shared__ __attribute__((aligned(16))) float sA[2][kTM][LD];
-  __shared__ __attribute__((aligned(16))) float sB[2][TN][LD];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = TN == 128 ? (wave & 1) : wave, wn = TN == 128 ? (wave >> 1) : 0;
-  const int ktot = g.K1 + g.K2;
-  const int stages = ktot / KS, stages1 = g.K1 / KS;
-  const int arow = tid >> 1, akq = (tid & 1) * (KS / 2);        // A tile 128 x KS: thread = (row t / 2, KS / 2 floats)
-  constexpr int TPR = 256 / TN;                                  // B tile TN x KS: thread = (row t / TPR, BF floats)
-  const int brow = tid / TPR, bkq = (tid % TPR) * BF;
-  const int lrow = lane & 31, lk = (lane >> 5) * 4;
-  const long long mblocks = (g.M + kTM - 1) / kTM;
-  const long long total = ((mblocks + 7) / 8) * 8 * g.n_tiles;   // tile ids; those whose M-block does not exist are skipped
-
-  // PERSISTENT over the tiles (grid = what the device holds at once): a workgroup walks tile, tile + grid, ...; the first stage
-  // of its next tile is loaded into registers before the epilogue of this one, so a tile's start-up latency hides behind the
-  // previous tile's stores.  Tile id -> (M-block, N-tile) is XCD-aware: id % 8 = the XCD the id lands on (grid is a multiple
-  // of 8), and the N-tiles of one M-block are consecutive ids of ONE XCD, run by neighbouring workgroups at the same time.
-  struct Tile { long long m0; int n0; const float* a1p; const float* a2p; const float* bp; };
-  auto coords = [&](long long t, Tile& tl) -> bool {
-    const int xcd = (int)(t & 7);
-    const long long j = t >> 3;
-    const long long mb = (j / g.n_tiles) * 8 + xcd;
-    tl.m0 = mb * kTM;
-    if (tl.m0 >= g.M) return false;
-    tl.n0 = (int)(j % g.n_tiles) * TN;
-    long long am = tl.m0 + arow;
-    if (am >= g.M) am = g.M - 1;                                 // clamped rows are computed and never stored
-    NSRW_CHECK(am >= 0 && am < g.M && akq + KS / 2 <= KS && tl.n0 + brow < g.n_tiles * TN);
-    tl.a1p = g.A1 + am * g.lda1 + akq;
-    tl.a2p = g.A2 ? g.A2 + am * g.lda2 + akq : nullptr;
-    tl.bp = g.Wt + (long long)(tl.n0 + brow) * ktot + bkq;
-    return true;
-  };
-  f32x4 ra[AV], rb[BV];
-  auto gload = [&](const Tile& tl, int s) {
-    NSRW_CHECK(s >= 0 && s < stages && (s < stages1 || tl.a2p) && bkq + BF <= KS);
-    const float* ap = s < stages1 ? tl.a1p + s * KS : tl.a2p + (s - stages1) * KS;
-#pragma unroll
-    for (int v = 0; v < AV; ++v) ra[v] = *reinterpret_cast<const f32x4*>(ap + 4 * v);
-#pragma unroll
-    for (int v = 0; v < BV; ++v) rb[v] = *reinterpret_cast<const f32x4*>(tl.bp + s * KS + 4 * v);
-  };
-  auto col = [](int row, int c4) { return SWZ ? 4 * ((c4 >> 2) ^ ((row >> 2) & 3)) : c4; };      // c4: column, a multiple of 4
-  auto lstore = [&](int buf) {
-    NSRW_CHECK((buf == 0 || buf == 1) && arow < kTM && brow < TN && col(arow, akq + 4 * (AV - 1)) + 4 <= LD &&
-               col(brow, bkq + 4 * (BV - 1)) + 4 <= LD);
-#pragma unroll
-    for (int v = 0; v < AV; ++v) *reinterpret_cast<f32x4*>(&sA[buf][arow][col(arow, akq + 4 * v)]) = ra[v];
-#pragma unroll
-    for (int v = 0; v < BV; ++v) *reinterpret_cast<f32x4*>(&sB[buf][brow][col(brow, bkq + 4 * v)]) = rb[v];
-  };
-
-  Tile cur, nxt;
-  long long t = blockIdx.x;
-  while (t < total && !coords(t, cur)) t += gridDim.x;
-  if (t >= total) return;
-  gload(cur, 0);
-  while (true) {
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.0f;
-    lstore(0);
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-      const int buf = s & 1;
-      if (s + 1 < stages) gload(cur, s + 1);
-#pragma unroll
-      for (int sub = 0; sub < KS / 8; ++sub) {
-        f32x4 fa[MI], fb[NJ];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-          fa[i] = *reinterpret_cast<const f32x4*>(&sA[buf][wm * (MI * 32) + i * 32 + lrow][col(lrow, sub * 8 + lk)]);
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-          fb[jj] = *reinterpret_cast<const f32x4*>(&sB[buf][wn * (NJ * 32) + jj * 32 + lrow][col(lrow, sub * 8 + lk)]);
-        NSRW_CHECK(wm * (MI * 32) + (MI - 1) * 32 + lrow < kTM && wn * (NJ * 32) + (NJ - 1) * 32 + lrow < TN &&
-                   col(lrow, sub * 8 + lk) + 4 <= LD);
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj)
-              acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][tt], fb[jj][tt], acc[i][jj], 0, 0, 0);
-      }
-      if (s + 1 < stages) lstore(buf ^ 1);
-      __syncthreads();
-    }
-    // the next tile's first stage is on its way while this tile's results are stored
-    long long tn = t + gridDim.x;
-    while (tn < total && !coords(tn, nxt)) tn += gridDim.x;
-    const bool more = tn < total;
-    if (more) gload(nxt, 0);
-
-    // epilogue: lane owns column n, rows 8 (r / 4) + 4 (lane / 32) + r % 4 of each 32 x 32 tile.  A tile that lies inside the
-    // matrix takes the predicate-free form, 16 stores per block back to back (r06: per-row predicates put every store into a
-    // conditional block of its own and hipcc waits vmcnt(0) in front of each -- the stores of a tile serialise on the memory
-    // round trip; found on kw_gemm_b3, profiles/r06/extra/ab_wide_w512.txt).
-    const bool inside = cur.m0 + kTM <= g.M && cur.n0 + TN <= g.N;
-    if (inside) {
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        const int n = cur.n0 + wn * (NJ * 32) + jj * 32 + lrow;
-        float b = 0.0f;
-        if (g.bias) b = g.bias[n];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
-          float* cb = g.C + mt * g.ldc + n;
-          NSRW_CHECK(mt + 27 < g.M && n < g.ldc && n < g.N);
-          constexpr int G = EPI == kAccum ? 4 : 16;                            // rows in flight (register pressure of the kAccum form)
-#pragma unroll
-          for (int r0 = 0; r0 < 16; r0 += G) {
-            float aux[G];
-            if constexpr (EPI == kMaskEpi) {
-              const float* sb = g.mask + mt * g.ldm + n;
-#pragma unroll
-              for (int r = 0; r < G; ++r) aux[r] = sb[(8 * ((r0 + r) >> 2) + ((r0 + r) & 3)) * g.ldm];
-            }
-            if constexpr (EPI == kAccum) {
-#pragma unroll
-              for (int r = 0; r < G; ++r) aux[r] = cb[(8 * ((r0 + r) >> 2) + ((r0 + r) & 3)) * g.ldc];
-            }
-#pragma unroll
-            for (int r = 0; r < G; ++r) {
-              float v = acc[i][jj][r0 + r] + b;
-              if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;             // NaN stays NaN, as through torch's relu
-              if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
-              if constexpr (EPI == kAccum) v = aux[r] + v;
-              cb[(8 * ((r0 + r) >> 2) + ((r0 + r) & 3)) * g.ldc] = v;
-            }
-          }
-        }
-      }
-    } else {
-      const bool full_rows = cur.m0 + kTM <= g.M;
-#pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        const int n = cur.n0 + wn * (NJ * 32) + jj * 32 + lrow;
-        const bool ncol = n < g.N;
-        const float b = (g.bias && ncol) ? g.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const long long mt = cur.m0 + wm * (MI * 32) + i * 32 + lk;
-          float* cb = g.C + mt * g.ldc + n;
-          const int rows_left = (int)(g.M - mt < 32 ? g.M - mt : 32);             // rows mt + ro with ro < rows_left exist
-          float aux[16];                                                           // the 16 mask values, loaded together
-          if constexpr (EPI == kMaskEpi) {
-            const float* sb = g.mask + mt * g.ldm + n;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int ro = 8 * (r >> 2) + (r & 3);
-              aux[r] = (ncol && (full_rows || ro < rows_left)) ? sb[ro * g.ldm] : 0.0f;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ro = 8 * (r >> 2) + (r & 3);
-            float v = acc[i][jj][r] + b;
-            if constexpr (EPI == kRelu) v = (v < 0.0f) ? 0.0f : v;                 // NaN stays NaN, as through torch's relu
-            if constexpr (EPI == kMaskEpi) v = (aux[r] > 0.0f) ? v : 0.0f;
-            if (ncol && (full_rows || ro < rows_left)) {
-              NSRW_CHECK(mt + ro < g.M && n < g.ldc && (EPI != kMaskEpi || n < g.ldm));
-              if constexpr (EPI == kAccum) v = cb[ro * g.ldc] + v;                 // (narrow outputs only: the encoding's gradient)
-              cb[ro * g.ldc] = v;
-            }
-          }
-        }
-      }
-    }
-    if (!more) break;
-    t = tn;
-    cur = nxt;
-  }
-}
-
-#undef NSRW_FILE_TAG
-#define NSRW_FILE_TAG 100000
 #include "nsr_wide_b3.inc"
 #undef NSRW_FILE_TAG
 #define NSRW_FILE_TAG 0
@@ -843,6 +622,7 @@ struct Mat {                 // one packed matrix [Np][K1p + K2p] and its (nulla
   int ncb = 0;               // ... and its col-blocks (Np / 32 rounded up to an even count; the padding holds zero weights)
   size_t wh = 0;             // f16x2 handles: byte offset of the two-piece fp16 image (same layout, 2 KiB per block) in Net::dWh
   float cscale = 1.0f;       // ... and 2^-sw, which undoes the image's weight scale in the epilogue
+  size_t wf = 0;             // fp32 handles: byte offset of the fp32 image [col-block][k16 block][2][64 lanes][4 floats] in Net::dWf
 };
 
 struct Net {
@@ -856,6 +636,8 @@ struct Net {
   size_t wb_bytes = 0;
   char* dWh = nullptr;                // f16x2 handles: the scaled two-piece fp16 images of every matrix (kw_gemm_h2)
   size_t wh_bytes = 0;
+  char* dWf = nullptr;                // fp32 handles: the fp32 images in the same LDS-image layout (kw_gemm_f32)
+  size_t wf_bytes = 0;
   std::vector<Mat> fwd;               // pts_linears
   Mat fa, al, hv, rgb, out;           // feature_linear, alpha_linear, views_linears.0, rgb_linear / output_linear
   std::vector<Mat> bwd_h, bwd_e;      // per pts layer: G W_i[:, hidden part] (i >= 1), G W_i[:, encoding part] (layer 0, skip layers)
@@ -891,13 +673,9 @@ size_t net_floats(const NsrwNet& n) {
   return t;
 }
 
-// How the 128-wide GEMM kernel is launched: fixed per handle by nsrw_create (a setup call; launch calls read no environment).
+// How the GEMM kernels are launched: fixed per handle by nsrw_create (a setup call; launch calls read no environment).
 struct GemmCfg {
   int cus = 256;       // compute units of the handle's device
-  int ks = 16;         // K extent of a stage: 16 = unpadded swizzled LDS tiles, 32 KiB per workgroup, four workgroups per CU --
-                       // measured 0.75 against 0.665 of the fp32-MFMA peak for 32 / two per CU on an 8 x 512 network
-                       // (profiles/r05/extra/layered_gemm_ab.txt); NSRW_GEMM_KS = 32 selects the other (A/B of tools/bench_wide.py)
-  int wgs = 4;         // persistent workgroups per CU of the 16-wide-stage kernel (NSRW_GEMM_WGS = 3 | 4)
   bool b3 = false;     // NSRW_FLAG_MLP_BF16X3: every GEMM on bf16 MFMAs with three-way split operands (kw_gemm_b3)
   int b3_wm = 4;       // ... 256-column tiles with 256 rows / 512 threads (4) or 128 rows / 256 threads (2: NSRW_B3_WM = 2)
   // NSRW_FLAG_MLP_F16X2 (b3 is set as well: it is the re-run arithmetic and the backward's).  A forward network pass runs on
@@ -1010,6 +788,24 @@ size_t pack_h2(std::vector<uint16_t>& imgh, const float* src, int Np, int Kp, fl
   return off * sizeof(uint16_t);
 }
 
+// fp32 handles: the matrix as it is, in the LDS-image layout of kw_gemm_f32 -- [col-block][k16 block][chunk 2][64 lanes][4 floats],
+// lane l <-> (column 32 cb + l % 32, k = 16 kb + 8 (l / 32) + 4 chunk .. + 3)
+size_t pack_f32img(std::vector<float>& imgf, const float* src, int Np, int Kp) {
+  const int cbs = ((Np + 31) / 32 + 1) / 2 * 2, KB = Kp / 16;
+  const size_t off = imgf.size();
+  imgf.resize(off + (size_t)cbs * KB * 512, 0.0f);
+  for (int cb = 0; cb < cbs; ++cb)
+    for (int kb = 0; kb < KB; ++kb) {
+      float* blk = imgf.data() + off + ((size_t)cb * KB + kb) * 512;
+      for (int l = 0; l < 64; ++l) {
+        const int n = 32 * cb + (l & 31);
+        if (n >= Np) continue;
+        for (int e = 0; e < 8; ++e) blk[(e >> 2) * 256 + l * 4 + (e & 3)] = src[(size_t)n * Kp + 16 * kb + 8 * (l >> 5) + e];
+      }
+    }
+  return off * sizeof(float);
+}
+
 // Chunk workspace: the same carve runs with base = nullptr to size it.
 struct Carve {
   char* base; size_t off = 0;
@@ -1054,16 +850,6 @@ void carve_chunk(const Handle& h, long long R, bool grad, Carve& c, Chunk& k) {
   }
 }
 
-template <int TN, int KS>
-void launch_gemm(hipStream_t st, unsigned grid, const GemmArgs& g, int epi) {
-  switch (epi) {
-    case kRelu: hipLaunchKernelGGL((kw_gemm<TN, kRelu, KS>), dim3(grid), dim3(256), 0, st, g); break;
-    case kMaskEpi: hipLaunchKernelGGL((kw_gemm<TN, kMaskEpi, KS>), dim3(grid), dim3(256), 0, st, g); break;
-    case kAccum: hipLaunchKernelGGL((kw_gemm<TN, kAccum, KS>), dim3(grid), dim3(256), 0, st, g); break;
-    default: hipLaunchKernelGGL((kw_gemm<TN, 0, KS>), dim3(grid), dim3(256), 0, st, g); break;
-  }
-}
-
 template <int NJ, int WM>
 void launch_gemm_b3(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi) {
   switch (epi) {
@@ -1084,6 +870,16 @@ void launch_gemm_h2(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi)
   }
 }
 
+template <int NJ, int WM>
+void launch_gemm_f32(hipStream_t st, unsigned grid, const GemmB3Args& g, int epi) {
+  switch (epi) {
+    case kRelu: hipLaunchKernelGGL((kw_gemm_f32<NJ, kRelu, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    case kMaskEpi: hipLaunchKernelGGL((kw_gemm_f32<NJ, kMaskEpi, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    case kAccum: hipLaunchKernelGGL((kw_gemm_f32<NJ, kAccum, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+    default: hipLaunchKernelGGL((kw_gemm_f32<NJ, 0, WM>), dim3(grid), dim3(128 * WM), 0, st, g); break;
+  }
+}
+
 // bf16x3 handles: the N extent is cut into tiles of 256 columns, then one of 128 and one of 64 for what is left (the image is
 // padded to an even number of 32-column blocks with zero weights; columns >= N are never stored)
 int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const float* bias, const float* A1, int lda1,
@@ -1091,8 +887,8 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
   GemmB3Args g{};
   g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
   g.M = M; g.ldc = ldc; g.ldm = ldm;
-  const bool h2 = cfg.use_h2;
-  const int kfrag = h2 ? 2048 : 3072;                               // bytes of one (col-block, k16 block) of the image
+  const bool h2 = cfg.use_h2, f32 = !cfg.b3;
+  const int kfrag = (h2 || f32) ? 2048 : 3072;                      // bytes of one (col-block, k16 block) of the image
   g.cscale = h2 ? m.cscale : 1.0f; g.range_flag = cfg.d_range; g.run_if = cfg.run_if;
   const int KB = (m.K1p + m.K2p) / 16;
   int cb = 0;
@@ -1103,7 +899,7 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
     const long long mblocks = (M + tm - 1) / tm, mgroups = (mblocks + 7) / 8;
     GemmB3Args t = g;
     const size_t boff = (size_t)cb * KB * kfrag;
-    t.Wb = (h2 ? net.dWh + m.wh : net.dWb + m.wb) + boff;
+    t.Wb = (h2 ? net.dWh + m.wh : f32 ? net.dWf + m.wf : net.dWb + m.wb) + boff;
     t.wb_bytes = (unsigned)((size_t)m.ncb * KB * kfrag - boff);
     t.bias = bias ? bias + cb * 32 : nullptr;
     t.C = C + cb * 32; t.N = N - cb * 32;
@@ -1113,7 +909,13 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
       const long long all = mgroups * 8 * tiles;
       const int per_cu = tall ? (nj == 4 ? 1 : 2) : nj == 4 ? 2 : nj == 2 ? 3 : 4;
       const unsigned grid = (unsigned)std::max<long long>(8, std::min<long long>(all, (long long)cfg.cus * per_cu / 8 * 8));
-      if (h2) {
+      if (f32) {
+        if (tall && nj == 4) launch_gemm_f32<4, 4>(st, grid, t, epi);
+        else if (tall) launch_gemm_f32<2, 4>(st, grid, t, epi);
+        else if (nj == 4) launch_gemm_f32<4, 2>(st, grid, t, epi);
+        else if (nj == 2) launch_gemm_f32<2, 2>(st, grid, t, epi);
+        else launch_gemm_f32<1, 2>(st, grid, t, epi);
+      } else if (h2) {
         if (tall && nj == 4) launch_gemm_h2<4, 4>(st, grid, t, epi);
         else if (tall) launch_gemm_h2<2, 4>(st, grid, t, epi);
         else if (nj == 4) launch_gemm_h2<4, 2>(st, grid, t, epi);
@@ -1136,40 +938,8 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
 int gemm(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, const float* A1, int lda1, const float* A2, int lda2,
          float* C, int ldc, int N, long long M, int flags, const float* mask = nullptr, int ldm = 0, bool with_bias = true) {
   if (M <= 0) return 0;
-  const float* dW = net.dW;
-  if (cfg.b3) {
-    const int epi_b3 = mask ? kMaskEpi : (flags & kAccum) ? kAccum : (flags & kRelu) ? kRelu : 0;
-    return gemm_b3(cfg, st, net, m, (with_bias && m.b != (size_t)-1) ? dW + m.b : nullptr, A1, lda1, A2, lda2, C, ldc, N, M, epi_b3,
-                   mask, ldm);
-  }
-  GemmArgs g{};
-  g.A1 = A1; g.A2 = m.K2p ? A2 : nullptr; g.lda1 = lda1; g.lda2 = lda2; g.K1 = m.K1p; g.K2 = m.K2p;
-  g.bias = (with_bias && m.b != (size_t)-1) ? dW + m.b : nullptr;
-  g.C = C; g.ldc = ldc; g.N = N; g.M = M; g.flags = flags; g.mask = mask; g.ldm = ldm;
   const int epi = mask ? kMaskEpi : (flags & kAccum) ? kAccum : (flags & kRelu) ? kRelu : 0;     // (never combined: net_*)
-  const long long mblocks = (M + kTM - 1) / kTM, mgroups = (mblocks + 7) / 8;
-  const int full = m.Np / 128, rem = (m.Np % 128) / 32;
-  const int ktot = m.K1p + m.K2p;
-  auto grid_for = [&](long long tiles, int per_cu) {         // persistent workgroups: what the device holds at once (a multiple of 8)
-    const long long cap = (long long)cfg.cus * per_cu / 8 * 8;
-    return (unsigned)std::max<long long>(8, std::min(tiles, cap));
-  };
-  if (full) {
-    g.Wt = dW + m.w; g.n_tiles = full;
-    const long long tiles = mgroups * 8 * full;
-    if (cfg.ks == 16) launch_gemm<128, 16>(st, grid_for(tiles, epi == kMaskEpi ? std::min(cfg.wgs, 3) : cfg.wgs), g, epi);
-    else launch_gemm<128, 32>(st, grid_for(tiles, 2), g, epi);
-  }
-  if (rem) {
-    GemmArgs t = g;
-    t.Wt = dW + m.w + (size_t)full * 128 * ktot;
-    if (t.bias) t.bias += full * 128;
-    t.C = C + full * 128; t.N = N - full * 128;
-    if (t.mask) t.mask += full * 128;
-    t.n_tiles = rem;
-    if (t.N > 0) launch_gemm<32, 32>(st, grid_for(mgroups * 8 * rem, 3), t, epi);
-  }
-  return 0;
+  return gemm_b3(cfg, st, net, m, (with_bias && m.b != (size_t)-1) ? net.dW + m.b : nullptr, A1, lda1, A2, lda2, C, ldc, N, M, epi, mask, ldm);
 }
 
 // RH:99-122 over P points whose encodings are in k.E / k.ED: leaves the rgb logits in k.RAW (ld 32; all output_linear rows
@@ -1445,8 +1215,6 @@ int nsrw_create(const NsrwConfig* cfg, nsrw_handle* out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) gc.cus = prop.multiProcessorCount;
   }
-  if (const char* w = getenv("NSRW_GEMM_WGS")) gc.wgs = atoi(w) == 3 ? 3 : 4;
-  if (const char* ks = getenv("NSRW_GEMM_KS")) gc.ks = atoi(ks) == 32 ? 32 : 16;     // setup call: A/B switches of tools/bench_wide.py
   gc.h2 = (cfg->flags & NSRW_FLAG_MLP_F16X2) != 0;
   gc.b3 = gc.h2 || (cfg->flags & NSRW_FLAG_MLP_BF16X3) != 0;
   if (const char* wm = getenv("NSRW_B3_WM")) gc.b3_wm = atoi(wm) == 2 ? 2 : 4;
@@ -1489,6 +1257,7 @@ int nsrw_destroy(nsrw_handle hh) {
     if (n.dW) (void)hipFree(n.dW);
     if (n.dWb) (void)hipFree(n.dWb);
     if (n.dWh) (void)hipFree(n.dWh);
+    if (n.dWf) (void)hipFree(n.dWf);
   }
   if (h->d_tab) (void)hipFree(h->d_tab);
   if (h->d_range) (void)hipFree(h->d_range);
@@ -1650,6 +1419,21 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
       if (m->Np > 0) m->wh = pack_h2(imgh, img.data() + m->w, m->Np, m->K1p + m->K2p, &m->cscale);
     if (imgh.size() * sizeof(uint16_t) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the f16x2 image");
   }
+  // fp32 handles: the matrices in the LDS-image layout of kw_gemm_f32 (4 bytes per weight; dW keeps the biases)
+  std::vector<float> imgf;
+  if (!h->gemm_cfg.b3) {
+    std::vector<Mat*> all;
+    for (Mat& m : n.fwd) all.push_back(&m);
+    for (Mat& m : n.bwd_h) all.push_back(&m);
+    for (Mat& m : n.bwd_e) all.push_back(&m);
+    for (Mat* m : {&n.fa, &n.al, &n.hv, &n.rgb, &n.out, &n.b_rgb, &n.b_feat, &n.b_ed, &n.b_head}) all.push_back(m);
+    for (Mat* m : all)
+      if (m->Np > 0) {
+        m->wf = pack_f32img(imgf, img.data() + m->w, m->Np, m->K1p + m->K2p);
+        m->ncb = ((m->Np + 31) / 32 + 1) / 2 * 2;
+      }
+    if (imgf.size() * sizeof(float) >= 0x7fffffffull) return fail("nsrw_upload_network: network too large for the fp32 image");
+  }
   NSRW_DEVICE(h);
   // (every failure path below frees what this call allocated: ADVICE r05)
   hipError_t e = hipMalloc(&n.dW, img.size() * sizeof(float));
@@ -1664,17 +1448,24 @@ int nsrw_upload_network(nsrw_handle hh, int net_id, const NsrwNet* desc, const f
     e = hipMalloc(&n.dWh, n.wh_bytes);
     if (e == hipSuccess) e = hipMemcpy(n.dWh, imgh.data(), n.wh_bytes, hipMemcpyHostToDevice);
   }
+  if (e == hipSuccess && !imgf.empty()) {
+    n.wf_bytes = imgf.size() * sizeof(float);
+    e = hipMalloc(&n.dWf, n.wf_bytes);
+    if (e == hipSuccess) e = hipMemcpy(n.dWf, imgf.data(), n.wf_bytes, hipMemcpyHostToDevice);
+  }
   Net& slot = h->net[net_id];
   if (e == hipSuccess && (slot.dW || slot.dWb)) e = hipDeviceSynchronize();      // a launch may still read the images being replaced
   if (e != hipSuccess) {
     if (n.dW) (void)hipFree(n.dW);
     if (n.dWb) (void)hipFree(n.dWb);
     if (n.dWh) (void)hipFree(n.dWh);
+    if (n.dWf) (void)hipFree(n.dWf);
     return fail(std::string("nsrw_upload_network: ") + hipGetErrorString(e));
   }
   if (slot.dW) (void)hipFree(slot.dW);
   if (slot.dWb) (void)hipFree(slot.dWb);
   if (slot.dWh) (void)hipFree(slot.dWh);
+  if (slot.dWf) (void)hipFree(slot.dWf);
   slot = n;
   slot.loaded = true;
   return 0;

@@ -100,16 +100,19 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
     assert res["k_render_h2"]["vgpr_count"] + 0 <= 420, res["k_render_h2"]
     # the x32-structured kernels own a whole SIMD's register file (one workgroup per CU); the x16 ones share it two ways
     assert res["k_render_h2"]["vgpr_count"] > 256 and res["k_render16p"]["vgpr_count"] <= 256
-    # the layered renderer (csrc/nsr_wide.hip, a translation unit of its own in the same library): nothing spills, and the
-    # GEMM kernel it launches by default fits FOUR waves per SIMD (128 registers, 32 KiB of LDS per workgroup: DESIGN.md 8)
+    # the layered renderer (csrc/nsr_wide.hip, a translation unit of its own in the same library): nothing spills
     layered = [k for k in res if k.startswith("kw_")]
-    assert {"kw_gemm<128, %d, 16>" % e for e in (0, 1, 2, 4)} <= set(layered) and "kw_composite" in layered and "kw_sort" in layered
+    assert "kw_composite" in layered and "kw_sort" in layered and "kw_embed" in layered
     for k in layered:
         assert res[k]["vgpr_spill_count"] == 0 and res[k]["private_segment_fixed_size"] == 0, (k, res[k])
+    # r06: ONE GEMM body for the three arithmetics (csrc/nsr_wide_b3.inc) -- r05's separate fp32 kernel kw_gemm<...> is gone; the
+    # strict fp32 mode is the same body on fp32 MFMAs with the f16x2 form's LDS footprint
+    assert not [k for k in layered if k.startswith("kw_gemm<")]
+    f32 = [k for k in layered if k.startswith("kw_gemm_f32<")]
+    assert {"kw_gemm_f32<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(f32), f32
     for e in (0, 1, 2, 4):
-        r = res["kw_gemm<128, %d, 16>" % e]
-        # (the mask epilogue keeps 16 mask values next to the 64 accumulators: three workgroups per CU, 168 registers -- r06)
-        assert r["vgpr_count"] <= (168 if e == 4 else 128) and r["group_segment_fixed_size"] == 32768, r
+        r = res["kw_gemm_f32<4, %d, 4>" % e]
+        assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 65536, r
     # r06: the bf16x3 GEMM (csrc/nsr_wide_b3.inc).  Its 256 x 256 tile (512 threads, two waves per SIMD) lives on <= 256 registers
     # and 96 KiB of LDS -- one workgroup per CU; the 128-row form on 72 KiB, two per CU
     b3 = [k for k in layered if k.startswith("kw_gemm_b3<")]
