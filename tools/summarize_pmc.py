@@ -101,7 +101,7 @@ for mlp in ("f16x2", "bf16x3", "fp32"):
     if os.path.exists(f) and os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "extra", "layered_bench_%s.txt" % mlp))
 lp = {}
-for tag in ("f16x2_w512", "f16x2_ycbv", "bf16x3_w512"):
+for tag in ("f16x2_w512", "f16x2_ycbv", "bf16x3_w512", "fp32_w512"):
     f = os.path.join(src, "layered_pmc_%s" % tag, "pmc_summary.json")
     if os.path.exists(f):
         try:
