@@ -131,9 +131,11 @@ def _stream_ptr(device):
 
 
 def workspace_cap_env():
-    """Upper bound of the workspace a launch call may use: $NSR_WIDE_WORKSPACE_GB, else 16 GiB.  A smaller workspace means more,
+    """Upper bound of the workspace a launch call may use: $NSR_WIDE_WORKSPACE_GB, else 64 GiB (r06: of 288 GB; 16 GiB cost a 400x400 forward + gradient call
+    6-8 % in chunk overheads, profiles/r06/extra/ab_wide_h2_w512.txt) -- and never more than half of the free memory
+    (workspace_cap_bytes).  A smaller workspace means more,
     smaller chunks of rays -- never another result."""
-    return int(float(os.environ.get("NSR_WIDE_WORKSPACE_GB", "16")) * (1 << 30))
+    return int(float(os.environ.get("NSR_WIDE_WORKSPACE_GB", "64")) * (1 << 30))
 
 
 def workspace_cap_bytes(device, reusable=0):
@@ -190,7 +192,7 @@ def embed_vjp(x, grad_out, multires):
 
 # ONE workspace per (device, stream), shared by every handle that launches there: a handle's launch calls are stream-ordered, so
 # two handles on one stream can never use it at the same time, and the drop-in API's cache of up to eight handles per module
-# (render options x streams) does not multiply a 16 GiB buffer.  release_workspaces() hands the memory back to torch.
+# (render options x streams) does not multiply a buffer of tens of GiB.  release_workspaces() hands the memory back to torch.
 _WORKSPACES = {}
 
 
