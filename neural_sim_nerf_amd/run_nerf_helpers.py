@@ -24,7 +24,7 @@ class _Embed(torch.autograd.Function):
         from .run_nerf_noscale import _util_model
         m = _util_model(x.device if x.is_cuda else None)
         ctx.num_freqs = num_freqs
-        ctx.was_cuda = x.is_cuda
+        ctx.was_cuda, ctx.in_dtype = x.is_cuda, x.dtype
         xd = m._f32(x.detach())
         ctx.save_for_backward(xd)
         return m.embed(xd, num_freqs)
@@ -33,7 +33,7 @@ class _Embed(torch.autograd.Function):
     def backward(ctx, g):
         from .wide import embed_vjp
         (xd,) = ctx.saved_tensors
-        gx = embed_vjp(xd, g.contiguous(), ctx.num_freqs)
+        gx = embed_vjp(xd, g.contiguous(), ctx.num_freqs).to(ctx.in_dtype)
         return (gx if ctx.was_cuda else gx.cpu()), None
 
 
@@ -128,9 +128,11 @@ class NeRF(nn.Module):
         shared storage); it is cached on the foreign module.  None and drop-in modules pass through."""
         if module is None or isinstance(module, NeRF):
             return module
+        layers = ("pts_linears", "views_linears", "feature_linear", "alpha_linear", "rgb_linear", "output_linear")
         cached = module.__dict__.get("_nsr_adopted")
-        if cached is not None and cached.pts_linears is getattr(module, "pts_linears", None):
-            return cached
+        if cached is not None and all(getattr(cached, n, None) is getattr(module, n, None) for n in layers
+                                      if hasattr(cached, n) or hasattr(module, n)):
+            return cached                                      # (a layer replaced on the foreign module makes a new wrapper)
         need = ("D", "W", "input_ch", "input_ch_views", "skips", "use_viewdirs", "pts_linears", "views_linears")
         missing = [n for n in need if not hasattr(module, n)]
         if missing:

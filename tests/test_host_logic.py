@@ -748,6 +748,11 @@ def test_adopting_a_module_with_the_references_layout():
             f.pts_linears[1].bias.add_(1.0)
         assert torch.equal(a.pts_linears[1].bias, f.pts_linears[1].bias)
         assert "_nsr_adopted" not in dict(f.named_modules()) and len(list(f.parameters())) == len(list(a.parameters()))
+    f = Foreign(True)
+    a1 = R.NeRF.adopt(f)
+    f.rgb_linear = nn.Linear(20, 3)                                                # a layer REPLACED on the foreign module ...
+    a2 = R.NeRF.adopt(f)
+    assert a2 is not a1 and a2.rgb_linear is f.rgb_linear and a2 is R.NeRF.adopt(f)   # ... is not served from the stale wrapper
     with pytest.raises(NotImplementedError, match="reference's NeRF layout"):
         R.NeRF.adopt(nn.Linear(3, 4))
     bad = Foreign(True)
