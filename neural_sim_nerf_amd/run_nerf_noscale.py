@@ -117,7 +117,7 @@ def _model_for(network_fn, network_fine, n_importance, kw=None, trust=False):
 
 def _layered_why(network_fn, network_fine, n_samples, n_importance, mlp=None, retraw=False):
     """None when the fused kernels serve this (networks, sample counts) pair, else the reason the layered renderer
-    (wide.WideModel: one fp32-MFMA GEMM per layer, activations in HBM) takes it: a network that is not expressible as the
+    (wide.WideModel: one MFMA GEMM launch per layer, activations in HBM) takes it: a network that is not expressible as the
     kernels' 8 x 256 (NeRF.fused_why_not), or sample counts no fused kernel is built for.  NSR_LAYERED=1 sends everything
     there (cross-checks of the two renderers against each other)."""
     from .engine import IMPORTANCE_COUNTS, NATIVE_COUNTS, DEFAULT_MLP
@@ -156,6 +156,8 @@ def _note_range(model, network_fn=None):
     sends more than a tenth of its rays down that route pays for both kernels: its later handles are built with the bf16x3
     kernels (`_model_for` reads the mark), which is the same arithmetic without the detour -- 157 against 94 Mray-samples/s
     for the fp32-MFMA kernels r04 switched to."""
+    if network_fn is not None and not isinstance(network_fn, NeRF):
+        network_fn = NeRF.adopt(network_fn)        # (the mark below lives on the wrapper _model_for reads it from)
     if getattr(model, "mlp", None) == "layered-f16x2":
         # the layered renderer's unit is a network PASS over a chunk of rays, re-run on bf16x3 as a whole (include/nsr_wide.h)
         st = model.range_status()

@@ -184,6 +184,8 @@ def embed_vjp(x, grad_out, multires):
     lib = load()
     x = _cuda_f32(x)
     g = _cuda_f32(grad_out, x.device)
+    if x.shape[-1:] != (3,) or tuple(g.shape) != tuple(x.shape[:-1]) + (3 + 6 * int(multires),):
+        raise ValueError("embed_vjp: x [..., 3] and grad_out [..., 3 + 6 multires] (got %r, %r)" % (tuple(x.shape), tuple(g.shape)))
     gx = torch.empty_like(x)
     n = x.numel() // 3
     check(lib.nsrw_embed_vjp(x.device.index, _dev(x), _dev(g), n, int(multires), _dev(gx), _stream_ptr(x.device)))
