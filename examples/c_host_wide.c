@@ -39,7 +39,7 @@ int main(int argc, char** argv) {
   const int ns = hd[23], ni = hd[24];
   const size_t n = (size_t)hd[25];
   const int64_t ws_rays = hd[26];
-  const int flags = hd[27];                 /* NSRW_FLAG_* (0 = fp32 MFMAs, NSRW_FLAG_MLP_BF16X3 = the split-precision GEMMs) */
+  const int flags = hd[27];                 /* NSRW_FLAG_* (0 = fp32 MFMAs, NSRW_FLAG_MLP_BF16X3 / NSRW_FLAG_MLP_F16X2 = the split-precision GEMMs) */
   const size_t nw = nsrw_network_floats(&net);
   if (nw == 0) { fprintf(stderr, "network description: %s\n", nsrw_last_error()); return 1; }
   const size_t n_in = 2 * nw + ns + ni + 9 * n + 2;

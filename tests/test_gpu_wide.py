@@ -209,7 +209,7 @@ def test_layered_renderer_nan_rays_stay_nan_and_alone(mlp, oracle):
     m.close()
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 def test_layered_renderer_options(mlp, oracle):
     """The per-ray options on the layered renderer (g25 b: two skips, (48, 100) samples): stratified depths, random uniforms,
     density noise, per-ray bounds, given view directions, white background + lindisp -- stage-wise against the oracle on the
@@ -355,7 +355,7 @@ def test_dropin_api_serves_networks_beyond_the_fused_kernels(oracle, tmp_path):
             assert np.abs(got - want).max() <= 1e-3 * np.abs(want).max() + 1e-9, (i, p, got, want)
 
 
-@pytest.mark.parametrize("mlp", MLPS)
+@pytest.mark.parametrize("mlp", MLPS3)
 def test_c_host_of_the_layered_renderer(mlp, tmp_path, oracle):
     """The layered renderer's boundary is a C ABI too: examples/c_host_wide.c (plain C + the HIP runtime C API +
     include/nsr_wide.h; no Python, no torch) describes the 6 x 300 two-skip network of g25 b, uploads the parameters in the
@@ -364,7 +364,7 @@ def test_c_host_of_the_layered_renderer(mlp, tmp_path, oracle):
     workspace holds 64 rays only... and when it holds all of them."""
     import shutil
     import subprocess
-    from neural_sim_nerf_amd.wide import describe, FLAG_MLP_BF16X3
+    from neural_sim_nerf_amd.wide import describe, FLAG_MLP_BF16X3, FLAG_MLP_F16X2
     WideModel = _wide(mlp)
     if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
         pytest.skip("needs gcc and the ROCm headers")
@@ -389,7 +389,7 @@ def test_c_host_of_the_layered_renderer(mlp, tmp_path, oracle):
         hd = np.zeros(32, np.int32)
         hd[:7] = [net.D, net.W, net.multires, net.multires_views, net.use_viewdirs, net.output_ch, net.n_skips]
         hd[7:23] = list(net.skips)
-        hd[23:28] = [ns, ni, n, ws_rays, FLAG_MLP_BF16X3 if mlp == "bf16x3" else 0]
+        hd[23:28] = [ns, ni, n, ws_rays, {"bf16x3": FLAG_MLP_BF16X3, "f16x2": FLAG_MLP_F16X2}.get(mlp, 0)]
         with open(str(tmp_path / "in.bin"), "wb") as f:
             f.write(hd.tobytes())
             for a in (flat_c, flat_f, torch.linspace(0., 1., ns).numpy(), torch.linspace(0., 1., ni).numpy(), ro, rd, cot,
