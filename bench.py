@@ -39,8 +39,12 @@ import sys
 import tempfile
 import time
 
-import numpy as np
-import torch
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL otherwise fails in hipIpcGetMemHandle); the launcher's environment
+# normally carries it -- set here too, before the HIP runtime initialises, so that a rank started without it still comes up
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
