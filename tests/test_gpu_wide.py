@@ -603,6 +603,68 @@ def test_layered_f16x2_gradient_over_twelve_orders_of_magnitude(oracle):
     b3.close()
 
 
+@pytest.mark.parametrize("mlp", MLPS3)
+def test_layered_renderer_on_random_network_shapes(mlp, oracle):
+    """Sixteen seeded random shapes -- depth 1..11, width 34..600 (every mix of 256- / 128- / 64-column GEMM tiles and padded tails),
+    random skip lists, 0..10 / 0..4 encoding frequencies, with and without view directions (4 or 5 output rows), random sample
+    counts -- each rendered on 33 rays: network outputs against the oracle, compositing on the renderer's own raw, resampling
+    indices / samples / merged depths BIT FOR BIT on its own coarse weights, the input gradient against the oracle's fp64
+    backprop.  What the fixed cases (g25, the edge shapes) cannot enumerate."""
+    WideModel = _wide(mlp)
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    rng = np.random.RandomState(2026)
+    K = oracle.scaled_K(40.0)
+    pose = np.asarray(oracle.sweep_poses(1, seed=9))[0]
+    ro_all, rd_all = (a.reshape(-1, 3) for a in oracle.get_rays(40, 40, K, pose[:3, :4]))
+    for case in range(16):
+        D = int(rng.randint(1, 12))
+        W = int(rng.choice([34, 40, 72, 100, 136, 200, 264, 300, 392, 520, 600]))
+        skips = sorted(int(x) for x in rng.choice(np.arange(max(D - 1, 1)), size=min(int(rng.randint(0, 3)), max(D - 1, 0)), replace=False)) if D > 1 else []
+        L, Lv = int(rng.randint(0, 11)), int(rng.randint(0, 5))
+        uv = bool(rng.randint(0, 2))
+        oc = int(rng.choice([4, 5]))
+        ns, ni = int(rng.randint(3, 41)), int(rng.choice([0, 1, 1]) * rng.randint(1, 41))
+        sd_c = oracle.synth_weights_shape(100 + case, D, W, L, Lv, skips, uv, oc)
+        sd_f = oracle.synth_weights_shape(200 + case, D, W, L, Lv, skips, uv, oc)
+        tag = "case %d: %d x %d skips %s L %d Lv %d viewdirs %s oc %d samples %d + %d" % (case, D, W, skips, L, Lv, uv, oc, ns, ni)
+        sel = rng.choice(len(ro_all), 33, replace=False)
+        ro, rd = ro_all[sel], rd_all[sel]
+        n = len(ro)
+        vd = oracle.normalize_dirs(rd)
+        m = WideModel(sd_c, sd_f if ni else None, n_samples=ns, n_importance=ni)
+        r = m.render_rays(ro, rd, near, far, debug=True)
+        z = oracle.coarse_z(np.full(n, near, np.float32), np.full(n, far, np.float32), n=ns)
+        raw0 = oracle.run_network(sd_c, (ro[:, None] + rd[:, None] * z[..., None]).astype(np.float32), vd)
+        k_raw0 = cpu(r["raw0"])                     # (coarse only: the last pass IS the coarse pass, same tap)
+        scale = max(1.0, float(np.abs(raw0).max()))
+        assert_close(k_raw0[..., :4], raw0[..., :4], atol=5e-5 * scale, rtol=5e-5, what=tag + ": coarse raw")
+        _, _, _, w0, _ = oracle.raw2outputs(k_raw0[..., :4], z, rd)
+        if ni:
+            assert_close(cpu(r["weights0"]), w0, atol=2e-6, what=tag + ": weights0 | own raw")
+            z_mid = (np.float32(0.5) * (z[:, 1:] + z[:, :-1])).astype(np.float32)
+            s_, inds, _ = oracle.sample_pdf(z_mid, cpu(r["weights0"])[:, 1:-1], ni)
+            assert np.array_equal(cpu(r["inds"]), inds) and np.array_equal(cpu(r["z_samples"]), s_), tag
+            zf = np.sort(np.concatenate([z, s_], -1), -1)
+            assert np.array_equal(cpu(r["z_fine"]), zf), tag
+            raw = oracle.run_network(sd_f, (ro[:, None] + rd[:, None] * zf[..., None]).astype(np.float32), vd)
+            k_raw = cpu(r["raw"])
+            assert_close(k_raw[..., :4], raw[..., :4], atol=5e-5 * max(1.0, float(np.abs(raw).max())), rtol=5e-5, what=tag + ": fine raw | own z")
+        else:
+            zf, k_raw = z, k_raw0
+        rgb, _, acc, _, _ = oracle.raw2outputs(k_raw[..., :4], zf, rd)
+        assert_close(cpu(r["rgb_map"]), rgb, atol=3e-6, what=tag + ": rgb | own raw")
+        assert_close(cpu(r["acc_map"]), acc, atol=3e-6, what=tag + ": acc | own raw")
+        cot = rng.standard_normal((n, 3)).astype(np.float32)
+        go, gd = m.render_rays_vjp(ro, rd, near, far, cot, z_fine=zf if ni else None)
+        wo, wd, _ = oracle.render_rays_vjp(sd_c, sd_f if ni else None, ro, rd, near, far, cot, n_samples=ns, n_importance=ni, z_fine=zf)
+        for a_, b_, what in ((cpu(go), wo, "grad_o"), (cpu(gd), wd, "grad_d")):
+            e = _rel_rows(a_, b_)
+            assert np.isfinite(a_).all() and np.percentile(e, 90) < 2e-4 and np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-20) < 1e-2, \
+                (tag, what, np.percentile(e, 90), e.max())
+        assert m.range_status()["passes_rerun"] == 0, tag
+        m.close()
+
+
 def test_two_layered_handles_on_two_streams(oracle):
     """One handle per (model, stream): two handles -- one per arithmetic -- launched back to back on two streams, each with
     its stream's own workspace, give what each gives alone."""

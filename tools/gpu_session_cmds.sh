@@ -1,4 +1,3 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session AG: whole GPU suite + smoke on the final tree)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session AH: random network shapes through the layered renderer)
 cd $GRAFT_REPO_ROOT
-timeout 2400 python -m pytest tests -q -m gpu -x --durations=6 2>&1 | tail -14
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_wide.py -q -m gpu -k "random_network_shapes or c_host or options" 2>&1 | tail -40
