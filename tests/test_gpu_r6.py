@@ -278,3 +278,59 @@ def test_a_module_of_the_references_own_class_layout_is_adopted(oracle):
     for n_ in ours:
         n_.invalidate()
 
+
+def test_random_network_shapes_that_the_fused_kernels_serve_by_re_expression(oracle):
+    """Twelve seeded random shapes INSIDE fits_kernel (depth 1..8, even width 8..256, 0..10 / 0..4 frequencies, no skip or one skip
+    the kernels' skip can absorb, with and without view directions, 4 or 5 output rows): each is served by the fused 8 x 256 kernels
+    through the host-side re-expression of its weights (run_nerf_helpers.as_kernel_network: zero padding, identity layers, the
+    +y / -y view layer).  NeRF.evaluate against the oracle's evaluation of the ORIGINAL network on random points, a 12 x 12 render
+    against the oracle's render of the original network, the input gradient finite and close.  What g15 / g16 pin on two shapes."""
+    import torch
+    import neural_sim_nerf_amd.run_nerf_noscale as R
+    from neural_sim_nerf_amd.run_nerf_helpers import fits_kernel
+    near, far = oracle.YCBV_NEAR, oracle.YCBV_FAR
+    rng = np.random.RandomState(77)
+    K = oracle.scaled_K(400.0 / 12)
+    pose = np.asarray(oracle.sweep_poses(1, seed=6))[0]
+    ro, rd = (a.reshape(-1, 3) for a in oracle.get_rays(12, 12, K, pose[:3, :4]))
+    vd = oracle.normalize_dirs(rd)
+    done = 0
+    while done < 12:
+        D = int(rng.randint(1, 9))
+        W = int(2 * rng.randint(4, 129))
+        L, Lv = int(rng.randint(0, 11)), int(rng.randint(0, 5))
+        uv = bool(rng.randint(0, 2))
+        oc = int(rng.choice([4, 5]))
+        skips = [int(rng.randint(0, max(D - 1, 1)))] if (D > 1 and rng.randint(0, 2)) else []
+        in_ch, in_v = 3 + 6 * L, (3 + 6 * Lv if uv else 0)
+        if fits_kernel(D, W, in_ch, in_v, skips, uv, oc):
+            continue
+        done += 1
+        tag = "%d x %d skips %s L %d Lv %d viewdirs %s oc %d" % (D, W, skips, L, Lv, uv, oc)
+        sd_c = oracle.synth_weights_shape(300 + done, D, W, L, Lv, skips, uv, oc)
+        sd_f = oracle.synth_weights_shape(400 + done, D, W, L, Lv, skips, uv, oc)
+        nets = []
+        for sd in (sd_c, sd_f):
+            n_ = R.NeRF(D=D, W=W, input_ch=in_ch, output_ch=oc, skips=skips, input_ch_views=in_v, use_viewdirs=uv)
+            assert n_.fused_why_not is None, (tag, n_.fused_why_not)
+            n_.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+            nets.append(n_.to(R.device))
+        pts = (rng.rand(200, 3).astype(np.float32) - 0.5) * 0.5
+        dirs = oracle.normalize_dirs(rng.standard_normal((200, 3)).astype(np.float32))
+        want = oracle.run_network(sd_f, pts[:, None], dirs)[:, 0]
+        got = cpu(nets[1].evaluate(torch.tensor(pts, device=R.device), torch.tensor(dirs, device=R.device)))
+        assert_close(got[:, :4], want[:, :4], atol=5e-5 * max(1.0, float(np.abs(want).max())), rtol=5e-5, what=tag + ": evaluate")
+        kw = dict(network_query_fn=None, perturb=False, N_importance=128, network_fine=nets[1], N_samples=64, network_fn=nets[0],
+                  use_viewdirs=uv, white_bkgd=False, raw_noise_std=0., ndc=False, lindisp=False, near=near, far=far)
+        rays = torch.tensor(np.stack([ro, rd]), device=R.device, requires_grad=True)
+        rgb, _, acc, ex = R.render(12, 12, K, rays=rays, **kw)
+        assert R._model_for(nets[0], nets[1], 128, kw).mlp == "f16x2", tag
+        ref = oracle.render_rays(sd_c, sd_f, ro, rd, vd, near, far)
+        d = np.abs(cpu(rgb) - ref["rgb_map"]).max(-1)
+        assert_close(cpu(ex["rgb0"]), ref["rgb0"], atol=1e-5, what=tag + ": coarse image")
+        assert (d > 1e-4).mean() <= 0.1 and oracle.psnr(cpu(rgb), ref["rgb_map"]) > 50.0, (tag, (d > 1e-4).sum(), d.max())
+        (gr,) = torch.autograd.grad(rgb, rays, grad_outputs=torch.ones_like(rgb))
+        assert np.isfinite(cpu(gr)).all(), tag
+        for n_ in nets:
+            n_.invalidate()
+
