@@ -885,6 +885,9 @@ def main():
     ap.add_argument("--workload", choices=("view400", "sweep100", "models21"), default="view400")
     ap.add_argument("--views", type=int, default=100, help="sweep100: number of views in the sweep (config 3 uses 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trained-side", type=int, default=160,
+                    help="side of the view of extra_workloads.trained (the census on the TRAINED pair g26 against the oracle's render: 19 s of "
+                         "host time at 160, 2.5 min at the full 400)")
     ap.add_argument("--cpu-sample-side", type=int, default=400,
                     help="side of the view the oracle renders for cpu_baseline and parity (default: the metric's own "
                          "400x400 view, ~2-3 min of CPU time; e.g. 128 for a quick run)")
@@ -1059,7 +1062,7 @@ def main():
                 except Exception as e:                     # noqa: BLE001
                     line["extra_workloads"]["layered"] = {"error": repr(e)}
                 try:
-                    line["extra_workloads"]["trained"] = trained_workload(local, cpu_setting)
+                    line["extra_workloads"]["trained"] = trained_workload(local, cpu_setting, side=args.trained_side)
                 except Exception as e:                     # noqa: BLE001
                     line["extra_workloads"]["trained"] = {"error": repr(e)}
                 for mlp in MLP_MODES:
