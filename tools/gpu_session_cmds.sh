@@ -1,11 +1,13 @@
-# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session AL: smoke + default bench on the final tree; two ranks sharing the GPU)
+# scratch file: tools/gpu_session.sh <label> executes it on the gpurun box (r06 session AM: the trained-network census on the FULL 400x400 view)
 cd $GRAFT_REPO_ROOT
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+timeout 1500 python bench.py --steps 3 --warmup 1 --trained-side 400 > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
 python - <<PY
 import json
 d = json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
-print({k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "vs_baseline")})
-print(d["roofline"]["frac"], d["roofline"]["issued_frac"], d["cpu_baseline"]["value"], d["parity_summary"], sorted(d["extra_workloads"]))
+t = d["extra_workloads"]["trained"]
+print(t["workload"]); print(t["network"])
+for k, v in t.items():
+    if isinstance(v, dict) and "rays" in v: print(k, {x: v[x] for x in ("rays", "rays_above_tol", "unattributed", "cliff_rays", "index_flip_rays", "denom_switch_rays", "illconditioned_shift_rays", "psnr_delta_db", "max_abs_rgb", "inds_exact", "passes")}, v["range_status"])
+json.dump(t, open("$O/trained_full_view.json", "w"), indent=1)
+print(d["value"], t["passes"])
 PY
-timeout 600 python bench.py --gpus 2 --backend gloo --share-gpu --steps 3 --warmup 1 2>&1 | tail -1 | cut -c1-400
