@@ -693,8 +693,8 @@ def test_two_layered_handles_on_two_streams(oracle):
 
 
 def test_layered_debug_bounds_build_is_clean(tmp_path):
-    """`make debug` compiles nsr_wide.hip with -DNSR_DEBUG_BOUNDS too (r06): every global / LDS index of kw_gemm, kw_gemm_b3 and
-    the per-ray kernels is checked against its extent.  A fresh process runs, on BOTH arithmetics, the edge shapes (W = 34,
+    """`make debug` compiles nsr_wide.hip with -DNSR_DEBUG_BOUNDS too (r06): every global / LDS index of the GEMM body (kw_gemm_h2 /
+    _b3 / _f32) and of the per-ray kernels is checked against its extent.  A fresh process runs, on ALL THREE arithmetics, the edge shapes (W = 34,
     3 + 512 samples, 61 rays), ragged run_network calls, NaN / zero / infinite rays, a 64-ray-chunk workspace and the
     gradient; no check may trip, and every output equals the release build's."""
     import subprocess
@@ -711,7 +711,7 @@ from test_oracle_golden import wide_case
 g = np.load(%r)
 out = {}
 res = []
-for mlp in ("bf16x3", "fp32"):
+for mlp in ("bf16x3", "fp32", "f16x2"):
     sd_c, sd_f, ro, rd = _edge_case(O)
     ro, rd = ro.copy(), rd.copy()
     ro[3] = np.nan; rd[5] = 0.0; rd[7] = np.inf
@@ -740,9 +740,9 @@ print(out)
                            timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         res[name] = eval(r.stdout.strip().splitlines()[-1])
-    assert len(res["debug"]) == 16 and all(v == (True, 0) for v in res["debug"].values()), res["debug"]
+    assert len(res["debug"]) == 24 and all(v == (True, 0) for v in res["debug"].values()), res["debug"]
     assert all(v == (False, 0) for v in res["release"].values()), res["release"]
     a, b = np.load(tmp_path / "debug" / "res.npz"), np.load(tmp_path / "release" / "res.npz")
-    assert len(a.files) == len(b.files) == 80
+    assert len(a.files) == len(b.files) == 120
     for k in a.files:
         assert np.array_equal(a[k], b[k], equal_nan=True), k
