@@ -26,6 +26,11 @@ CASES = {
     "d10w384": (10, 384, 10, 4, [4], 64, 128),
     "w1024": (8, 1024, 10, 4, [4], 64, 128),
     "small": (4, 128, 6, 2, [1], 48, 100),
+    # networks the FUSED kernels serve by re-expression at the 8 x 256 price (108 ms per view): is the layered renderer cheaper?
+    "d8w64": (8, 64, 10, 4, [4], 64, 128),
+    "d8w128": (8, 128, 10, 4, [4], 64, 128),
+    "d8w192": (8, 192, 10, 4, [4], 64, 128),
+    "d4w256": (4, 256, 10, 4, [], 64, 128),
 }
 
 
