@@ -907,21 +907,24 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
     t.n_tiles = tiles;
     if (t.N > 0) {
       const long long all = mgroups * 8 * tiles;
-      const int per_cu = tall ? (nj == 4 ? 1 : 2) : nj == 4 ? 2 : nj == 2 ? 3 : 4;
+      const int per_cu = tall ? (nj >= 3 ? 1 : 2) : nj == 4 ? 2 : nj == 2 ? 3 : 4;
       const unsigned grid = (unsigned)std::max<long long>(8, std::min<long long>(all, (long long)cfg.cus * per_cu / 8 * 8));
       if (f32) {
         if (tall && nj == 4) launch_gemm_f32<4, 4>(st, grid, t, epi);
+        else if (tall && nj == 3) launch_gemm_f32<3, 4>(st, grid, t, epi);
         else if (tall) launch_gemm_f32<2, 4>(st, grid, t, epi);
         else if (nj == 4) launch_gemm_f32<4, 2>(st, grid, t, epi);
         else if (nj == 2) launch_gemm_f32<2, 2>(st, grid, t, epi);
         else launch_gemm_f32<1, 2>(st, grid, t, epi);
       } else if (h2) {
         if (tall && nj == 4) launch_gemm_h2<4, 4>(st, grid, t, epi);
+        else if (tall && nj == 3) launch_gemm_h2<3, 4>(st, grid, t, epi);
         else if (tall) launch_gemm_h2<2, 4>(st, grid, t, epi);
         else if (nj == 4) launch_gemm_h2<4, 2>(st, grid, t, epi);
         else if (nj == 2) launch_gemm_h2<2, 2>(st, grid, t, epi);
         else launch_gemm_h2<1, 2>(st, grid, t, epi);
       } else if (tall && nj == 4) launch_gemm_b3<4, 4>(st, grid, t, epi);
+      else if (tall && nj == 3) launch_gemm_b3<3, 4>(st, grid, t, epi);
       else if (tall) launch_gemm_b3<2, 4>(st, grid, t, epi);
       else if (nj == 4) launch_gemm_b3<4, 2>(st, grid, t, epi);
       else if (nj == 2) launch_gemm_b3<2, 2>(st, grid, t, epi);
@@ -929,9 +932,20 @@ int gemm_b3(const GemmCfg& cfg, hipStream_t st, const Net& net, const Mat& m, co
     }
     cb += tiles * nj * 2;
   };
-  if (m.ncb / 8) part(4, m.ncb / 8);
-  if ((m.ncb % 8) / 4) part(2, 1);
-  if ((m.ncb % 4) / 2) part(1, 1);
+  // N in units of 64 columns: tiles of 256 where they divide it; else tiles of 192 where THEY do (r06: 384 = 2 x 192 and 192 itself are ONE
+  // launch -- as 256 + 128 resp. 128 + 64 the second launch read the whole A matrix from HBM again); else 256s and one remainder tile
+  const int u = m.ncb / 2, three = cfg.b3_wm == 4;
+  if (u % 4 != 0 && u % 3 == 0 && three) {
+    part(3, u / 3);
+  } else {
+    if (u / 4) part(4, u / 4);
+    const int r = u % 4;
+    if (r == 3 && three) part(3, 1);
+    else {
+      if (r >= 2) part(2, 1);
+      if (r & 1) part(1, 1);
+    }
+  }
   return 0;
 }
 
