@@ -109,14 +109,14 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
     # strict fp32 mode is the same body on fp32 MFMAs with the f16x2 form's LDS footprint
     assert not [k for k in layered if k.startswith("kw_gemm<")]
     f32 = [k for k in layered if k.startswith("kw_gemm_f32<")]
-    assert {"kw_gemm_f32<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(f32), f32
+    assert {"kw_gemm_f32<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (3, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(f32), f32
     for e in (0, 1, 2, 4):
         r = res["kw_gemm_f32<4, %d, 4>" % e]
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 65536, r
     # r06: the bf16x3 GEMM (csrc/nsr_wide_b3.inc).  Its 256 x 256 tile (512 threads, two waves per SIMD) lives on <= 256 registers
     # and 96 KiB of LDS -- one workgroup per CU; the 128-row form on 72 KiB, two per CU
     b3 = [k for k in layered if k.startswith("kw_gemm_b3<")]
-    assert {"kw_gemm_b3<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(b3), b3
+    assert {"kw_gemm_b3<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (3, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(b3), b3
     for e in (0, 1, 2, 4):
         r = res["kw_gemm_b3<4, %d, 4>" % e]
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 98304, r
@@ -124,7 +124,7 @@ def test_shipped_kernels_target_gfx950_only_and_do_not_spill():
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 73728, r
     # r06: the same kernel body on two fp16 pieces (kw_gemm_h2, the layered default): two thirds of the LDS, the same occupancy
     h2 = [k for k in layered if k.startswith("kw_gemm_h2<")]
-    assert {"kw_gemm_h2<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(h2), h2
+    assert {"kw_gemm_h2<%d, %d, %d>" % (nj, e, wm) for nj, wm in ((4, 4), (3, 4), (2, 4), (4, 2), (2, 2), (1, 2)) for e in (0, 1, 2, 4)} <= set(h2), h2
     for e in (0, 1, 2, 4):
         r = res["kw_gemm_h2<4, %d, 4>" % e]
         assert r["vgpr_count"] <= 256 and r["group_segment_fixed_size"] == 65536, r
